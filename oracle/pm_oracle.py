@@ -1,0 +1,657 @@
+"""
+TEST INFRASTRUCTURE (see oracle/__init__.py) -- numpy float64 restatement of the PM hot path of
+hsimonfroy/montecosmo, function by function, each citing the reference lines it follows
+(paths relative to /root/reference), plus hand-derived VJPs (validated against central finite
+differences of this same oracle in tests/test_oracle_vjp.py).
+
+Third-party semantics restated here (none vendored in the reference; "parity unpinned"):
+  * jax.numpy (jax==0.4.25): rfftn unnormalised / irfftn x 1/M and = ifft over leading axes then
+    c2r over the last; `.at[].add` scatter-add; gather; jnp.interp clamps; jnp.round half-to-even;
+    d|s|/ds = sign(s) (0 at s = 0).  numpy has the same semantics.
+  * diffrax==0.5.0 `diffeqsolve(ODETerm(vf), Euler(), t0, t1, dt0, y0, max_steps)`: constant
+    step, t_{i+1} = min(t_i + dt0, t1) (last step clipped to t1), y <- y + vf(t_i, y)*(t_{i+1}-t_i);
+    SaveAt(t1=True) returns ys with a leading axis of length 1.
+Cotangent convention for complex arrays: "real pair", bar = dL/dRe + i dL/dIm, so that
+dL = Re(sum(conj(bar) * dz)) (this is the conjugate of what jax.grad returns).
+"""
+from itertools import product
+import numpy as np
+
+from . import background
+
+
+# --------------------------------------------------------------------------- helpers
+def safe_div(x, y):
+    """montecosmo/utils.py:21-29"""
+    y = np.asarray(y)
+    y_nozeros = np.where(y == 0, 1, y)
+    return np.where(y == 0, 0, x / y_nozeros)
+
+
+def ch2rshape(shape):
+    """montecosmo/utils.py:769-776"""
+    return (*shape[:-1], 2 * (shape[-1] - 1))
+
+
+def r2chshape(shape):
+    """montecosmo/utils.py:778-782"""
+    return (*shape[:-1], shape[-1] // 2 + 1)
+
+
+def scale_shape(shape, scale=1.):
+    """montecosmo/utils.py:1163-1168"""
+    out = 2 * np.rint(np.multiply(shape, scale) / 2).astype(int)
+    return tuple(map(int, out))
+
+
+def regular_pos(mesh_shape, ptcl_shape=None):
+    """montecosmo/bricks.py:593-603: x slowest, z fastest."""
+    if ptcl_shape is None:
+        ptcl_shape = mesh_shape
+    pos = [np.linspace(0, m, p, endpoint=False) for m, p in zip(mesh_shape, ptcl_shape)]
+    return np.stack(np.meshgrid(*pos, indexing='ij'), axis=-1).reshape(-1, 3)
+
+
+# --------------------------------------------------------------------------- k-space kernels
+def rfftk(shape, box_size=None):
+    """montecosmo/nbody.py:50-77"""
+    dim = len(shape)
+    if box_size is None:
+        scales = dim * (2 * np.pi,)
+    else:
+        scales = tuple(2 * np.pi * s / b for s, b in zip(shape, box_size))
+    kvec = ()
+    shapes = np.eye(dim, dtype=int) * -2 + 1
+    for ax, (s, sc, ss) in enumerate(zip(shape, scales, shapes)):
+        if ax < dim - 1:
+            kvec += ((np.fft.fftfreq(s) * sc).reshape(ss),)
+        else:
+            kvec += ((np.fft.rfftfreq(s) * sc).reshape(ss),)
+    return kvec
+
+
+def fftk(shape, box_size=None):
+    """montecosmo/nbody.py:80-103"""
+    dim = len(shape)
+    if box_size is None:
+        scales = dim * (2 * np.pi,)
+    else:
+        scales = tuple(2 * np.pi * s / b for s, b in zip(shape, box_size))
+    shapes = np.eye(dim, dtype=int) * -2 + 1
+    return tuple((np.fft.fftfreq(s) * sc).reshape(ss) for s, sc, ss in zip(shape, scales, shapes))
+
+
+def invlaplace_hat(kvec, fd_order=np.inf):
+    """montecosmo/nbody.py:109-133"""
+    if fd_order == 2:
+        kk = sum((np.cos(ki) - 1) * 2 for ki in kvec)
+    elif fd_order == 4:
+        kk = sum((np.cos(2 * ki) - 16 * np.cos(ki) + 15) / 6 for ki in kvec)
+    elif fd_order == np.inf:
+        kk = sum(ki ** 2 for ki in kvec)
+    else:
+        raise ValueError("Only orders 2, 4, and inf are supported.")
+    return -safe_div(1, kk)
+
+
+def gradient_hat(kvec, direction, fd_order=np.inf):
+    """montecosmo/nbody.py:136-163.  NB: no Nyquist zeroing."""
+    ki = kvec[direction]
+    if fd_order == 2:
+        ki = np.sin(ki)
+    elif fd_order == 4:
+        ki = (8 * np.sin(ki) - np.sin(2 * ki)) / 6
+    elif fd_order == np.inf:
+        pass
+    else:
+        raise ValueError("Only orders 2, 4, and inf are supported.")
+    return 1j * ki
+
+
+def gaussian_hat(kvec, kcut=np.inf):
+    """montecosmo/nbody.py:166-188"""
+    if kcut == np.inf:
+        return 1.
+    kk = sum(ki ** 2 for ki in kvec)
+    rcut = 2 * np.pi / kcut
+    return np.exp(-kk * rcut ** 2 / 2)
+
+
+def rectangular(s, order):
+    """montecosmo/nbody.py:220-246, applied to |s|.  Order 1 (NGP) is the constant 1 (the
+    reference returns a length-3 vector of ones whose product over axes is 1)."""
+    s = np.abs(s)
+    if order == 0:
+        return np.full(np.shape(s), np.inf)
+    if order == 1:
+        return np.ones(np.shape(s))
+    if order == 2:
+        return 1 - s
+    if order == 3:
+        return (s <= 1 / 2) * (3 / 4 - s ** 2) + (1 / 2 < s) / 2 * (3 / 2 - s) ** 2
+    if order == 4:
+        return (s <= 1) / 6 * (4 - 6 * s ** 2 + 3 * s ** 3) + (1 < s) / 6 * (2 - s) ** 3
+    raise ValueError(order)
+
+
+def rectangular_grad(s, order):
+    """d/ds rectangular(s, order) = k'(|s|) sign(s); sign(0) = 0 as in jax's abs JVP."""
+    u = np.abs(s)
+    sg = np.sign(s)
+    if order == 1:
+        return np.zeros(np.shape(s))
+    if order == 2:
+        return -sg
+    if order == 3:
+        return ((u <= 1 / 2) * (-2 * u) + (1 / 2 < u) * (-(3 / 2 - u))) * sg
+    if order == 4:
+        return ((u <= 1) / 6 * (-12 * u + 9 * u ** 2) + (1 < u) / 6 * (-3) * (2 - u) ** 2) * sg
+    raise ValueError(order)
+
+
+def rectangular_hat(kvec, order=2):
+    """montecosmo/nbody.py:249-277"""
+    out = 1.
+    for ki in kvec:
+        out = out * np.sinc(ki / (2 * np.pi)) ** order
+    return out
+
+
+# --------------------------------------------------------------------------- paint / read
+def _id0_shifts(pos, ndim, order):
+    """montecosmo/nbody.py:375-377: id0 = floor (even order) or round-half-even (odd order), cast to
+    int16; shifts in itertools.product (lexicographic) order."""
+    id0 = (np.round if order % 2 else np.floor)(pos).astype(np.int16)
+    ishifts = np.arange(order) - (order - 1) // 2
+    ishifts = np.array(list(product(*ndim * (ishifts,))), dtype=np.int16)
+    return id0, ishifts
+
+
+def cell_index(pos, shape, order=2):
+    """Wrapped base-cell index of every particle, (N,3) int16: `wrap(id0)` of nbody.py:372-375."""
+    shape16 = np.asarray(shape, dtype=np.int16)
+    id0, _ = _id0_shifts(np.asarray(pos, dtype=np.float64), len(shape), order)
+    return id0 % shape16
+
+
+def stencil(pos, shape, order):
+    """Yield (flat wrapped index (N,), per-axis kernel values (N,3), per-axis kernel derivatives
+    w.r.t. pos (N,3)) for each stencil point, following nbody.py:386-389."""
+    pos = np.asarray(pos, dtype=np.float64)
+    shape16 = np.asarray(shape, dtype=np.int16)
+    id0, ishifts = _id0_shifts(pos, len(shape), order)
+    for ishift in ishifts:
+        idx = id0 + ishift                      # int16, unwrapped
+        s = idx - pos                           # kernel argument on the UNWRAPPED index
+        ker = rectangular(s, order)
+        dker = -rectangular_grad(s, order)      # d/dpos K(idx - pos)
+        flat = np.ravel_multi_index(tuple((idx % shape16).T.astype(np.int64)), tuple(int(v) for v in shape))
+        yield flat, ker, dker
+
+
+def paint(pos, shape, weights=1., order=2):
+    """montecosmo/nbody.py:365-396 (kernel_type='rectangular')."""
+    shape = tuple(int(s) for s in shape)
+    size = int(np.prod(shape))
+    mesh = np.zeros(size)
+    n = len(pos)
+    weights = np.broadcast_to(np.asarray(weights, dtype=np.float64), (n,))
+    for flat, ker, _ in stencil(pos, shape, order):
+        mesh += np.bincount(flat, weights=weights * ker.prod(-1), minlength=size)
+    return mesh.reshape(shape)
+
+
+def read(pos, mesh, order=2):
+    """montecosmo/nbody.py:398-427"""
+    mesh = np.asarray(mesh)
+    out = np.zeros(len(pos), dtype=mesh.dtype)
+    flatmesh = mesh.reshape(-1)
+    for flat, ker, _ in stencil(pos, mesh.shape, order):
+        out = out + flatmesh[flat] * ker.prod(-1)
+    return out
+
+
+def _dprod(ker, dker):
+    """d/dpos_a of prod_b ker_b, (N,3)."""
+    out = np.empty_like(ker)
+    for a in range(ker.shape[-1]):
+        t = dker[:, a].copy()
+        for b in range(ker.shape[-1]):
+            if b != a:
+                t = t * ker[:, b]
+        out[:, a] = t
+    return out
+
+
+def paint_vjp(pos, shape, weights, mesh_bar, order=2):
+    """VJP of paint w.r.t. (pos, weights).  weights may be a scalar (its bar is then summed)."""
+    n = len(pos)
+    w = np.broadcast_to(np.asarray(weights, dtype=np.float64), (n,))
+    flatbar = np.asarray(mesh_bar).reshape(-1)
+    pos_bar = np.zeros((n, len(shape)))
+    w_bar = np.zeros(n)
+    for flat, ker, dker in stencil(pos, shape, order):
+        mb = flatbar[flat]
+        w_bar += mb * ker.prod(-1)
+        pos_bar += (w * mb)[:, None] * _dprod(ker, dker)
+    if np.ndim(weights) == 0:
+        w_bar = w_bar.sum()
+    return pos_bar, w_bar
+
+
+def read_vjp(pos, mesh, out_bar, order=2):
+    """VJP of read w.r.t. (pos, mesh)."""
+    mesh = np.asarray(mesh)
+    flatmesh = mesh.reshape(-1)
+    pos_bar = np.zeros((len(pos), mesh.ndim))
+    for flat, ker, dker in stencil(pos, mesh.shape, order):
+        pos_bar += (out_bar * flatmesh[flat])[:, None] * _dprod(ker, dker)
+    mesh_bar = paint(pos, mesh.shape, weights=out_bar, order=order)
+    return pos_bar, mesh_bar
+
+
+# --------------------------------------------------------------------------- FFT adjoints
+def _zweights(shape_r):
+    """w = (1,2,...,2,1) along the half axis: multiplicity of each stored mode in irfftn."""
+    nzh = shape_r[-1] // 2 + 1
+    w = np.full(nzh, 2.0)
+    w[0] = 1.0
+    if shape_r[-1] % 2 == 0:
+        w[-1] = 1.0
+    return w
+
+
+def irfftn_vjp(real_bar):
+    """y = irfftn(X) (numpy: ifft over leading axes, c2r over last)  ->  X_bar = (w/M) rfftn(y_bar)."""
+    M = real_bar.size
+    return np.fft.rfftn(real_bar) * (_zweights(real_bar.shape) / M)
+
+
+def rfftn_vjp(spec_bar, shape_r):
+    """X = rfftn(rho), rho real  ->  rho_bar = M * irfftn(X_bar / w)."""
+    M = int(np.prod(shape_r))
+    return np.fft.irfftn(spec_bar / _zweights(shape_r), s=shape_r) * M
+
+
+# --------------------------------------------------------------------------- forces
+def pm_forces(pos, mesh, read_order=2, paint_deconv=False, grad_fd=np.inf, lap_fd=np.inf, kcut=np.inf):
+    """montecosmo/nbody.py:583-604.  `mesh` a shape tuple (paint first) or a half-spectrum."""
+    if isinstance(mesh, tuple):
+        mesh = np.fft.rfftn(paint(pos, mesh, order=read_order))
+        if paint_deconv:
+            kvec = rfftk(ch2rshape(mesh.shape))
+            mesh = mesh / rectangular_hat(kvec, order=read_order) ** 2
+    kvec = rfftk(ch2rshape(mesh.shape))
+    pot = mesh * invlaplace_hat(kvec, lap_fd)
+    if kcut != np.inf:
+        pot = pot * gaussian_hat(kvec, kcut)
+    return np.stack([read(pos, np.fft.irfftn(-gradient_hat(kvec, i, grad_fd) * pot), read_order)
+                     for i in range(len(kvec))], axis=-1)
+
+
+def force_meshes(mesh_k, grad_fd=np.inf, lap_fd=np.inf):
+    """The three real force meshes irfftn(-(i k_c) * (-1/k^2) * mesh_k) of nbody.py:597-603."""
+    kvec = rfftk(ch2rshape(mesh_k.shape))
+    pot = mesh_k * invlaplace_hat(kvec, lap_fd)
+    return [np.fft.irfftn(-gradient_hat(kvec, i, grad_fd) * pot) for i in range(3)]
+
+
+def pm_forces_vjp(pos, mesh, forces_bar, read_order=2, paint_deconv=False, grad_fd=np.inf, lap_fd=np.inf,
+                  kcut=np.inf):
+    """VJP of pm_forces.  Returns (pos_bar, mesh_bar) with mesh_bar None when `mesh` is a shape tuple
+    (then pos_bar also carries the dependence through the painted density)."""
+    painted = isinstance(mesh, tuple)
+    if painted:
+        shape = mesh
+        spec = np.fft.rfftn(paint(pos, shape, order=read_order))
+    else:
+        spec = mesh
+        shape = ch2rshape(mesh.shape)
+    kvec = rfftk(shape)
+    kern = invlaplace_hat(kvec, lap_fd)
+    if painted and paint_deconv:
+        kern = kern / rectangular_hat(kvec, order=read_order) ** 2
+    if kcut != np.inf:
+        kern = kern * gaussian_hat(kvec, kcut)
+    pot = spec * kern
+    pos_bar = np.zeros_like(pos, dtype=np.float64)
+    pot_bar = np.zeros_like(pot)
+    for c in range(3):
+        gk = -gradient_hat(kvec, c, grad_fd)
+        fmesh = np.fft.irfftn(gk * pot)
+        pb, mb = read_vjp(pos, fmesh, forces_bar[:, c], read_order)
+        pos_bar += pb
+        pot_bar += np.conj(gk) * irfftn_vjp(mb)
+    spec_bar = pot_bar * np.conj(kern)
+    if painted:
+        rho_bar = rfftn_vjp(spec_bar, shape)
+        pos_bar += paint_vjp(pos, shape, 1., rho_bar, order=read_order)[0]
+        return pos_bar, None
+    return pos_bar, spec_bar
+
+
+def delta2_mesh(mesh_k, grad_fd=np.inf, lap_fd=np.inf, return_hess=False):
+    """2LPT source of nbody.py:611-627 (running-sum form kept)."""
+    kvec = rfftk(ch2rshape(mesh_k.shape))
+    pot = mesh_k * invlaplace_hat(kvec, lap_fd)
+    delta2 = 0.
+    hesses = 0.
+    hess = {}
+    for i in range(3):
+        hess_ii = np.fft.irfftn(gradient_hat(kvec, i, grad_fd) ** 2 * pot)
+        hess[(i, i)] = hess_ii
+        delta2 = delta2 + hess_ii * hesses
+        hesses = hesses + hess_ii
+        for j in range(i + 1, 3):
+            hess_ij = np.fft.irfftn(gradient_hat(kvec, i, grad_fd) * gradient_hat(kvec, j, grad_fd) * pot)
+            hess[(i, j)] = hess_ij
+            delta2 = delta2 - hess_ij ** 2
+    return (delta2, hess) if return_hess else delta2
+
+
+def pm_forces2(pos, mesh_k, read_order=2, grad_fd=np.inf, lap_fd=np.inf):
+    """montecosmo/nbody.py:607-631"""
+    delta2 = delta2_mesh(mesh_k, grad_fd, lap_fd)
+    return pm_forces(pos, np.fft.rfftn(delta2), read_order, grad_fd=grad_fd, lap_fd=lap_fd)
+
+
+def pm_forces2_vjp(pos, mesh_k, forces_bar, read_order=2, grad_fd=np.inf, lap_fd=np.inf):
+    """VJP of pm_forces2 w.r.t. (pos, mesh_k)."""
+    shape = ch2rshape(mesh_k.shape)
+    kvec = rfftk(shape)
+    delta2, hess = delta2_mesh(mesh_k, grad_fd, lap_fd, return_hess=True)
+    pos_bar, d2k_bar = pm_forces_vjp(pos, np.fft.rfftn(delta2), forces_bar, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
+    d2_bar = rfftn_vjp(d2k_bar, shape)
+    pot_bar = 0.
+    for i in range(3):
+        others = sum(hess[(j, j)] for j in range(3) if j != i)
+        pot_bar = pot_bar + np.conj(gradient_hat(kvec, i, grad_fd) ** 2) * irfftn_vjp(d2_bar * others)
+        for j in range(i + 1, 3):
+            gij = gradient_hat(kvec, i, grad_fd) * gradient_hat(kvec, j, grad_fd)
+            pot_bar = pot_bar + np.conj(gij) * irfftn_vjp(-2 * d2_bar * hess[(i, j)])
+    return pos_bar, pot_bar * invlaplace_hat(kvec, lap_fd)
+
+
+def lpt(cosmo, init_mesh, pos, a, lpt_order=2, read_order=2, grad_fd=np.inf, lap_fd=np.inf):
+    """montecosmo/nbody.py:634-667"""
+    if np.isrealobj(init_mesh):
+        init_mesh = np.fft.rfftn(init_mesh)
+    force1 = pm_forces(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
+    dpos = a2g(cosmo, a) * force1
+    vel = force1
+    if lpt_order == 2:
+        force2 = pm_forces2(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
+        dpos = dpos - a2g2(cosmo, a) * force2
+        vel = vel - a2dg2dg(cosmo, a) * force2
+    return dpos, vel
+
+
+def lpt_vjp(cosmo, init_mesh, pos, a, dpos_bar, vel_bar, lpt_order=2, read_order=2, grad_fd=np.inf, lap_fd=np.inf):
+    """VJP of lpt w.r.t. init_mesh (complex half-spectrum), pos, and the three growth scalars.
+    Returns (init_mesh_bar, pos_bar, {'g':..., 'g2':..., 'dg2dg':...}); scalar `a` only."""
+    g, g2, c = a2g(cosmo, a), a2g2(cosmo, a), a2dg2dg(cosmo, a)
+    force1 = pm_forces(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
+    f1_bar = g * dpos_bar + vel_bar
+    sbar = {'g': float(np.sum(dpos_bar * force1)), 'g2': 0., 'dg2dg': 0.}
+    pos_bar, mesh_bar = pm_forces_vjp(pos, init_mesh, f1_bar, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
+    if lpt_order == 2:
+        force2 = pm_forces2(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
+        sbar['g2'] = -float(np.sum(dpos_bar * force2))
+        sbar['dg2dg'] = -float(np.sum(vel_bar * force2))
+        f2_bar = -g2 * dpos_bar - c * vel_bar
+        pb, mb = pm_forces2_vjp(pos, init_mesh, f2_bar, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
+        pos_bar = pos_bar + pb
+        mesh_bar = mesh_bar + mb
+    return mesh_bar, pos_bar, sbar
+
+
+# --------------------------------------------------------------------------- growth tables
+growth_log10_amin = -3.
+growth_steps = 128
+
+
+def growth_table(cosmo, log10_amin=growth_log10_amin, steps=growth_steps):
+    """montecosmo/nbody.py:679-745: RK4 on atab = logspace(-3, 0, 128) for (D, D2, D', D2')."""
+    if "background.growth_factor" in cosmo._workspace:
+        return cosmo._workspace["background.growth_factor"]
+    atab = np.logspace(log10_amin, 0.0, steps)
+
+    def D_derivs(y, x):
+        q = 2.0
+        q = q - (background.Omega_m_a(cosmo, x) + (1.0 + 3.0 * background.w(cosmo, x)) * background.Omega_de_a(cosmo, x)) / 2
+        q = q / x
+        r = 1.5 * background.Omega_m_a(cosmo, x) / x ** 2
+        g1, g2 = y[0]
+        f1, f2 = y[1]
+        dy1da = [f1, -q * f1 + r * g1]
+        dy2da = [f2, -q * f2 + r * g2 - r * g1 ** 2]
+        return np.array([[dy1da[0], dy2da[0]], [dy1da[1], dy2da[1]]])
+
+    y0 = np.array([[atab[0], -3.0 / 7 * atab[0] ** 2], [1.0, -6.0 / 7 * atab[0]]])
+    y = background.odeint(D_derivs, y0, atab)
+    dyda2 = D_derivs(np.transpose(y, (1, 2, 0)), atab)
+    dyda2 = np.transpose(dyda2, (2, 0, 1))
+    y1 = y[:, 0, 0]
+    gtab = y1 / y1[-1]
+    y2 = y[:, 0, 1]
+    g2tab = y2 / y2[-1]
+    ftab = y[:, 1, 0] / y1[-1] * atab / gtab
+    f2tab = y[:, 1, 1] / y2[-1] * atab / g2tab
+    htab = dyda2[:, 1, 0] / y1[-1] * atab / gtab
+    h2tab = dyda2[:, 1, 1] / y2[-1] * atab / g2tab
+    cache = {"a": atab, "g": gtab, "f": ftab, "h": htab, "g2": g2tab, "f2": f2tab, "h2": h2tab}
+    cosmo._workspace["background.growth_factor"] = cache
+    return cache
+
+
+def a2g(cosmo, a):
+    """nbody.py:750-754 (np.interp clamps like jnp.interp)."""
+    c = growth_table(cosmo)
+    return np.interp(a, c["a"], c["g"])
+
+
+def a2g2(cosmo, a):
+    """nbody.py:756-761"""
+    c = growth_table(cosmo)
+    return np.interp(a, c["a"], c["g2"]) * -3 / 7
+
+
+def a2f(cosmo, a):
+    """nbody.py:763-767"""
+    c = growth_table(cosmo)
+    return np.interp(a, c["a"], c["f"])
+
+
+def a2f2(cosmo, a):
+    """nbody.py:769-773"""
+    c = growth_table(cosmo)
+    return np.interp(a, c["a"], c["f2"])
+
+
+def a2dg2dg(cosmo, a):
+    """nbody.py:775-777"""
+    g, g2, f, f2 = a2g(cosmo, a), a2g2(cosmo, a), a2f(cosmo, a), a2f2(cosmo, a)
+    return safe_div(g2 * f2, g * f)
+
+
+def g2a(cosmo, g):
+    """nbody.py:781-785"""
+    c = growth_table(cosmo)
+    return np.interp(g, c["g"], c["a"])
+
+
+def g2g2(cosmo, g):
+    """nbody.py:787-792"""
+    c = growth_table(cosmo)
+    return np.interp(g, c["g"], c["g2"]) * -3 / 7
+
+
+def g2f(cosmo, g):
+    """nbody.py:794-798"""
+    c = growth_table(cosmo)
+    return np.interp(g, c["g"], c["f"])
+
+
+def g2f2(cosmo, g):
+    """nbody.py:800-804"""
+    c = growth_table(cosmo)
+    return np.interp(g, c["g"], c["f2"])
+
+
+def g2dg2dg(cosmo, g):
+    """nbody.py:806-808"""
+    g2, f, f2 = g2g2(cosmo, g), g2f(cosmo, g), g2f2(cosmo, g)
+    return safe_div(g2 * f2, g * f)
+
+
+dist_log10_amin = -3.
+dist_steps = 256
+
+
+def _dist_table(cosmo, log10_amin=dist_log10_amin, steps=dist_steps):
+    """nbody.py:842-856"""
+    key = "background.radial_comoving_distance"
+    if key not in cosmo._workspace:
+        atab = np.logspace(log10_amin, 0.0, steps)
+
+        def dchioverdlna(y, x):
+            xa = np.exp(x)
+            return background.dchioverda(cosmo, xa) * xa
+
+        chitab = background.odeint(dchioverdlna, 0.0, np.log(atab))
+        chitab = chitab[-1] - chitab
+        cosmo._workspace[key] = {"a": atab, "chi": chitab}
+    return cosmo._workspace[key]
+
+
+def a2chi(cosmo, a):
+    """nbody.py:817-859"""
+    c = _dist_table(cosmo)
+    return np.clip(np.interp(a, c["a"], c["chi"]), 0.0, None)
+
+
+def chi2a(cosmo, chi):
+    """nbody.py:862-884"""
+    c = _dist_table(cosmo)
+    return np.interp(chi, c["chi"][::-1], c["a"][::-1])
+
+
+# --------------------------------------------------------------------------- BullFrog / FastPM
+def alpha_bf(cosmo, g0, dg):
+    """nbody.py:907-919"""
+    g1 = g0 + dg / 2
+    g2 = g0 + dg
+    dg2dg0, dg2dg2 = g2dg2dg(cosmo, g0), g2dg2dg(cosmo, g2)
+    lin_ratio = (g2g2(cosmo, g0) + dg2dg0 * dg / 2) / g1 - g1
+    return (dg2dg2 - lin_ratio) / (dg2dg0 - lin_ratio)
+
+
+def alpha_fpm(cosmo, g0, dg):
+    """nbody.py:921-931"""
+    g2 = g0 + dg
+    a0, a2 = g2a(cosmo, g0), g2a(cosmo, g2)
+    coeff0 = background.Esqr(cosmo, a0) ** .5 * g0 * g2f(cosmo, g0) * a0 ** 2
+    coeff2 = background.Esqr(cosmo, a2) ** .5 * g2 * g2f(cosmo, g2) * a2 ** 2
+    return coeff0 / coeff2
+
+
+def bullfrog_vf(cosmo, dg, mesh_shape, paint_order=2, paint_deconv=False, grad_fd=np.inf, lap_fd=np.inf,
+                alpha_fn=alpha_bf):
+    """nbody.py:902-959.  The reference's kick always calls alpha_bf (nbody.py:937); `alpha_fn` lets the
+    unused closure alpha_fpm (nbody.py:921-931) be selected for the "FastPM" configs."""
+    mesh_shape = tuple(int(s) for s in mesh_shape)
+
+    def kick(state, g0):
+        pos, vel = state
+        g1 = g0 + dg / 2
+        forces = pm_forces(pos, mesh_shape, paint_order, paint_deconv=paint_deconv, grad_fd=grad_fd, lap_fd=lap_fd)
+        alpha = alpha_fn(cosmo, g0, dg)
+        return pos, alpha * vel + (1 - alpha) * forces / g1
+
+    def drift(state, d):
+        pos, vel = state
+        return pos + vel * d, vel
+
+    def vector_field(g0, state, args=None):
+        old = state
+        state = drift(state, dg / 2)
+        state = kick(state, g0)
+        state = drift(state, dg / 2)
+        return tuple((new - o) / dg for new, o in zip(state, old))
+
+    return vector_field
+
+
+def euler_times(g0, g1, dg, n_steps):
+    """diffrax Euler/ConstantStepSize time grid: t accumulates by +dg, clipped to g1."""
+    ts = [g0]
+    for _ in range(n_steps):
+        ts.append(min(ts[-1] + dg, g1))
+    return ts
+
+
+def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order=2, lpt_order=2, paint_deconv=False,
+             grad_fd=np.inf, lap_fd=np.inf, snapshots=None, alpha_fn=alpha_bf, return_traj=False):
+    """nbody.py:967-1002 with snapshots=None (SaveAt(t1=True) -> leading axis of 1)."""
+    assert snapshots is None or (isinstance(snapshots, int) and snapshots <= 1)
+    n_steps = int(n_steps)
+    g0 = float(a2g(cosmo, a0))
+    g1 = float(a2g(cosmo, a1))
+    dg = (g1 - g0) / n_steps
+    mesh_shape = ch2rshape(init_mesh.shape)
+    vf = bullfrog_vf(cosmo, dg, mesh_shape, paint_order, paint_deconv, grad_fd, lap_fd, alpha_fn)
+    dpos, vel = lpt(cosmo, init_mesh, pos=pos, a=a0, lpt_order=lpt_order, read_order=1, grad_fd=grad_fd, lap_fd=lap_fd)
+    state = (pos + dpos, vel)
+    ts = euler_times(g0, g1, dg, n_steps)
+    traj = [state]
+    for i in range(n_steps):
+        d = vf(ts[i], state)
+        dt = ts[i + 1] - ts[i]
+        state = tuple(y + v * dt for y, v in zip(state, d))
+        traj.append(state)
+    out = (state[0][None], state[1][None])
+    return (out, traj, ts, dg) if return_traj else out
+
+
+def dkd_vjp(pos, vel, pos2_bar, vel1_bar, dg, alpha, g1mid, mesh_shape, paint_order=2):
+    """VJP of one drift-kick-drift map (nbody.py:946-950) at fixed scalars.
+    Returns (pos_bar, vel_bar, alpha_bar, beta_bar, dg_bar) with beta = (1-alpha)/g1mid."""
+    beta = (1 - alpha) / g1mid
+    x1 = pos + vel * (dg / 2)
+    F = pm_forces(x1, tuple(mesh_shape), paint_order)
+    v1 = alpha * vel + beta * F
+    dg_bar = 0.5 * float(np.sum(pos2_bar * v1))
+    v1_bar = vel1_bar + pos2_bar * (dg / 2)
+    x1_bar = pos2_bar.copy()
+    alpha_bar = float(np.sum(v1_bar * vel))
+    beta_bar = float(np.sum(v1_bar * F))
+    x1_bar += pm_forces_vjp(x1, tuple(mesh_shape), beta * v1_bar, paint_order)[0]
+    vel_bar = alpha * v1_bar + x1_bar * (dg / 2)
+    dg_bar += 0.5 * float(np.sum(x1_bar * vel))
+    return x1_bar, vel_bar, alpha_bar, beta_bar, dg_bar
+
+
+def nbody_bf_vjp(cosmo, init_mesh, pos, pos_bar, vel_bar, a0=0., a1=1., n_steps=5, paint_order=2, lpt_order=2,
+                 alpha_fn=alpha_bf):
+    """Reverse sweep of nbody_bf (paint_deconv=False, spectral kernels) at fixed growth scalars.
+    Returns (init_mesh_bar, scalar_bars) where scalar_bars holds per-step alpha_bar/beta_bar, dg_bar and the
+    LPT growth-scalar bars; `pos_bar`/`vel_bar` are cotangents of the final (pos, vel), shape (N,3)."""
+    (_, traj, ts, dg) = nbody_bf(cosmo, init_mesh, pos, a0, a1, n_steps, paint_order, lpt_order,
+                                 alpha_fn=alpha_fn, return_traj=True)
+    mesh_shape = ch2rshape(init_mesh.shape)
+    xb, vb = np.array(pos_bar, dtype=np.float64), np.array(vel_bar, dtype=np.float64)
+    abar, bbar, dgbar = np.zeros(n_steps), np.zeros(n_steps), 0.
+    for i in reversed(range(n_steps)):
+        x, v = traj[i]
+        r = (ts[i + 1] - ts[i]) / dg
+        alpha = float(alpha_fn(cosmo, ts[i], dg))
+        g1mid = ts[i] + dg / 2
+        # y_{i+1} = y_i + (DKD(y_i) - y_i) * r
+        xb2, vb2, ab, bb, db = dkd_vjp(x, v, r * xb, r * vb, dg, alpha, g1mid, mesh_shape, paint_order)
+        xb = (1 - r) * xb + xb2
+        vb = (1 - r) * vb + vb2
+        abar[i], bbar[i] = ab, bb
+        dgbar += db
+    mesh_bar, _, sbar = lpt_vjp(cosmo, init_mesh, pos, a0, xb, vb, lpt_order=lpt_order, read_order=1)
+    sbar.update(alpha=abar, beta=bbar, dg=dgbar)
+    return mesh_bar, sbar
