@@ -1,0 +1,170 @@
+/*
+ * mcpm.h -- C ABI of the MI355X-native particle-mesh (PM) forward model + hand-written adjoint.
+ *
+ * Drop-in boundary for the hot path of hsimonfroy/montecosmo.  The reference has no FFI: its
+ * boundary is the Python function surface of montecosmo/nbody.py (consumed by bricks.py:10 and
+ * model.py:23-25).  Each entry point below names the reference function it replaces
+ * (file:line relative to the reference checkout); `montecosmo_amd/nbody.py` binds them with ctypes
+ * and re-exports the reference's names.  INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", POD only.  Every `*_d` / unnamed array pointer is a DEVICE pointer owned by the
+ *     caller; the library owns only the plan (rocFFT plans, scratch meshes, outlier list).
+ *   - Every function returns 0 (MCPM_OK) or a negative MCPM_E_* code; mcpm_last_error() gives text.
+ *     No C++ exception crosses the ABI, nothing aborts.
+ *   - Work is enqueued on the plan's HIP stream and the call returns without synchronising.
+ *   - Meshes are C-order [x][y][z] float32 (z fastest); half-spectra are [x][y][z/2+1] interleaved
+ *     complex64 -- the layout of jnp.fft.rfftn (nbody.py:589).  nz must be even (utils.py:769-776).
+ *   - Particles are AoS float32 [N][3].  Positions are in cell units of the mesh, periodic, any real
+ *     value with |pos| < 32767 (the reference does its index arithmetic in int16, nbody.py:369).
+ *   - FFTs are unnormalised in both directions (rocFFT); the 1/M of numpy/jax `irfftn` is folded into
+ *     the `scale` argument of the k-space kernels.
+ */
+#ifndef MCPM_H
+#define MCPM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcpm_plan mcpm_plan;
+
+#define MCPM_OK 0
+#define MCPM_E_SHAPE (-1)       /* bad mesh / lattice shape */
+#define MCPM_E_ORDER (-2)       /* unsupported assignment or finite-difference order */
+#define MCPM_E_HIP (-3)         /* HIP runtime error */
+#define MCPM_E_ROCFFT (-4)      /* rocFFT error */
+#define MCPM_E_RCCL (-5)        /* RCCL error */
+#define MCPM_E_ARG (-6)         /* null pointer / bad argument */
+#define MCPM_E_NOMEM (-7)       /* device allocation failed */
+#define MCPM_E_UNSUPPORTED (-8) /* valid request not implemented on this path */
+
+/* Position encodings of a float32 [N][3] particle array. */
+#define MCPM_POS_ABSOLUTE 0 /* absolute cell coordinates */
+#define MCPM_POS_LATTICE 1  /* displacement from the plan's particle lattice point of particle i, the
+                               i-th row of regular_pos(mesh_shape, ptcl_shape) (bricks.py:593-603);
+                               requires n == px*py*pz.  Keeps fp32 precision at large meshes. */
+
+/* Finite-difference order selectors for the k-space kernels (nbody.py:109-163). */
+#define MCPM_FD_INF 0
+#define MCPM_FD_2 2
+#define MCPM_FD_4 4
+
+/* ---- plan ------------------------------------------------------------------------------------ */
+/* mesh (nx,ny,nz), particle lattice (px,py,pz), HIP stream (hipStream_t, may be NULL). */
+int mcpm_plan_create(int nx, int ny, int nz, int px, int py, int pz, void *stream, mcpm_plan **plan);
+int mcpm_plan_destroy(mcpm_plan *plan);
+const char *mcpm_last_error(const mcpm_plan *plan); /* plan may be NULL: last error of a failed create */
+const char *mcpm_version(void);
+/* Number of particles the last tiled paint routed through the global-atomic outlier path (host sync). */
+int mcpm_plan_last_outliers(mcpm_plan *plan, int64_t *count);
+/* Tuning knob: halo radius (cells) of the LDS-tiled paint; displacements beyond it take the outlier path. */
+int mcpm_plan_set_halo(mcpm_plan *plan, int halo);
+
+/* ---- FFT (replaces jnp.fft.rfftn / irfftn at nbody.py:589,603,620,627,630) ------------------ */
+int mcpm_fft_r2c(mcpm_plan *plan, const float *real, float *spec, int batch);
+/* Unnormalised (M x irfftn); `spec` is destroyed. */
+int mcpm_fft_c2r(mcpm_plan *plan, float *spec, float *real, int batch);
+
+/* ---- mass assignment (nbody.py:365-427) ----------------------------------------------------- */
+/* wrap(id0) of nbody.py:372-375 for every particle, int16 [N][3]: the integer part of the path. */
+int mcpm_cell_index(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, int order, int16_t *idx);
+/* paint (nbody.py:365-396): mesh (+)= sum_p w_p prod_a K(c_a - x_pa).  weights may be NULL (then
+   wscalar is used); element p is weights[p*wstride].  order 1 (NGP) or 2 (CIC).
+   accumulate = 0 overwrites mesh, 1 adds to it. */
+int mcpm_paint_f32(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, const float *weights,
+                   int64_t wstride, float wscalar, int order, float *mesh, int accumulate);
+/* read (nbody.py:398-427) of `ncomp` contiguous meshes at once: out[p*ncomp + c]. */
+int mcpm_read_f32(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, const float *meshes,
+                  int ncomp, int order, float *out);
+/* VJP of paint w.r.t. pos and weights: pos_bar[N][3] (overwritten), weights_bar[N] (may be NULL). */
+int mcpm_paint_vjp_f32(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, const float *weights,
+                       int64_t wstride, float wscalar, int order, const float *mesh_bar, float *pos_bar,
+                       float *weights_bar);
+/* VJP of read w.r.t. pos: pos_bar[N][3] = sum_c out_bar[p][c] * d read_c / d pos (overwritten).
+   (The VJP w.r.t. the mesh is mcpm_paint_f32 with weights = out_bar[:, c].) */
+int mcpm_read_vjp_pos_f32(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, const float *meshes,
+                          int ncomp, int order, const float *out_bar, float *pos_bar);
+
+/* ---- k-space kernels (nbody.py:109-163, :596-603, :611-627) --------------------------------- */
+/* out[c] = scale * (-(i k_c)) * invlaplace(k) * [gaussian(kcut)] * [1/sinc^(2*deconv_order)] * in,
+   c = 0..2, three contiguous half-spectra (pm_forces, nbody.py:596-603).  kcut <= 0 means inf. */
+int mcpm_kspace_force_f32(mcpm_plan *plan, const float *spec_in, float *spec_out3, float scale,
+                          int lap_fd, int grad_fd, float kcut, int deconv_order);
+/* Adjoint: out = scale * sum_c conj(multiplier_c) * in3[c].  zweights=1 multiplies by the irfftn
+   multiplicity (1,2,..,2,1) along kz (cotangent of a half-spectrum returned to the caller);
+   hermitian=1 applies the Hermitian projection on the kz=0 / Nyquist planes (spectrum fed to a C2R). */
+int mcpm_kspace_force_vjp_f32(mcpm_plan *plan, const float *spec_in3, float *spec_out, float scale,
+                              int lap_fd, int grad_fd, float kcut, int deconv_order, int zweights,
+                              int hermitian, int accumulate);
+/* out[ab] = scale * (i k_a)(i k_b) * invlaplace(k) * in for ab = 00,01,02,11,12,22 (nbody.py:611-627). */
+int mcpm_kspace_hessian_f32(mcpm_plan *plan, const float *spec_in, float *spec_out6, float scale,
+                            int lap_fd, int grad_fd);
+int mcpm_kspace_hessian_vjp_f32(mcpm_plan *plan, const float *spec_in6, float *spec_out, float scale,
+                                int lap_fd, int grad_fd, int zweights, int accumulate);
+/* delta2 = sum_{i<j} h_ii h_jj - h_ij^2 from six contiguous real meshes (nbody.py:615-627). */
+int mcpm_hessian_combine_f32(mcpm_plan *plan, const float *hess6, float *delta2);
+int mcpm_hessian_combine_vjp_f32(mcpm_plan *plan, const float *hess6, const float *delta2_bar, float *hess6_bar);
+
+/* ---- forces (nbody.py:583-631) -------------------------------------------------------------- */
+/* pm_forces with mesh = shape tuple: paint -> R2C -> k-space -> 3 C2R -> read; forces[N][3].
+   Leaves the three force meshes in the plan (mcpm_plan_force_meshes). */
+int mcpm_pm_forces_f32(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, int order,
+                       int paint_deconv, int lap_fd, int grad_fd, float kcut, float *forces);
+/* pm_forces with mesh = half-spectrum (not modified). */
+int mcpm_pm_forces_spec_f32(mcpm_plan *plan, const float *spec, const float *pos, int64_t n, int pos_mode,
+                            int order, int lap_fd, int grad_fd, float kcut, float *forces);
+/* pm_forces2 (2LPT source, nbody.py:607-631). */
+int mcpm_pm_forces2_f32(mcpm_plan *plan, const float *spec, const float *pos, int64_t n, int pos_mode,
+                        int order, int lap_fd, int grad_fd, float *forces);
+int mcpm_plan_force_meshes(mcpm_plan *plan, float **meshes3);
+
+/* ---- BullFrog / FastPM stepping (nbody.py:902-1002) ----------------------------------------- */
+/* drift (nbody.py:942-944): pos_out = pos_in + vel * dt. */
+int mcpm_drift_f32(mcpm_plan *plan, const float *pos_in, const float *vel, int64_t n, float dt, float *pos_out);
+/* kick (nbody.py:933-938) given forces: vel_out = alpha * vel_in + beta * forces. */
+int mcpm_kick_f32(mcpm_plan *plan, const float *vel_in, const float *forces, int64_t n, float alpha,
+                  float beta, float *vel_out);
+/* Fused CIC read of three force meshes + kick + drift: vel_out = alpha vel_in + beta F(pos_in),
+   pos_out = pos_in + vel_out * dt. */
+int mcpm_kick_drift_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in, int64_t n, int pos_mode,
+                        const float *meshes3, int order, float alpha, float beta, float dt, float *pos_out,
+                        float *vel_out);
+/* lpt (nbody.py:634-667) on the plan's particle lattice, read_order = 1, scalar a:
+   dpos = g F1 - g2 F2, vel = F1 - dg2dg F2 (lpt_order 2) from the half-spectrum init_mesh. */
+int mcpm_lpt_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg,
+                 int lap_fd, int grad_fd, float *dpos, float *vel);
+/* nbody_bf (nbody.py:967-1002), snapshots=None: LPT start at a0 then n_steps drift-kick-drift steps of size
+   dg in growth-factor time.  alpha[i] and beta[i] = (1-alpha_i)/(g_i + dg/2) are host float64 arrays computed
+   from the growth tables (alpha_bf nbody.py:907-919 or alpha_fpm :921-931, evaluated at the accumulated Euler
+   time g_i); `lpt_scalars` = {a2g, a2g2, a2dg2dg}(a0).  pos_out is the displacement from the lattice
+   (MCPM_POS_LATTICE), vel_out the velocity.  ckpt (may be NULL) receives what the adjoint needs; its size is
+   mcpm_nbody_ckpt_floats() floats. */
+int mcpm_nbody_bf_f32(mcpm_plan *plan, const float *init_mesh, int n_steps, const double *alpha,
+                      const double *beta, double dg, const double *lpt_scalars, int lpt_order, int paint_order,
+                      float *pos_out, float *vel_out, float *ckpt);
+int64_t mcpm_nbody_ckpt_floats(const mcpm_plan *plan, int n_steps, int lpt_order);
+/* Reverse sweep: cotangents of (pos_out, vel_out) -> init_mesh_bar (half-spectrum, real-pair convention
+   dL = Re sum conj(bar) dz) and host scalar bars (may be NULL; forces a stream sync when given):
+   scalar_bars[0..n_steps) = alpha_bar, [n_steps..2 n_steps) = beta_bar, then {g_bar, g2_bar, dg2dg_bar}. */
+int mcpm_nbody_bf_vjp_f32(mcpm_plan *plan, const float *init_mesh, int n_steps, const double *alpha,
+                          const double *beta, double dg, const double *lpt_scalars, int lpt_order,
+                          int paint_order, const float *ckpt, const float *pos_bar, const float *vel_bar,
+                          float *init_mesh_bar, double *scalar_bars);
+
+/* ---- host-side float64 growth tables (nbody.py:679-745) ------------------------------------- */
+/* RK4 on atab = logspace(log10_amin, 0, steps); writes seven host arrays of length `steps`. */
+int mcpm_growth_table(double Omega_m, double Omega_de, double Omega_k, double w0, double wa,
+                      double log10_amin, int steps, double *a, double *g, double *f, double *h, double *g2,
+                      double *f2, double *h2);
+/* chi(a) table of nbody.py:842-856 (256-point RK4 in ln a); host arrays of length `steps`. */
+int mcpm_distance_table(double Omega_m, double Omega_de, double Omega_k, double w0, double wa,
+                        double log10_amin, int steps, double *a, double *chi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCPM_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libmcpm.so (the C ABI declared in include/mcpm.h).
+
+The HIP library is the product: there is NO CPU fallback.  Importing this module without a built
+`libmcpm.so` next to it raises ImportError with the build command.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- must be imported first: libmcpm.so binds to the HIP runtime / rocFFT torch loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcpm.so")
+
+OK = 0
+POS_ABSOLUTE, POS_LATTICE = 0, 1
+FD_INF, FD_2, FD_4 = 0, 2, 4
+
+_f32p = C.c_void_p  # device pointers travel as integers
+_f64p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); mirrors include/mcpm.h one to one
+SIGNATURES = {
+    "mcpm_plan_create": (C.c_int, [C.c_int] * 6 + [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mcpm_plan_destroy": (C.c_int, [C.c_void_p]),
+    "mcpm_last_error": (C.c_char_p, [C.c_void_p]),
+    "mcpm_version": (C.c_char_p, []),
+    "mcpm_plan_last_outliers": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mcpm_plan_set_halo": (C.c_int, [C.c_void_p, C.c_int]),
+    "mcpm_fft_r2c": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int]),
+    "mcpm_fft_c2r": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int]),
+    "mcpm_cell_index": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "mcpm_paint_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int64, C.c_float, C.c_int, _f32p, C.c_int]),
+    "mcpm_read_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_int, _f32p]),
+    "mcpm_paint_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int64, C.c_float, C.c_int, _f32p, _f32p, _f32p]),
+    "mcpm_read_vjp_pos_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_int, _f32p, _f32p]),
+    "mcpm_kspace_force_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "mcpm_kspace_force_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mcpm_kspace_hessian_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_int, C.c_int]),
+    "mcpm_kspace_hessian_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mcpm_hessian_combine_f32": (C.c_int, [C.c_void_p, _f32p, _f32p]),
+    "mcpm_hessian_combine_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p]),
+    "mcpm_pm_forces_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f32p]),
+    "mcpm_pm_forces_spec_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f32p]),
+    "mcpm_pm_forces2_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
+    "mcpm_plan_force_meshes": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mcpm_drift_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_float, _f32p]),
+    "mcpm_kick_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_float, C.c_float, _f32p]),
+    "mcpm_kick_drift_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_float, C.c_float, C.c_float, _f32p, _f32p]),
+    "mcpm_lpt_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _f32p, _f32p]),
+    "mcpm_nbody_bf_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f64p, C.c_double, _f64p, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
+    "mcpm_nbody_ckpt_floats": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    "mcpm_nbody_bf_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f64p, C.c_double, _f64p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _f64p]),
+    "mcpm_growth_table": (C.c_int, [C.c_double] * 6 + [C.c_int] + [_f64p] * 7),
+    "mcpm_distance_table": (C.c_int, [C.c_double] * 6 + [C.c_int] + [_f64p] * 2),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is the product and there is no CPU fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C montecosmo_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+class McpmError(RuntimeError):
+    pass
+
+
+def check(rc, plan=None, what=""):
+    if rc != OK:
+        msg = lib.mcpm_last_error(plan)
+        raise McpmError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,366 @@
+// Composite operators of libmcpm.so: pm_forces, pm_forces2, lpt, nbody_bf and the hand-written reverse
+// sweep (VJP) of nbody_bf.  Reference: montecosmo/nbody.py:583-667 (forces, lpt), :902-1002 (BullFrog
+// vector field + diffrax Euler driver).
+//
+// Stepping form.  The reference evaluates drift(dg/2) . kick . drift(dg/2) as a vector field and lets
+// diffrax's Euler add it back (nbody.py:946-951, :999).  Consecutive half drifts commute with nothing in
+// between, so the loop below runs the identical map as
+//     x'_0 = x_0 + v_0 dg/2;   v_{i+1} = alpha_i v_i + beta_i F(x'_i);   x'_{i+1} = x'_i + v_{i+1} tau_i
+// with tau_i = dg (dg/2 on the last step): ONE fused read+kick+drift particle kernel per step, whose output
+// is written straight into the next checkpoint slot.  The three force meshes of each step are C2R-ed
+// straight into the checkpoint as well, so the adjoint needs no force recomputation.
+#include "particles_dev.h"
+
+// ------------------------------------------------------------------------------------------------
+// NGP cell of a lattice point (read_order = 1 at pos = regular_pos, nbody.py:984-985): exact integer
+// round-half-even of ip*n/p.
+__device__ __forceinline__ int lattice_ngp(int ip, int n, int p, int same) {
+    if (same) return ip;
+    int qn = ip * n, qi = qn / p, qr = qn - qi * p;
+    int c = qi + ((2 * qr > p || (2 * qr == p && (qi & 1))) ? 1 : 0);
+    return c >= n ? c - n : c;
+}
+
+__device__ __forceinline__ int64_t lattice_cell(const Geom &g, const PIdx &pi) {
+    int cx = lattice_ngp(pi.ipx, g.nx, g.px, g.same_lattice);
+    int cy = lattice_ngp(pi.ipy, g.ny, g.py, g.same_lattice);
+    int cz = lattice_ngp(pi.ipz, g.nz, g.pz, g.same_lattice);
+    return ((int64_t)cx * g.ny + cy) * g.nz + cz;
+}
+
+// dpos = (init ? 0 : dpos) + ad * F(q), vel likewise with av; F from three contiguous meshes.
+__global__ __launch_bounds__(256) void lpt_accum_kernel(Geom g, const float *__restrict__ meshes, int64_t M, float ad,
+                                                        float av, int init, float *__restrict__ dpos,
+                                                        float *__restrict__ vel) {
+    PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
+    if (!pi.valid) return;
+    int64_t c = lattice_cell(g, pi);
+    float F0 = meshes[c], F1 = meshes[M + c], F2 = meshes[2 * M + c];
+    P3 d = {0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f};
+    if (!init) {
+        d = load3(dpos, pi.i);
+        v = load3(vel, pi.i);
+    }
+    d.x += ad * F0; d.y += ad * F1; d.z += ad * F2;
+    v.x += av * F0; v.y += av * F1; v.z += av * F2;
+    store3(dpos, pi.i, d);
+    store3(vel, pi.i, v);
+}
+
+// Adjoint of the NGP lattice read: out_c[cell(i)] (+)= a*xb[i][c] + b*vb[i][c].  On the identity
+// lattice every cell is hit exactly once (plain store); otherwise float atomics onto zeroed meshes.
+__global__ __launch_bounds__(256) void lattice_scatter_kernel(Geom g, const float *__restrict__ xb,
+                                                              const float *__restrict__ vb, float a, float b,
+                                                              float *__restrict__ out, int64_t M) {
+    PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
+    if (!pi.valid) return;
+    int64_t c = lattice_cell(g, pi);
+    P3 x = load3(xb, pi.i), v = load3(vb, pi.i);
+    float o0 = a * x.x + b * v.x, o1 = a * x.y + b * v.y, o2 = a * x.z + b * v.z;
+    if (g.same_lattice) {
+        out[c] = o0; out[M + c] = o1; out[2 * M + c] = o2;
+    } else {
+        atomicAdd(out + c, o0); atomicAdd(out + M + c, o1); atomicAdd(out + 2 * M + c, o2);
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// block-reduce two doubles and add them to out[0], out[1]
+__device__ __forceinline__ void block_add2(double a, double b, double *out0, double *out1) {
+    __shared__ double sh[2][4];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) {
+        sh[0][w] = a;
+        sh[1][w] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nw = (blockDim.x + 63) >> 6;
+        double sa = 0., sb = 0.;
+        for (int i = 0; i < nw; ++i) {
+            sa += sh[0][i];
+            sb += sh[1][i];
+        }
+        if (out0) atomicAdd(out0, sa);
+        if (out1) atomicAdd(out1, sb);
+    }
+}
+
+// out0 += sum_i a[i].F(q_i), out1 += sum_i b[i].F(q_i)  (growth-scalar cotangents of lpt)
+__global__ __launch_bounds__(256) void lattice_dot_kernel(Geom g, const float *__restrict__ meshes, int64_t M,
+                                                          const float *__restrict__ a, const float *__restrict__ b,
+                                                          double *out0, double *out1) {
+    PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
+    double ra = 0., rb = 0.;
+    if (pi.valid) {
+        int64_t c = lattice_cell(g, pi);
+        float F0 = meshes[c], F1 = meshes[M + c], F2 = meshes[2 * M + c];
+        if (a) {
+            P3 x = load3(a, pi.i);
+            ra = (double)(x.x * F0 + x.y * F1 + x.z * F2);
+        }
+        if (b) {
+            P3 x = load3(b, pi.i);
+            rb = (double)(x.x * F0 + x.y * F1 + x.z * F2);
+        }
+    }
+    block_add2(ra, rb, out0, out1);
+}
+
+// Adjoint of one fused step (see file header).  Inputs: x'_i, v_i (checkpoint), cotangents xb, vb of
+// (x'_{i+1}, v_{i+1}) (updated in place to those of (x'_i, v_i)), the step's three force meshes and
+// rho_bar = cotangent of the painted density.
+template <int ORDER>
+__global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *__restrict__ x, const float *__restrict__ v,
+                                                           float *__restrict__ xb, float *__restrict__ vb,
+                                                           const float *__restrict__ fm, const float *__restrict__ rho_bar,
+                                                           int64_t M, float alpha, float beta, float tau,
+                                                           double *alpha_bar, double *beta_bar) {
+    PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
+    double ra = 0., rb = 0.;
+    if (pi.valid) {
+        const P3 d = load3(x, pi.i), vi = load3(v, pi.i);
+        P3 xbi = load3(xb, pi.i), vbi = load3(vb, pi.i);
+        int c[3];
+        float f[3];
+        locate<MCPM_POS_LATTICE, ORDER>(g, pi, d, c, f);
+        Stencil<ORDER> s(g, c);
+        const P3 vt = {vbi.x + tau * xbi.x, vbi.y + tau * xbi.y, vbi.z + tau * xbi.z};
+        const float Fb[3] = {beta * vt.x, beta * vt.y, beta * vt.z};
+        float F[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float gx, gy, gz;
+            interp<ORDER, true>(fm + k * M, s, f, F[k], gx, gy, gz);
+            xbi.x += Fb[k] * gx;
+            xbi.y += Fb[k] * gy;
+            xbi.z += Fb[k] * gz;
+        }
+        {
+            float val, gx, gy, gz;
+            interp<ORDER, true>(rho_bar, s, f, val, gx, gy, gz);
+            xbi.x += gx;
+            xbi.y += gy;
+            xbi.z += gz;
+        }
+        ra = (double)(vt.x * vi.x + vt.y * vi.y + vt.z * vi.z);
+        rb = (double)(vt.x * F[0] + vt.y * F[1] + vt.z * F[2]);
+        store3(xb, pi.i, xbi);
+        store3(vb, pi.i, P3{alpha * vt.x, alpha * vt.y, alpha * vt.z});
+    }
+    block_add2(ra, rb, alpha_bar, beta_bar);
+}
+
+__global__ void axpby_kernel(const float *__restrict__ x, const float *__restrict__ y, int64_t n, float a, float b,
+                             float *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + b * y[i];
+}
+
+static inline void lattice_launch(const Geom &g, dim3 &grid, dim3 &block) {
+    int bs = g.pz >= 256 ? 256 : ((g.pz + 63) / 64) * 64;
+    int cpr = (g.pz + bs - 1) / bs;
+    block = dim3(bs);
+    grid = dim3((unsigned)((int64_t)g.px * g.py * cpr));
+}
+
+static int axpby(mcpm_plan *p, const float *x, const float *y, int64_t n, float a, float b, float *out) {
+    unsigned nb = (unsigned)((n + 255) / 256);
+    axpby_kernel<<<nb, 256, 0, p->stream>>>(x, y, n, a, b, out);
+    MCPM_LAUNCH_CHECK(p, "axpby_kernel");
+    return MCPM_OK;
+}
+
+// spectrum -> three force meshes (C2R output buffer `fm`), using plan->spec as spectral scratch
+static int spec_to_force_meshes(mcpm_plan *p, const float *spec, int lap_fd, int grad_fd, float kcut, int deconv,
+                                float *fm) {
+    MCPM_TRY(mcpm_kspace_force_f32(p, spec, p->spec, 1.f / (float)p->M, lap_fd, grad_fd, kcut, deconv));
+    MCPM_TRY(mcpm_fft_c2r(p, p->spec, fm, 3));
+    return MCPM_OK;
+}
+
+// half-spectrum -> delta2 spectrum in plan->spec1; leaves the six Hessian meshes in fmesh[0:6]
+static int spec_to_delta2(mcpm_plan *p, const float *spec, int lap_fd, int grad_fd) {
+    MCPM_TRY(mcpm_kspace_hessian_f32(p, spec, p->spec, 1.f / (float)p->M, lap_fd, grad_fd));
+    MCPM_TRY(mcpm_fft_c2r(p, p->spec, p->fmesh, 6));
+    MCPM_TRY(mcpm_hessian_combine_f32(p, p->fmesh, p->rho));
+    MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
+    return MCPM_OK;
+}
+
+extern "C" {
+
+int mcpm_pm_forces_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, int order, int paint_deconv, int lap_fd,
+                       int grad_fd, float kcut, float *forces) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, forces != nullptr, MCPM_E_ARG, "mcpm_pm_forces_f32: null output");
+    MCPM_TRY(mcpm_paint_f32(p, pos, n, mode, nullptr, 1, 1.f, order, p->rho, 0));
+    MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
+    MCPM_TRY(spec_to_force_meshes(p, p->spec1, lap_fd, grad_fd, kcut, paint_deconv ? order : 0, p->fmesh));
+    MCPM_TRY(mcpm_read_f32(p, pos, n, mode, p->fmesh, 3, order, forces));
+    return MCPM_OK;
+}
+
+int mcpm_pm_forces_spec_f32(mcpm_plan *p, const float *spec, const float *pos, int64_t n, int mode, int order,
+                            int lap_fd, int grad_fd, float kcut, float *forces) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, spec && forces, MCPM_E_ARG, "mcpm_pm_forces_spec_f32: null buffer");
+    MCPM_TRY(spec_to_force_meshes(p, spec, lap_fd, grad_fd, kcut, 0, p->fmesh));
+    MCPM_TRY(mcpm_read_f32(p, pos, n, mode, p->fmesh, 3, order, forces));
+    return MCPM_OK;
+}
+
+int mcpm_pm_forces2_f32(mcpm_plan *p, const float *spec, const float *pos, int64_t n, int mode, int order, int lap_fd,
+                        int grad_fd, float *forces) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, spec && forces, MCPM_E_ARG, "mcpm_pm_forces2_f32: null buffer");
+    MCPM_TRY(spec_to_delta2(p, spec, lap_fd, grad_fd));
+    MCPM_TRY(spec_to_force_meshes(p, p->spec1, lap_fd, grad_fd, 0.f, 0, p->fmesh));
+    MCPM_TRY(mcpm_read_f32(p, pos, n, mode, p->fmesh, 3, order, forces));
+    return MCPM_OK;
+}
+
+int mcpm_lpt_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg, int lap_fd,
+                 int grad_fd, float *dpos, float *vel) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, init_mesh && dpos && vel, MCPM_E_ARG, "mcpm_lpt_f32: null buffer");
+    MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_lpt_f32: lpt_order must be 1 or 2");
+    dim3 grid, block;
+    lattice_launch(p->g, grid, block);
+    MCPM_TRY(spec_to_force_meshes(p, init_mesh, lap_fd, grad_fd, 0.f, 0, p->fmesh));
+    lpt_accum_kernel<<<grid, block, 0, p->stream>>>(p->g, p->fmesh, p->M, g, 1.f, 1, dpos, vel);
+    MCPM_LAUNCH_CHECK(p, "lpt_accum_kernel");
+    if (lpt_order == 2) {
+        MCPM_TRY(spec_to_delta2(p, init_mesh, lap_fd, grad_fd));
+        MCPM_TRY(spec_to_force_meshes(p, p->spec1, lap_fd, grad_fd, 0.f, 0, p->fmesh));
+        lpt_accum_kernel<<<grid, block, 0, p->stream>>>(p->g, p->fmesh, p->M, -g2, -dg2dg, 0, dpos, vel);
+        MCPM_LAUNCH_CHECK(p, "lpt_accum_kernel");
+    }
+    return MCPM_OK;
+}
+
+int64_t mcpm_nbody_ckpt_floats(const mcpm_plan *p, int n_steps, int lpt_order) {
+    (void)lpt_order;
+    if (!p || n_steps < 1) return 0;
+    return (int64_t)n_steps * (6 * p->Np + 3 * p->M);
+}
+
+int mcpm_nbody_bf_f32(mcpm_plan *p, const float *init_mesh, int n_steps, const double *alpha, const double *beta,
+                      double dg, const double *lpt_scalars, int lpt_order, int paint_order, float *pos_out,
+                      float *vel_out, float *ckpt) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, init_mesh && alpha && beta && lpt_scalars && pos_out && vel_out, MCPM_E_ARG, "mcpm_nbody_bf_f32: null argument");
+    MCPM_REQUIRE(p, n_steps >= 1, MCPM_E_ARG, "mcpm_nbody_bf_f32: n_steps must be >= 1");
+    MCPM_REQUIRE(p, paint_order == 1 || paint_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_f32: paint_order must be 1 or 2");
+    const int64_t N = p->Np, M = p->M;
+    auto state_x = [&](int i) { return ckpt + (int64_t)i * 6 * N; };
+    auto state_v = [&](int i) { return ckpt + (int64_t)i * 6 * N + 3 * N; };
+    auto force_m = [&](int i) { return ckpt + (int64_t)n_steps * 6 * N + (int64_t)i * 3 * M; };
+    float *x = ckpt ? state_x(0) : pos_out, *v = ckpt ? state_v(0) : vel_out;
+    MCPM_TRY(mcpm_lpt_f32(p, init_mesh, lpt_order, (float)lpt_scalars[0], (float)lpt_scalars[1], (float)lpt_scalars[2],
+                          MCPM_FD_INF, MCPM_FD_INF, x, v));
+    MCPM_TRY(mcpm_drift_f32(p, x, v, N, (float)(dg / 2), x));
+    for (int i = 0; i < n_steps; ++i) {
+        float *fm = ckpt ? force_m(i) : p->fmesh;
+        MCPM_TRY(mcpm_paint_f32(p, x, N, MCPM_POS_LATTICE, nullptr, 1, 1.f, paint_order, p->rho, 0));
+        MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
+        MCPM_TRY(spec_to_force_meshes(p, p->spec1, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, fm));
+        const bool last = (i == n_steps - 1);
+        float *xn = (ckpt && !last) ? state_x(i + 1) : pos_out, *vn = (ckpt && !last) ? state_v(i + 1) : vel_out;
+        MCPM_TRY(mcpm_kick_drift_f32(p, x, v, N, MCPM_POS_LATTICE, fm, paint_order, (float)alpha[i], (float)beta[i],
+                                     (float)(last ? dg / 2 : dg), xn, vn));
+        x = xn;
+        v = vn;
+    }
+    return MCPM_OK;
+}
+
+int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, const double *alpha, const double *beta,
+                          double dg, const double *lpt_scalars, int lpt_order, int paint_order, const float *ckpt,
+                          const float *pos_bar, const float *vel_bar, float *init_mesh_bar, double *scalar_bars) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, init_mesh && alpha && beta && lpt_scalars && ckpt && pos_bar && vel_bar && init_mesh_bar, MCPM_E_ARG,
+                 "mcpm_nbody_bf_vjp_f32: null argument");
+    MCPM_REQUIRE(p, n_steps >= 1 && 2 * n_steps + 3 <= MCPM_NREDUCE, MCPM_E_ARG, "mcpm_nbody_bf_vjp_f32: bad n_steps");
+    MCPM_REQUIRE(p, paint_order == 1 || paint_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: paint_order must be 1 or 2");
+    MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: lpt_order must be 1 or 2");
+    const int64_t N = p->Np, M = p->M;
+    if (!p->pscratch) {
+        if (hipMalloc((void **)&p->pscratch, sizeof(float) * 9 * N) != hipSuccess)
+            return mcpm_fail(p, MCPM_E_NOMEM, "adjoint particle scratch");
+    }
+    float *xb = p->pscratch, *vb = p->pscratch + 3 * N, *Fb = p->pscratch + 6 * N;
+    auto state_x = [&](int i) { return ckpt + (int64_t)i * 6 * N; };
+    auto state_v = [&](int i) { return ckpt + (int64_t)i * 6 * N + 3 * N; };
+    auto force_m = [&](int i) { return ckpt + (int64_t)n_steps * 6 * N + (int64_t)i * 3 * M; };
+    MCPM_HIP(p, hipMemcpyAsync(xb, pos_bar, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, p->stream));
+    MCPM_HIP(p, hipMemcpyAsync(vb, vel_bar, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, p->stream));
+    MCPM_HIP(p, hipMemsetAsync(p->reduce, 0, sizeof(double) * (2 * n_steps + 3), p->stream));
+    dim3 grid, block;
+    lattice_launch(p->g, grid, block);
+    const float invM = 1.f / (float)M;
+    for (int i = n_steps - 1; i >= 0; --i) {
+        const float tau = (float)((i == n_steps - 1) ? dg / 2 : dg), a = (float)alpha[i], b = (float)beta[i];
+        // force cotangent F_bar = beta (v_bar + tau x_bar), scattered onto three meshes (adjoint of read)
+        MCPM_TRY(axpby(p, vb, xb, 3 * N, b, b * tau, Fb));
+        for (int c = 0; c < 3; ++c)
+            MCPM_TRY(mcpm_paint_f32(p, state_x(i), N, MCPM_POS_LATTICE, Fb + c, 3, 0.f, paint_order, p->fmesh + c * M, 0));
+        // adjoint of 3 C2R + k-space + R2C: rho_bar = C2R( (1/M) sum_c conj(m_c) R2C(f_bar_c) )
+        MCPM_TRY(mcpm_fft_r2c(p, p->fmesh, p->spec, 3));
+        MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, p->spec1, invM, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 0, 1, 0));
+        MCPM_TRY(mcpm_fft_c2r(p, p->spec1, p->rho, 1));
+        if (paint_order == 2)
+            step_adjoint_kernel<2><<<grid, block, 0, p->stream>>>(p->g, state_x(i), state_v(i), xb, vb, force_m(i), p->rho, M, a,
+                                                                  b, tau, p->reduce + i, p->reduce + n_steps + i);
+        else
+            step_adjoint_kernel<1><<<grid, block, 0, p->stream>>>(p->g, state_x(i), state_v(i), xb, vb, force_m(i), p->rho, M, a,
+                                                                  b, tau, p->reduce + i, p->reduce + n_steps + i);
+        MCPM_LAUNCH_CHECK(p, "step_adjoint_kernel");
+    }
+    // initial half drift x'_0 = x_0 + v_0 dg/2
+    MCPM_TRY(axpby(p, vb, xb, 3 * N, 1.f, (float)(dg / 2), vb));
+
+    // ---- adjoint of lpt (nbody.py:634-667) at the lattice, read_order = 1
+    const float g = (float)lpt_scalars[0], g2 = (float)lpt_scalars[1], c2 = (float)lpt_scalars[2];
+    double *sb = p->reduce + 2 * n_steps;
+    MCPM_TRY(spec_to_force_meshes(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, p->fmesh));
+    lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, p->fmesh, M, xb, nullptr, sb + 0, nullptr);
+    MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
+    if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(p->fmesh, 0, sizeof(float) * 3 * M, p->stream));
+    lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, g, 1.f, p->fmesh, M);
+    MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
+    MCPM_TRY(mcpm_fft_r2c(p, p->fmesh, p->spec, 3));
+    MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, init_mesh_bar, invM, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 1, 0, 0));
+    if (lpt_order == 2) {
+        float *h = p->fmesh, *f2 = p->fmesh + 6 * M;
+        MCPM_TRY(spec_to_delta2(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF));             // h in fmesh[0:6], delta2_k in spec1
+        MCPM_TRY(spec_to_force_meshes(p, p->spec1, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, f2));  // F2 meshes
+        lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, f2, M, xb, vb, sb + 1, sb + 2);  // negated on the host
+        MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
+        if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(f2, 0, sizeof(float) * 3 * M, p->stream));
+        lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, -g2, -c2, f2, M);
+        MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
+        MCPM_TRY(mcpm_fft_r2c(p, f2, p->spec, 3));
+        MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, p->spec1, invM, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 0, 1, 0));
+        MCPM_TRY(mcpm_fft_c2r(p, p->spec1, p->rho, 1));                               // delta2_bar
+        MCPM_TRY(mcpm_hessian_combine_vjp_f32(p, h, p->rho, h));                      // in place: h -> h_bar
+        MCPM_TRY(mcpm_fft_r2c(p, h, p->spec, 6));
+        MCPM_TRY(mcpm_kspace_hessian_vjp_f32(p, p->spec, init_mesh_bar, invM, MCPM_FD_INF, MCPM_FD_INF, 1, 1));
+    }
+    if (scalar_bars) {
+        MCPM_HIP(p, hipMemcpyAsync(scalar_bars, p->reduce, sizeof(double) * (2 * n_steps + 3), hipMemcpyDeviceToHost, p->stream));
+        MCPM_HIP(p, hipStreamSynchronize(p->stream));
+        scalar_bars[2 * n_steps + 1] = -scalar_bars[2 * n_steps + 1];
+        scalar_bars[2 * n_steps + 2] = -scalar_bars[2 * n_steps + 2];
+    }
+    return MCPM_OK;
+}
+
+}  // extern "C"

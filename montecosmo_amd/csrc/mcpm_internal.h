@@ -1,0 +1,76 @@
+// Internal declarations shared by the HIP translation units of libmcpm.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+
+#include "../../include/mcpm.h"
+
+#define MCPM_NREDUCE 1024
+
+// Mesh + particle-lattice geometry handed to kernels by value.
+struct Geom {
+    int nx, ny, nz;   // mesh
+    int px, py, pz;   // particle lattice (regular_pos(mesh, ptcl))
+    int nzh;          // nz/2 + 1
+    int same_lattice; // px==nx && py==ny && pz==nz
+};
+
+struct mcpm_plan {
+    Geom g;
+    hipStream_t stream;
+    int64_t M;   // nx*ny*nz
+    int64_t Mh;  // nx*ny*nzh
+    int64_t Np;  // px*py*pz
+    int halo;    // halo radius of the tiled paint
+
+    // rocFFT plans keyed by batch
+    std::map<int, rocfft_plan> r2c, c2r;
+    std::map<int, rocfft_execution_info> r2c_info, c2r_info;
+    std::map<int, void *> r2c_work, c2r_work;
+
+    // scratch owned by the plan
+    float *rho;      // M floats: painted density / real scratch
+    float *spec;     // 6 half-spectra (complex64) scratch
+    float *fmesh;    // 9 real meshes scratch (force meshes / hessians)
+    float *spec1;    // 1 half-spectrum scratch
+    int *outliers;   // outlier particle list of the tiled paint (Np ints)
+    int *outlier_count;  // device counter (2 ints: live counter, copy of last)
+    double *reduce;  // device accumulators for scalar cotangents (MCPM_NREDUCE doubles)
+    float *pscratch; // 9*Np floats, allocated on first VJP (adjoint state + force cotangent)
+
+    std::string err;
+};
+
+extern thread_local std::string g_mcpm_create_error;
+
+int mcpm_fail(mcpm_plan *plan, int code, const std::string &msg);
+
+#define MCPM_HIP(plan, expr)                                                                         \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return mcpm_fail(plan, MCPM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+    } while (0)
+
+#define MCPM_LAUNCH_CHECK(plan, name)                                                                \
+    do {                                                                                             \
+        hipError_t _e = hipGetLastError();                                                           \
+        if (_e != hipSuccess)                                                                        \
+            return mcpm_fail(plan, MCPM_E_HIP, std::string("launch ") + name + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define MCPM_REQUIRE(plan, cond, code, msg)                  \
+    do {                                                     \
+        if (!(cond)) return mcpm_fail(plan, code, msg);      \
+    } while (0)
+
+#define MCPM_TRY(expr)               \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != MCPM_OK) return _rc; \
+    } while (0)

@@ -1,0 +1,469 @@
+// Particle <-> mesh kernels of libmcpm.so for gfx950: paint, read, fused kick/drift and their VJPs.
+//
+// Reference semantics: montecosmo/nbody.py:365-396 (paint), :398-427 (read), :933-944 (kick, drift).
+//
+// Paint design (MI355X-first, not a translation of the reference's 8 scatter-add passes):
+//   * fast path `paint_tile_kernel`: particles are stored in Lagrangian (lattice) order as fp32
+//     displacements from their lattice point.  One workgroup owns one Eulerian tile of the mesh in
+//     LDS and *pulls* every lattice particle whose lattice point lies within `H` cells of the tile
+//     (coalesced 12-byte loads, wave lanes along z), depositing with LDS float atomics only the
+//     stencil points that fall inside its own tile.  The tile is then written to HBM with plain
+//     16-byte stores: no global atomics, no sort.  Particles displaced by more than H cells are
+//     appended to an outlier list by their home tile and deposited by a small global-atomic kernel.
+//   * generic path `paint_atomic_kernel`: arbitrary (absolute) positions, global float atomics.
+#include "particles_dev.h"
+
+// ------------------------------------------------------------------------------------------------
+// cell index (integer part of the path, checked bit-exactly against the oracle)
+template <int MODE, int ORDER>
+__global__ __launch_bounds__(256) void cell_index_kernel(Geom g, const float *__restrict__ pos, int64_t n,
+                                                         int16_t *__restrict__ idx) {
+    PIdx pi = particle_index<MODE>(g, n);
+    if (!pi.valid) return;
+    P3 d = load3(pos, pi.i);
+    int c[3];
+    float f[3];
+    locate<MODE, ORDER>(g, pi, d, c, f);
+    idx[3 * pi.i + 0] = (int16_t)wrapi(c[0], g.nx);
+    idx[3 * pi.i + 1] = (int16_t)wrapi(c[1], g.ny);
+    idx[3 * pi.i + 2] = (int16_t)wrapi(c[2], g.nz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic paint: one thread per particle, global float atomics
+template <int MODE, int ORDER>
+__global__ __launch_bounds__(256) void paint_atomic_kernel(Geom g, const float *__restrict__ pos, int64_t n,
+                                                           const float *__restrict__ w, int64_t wstride,
+                                                           float wscalar, float *__restrict__ mesh) {
+    PIdx pi = particle_index<MODE>(g, n);
+    if (!pi.valid) return;
+    P3 d = load3(pos, pi.i);
+    int c[3];
+    float f[3];
+    locate<MODE, ORDER>(g, pi, d, c, f);
+    float wt = w ? w[pi.i * wstride] : wscalar;
+    Stencil<ORDER> s(g, c);
+    if (ORDER == 1) {
+        atomicAdd(mesh + s.xo[0] + s.yo[0] + s.zo[0], wt);
+        return;
+    }
+    float kx[2] = {1.f - f[0], f[0]}, ky[2] = {1.f - f[1], f[1]}, kz[2] = {1.f - f[2], f[2]};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) atomicAdd(mesh + s.xo[a] + s.yo[b] + s.zo[e], wt * kx[a] * ky[b] * kz[e]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tiled paint (lattice displacements, lattice == mesh, CIC)
+template <int BX, int BY, int BZ, int H, bool WEIGHTED>
+__global__ __launch_bounds__(256) void paint_tile_kernel(Geom g, const float *__restrict__ disp,
+                                                         const float *__restrict__ w, int64_t wstride, float wscalar,
+                                                         float *__restrict__ mesh, int accumulate,
+                                                         int *__restrict__ outliers, int *__restrict__ ocount) {
+    constexpr int WX = BX + 2 * H + 1, WY = BY + 2 * H + 1, WZ = BZ + 2 * H + 1, NW = WX * WY * WZ;
+    constexpr int NT = BX * BY * BZ;
+    __shared__ float tile[NT];
+
+    // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
+    // run of tiles so that neighbouring tiles, which re-read each other's halo particles, share L2.
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int t = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+    const int ntz = g.nz / BZ, nty = g.ny / BY;
+    const int tz = t % ntz, tt = t / ntz, ty = tt % nty, tx = tt / nty;
+    const int x0 = tx * BX, y0 = ty * BY, z0 = tz * BZ;
+
+    float4 *tile4 = reinterpret_cast<float4 *>(tile);
+    for (int i = threadIdx.x; i < NT / 4; i += 256) tile4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    for (int j = threadIdx.x; j < NW; j += 256) {
+        const int jz = j % WZ, r = j / WZ, jy = r % WY, jx = r / WY;
+        const int rx = jx - (H + 1), ry = jy - (H + 1), rz = jz - (H + 1);  // lattice point relative to the tile
+        int gx = x0 + rx, gy = y0 + ry, gz = z0 + rz;
+        gx += gx < 0 ? g.nx : 0;
+        gx -= gx >= g.nx ? g.nx : 0;
+        gy += gy < 0 ? g.ny : 0;
+        gy -= gy >= g.ny ? g.ny : 0;
+        gz += gz < 0 ? g.nz : 0;
+        gz -= gz >= g.nz ? g.nz : 0;
+        const int64_t gi = ((int64_t)gx * g.ny + gy) * g.nz + gz;
+        const P3 d = load3(disp, gi);
+        const float fx = floorf(d.x), fy = floorf(d.y), fz = floorf(d.z);
+        // outliers: |floor(d)| > H on any axis (NaN compares false everywhere -> treated as outlier)
+        const bool inl = fx >= (float)-H && fx <= (float)H && fy >= (float)-H && fy <= (float)H && fz >= (float)-H &&
+                         fz <= (float)H;
+        if (!inl) {
+            const bool home = (unsigned)rx < (unsigned)BX && (unsigned)ry < (unsigned)BY && (unsigned)rz < (unsigned)BZ;
+            if (home) {
+                int k = atomicAdd(ocount, 1);
+                outliers[k] = (int)gi;
+            }
+            continue;
+        }
+        const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
+        if (cx < -1 || cx >= BX || cy < -1 || cy >= BY || cz < -1 || cz >= BZ) continue;
+        const float tx1 = d.x - fx, ty1 = d.y - fy, tz1 = d.z - fz;
+        const float wt = WEIGHTED ? w[gi * wstride] : wscalar;
+        const float kx[2] = {1.f - tx1, tx1}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int x = cx + a;
+            if ((unsigned)x >= (unsigned)BX) continue;
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int y = cy + bb;
+                if ((unsigned)y >= (unsigned)BY) continue;
+                const float wxy = wt * kx[a] * ky[bb];
+                float *row = tile + (x * BY + y) * BZ;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int z = cz + e;
+                    if ((unsigned)z < (unsigned)BZ) atomicAdd(row + z, wxy * kz[e]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int i = threadIdx.x; i < NT / 4; i += 256) {
+        const int lz = (i % (BZ / 4)) * 4, r = i / (BZ / 4), ly = r % BY, lx = r / BY;
+        float4 v = tile4[i];
+        float4 *dst = reinterpret_cast<float4 *>(mesh + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz);
+        if (accumulate) {
+            float4 o = *dst;
+            v.x += o.x;
+            v.y += o.y;
+            v.z += o.z;
+            v.w += o.w;
+        }
+        *dst = v;
+    }
+}
+
+// outliers of the tiled paint: global atomics, grid-stride over the device-side count
+__global__ __launch_bounds__(256) void paint_outlier_kernel(Geom g, const float *__restrict__ disp,
+                                                            const float *__restrict__ w, int64_t wstride, float wscalar,
+                                                            float *__restrict__ mesh, const int *__restrict__ outliers,
+                                                            int *__restrict__ ocount) {
+    const int count = ocount[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ocount[1] = count;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        const int gi = outliers[k];
+        PIdx pi;
+        pi.i = gi;
+        pi.ipz = gi % g.nz;
+        const int r = gi / g.nz;
+        pi.ipy = r % g.ny;
+        pi.ipx = r / g.ny;
+        pi.valid = true;
+        const P3 d = load3(disp, gi);
+        int c[3];
+        float f[3];
+        locate<MCPM_POS_LATTICE, 2>(g, pi, d, c, f);
+        const float wt = w ? w[(int64_t)gi * wstride] : wscalar;
+        Stencil<2> s(g, c);
+        const float kx[2] = {1.f - f[0], f[0]}, ky[2] = {1.f - f[1], f[1]}, kz[2] = {1.f - f[2], f[2]};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) atomicAdd(mesh + s.xo[a] + s.yo[b] + s.zo[e], wt * kx[a] * ky[b] * kz[e]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// read: gather NCOMP contiguous meshes
+template <int MODE, int ORDER, int NCOMP>
+__global__ __launch_bounds__(256) void read_kernel(Geom g, const float *__restrict__ pos, int64_t n,
+                                                   const float *__restrict__ meshes, int64_t M,
+                                                   float *__restrict__ out) {
+    PIdx pi = particle_index<MODE>(g, n);
+    if (!pi.valid) return;
+    P3 d = load3(pos, pi.i);
+    int c[3];
+    float f[3];
+    locate<MODE, ORDER>(g, pi, d, c, f);
+    Stencil<ORDER> s(g, c);
+    float v[NCOMP], gx, gy, gz;
+#pragma unroll
+    for (int k = 0; k < NCOMP; ++k) interp<ORDER, false>(meshes + k * M, s, f, v[k], gx, gy, gz);
+#pragma unroll
+    for (int k = 0; k < NCOMP; ++k) out[pi.i * NCOMP + k] = v[k];
+}
+
+// VJP of read w.r.t. pos (also the pos-VJP of paint with NCOMP = 1 and out_bar = weights).
+// If val_out != nullptr also writes the read values (the weights-VJP of paint).
+template <int MODE, int ORDER, int NCOMP>
+__global__ __launch_bounds__(256) void read_vjp_pos_kernel(Geom g, const float *__restrict__ pos, int64_t n,
+                                                           const float *__restrict__ meshes, int64_t M,
+                                                           const float *__restrict__ ob, int64_t obstride, float obscalar,
+                                                           float *__restrict__ pos_bar, float *__restrict__ val_out) {
+    PIdx pi = particle_index<MODE>(g, n);
+    if (!pi.valid) return;
+    P3 d = load3(pos, pi.i);
+    int c[3];
+    float f[3];
+    locate<MODE, ORDER>(g, pi, d, c, f);
+    Stencil<ORDER> s(g, c);
+    P3 acc = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NCOMP; ++k) {
+        float v, gx, gy, gz;
+        interp<ORDER, true>(meshes + k * M, s, f, v, gx, gy, gz);
+        const float o = ob ? ob[pi.i * obstride + k] : obscalar;
+        acc.x += o * gx;
+        acc.y += o * gy;
+        acc.z += o * gz;
+        if (val_out) val_out[pi.i * NCOMP + k] = v;
+    }
+    store3(pos_bar, pi.i, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// drift / kick / fused read+kick+drift  (nbody.py:933-944)
+__global__ __launch_bounds__(256) void axpy_kernel(const float *__restrict__ x, const float *__restrict__ y, int64_t n,
+                                                   float a, float b, float *__restrict__ out) {
+    // out = a*x + b*y over n floats
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + b * y[i];
+}
+
+template <int MODE, int ORDER>
+__global__ __launch_bounds__(256) void kick_drift_kernel(Geom g, const float *__restrict__ pos_in,
+                                                         const float *__restrict__ vel_in, int64_t n,
+                                                         const float *__restrict__ meshes, int64_t M, float alpha,
+                                                         float beta, float dt, float *__restrict__ pos_out,
+                                                         float *__restrict__ vel_out) {
+    PIdx pi = particle_index<MODE>(g, n);
+    if (!pi.valid) return;
+    const P3 d = load3(pos_in, pi.i);
+    const P3 v = load3(vel_in, pi.i);
+    int c[3];
+    float f[3];
+    locate<MODE, ORDER>(g, pi, d, c, f);
+    Stencil<ORDER> s(g, c);
+    float F[3], gx, gy, gz;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) interp<ORDER, false>(meshes + k * M, s, f, F[k], gx, gy, gz);
+    P3 v1 = {alpha * v.x + beta * F[0], alpha * v.y + beta * F[1], alpha * v.z + beta * F[2]};
+    P3 d1 = {d.x + v1.x * dt, d.y + v1.y * dt, d.z + v1.z * dt};
+    store3(vel_out, pi.i, v1);
+    store3(pos_out, pi.i, d1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+static inline void lattice_launch(const Geom &g, dim3 &grid, dim3 &block) {
+    int bs = g.pz >= 256 ? 256 : ((g.pz + 63) / 64) * 64;
+    int cpr = (g.pz + bs - 1) / bs;
+    block = dim3(bs);
+    grid = dim3((unsigned)((int64_t)g.px * g.py * cpr));
+}
+static inline void flat_launch(int64_t n, dim3 &grid, dim3 &block) {
+    block = dim3(256);
+    grid = dim3((unsigned)((n + 255) / 256));
+}
+
+static int check_particles(mcpm_plan *p, const void *pos, int64_t n, int mode, int order, const char *who) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, pos != nullptr, MCPM_E_ARG, std::string(who) + ": null particle array");
+    MCPM_REQUIRE(p, n >= 0 && n < ((int64_t)1 << 31), MCPM_E_ARG, std::string(who) + ": bad particle count");
+    MCPM_REQUIRE(p, mode == MCPM_POS_ABSOLUTE || mode == MCPM_POS_LATTICE, MCPM_E_ARG, std::string(who) + ": bad pos_mode");
+    MCPM_REQUIRE(p, mode != MCPM_POS_LATTICE || n == p->Np, MCPM_E_SHAPE,
+                 std::string(who) + ": MCPM_POS_LATTICE needs n == px*py*pz");
+    MCPM_REQUIRE(p, order == 1 || order == 2, MCPM_E_ORDER, std::string(who) + ": only orders 1 (NGP) and 2 (CIC) are implemented");
+    return MCPM_OK;
+}
+
+#define DISPATCH_MODE_ORDER(mode, order, CALL)             \
+    do {                                                   \
+        if (mode == MCPM_POS_LATTICE) {                    \
+            if (order == 2) {                              \
+                CALL(MCPM_POS_LATTICE, 2);                 \
+            } else {                                       \
+                CALL(MCPM_POS_LATTICE, 1);                 \
+            }                                              \
+        } else {                                           \
+            if (order == 2) {                              \
+                CALL(MCPM_POS_ABSOLUTE, 2);                \
+            } else {                                       \
+                CALL(MCPM_POS_ABSOLUTE, 1);                \
+            }                                              \
+        }                                                  \
+    } while (0)
+
+template <int BX, int BY, int BZ, int H>
+static void launch_tile(mcpm_plan *p, const float *pos, const float *w, int64_t wstride, float wscalar, float *mesh,
+                        int accumulate) {
+    const Geom &g = p->g;
+    unsigned nb = (unsigned)((g.nx / BX) * (g.ny / BY) * (g.nz / BZ));
+    if (w)
+        paint_tile_kernel<BX, BY, BZ, H, true><<<nb, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate,
+                                                                          p->outliers, p->outlier_count);
+    else
+        paint_tile_kernel<BX, BY, BZ, H, false><<<nb, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate,
+                                                                           p->outliers, p->outlier_count);
+}
+
+// Tiled paint if the geometry allows; returns false if the caller must use the generic path.
+static bool try_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t wstride, float wscalar, float *mesh,
+                            int accumulate) {
+    const Geom &g = p->g;
+    if (!g.same_lattice) return false;
+    if (g.nx % 16 || g.ny % 16 || g.nz % 16) return false;
+    const int H = p->halo;
+    if (g.nx < H + 1 || g.ny < H + 1 || g.nz < H + 1) return false;
+    if (((uintptr_t)mesh) & 15) return false;
+    hipMemsetAsync(p->outlier_count, 0, sizeof(int), p->stream);
+    const bool z64 = (g.nz % 64 == 0);
+    if (z64) {
+        switch (H) {
+            case 1: launch_tile<16, 16, 64, 1>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 2: launch_tile<16, 16, 64, 2>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 4: launch_tile<16, 16, 64, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            default: launch_tile<16, 16, 64, 6>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+        }
+    } else {
+        switch (H) {
+            case 1: launch_tile<16, 16, 16, 1>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 2: launch_tile<16, 16, 16, 2>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 4: launch_tile<16, 16, 16, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            default: launch_tile<16, 16, 16, 6>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+        }
+    }
+    paint_outlier_kernel<<<256, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->outliers, p->outlier_count);
+    return true;
+}
+
+extern "C" {
+
+int mcpm_cell_index(mcpm_plan *p, const float *pos, int64_t n, int mode, int order, int16_t *idx) {
+    MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_cell_index"));
+    MCPM_REQUIRE(p, idx != nullptr, MCPM_E_ARG, "mcpm_cell_index: null output");
+    if (n == 0) return MCPM_OK;
+    dim3 grid, block;
+    if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
+#define CALL(MO, OR) cell_index_kernel<MO, OR><<<grid, block, 0, p->stream>>>(p->g, pos, n, idx)
+    DISPATCH_MODE_ORDER(mode, order, CALL);
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "cell_index_kernel");
+    return MCPM_OK;
+}
+
+int mcpm_paint_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *weights, int64_t wstride,
+                   float wscalar, int order, float *mesh, int accumulate) {
+    MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_paint_f32"));
+    MCPM_REQUIRE(p, mesh != nullptr, MCPM_E_ARG, "mcpm_paint_f32: null mesh");
+    if (weights && wstride < 1) return mcpm_fail(p, MCPM_E_ARG, "mcpm_paint_f32: wstride must be >= 1");
+    if (mode == MCPM_POS_LATTICE && order == 2 && n > 0 && try_paint_tiled(p, pos, weights, wstride, wscalar, mesh, accumulate)) {
+        MCPM_LAUNCH_CHECK(p, "paint_tile_kernel");
+        return MCPM_OK;
+    }
+    if (!accumulate) MCPM_HIP(p, hipMemsetAsync(mesh, 0, sizeof(float) * p->M, p->stream));
+    if (n == 0) return MCPM_OK;
+    dim3 grid, block;
+    if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
+#define CALL(MO, OR) paint_atomic_kernel<MO, OR><<<grid, block, 0, p->stream>>>(p->g, pos, n, weights, wstride, wscalar, mesh)
+    DISPATCH_MODE_ORDER(mode, order, CALL);
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "paint_atomic_kernel");
+    return MCPM_OK;
+}
+
+int mcpm_read_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *meshes, int ncomp, int order,
+                  float *out) {
+    MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_read_f32"));
+    MCPM_REQUIRE(p, meshes && out, MCPM_E_ARG, "mcpm_read_f32: null buffer");
+    MCPM_REQUIRE(p, ncomp == 1 || ncomp == 3, MCPM_E_ARG, "mcpm_read_f32: ncomp must be 1 or 3");
+    if (n == 0) return MCPM_OK;
+    dim3 grid, block;
+    if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
+#define CALL(MO, OR)                                                                               \
+    if (ncomp == 1) read_kernel<MO, OR, 1><<<grid, block, 0, p->stream>>>(p->g, pos, n, meshes, p->M, out); \
+    else read_kernel<MO, OR, 3><<<grid, block, 0, p->stream>>>(p->g, pos, n, meshes, p->M, out)
+    DISPATCH_MODE_ORDER(mode, order, CALL);
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "read_kernel");
+    return MCPM_OK;
+}
+
+int mcpm_read_vjp_pos_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *meshes, int ncomp,
+                          int order, const float *out_bar, float *pos_bar) {
+    MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_read_vjp_pos_f32"));
+    MCPM_REQUIRE(p, meshes && out_bar && pos_bar, MCPM_E_ARG, "mcpm_read_vjp_pos_f32: null buffer");
+    MCPM_REQUIRE(p, ncomp == 1 || ncomp == 3, MCPM_E_ARG, "mcpm_read_vjp_pos_f32: ncomp must be 1 or 3");
+    if (n == 0) return MCPM_OK;
+    dim3 grid, block;
+    if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
+#define CALL(MO, OR)                                                                                           \
+    if (ncomp == 1)                                                                                            \
+        read_vjp_pos_kernel<MO, OR, 1><<<grid, block, 0, p->stream>>>(p->g, pos, n, meshes, p->M, out_bar, 1, 0.f, pos_bar, nullptr); \
+    else                                                                                                       \
+        read_vjp_pos_kernel<MO, OR, 3><<<grid, block, 0, p->stream>>>(p->g, pos, n, meshes, p->M, out_bar, 3, 0.f, pos_bar, nullptr)
+    DISPATCH_MODE_ORDER(mode, order, CALL);
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "read_vjp_pos_kernel");
+    return MCPM_OK;
+}
+
+int mcpm_paint_vjp_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *weights, int64_t wstride,
+                       float wscalar, int order, const float *mesh_bar, float *pos_bar, float *weights_bar) {
+    MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_paint_vjp_f32"));
+    MCPM_REQUIRE(p, mesh_bar && pos_bar, MCPM_E_ARG, "mcpm_paint_vjp_f32: null buffer");
+    if (weights && wstride < 1) return mcpm_fail(p, MCPM_E_ARG, "mcpm_paint_vjp_f32: wstride must be >= 1");
+    if (n == 0) return MCPM_OK;
+    dim3 grid, block;
+    if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
+#define CALL(MO, OR)                                                                                                   \
+    read_vjp_pos_kernel<MO, OR, 1><<<grid, block, 0, p->stream>>>(p->g, pos, n, mesh_bar, p->M, weights, wstride, wscalar, \
+                                                                  pos_bar, weights_bar)
+    DISPATCH_MODE_ORDER(mode, order, CALL);
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "read_vjp_pos_kernel(paint_vjp)");
+    return MCPM_OK;
+}
+
+int mcpm_drift_f32(mcpm_plan *p, const float *pos_in, const float *vel, int64_t n, float dt, float *pos_out) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, pos_in && vel && pos_out && n >= 0, MCPM_E_ARG, "mcpm_drift_f32: bad argument");
+    if (n == 0) return MCPM_OK;
+    dim3 grid, block;
+    flat_launch(3 * n, grid, block);
+    axpy_kernel<<<grid, block, 0, p->stream>>>(pos_in, vel, 3 * n, 1.f, dt, pos_out);
+    MCPM_LAUNCH_CHECK(p, "axpy_kernel(drift)");
+    return MCPM_OK;
+}
+
+int mcpm_kick_f32(mcpm_plan *p, const float *vel_in, const float *forces, int64_t n, float alpha, float beta,
+                  float *vel_out) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, vel_in && forces && vel_out && n >= 0, MCPM_E_ARG, "mcpm_kick_f32: bad argument");
+    if (n == 0) return MCPM_OK;
+    dim3 grid, block;
+    flat_launch(3 * n, grid, block);
+    axpy_kernel<<<grid, block, 0, p->stream>>>(vel_in, forces, 3 * n, alpha, beta, vel_out);
+    MCPM_LAUNCH_CHECK(p, "axpy_kernel(kick)");
+    return MCPM_OK;
+}
+
+int mcpm_kick_drift_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, int64_t n, int mode,
+                        const float *meshes3, int order, float alpha, float beta, float dt, float *pos_out,
+                        float *vel_out) {
+    MCPM_TRY(check_particles(p, pos_in, n, mode, order, "mcpm_kick_drift_f32"));
+    MCPM_REQUIRE(p, vel_in && meshes3 && pos_out && vel_out, MCPM_E_ARG, "mcpm_kick_drift_f32: null buffer");
+    if (n == 0) return MCPM_OK;
+    dim3 grid, block;
+    if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
+#define CALL(MO, OR) \
+    kick_drift_kernel<MO, OR><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, n, meshes3, p->M, alpha, beta, dt, pos_out, vel_out)
+    DISPATCH_MODE_ORDER(mode, order, CALL);
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "kick_drift_kernel");
+    return MCPM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+// Device helpers shared by the particle kernels: lattice decoding, base cell + fraction, periodic wrap.
+// Index semantics follow montecosmo/nbody.py:369-377 (floor for CIC, round-half-even for NGP, Python
+// modulo wrap); the int16 range of the reference (|pos| < 32767) is a documented precondition.
+#pragma once
+#include "mcpm_internal.h"
+
+struct P3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ P3 load3(const float *__restrict__ p, int64_t i) {
+    return reinterpret_cast<const P3 *>(p)[i];
+}
+__device__ __forceinline__ void store3(float *__restrict__ p, int64_t i, P3 v) { reinterpret_cast<P3 *>(p)[i] = v; }
+
+// Python-style modulo for |c| < 2^16, n < 2^15.
+__device__ __forceinline__ int wrapi(int c, int n) {
+    if ((n & (n - 1)) == 0) return c & (n - 1);
+    int q = (int)floorf((float)c / (float)n);
+    int r = c - q * n;
+    r += (r < 0) ? n : 0;
+    r -= (r >= n) ? n : 0;
+    return r;
+}
+
+// Lattice point of particle-lattice index ip on an axis with n mesh cells and p lattice points:
+// q = ip*n/p = qi + qf, qi integer, qf in [0,1).
+__device__ __forceinline__ void lattice_q(int ip, int n, int p, int same, int &qi, float &qf) {
+    if (same) {
+        qi = ip;
+        qf = 0.f;
+    } else {
+        int qn = ip * n;
+        qi = qn / p;
+        qf = (float)(qn - qi * p) / (float)p;
+    }
+}
+
+// Base cell (unwrapped) and fraction along one axis.  t = qf + d is the coordinate relative to qi.
+// ORDER 2: c = qi + floor(t), f = t - floor(t) in [0,1].
+// ORDER 1: c = round-half-even(qi + t), f unused (0).
+template <int ORDER>
+__device__ __forceinline__ void axis_cell(int qi, float t, int &c, float &f) {
+    float fl = floorf(t);
+    float fr = t - fl;
+    int b = qi + (int)fl;
+    if (ORDER == 2) {
+        c = b;
+        f = fr;
+    } else {
+        c = b + ((fr > 0.5f || (fr == 0.5f && (b & 1))) ? 1 : 0);
+        f = 0.f;
+    }
+}
+
+// Thread -> particle mapping.
+// LATTICE mode: one block row-chunk per lattice row (x,y), lanes along z, so that a wave touches
+// consecutive z cells; ABSOLUTE mode: flat index.
+struct PIdx {
+    int64_t i;       // particle index
+    int ipx, ipy, ipz;
+    bool valid;
+};
+
+template <int MODE>
+__device__ __forceinline__ PIdx particle_index(const Geom &g, int64_t n) {
+    PIdx r;
+    if (MODE == MCPM_POS_LATTICE) {
+        int cpr = (g.pz + blockDim.x - 1) / blockDim.x;
+        int row = blockIdx.x / cpr;
+        int chunk = blockIdx.x - row * cpr;
+        r.ipz = chunk * blockDim.x + threadIdx.x;
+        r.ipx = row / g.py;
+        r.ipy = row - r.ipx * g.py;
+        r.valid = r.ipz < g.pz;
+        r.i = (int64_t)row * g.pz + r.ipz;
+    } else {
+        r.i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        r.ipx = r.ipy = r.ipz = 0;
+        r.valid = r.i < n;
+    }
+    return r;
+}
+
+// Base cell + fractions of one particle.
+template <int MODE, int ORDER>
+__device__ __forceinline__ void locate(const Geom &g, const PIdx &pi, P3 d, int (&c)[3], float (&f)[3]) {
+    int qx = 0, qy = 0, qz = 0;
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (MODE == MCPM_POS_LATTICE) {
+        lattice_q(pi.ipx, g.nx, g.px, g.same_lattice, qx, fx);
+        lattice_q(pi.ipy, g.ny, g.py, g.same_lattice, qy, fy);
+        lattice_q(pi.ipz, g.nz, g.pz, g.same_lattice, qz, fz);
+    }
+    axis_cell<ORDER>(qx, fx + d.x, c[0], f[0]);
+    axis_cell<ORDER>(qy, fy + d.y, c[1], f[1]);
+    axis_cell<ORDER>(qz, fz + d.z, c[2], f[2]);
+}
+
+// Flat mesh offsets of the 2x2x2 (CIC) or single (NGP) stencil, periodic.
+template <int ORDER>
+struct Stencil {
+    int64_t xo[2], yo[2];
+    int zo[2];
+    __device__ __forceinline__ Stencil(const Geom &g, const int (&c)[3]) {
+        int x0 = wrapi(c[0], g.nx), y0 = wrapi(c[1], g.ny), z0 = wrapi(c[2], g.nz);
+        xo[0] = (int64_t)x0 * g.ny * g.nz;
+        yo[0] = (int64_t)y0 * g.nz;
+        zo[0] = z0;
+        if (ORDER == 2) {
+            int x1 = x0 + 1 == g.nx ? 0 : x0 + 1;
+            int y1 = y0 + 1 == g.ny ? 0 : y0 + 1;
+            int z1 = z0 + 1 == g.nz ? 0 : z0 + 1;
+            xo[1] = (int64_t)x1 * g.ny * g.nz;
+            yo[1] = (int64_t)y1 * g.nz;
+            zo[1] = z1;
+        } else {
+            xo[1] = xo[0];
+            yo[1] = yo[0];
+            zo[1] = zo[0];
+        }
+    }
+};
+
+// Trilinear value and gradient of one mesh at (cell, frac).  d/dpos of K(c - x) = sign(c - x):
+// -1 for the lower corner (0 when the fraction is exactly 0, jax's sign(0) = 0), +1 for the upper.
+template <int ORDER, bool GRAD>
+__device__ __forceinline__ void interp(const float *__restrict__ m, const Stencil<ORDER> &s, const float (&f)[3],
+                                       float &val, float &gx, float &gy, float &gz) {
+    if (ORDER == 1) {
+        val = m[s.xo[0] + s.yo[0] + s.zo[0]];
+        gx = gy = gz = 0.f;
+        return;
+    }
+    float v000 = m[s.xo[0] + s.yo[0] + s.zo[0]], v001 = m[s.xo[0] + s.yo[0] + s.zo[1]];
+    float v010 = m[s.xo[0] + s.yo[1] + s.zo[0]], v011 = m[s.xo[0] + s.yo[1] + s.zo[1]];
+    float v100 = m[s.xo[1] + s.yo[0] + s.zo[0]], v101 = m[s.xo[1] + s.yo[0] + s.zo[1]];
+    float v110 = m[s.xo[1] + s.yo[1] + s.zo[0]], v111 = m[s.xo[1] + s.yo[1] + s.zo[1]];
+    float ax = 1.f - f[0], bx = f[0], ay = 1.f - f[1], by = f[1], az = 1.f - f[2], bz = f[2];
+    // collapse z, then y, then x
+    float v00 = az * v000 + bz * v001, v01 = az * v010 + bz * v011;
+    float v10 = az * v100 + bz * v101, v11 = az * v110 + bz * v111;
+    float v0 = ay * v00 + by * v01, v1 = ay * v10 + by * v11;
+    val = ax * v0 + bx * v1;
+    if (GRAD) {
+        float lx = f[0] > 0.f ? 1.f : 0.f, ly = f[1] > 0.f ? 1.f : 0.f, lz = f[2] > 0.f ? 1.f : 0.f;
+        gx = v1 - lx * v0;
+        float d0 = v01 - ly * v00, d1 = v11 - ly * v10;
+        gy = ax * d0 + bx * d1;
+        float e00 = v001 - lz * v000, e01 = v011 - lz * v010, e10 = v101 - lz * v100, e11 = v111 - lz * v110;
+        gz = ax * (ay * e00 + by * e01) + bx * (ay * e10 + by * e11);
+    } else {
+        gx = gy = gz = 0.f;
+    }
+}

@@ -1,0 +1,156 @@
+// Plan lifetime, error plumbing and the rocFFT R2C / C2R wrappers of libmcpm.so.
+// Replaces the jnp.fft.rfftn / irfftn calls of montecosmo/nbody.py:589, :603, :620, :627, :630.
+#include <mutex>
+
+#include "mcpm_internal.h"
+
+thread_local std::string g_mcpm_create_error;
+
+int mcpm_fail(mcpm_plan *plan, int code, const std::string &msg) {
+    if (plan)
+        plan->err = msg;
+    else
+        g_mcpm_create_error = msg;
+    return code;
+}
+
+static std::once_flag g_rocfft_once;
+
+static int make_fft(mcpm_plan *p, bool forward, int batch) {
+    auto &plans = forward ? p->r2c : p->c2r;
+    if (plans.count(batch)) return MCPM_OK;
+    size_t lengths[3] = {(size_t)p->g.nz, (size_t)p->g.ny, (size_t)p->g.nx};
+    rocfft_plan plan = nullptr;
+    rocfft_status st = rocfft_plan_create(&plan, rocfft_placement_notinplace,
+                                          forward ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse,
+                                          rocfft_precision_single, 3, lengths, (size_t)batch, nullptr);
+    if (st != rocfft_status_success) return mcpm_fail(p, MCPM_E_ROCFFT, "rocfft_plan_create failed: " + std::to_string((int)st));
+    size_t wsz = 0;
+    rocfft_plan_get_work_buffer_size(plan, &wsz);
+    rocfft_execution_info info = nullptr;
+    rocfft_execution_info_create(&info);
+    void *work = nullptr;
+    if (wsz) {
+        if (hipMalloc(&work, wsz) != hipSuccess) return mcpm_fail(p, MCPM_E_NOMEM, "rocFFT work buffer");
+        rocfft_execution_info_set_work_buffer(info, work, wsz);
+    }
+    rocfft_execution_info_set_stream(info, p->stream);
+    plans[batch] = plan;
+    (forward ? p->r2c_info : p->c2r_info)[batch] = info;
+    (forward ? p->r2c_work : p->c2r_work)[batch] = work;
+    return MCPM_OK;
+}
+
+extern "C" {
+
+const char *mcpm_version(void) { return "mcpm 0.1 (gfx950)"; }
+
+const char *mcpm_last_error(const mcpm_plan *plan) { return plan ? plan->err.c_str() : g_mcpm_create_error.c_str(); }
+
+int mcpm_plan_create(int nx, int ny, int nz, int px, int py, int pz, void *stream, mcpm_plan **out) {
+    if (!out) return mcpm_fail(nullptr, MCPM_E_ARG, "plan output pointer is null");
+    *out = nullptr;
+    if (nx < 2 || ny < 2 || nz < 2 || (nz & 1)) return mcpm_fail(nullptr, MCPM_E_SHAPE, "mesh dims must be >= 2 and nz even");
+    if (nx > 32766 || ny > 32766 || nz > 32766) return mcpm_fail(nullptr, MCPM_E_SHAPE, "mesh side must stay below 32767 (int16 index math)");
+    if (px < 1 || py < 1 || pz < 1) return mcpm_fail(nullptr, MCPM_E_SHAPE, "particle lattice dims must be >= 1");
+    if ((int64_t)px * py * pz >= (int64_t)1 << 31) return mcpm_fail(nullptr, MCPM_E_SHAPE, "more than 2^31 particles per plan");
+    mcpm_plan *p = new (std::nothrow) mcpm_plan();
+    if (!p) return mcpm_fail(nullptr, MCPM_E_NOMEM, "host allocation");
+    p->g = Geom{nx, ny, nz, px, py, pz, nz / 2 + 1, (px == nx && py == ny && pz == nz) ? 1 : 0};
+    p->stream = (hipStream_t)stream;
+    p->M = (int64_t)nx * ny * nz;
+    p->Mh = (int64_t)nx * ny * p->g.nzh;
+    p->Np = (int64_t)px * py * pz;
+    p->halo = 4;
+    p->rho = p->spec = p->fmesh = p->spec1 = nullptr;
+    p->outliers = p->outlier_count = nullptr;
+    p->reduce = nullptr;
+    p->pscratch = nullptr;
+    std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void **ptr, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(ptr, bytes);
+    };
+    alloc((void **)&p->rho, sizeof(float) * p->M);
+    alloc((void **)&p->spec, sizeof(float) * 2 * p->Mh * 6);
+    alloc((void **)&p->fmesh, sizeof(float) * p->M * 9);
+    alloc((void **)&p->spec1, sizeof(float) * 2 * p->Mh);
+    alloc((void **)&p->outliers, sizeof(int) * p->Np);
+    alloc((void **)&p->outlier_count, sizeof(int) * 2);
+    alloc((void **)&p->reduce, sizeof(double) * MCPM_NREDUCE);
+    if (e != hipSuccess) {
+        std::string msg = std::string("hipMalloc of plan scratch: ") + hipGetErrorString(e);
+        mcpm_plan_destroy(p);
+        return mcpm_fail(nullptr, MCPM_E_NOMEM, msg);
+    }
+    hipMemsetAsync(p->outlier_count, 0, sizeof(int) * 2, p->stream);
+    *out = p;
+    return MCPM_OK;
+}
+
+int mcpm_plan_destroy(mcpm_plan *p) {
+    if (!p) return MCPM_OK;
+    hipStreamSynchronize(p->stream);
+    for (auto &kv : p->r2c) rocfft_plan_destroy(kv.second);
+    for (auto &kv : p->c2r) rocfft_plan_destroy(kv.second);
+    for (auto &kv : p->r2c_info) rocfft_execution_info_destroy(kv.second);
+    for (auto &kv : p->c2r_info) rocfft_execution_info_destroy(kv.second);
+    for (auto &kv : p->r2c_work) hipFree(kv.second);
+    for (auto &kv : p->c2r_work) hipFree(kv.second);
+    hipFree(p->rho);
+    hipFree(p->spec);
+    hipFree(p->fmesh);
+    hipFree(p->spec1);
+    hipFree(p->outliers);
+    hipFree(p->outlier_count);
+    hipFree(p->reduce);
+    hipFree(p->pscratch);
+    delete p;
+    return MCPM_OK;
+}
+
+int mcpm_plan_set_halo(mcpm_plan *p, int halo) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, halo == 1 || halo == 2 || halo == 4 || halo == 6, MCPM_E_ARG, "halo must be 1, 2, 4 or 6");
+    p->halo = halo;
+    return MCPM_OK;
+}
+
+int mcpm_plan_last_outliers(mcpm_plan *p, int64_t *count) {
+    if (!p || !count) return MCPM_E_ARG;
+    int h = 0;
+    MCPM_HIP(p, hipMemcpyAsync(&h, p->outlier_count + 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    MCPM_HIP(p, hipStreamSynchronize(p->stream));
+    *count = h;
+    return MCPM_OK;
+}
+
+int mcpm_plan_force_meshes(mcpm_plan *p, float **meshes3) {
+    if (!p || !meshes3) return MCPM_E_ARG;
+    *meshes3 = p->fmesh;
+    return MCPM_OK;
+}
+
+int mcpm_fft_r2c(mcpm_plan *p, const float *real, float *spec, int batch) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, real && spec && batch >= 1, MCPM_E_ARG, "mcpm_fft_r2c: null buffer or batch < 1");
+    MCPM_TRY(make_fft(p, true, batch));
+    void *in[1] = {(void *)real};
+    void *out[1] = {(void *)spec};
+    rocfft_status st = rocfft_execute(p->r2c[batch], in, out, p->r2c_info[batch]);
+    if (st != rocfft_status_success) return mcpm_fail(p, MCPM_E_ROCFFT, "rocfft_execute r2c: " + std::to_string((int)st));
+    return MCPM_OK;
+}
+
+int mcpm_fft_c2r(mcpm_plan *p, float *spec, float *real, int batch) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, real && spec && batch >= 1, MCPM_E_ARG, "mcpm_fft_c2r: null buffer or batch < 1");
+    MCPM_TRY(make_fft(p, false, batch));
+    void *in[1] = {(void *)spec};
+    void *out[1] = {(void *)real};
+    rocfft_status st = rocfft_execute(p->c2r[batch], in, out, p->c2r_info[batch]);
+    if (st != rocfft_status_success) return mcpm_fail(p, MCPM_E_ROCFFT, "rocfft_execute c2r: " + std::to_string((int)st));
+    return MCPM_OK;
+}
+
+}  // extern "C"

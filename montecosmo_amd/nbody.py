@@ -1,0 +1,655 @@
+"""
+MI355X-native operator surface with the names, argument names, defaults and return structure of
+`montecosmo/nbody.py` (reference file; line numbers below refer to it), so that `bricks.py` /
+`model.py` can `from montecosmo_amd.nbody import ...` unchanged.  Arrays are torch tensors on the
+GPU (numpy inputs are uploaded); every mesh/particle operation runs in hand-written HIP kernels of
+libmcpm.so through the C ABI of include/mcpm.h.  There is no autodiff: every differentiable entry
+has an explicit `*_vjp` twin.
+
+Host-side pieces (wavevector helpers, growth tables, BullFrog/FastPM coefficients) are float64 numpy,
+as in the reference where they are numpy / 128-entry tables.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from itertools import product
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, POS_ABSOLUTE, POS_LATTICE
+from .utils import safe_div, ch2rshape, r2chshape, scale_shape  # noqa: F401 (re-exported like the reference)
+
+__all__ = [
+    "rfftk", "fftk", "invlaplace_hat", "gradient_hat", "gaussian_hat", "rectangular", "rectangular_hat",
+    "paint", "read", "paint_vjp", "read_vjp", "pm_forces", "pm_forces2", "lpt", "lpt_vjp",
+    "a2g", "a2g2", "a2f", "a2f2", "a2dg2dg", "g2a", "g2g2", "g2f", "g2f2", "g2dg2dg", "a2chi", "chi2a",
+    "bullfrog_vf", "nbody_bf", "nbody_bf_vjp", "alpha_bf", "alpha_fpm", "LatticePos", "get_plan",
+    "safe_div", "ch2rshape", "r2chshape", "scale_shape",
+]
+
+
+# ------------------------------------------------------------------------------------------------
+# device plumbing
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("montecosmo_amd needs a ROCm GPU (MI355X): there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _fd(order):
+    if order == np.inf:
+        return _lib.FD_INF
+    if order in (2, 4):
+        return int(order)
+    raise ValueError("Only orders 2, 4, and inf are supported.")
+
+
+class Plan:
+    """Owns one `mcpm_plan` (rocFFT plans + scratch) for a (mesh shape, particle lattice) pair."""
+
+    def __init__(self, mesh_shape, ptcl_shape=None):
+        mesh_shape = tuple(int(s) for s in mesh_shape)
+        ptcl_shape = mesh_shape if ptcl_shape is None else tuple(int(s) for s in ptcl_shape)
+        if len(mesh_shape) != 3 or len(ptcl_shape) != 3:
+            raise ValueError("only 3D meshes are supported")
+        self.device = _device()
+        self.mesh_shape, self.ptcl_shape = mesh_shape, ptcl_shape
+        self.M = int(np.prod(mesh_shape))
+        self.Mh = mesh_shape[0] * mesh_shape[1] * (mesh_shape[2] // 2 + 1)
+        self.N = int(np.prod(ptcl_shape))
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        rc = lib.mcpm_plan_create(*mesh_shape, *ptcl_shape, C.c_void_p(self.stream.cuda_stream), C.byref(h))
+        check(rc, None, "mcpm_plan_create")
+        self.h = h
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            lib.mcpm_plan_destroy(h)
+
+    def call(self, name, *args):
+        check(getattr(lib, name)(self.h, *args), self.h, name)
+
+    def last_outliers(self):
+        n = C.c_int64()
+        self.call("mcpm_plan_last_outliers", C.byref(n))
+        return n.value
+
+
+_PLANS = {}
+
+
+def get_plan(mesh_shape, ptcl_shape=None) -> Plan:
+    mesh_shape = tuple(int(s) for s in mesh_shape)
+    ptcl_shape = mesh_shape if ptcl_shape is None else tuple(int(s) for s in ptcl_shape)
+    key = (mesh_shape, ptcl_shape, torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    if key not in _PLANS:
+        _PLANS[key] = Plan(mesh_shape, ptcl_shape)
+    return _PLANS[key]
+
+
+def clear_plans():
+    _PLANS.clear()
+
+
+def _f32(x, shape=None):
+    """Contiguous float32 CUDA tensor from numpy / torch input."""
+    if isinstance(x, LatticePos):
+        raise TypeError("LatticePos given where a plain array is expected")
+    t = torch.as_tensor(x)
+    t = t.to(device=_device(), dtype=torch.float32).contiguous()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def _c64(x, shape=None):
+    t = torch.as_tensor(x).to(device=_device(), dtype=torch.complex64).contiguous()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class LatticePos:
+    """Particle positions stored as float32 displacements from the regular lattice
+    `regular_pos(mesh_shape, ptcl_shape)` (bricks.py:593-603).  This is how the kernels keep cell
+    indices exact and fractions at full fp32 precision on large meshes (absolute fp32 coordinates lose
+    ~3e-5 cells at n = 512).  `to_absolute()` gives the reference's (N,3) array."""
+
+    def __init__(self, disp, mesh_shape, ptcl_shape=None):
+        self.mesh_shape = tuple(int(s) for s in mesh_shape)
+        self.ptcl_shape = self.mesh_shape if ptcl_shape is None else tuple(int(s) for s in ptcl_shape)
+        n = int(np.prod(self.ptcl_shape))
+        self.disp = _f32(disp, (n, 3))
+
+    @classmethod
+    def regular(cls, mesh_shape, ptcl_shape=None):
+        ptcl = mesh_shape if ptcl_shape is None else ptcl_shape
+        return cls(torch.zeros((int(np.prod(ptcl)), 3), dtype=torch.float32, device=_device()), mesh_shape, ptcl_shape)
+
+    def lattice(self, dtype=torch.float64):
+        axes = [torch.arange(p, device=self.disp.device, dtype=dtype) * (m / p)
+                for m, p in zip(self.mesh_shape, self.ptcl_shape)]
+        return torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1).reshape(-1, 3)
+
+    def to_absolute(self, dtype=torch.float64):
+        return self.lattice(dtype) + self.disp.to(dtype)
+
+    def __add__(self, dpos):
+        return LatticePos(self.disp + _f32(dpos, self.disp.shape), self.mesh_shape, self.ptcl_shape)
+
+    __radd__ = __add__
+
+    def __len__(self):
+        return self.disp.shape[0]
+
+
+def _pos_args(pos, mesh_shape):
+    """-> (plan, float32 tensor, n, pos_mode)"""
+    if isinstance(pos, LatticePos):
+        if tuple(pos.mesh_shape) != tuple(int(s) for s in mesh_shape):
+            raise ValueError("LatticePos mesh shape does not match the mesh")
+        return get_plan(mesh_shape, pos.ptcl_shape), pos.disp, pos.disp.shape[0], POS_LATTICE
+    t = _f32(pos)
+    if t.ndim != 2 or t.shape[1] != 3:
+        raise ValueError("pos must have shape (N, 3)")
+    return get_plan(mesh_shape), t, t.shape[0], POS_ABSOLUTE
+
+
+# ------------------------------------------------------------------------------------------------
+# wavevectors and k-space kernels: host numpy, exactly as the reference builds them (nbody.py:50-163)
+def _kaxes(shape, box_size, real_last):
+    dim = len(shape)
+    scales = dim * (2 * np.pi,) if box_size is None else tuple(2 * np.pi * s / b for s, b in zip(shape, box_size))
+    out = []
+    for ax, (s, sc) in enumerate(zip(shape, scales)):
+        freq = np.fft.rfftfreq(s) if (real_last and ax == dim - 1) else np.fft.fftfreq(s)
+        bshape = [1] * dim
+        bshape[ax] = -1
+        out.append((freq * sc).reshape(bshape))
+    return tuple(out)
+
+
+def rfftk(shape, box_size=None):
+    """Wavevectors for rfftn, broadcastable; cell units (k in [-pi, pi[) unless `box_size` (nbody.py:50-77)."""
+    return _kaxes(shape, box_size, True)
+
+
+def fftk(shape, box_size=None):
+    """Wavevectors for fftn (nbody.py:80-103)."""
+    return _kaxes(shape, box_size, False)
+
+
+def invlaplace_hat(kvec, fd_order=np.inf):
+    """Fourier transform of the inverse Laplace kernel (nbody.py:109-133)."""
+    if fd_order == 2:
+        kk = sum(2 * (np.cos(k) - 1) for k in kvec)
+    elif fd_order == 4:
+        kk = sum((np.cos(2 * k) - 16 * np.cos(k) + 15) / 6 for k in kvec)
+    elif fd_order == np.inf:
+        kk = sum(k ** 2 for k in kvec)
+    else:
+        raise ValueError("Only orders 2, 4, and inf are supported.")
+    return -safe_div(1, kk)
+
+
+def gradient_hat(kvec, direction: int, fd_order=np.inf):
+    """Fourier transform of the gradient kernel along `direction` (nbody.py:136-163)."""
+    k = kvec[direction]
+    if fd_order == 2:
+        k = np.sin(k)
+    elif fd_order == 4:
+        k = (8 * np.sin(k) - np.sin(2 * k)) / 6
+    elif fd_order != np.inf:
+        raise ValueError("Only orders 2, 4, and inf are supported.")
+    return 1j * k
+
+
+def gaussian_hat(kvec, kcut=np.inf):
+    """nbody.py:166-188"""
+    if kcut == np.inf:
+        return 1.
+    rcut = 2 * np.pi / kcut
+    return np.exp(-sum(k ** 2 for k in kvec) * rcut ** 2 / 2)
+
+
+def rectangular(s, order):
+    """1-D assignment weights of |s| (nbody.py:220-246); numpy or torch input."""
+    xp = torch if isinstance(s, torch.Tensor) else np
+    u = xp.abs(s)
+    if order == 1:
+        return xp.ones_like(u)
+    if order == 2:
+        return 1 - u
+    if order == 3:
+        return (u <= 0.5) * (0.75 - u ** 2) + (u > 0.5) * 0.5 * (1.5 - u) ** 2
+    if order == 4:
+        return (u <= 1) * (4 - 6 * u ** 2 + 3 * u ** 3) / 6 + (u > 1) * (2 - u) ** 3 / 6
+    raise ValueError("order must be 1 (NGP), 2 (CIC), 3 (TSC) or 4 (PCS)")
+
+
+def rectangular_hat(kvec, order: int = 2):
+    """nbody.py:249-277"""
+    out = 1.
+    for k in kvec:
+        out = out * np.sinc(k / (2 * np.pi)) ** order
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# mass assignment
+def _check_kernel(kernel_type, order):
+    if kernel_type != "rectangular":
+        raise NotImplementedError("only kernel_type='rectangular' is implemented on the HIP path")
+    if order not in (1, 2):
+        raise NotImplementedError("only orders 1 (NGP) and 2 (CIC) are implemented on the HIP path")
+
+
+def _weights_args(weights, n):
+    if np.ndim(weights) == 0 and not isinstance(weights, torch.Tensor):
+        return None, 1, float(weights)
+    w = _f32(weights)
+    if w.ndim == 0:
+        return None, 1, float(w)
+    if w.shape != (n,):
+        raise ValueError("weights must be a scalar or have shape (N,)")
+    return w, 1, 0.0
+
+
+def paint(pos, shape: tuple, weights=1., order: int = 2, kernel_type='rectangular', oversamp=1.):
+    """Paint the positions onto a mesh of given shape (nbody.py:365-396)."""
+    _check_kernel(kernel_type, order)
+    shape = tuple(int(s) for s in shape)
+    plan, p, n, mode = _pos_args(pos, shape)
+    w, ws, wsc = _weights_args(weights, n)
+    mesh = torch.empty(shape, dtype=torch.float32, device=p.device)
+    plan.call("mcpm_paint_f32", _ptr(p), n, mode, _ptr(w), ws, wsc, order, _ptr(mesh), 0)
+    return mesh
+
+
+def read(pos, mesh, order: int = 2, kernel_type='rectangular', oversamp=1.):
+    """Read the value at the positions from the mesh (nbody.py:398-427)."""
+    _check_kernel(kernel_type, order)
+    mesh = _f32(mesh)
+    plan, p, n, mode = _pos_args(pos, mesh.shape)
+    out = torch.empty((n,), dtype=torch.float32, device=p.device)
+    plan.call("mcpm_read_f32", _ptr(p), n, mode, _ptr(mesh), 1, order, _ptr(out))
+    return out
+
+
+def paint_vjp(pos, shape, weights, mesh_bar, order: int = 2):
+    """VJP of paint: -> (pos_bar (N,3), weights_bar (N,) or its sum for scalar weights)."""
+    _check_kernel('rectangular', order)
+    shape = tuple(int(s) for s in shape)
+    plan, p, n, mode = _pos_args(pos, shape)
+    w, ws, wsc = _weights_args(weights, n)
+    mb = _f32(mesh_bar, shape)
+    pos_bar = torch.empty((n, 3), dtype=torch.float32, device=p.device)
+    w_bar = torch.empty((n,), dtype=torch.float32, device=p.device)
+    plan.call("mcpm_paint_vjp_f32", _ptr(p), n, mode, _ptr(w), ws, wsc, order, _ptr(mb), _ptr(pos_bar), _ptr(w_bar))
+    return pos_bar, (w_bar if w is not None else w_bar.double().sum())
+
+
+def read_vjp(pos, mesh, out_bar, order: int = 2):
+    """VJP of read: -> (pos_bar (N,3), mesh_bar)."""
+    _check_kernel('rectangular', order)
+    mesh = _f32(mesh)
+    plan, p, n, mode = _pos_args(pos, mesh.shape)
+    ob = _f32(out_bar, (n,))
+    pos_bar = torch.empty((n, 3), dtype=torch.float32, device=p.device)
+    plan.call("mcpm_read_vjp_pos_f32", _ptr(p), n, mode, _ptr(mesh), 1, order, _ptr(ob), _ptr(pos_bar))
+    mesh_bar = torch.empty(tuple(mesh.shape), dtype=torch.float32, device=p.device)
+    plan.call("mcpm_paint_f32", _ptr(p), n, mode, _ptr(ob), 1, 0.0, order, _ptr(mesh_bar), 0)
+    return pos_bar, mesh_bar
+
+
+def cell_index(pos, shape, order: int = 2):
+    """wrap(id0) of nbody.py:372-375 as an (N,3) int16 tensor."""
+    shape = tuple(int(s) for s in shape)
+    plan, p, n, mode = _pos_args(pos, shape)
+    idx = torch.empty((n, 3), dtype=torch.int16, device=p.device)
+    plan.call("mcpm_cell_index", _ptr(p), n, mode, order, _ptr(idx))
+    return idx
+
+
+# ------------------------------------------------------------------------------------------------
+# FFT helpers (numpy/jax conventions on top of the unnormalised C ABI)
+def rfftn(mesh):
+    mesh = _f32(mesh)
+    plan = get_plan(mesh.shape)
+    out = torch.empty(r2chshape(mesh.shape), dtype=torch.complex64, device=mesh.device)
+    plan.call("mcpm_fft_r2c", _ptr(mesh), _ptr(out), 1)
+    return out
+
+
+def irfftn(spec):
+    spec = _c64(spec).clone()  # C2R destroys its input
+    shape = ch2rshape(spec.shape)
+    plan = get_plan(shape)
+    out = torch.empty(shape, dtype=torch.float32, device=spec.device)
+    plan.call("mcpm_fft_c2r", _ptr(spec), _ptr(out), 1)
+    return out / plan.M
+
+
+# ------------------------------------------------------------------------------------------------
+# forces
+def pm_forces(pos, mesh, read_order: int = 2, paint_deconv: bool = False, grad_fd=np.inf, lap_fd=np.inf, kcut=np.inf):
+    """Gravitational forces on particles with a PM scheme (nbody.py:583-604).  `mesh` is a shape tuple
+    (the particles are painted first) or a half-spectrum."""
+    kc = 0.0 if kcut == np.inf else float(kcut)
+    if isinstance(mesh, tuple):
+        shape = tuple(int(s) for s in mesh)
+        plan, p, n, mode = _pos_args(pos, shape)
+        out = torch.empty((n, 3), dtype=torch.float32, device=p.device)
+        plan.call("mcpm_pm_forces_f32", _ptr(p), n, mode, read_order, int(bool(paint_deconv)), _fd(lap_fd), _fd(grad_fd), kc, _ptr(out))
+        return out
+    spec = _c64(mesh)
+    shape = ch2rshape(spec.shape)
+    plan, p, n, mode = _pos_args(pos, shape)
+    out = torch.empty((n, 3), dtype=torch.float32, device=p.device)
+    plan.call("mcpm_pm_forces_spec_f32", _ptr(spec), _ptr(p), n, mode, read_order, _fd(lap_fd), _fd(grad_fd), kc, _ptr(out))
+    return out
+
+
+def pm_forces2(pos, mesh, read_order: int = 2, grad_fd=np.inf, lap_fd=np.inf):
+    """2LPT source term forces (nbody.py:607-631)."""
+    spec = _c64(mesh)
+    shape = ch2rshape(spec.shape)
+    plan, p, n, mode = _pos_args(pos, shape)
+    out = torch.empty((n, 3), dtype=torch.float32, device=p.device)
+    plan.call("mcpm_pm_forces2_f32", _ptr(spec), _ptr(p), n, mode, read_order, _fd(lap_fd), _fd(grad_fd), _ptr(out))
+    return out
+
+
+def lpt(cosmo, init_mesh, pos, a, lpt_order: int = 2, read_order: int = 2, grad_fd=np.inf, lap_fd=np.inf):
+    """First or second order LPT displacement and growth-time velocity at scale factor(s) `a`
+    (nbody.py:634-667).  `a` may be a scalar or an (N,1) array (light-cone)."""
+    init_mesh = torch.as_tensor(init_mesh)
+    if not init_mesh.is_complex():
+        init_mesh = rfftn(init_mesh)
+    force1 = pm_forces(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
+
+    def scal(x):
+        return float(x) if np.ndim(x) == 0 else _f32(np.asarray(x, dtype=np.float64))
+
+    dpos = scal(a2g(cosmo, a)) * force1
+    vel = force1
+    if lpt_order == 2:
+        force2 = pm_forces2(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
+        dpos = dpos - scal(a2g2(cosmo, a)) * force2
+        vel = vel - scal(a2dg2dg(cosmo, a)) * force2
+    return dpos, vel
+
+
+# ------------------------------------------------------------------------------------------------
+# growth and distance tables: host float64 (nbody.py:675-896); the RK4 integration runs in libmcpm.so
+growth_log10_amin: float = -3.
+growth_steps: int = 128
+dist_log10_amin: float = -3.
+dist_steps: int = 256
+
+
+def _cosmo_params(cosmo):
+    return [float(cosmo.Omega_m), float(cosmo.Omega_de), float(cosmo.Omega_k), float(cosmo.w0), float(cosmo.wa)]
+
+
+def _growth_cache(cosmo, log10_amin=growth_log10_amin, steps=growth_steps):
+    key = "background.growth_factor"
+    if key not in cosmo._workspace:
+        names = ["a", "g", "f", "h", "g2", "f2", "h2"]
+        arrs = [np.zeros(steps) for _ in names]
+        rc = lib.mcpm_growth_table(*_cosmo_params(cosmo), float(log10_amin), int(steps),
+                                   *[x.ctypes.data_as(C.POINTER(C.c_double)) for x in arrs])
+        check(rc, None, "mcpm_growth_table")
+        cosmo._workspace[key] = dict(zip(names, arrs))
+    return cosmo._workspace[key]
+
+
+def _interp(x, xp, fp):
+    return np.interp(np.asarray(x, dtype=np.float64), xp, fp)
+
+
+def a2g(cosmo, a):
+    c = _growth_cache(cosmo)
+    return _interp(a, c["a"], c["g"])
+
+
+def a2g2(cosmo, a):
+    c = _growth_cache(cosmo)
+    return _interp(a, c["a"], c["g2"]) * -3 / 7
+
+
+def a2f(cosmo, a):
+    c = _growth_cache(cosmo)
+    return _interp(a, c["a"], c["f"])
+
+
+def a2f2(cosmo, a):
+    c = _growth_cache(cosmo)
+    return _interp(a, c["a"], c["f2"])
+
+
+def a2dg2dg(cosmo, a):
+    g, g2, f, f2 = a2g(cosmo, a), a2g2(cosmo, a), a2f(cosmo, a), a2f2(cosmo, a)
+    return safe_div(g2 * f2, g * f)
+
+
+def g2a(cosmo, g):
+    c = _growth_cache(cosmo)
+    return _interp(g, c["g"], c["a"])
+
+
+def g2g2(cosmo, g):
+    c = _growth_cache(cosmo)
+    return _interp(g, c["g"], c["g2"]) * -3 / 7
+
+
+def g2f(cosmo, g):
+    c = _growth_cache(cosmo)
+    return _interp(g, c["g"], c["f"])
+
+
+def g2f2(cosmo, g):
+    c = _growth_cache(cosmo)
+    return _interp(g, c["g"], c["f2"])
+
+
+def g2dg2dg(cosmo, g):
+    g2, f, f2 = g2g2(cosmo, g), g2f(cosmo, g), g2f2(cosmo, g)
+    return safe_div(g2 * f2, g * f)
+
+
+def _dist_cache(cosmo, log10_amin=dist_log10_amin, steps=dist_steps):
+    key = "background.radial_comoving_distance"
+    if key not in cosmo._workspace:
+        a, chi = np.zeros(steps), np.zeros(steps)
+        rc = lib.mcpm_distance_table(*_cosmo_params(cosmo), float(log10_amin), int(steps),
+                                     a.ctypes.data_as(C.POINTER(C.c_double)), chi.ctypes.data_as(C.POINTER(C.c_double)))
+        check(rc, None, "mcpm_distance_table")
+        cosmo._workspace[key] = {"a": a, "chi": chi}
+    return cosmo._workspace[key]
+
+
+def a2chi(cosmo, a, log10_amin=dist_log10_amin, steps=dist_steps):
+    """Radial comoving distance in Mpc/h (nbody.py:817-859)."""
+    c = _dist_cache(cosmo, log10_amin, steps)
+    return np.clip(_interp(a, c["a"], c["chi"]), 0.0, None)
+
+
+def chi2a(cosmo, chi, log10_amin=dist_log10_amin, steps=dist_steps):
+    """nbody.py:862-884"""
+    c = _dist_cache(cosmo, log10_amin, steps)
+    return _interp(chi, c["chi"][::-1], c["a"][::-1])
+
+
+# ------------------------------------------------------------------------------------------------
+# BullFrog / FastPM
+def _Esqr(cosmo, a):
+    # jax_cosmo.background.Esqr (matter + curvature + w0-wa dark energy), the only background term alpha_fpm needs
+    a = np.asarray(a, dtype=np.float64)
+    eps = np.finfo(np.float32).eps
+    f_de = -3.0 * (1.0 + cosmo.w0) + 3.0 * cosmo.wa * ((a - 1.0) / np.log(a - eps) - 1.0)
+    return cosmo.Omega_m * a ** -3 + cosmo.Omega_k * a ** -2 + cosmo.Omega_de * a ** f_de
+
+
+def alpha_bf(cosmo, g0, dg):
+    """BullFrog growth-time integrator coefficient (closure at nbody.py:907-919)."""
+    g1, g2 = g0 + dg / 2, g0 + dg
+    d0, d2 = g2dg2dg(cosmo, g0), g2dg2dg(cosmo, g2)
+    lin = (g2g2(cosmo, g0) + d0 * dg / 2) / g1 - g1
+    return (d2 - lin) / (d0 - lin)
+
+
+def alpha_fpm(cosmo, g0, dg):
+    """FastPM growth-time integrator coefficient (closure at nbody.py:921-931)."""
+    g2 = g0 + dg
+    a0, a2 = g2a(cosmo, g0), g2a(cosmo, g2)
+    c0 = _Esqr(cosmo, a0) ** .5 * g0 * g2f(cosmo, g0) * a0 ** 2
+    c2 = _Esqr(cosmo, a2) ** .5 * g2 * g2f(cosmo, g2) * a2 ** 2
+    return c0 / c2
+
+
+_ALPHAS = {"bullfrog": alpha_bf, "fastpm": alpha_fpm}
+
+
+def bullfrog_vf(cosmo, dg, mesh_shape: tuple, paint_order: int = 2, paint_deconv=False, grad_fd=np.inf, lap_fd=np.inf,
+                integrator="bullfrog"):
+    """BullFrog vector field (nbody.py:902-959): state (pos, vel) -> ((new - old)/dg) after drift(dg/2),
+    kick, drift(dg/2).  `pos` may be an (N,3) array or a LatticePos."""
+    mesh_shape = tuple(int(s) for s in mesh_shape)
+    alpha_fn = _ALPHAS[integrator]
+
+    def vector_field(g0, state, args=None):
+        pos, vel = state
+        lat = isinstance(pos, LatticePos)
+        x = pos.disp if lat else _f32(pos)
+        v = _f32(vel)
+        x1 = x + v * (dg / 2)
+        p1 = LatticePos(x1, pos.mesh_shape, pos.ptcl_shape) if lat else x1
+        forces = pm_forces(p1, mesh_shape, paint_order, paint_deconv=paint_deconv, grad_fd=grad_fd, lap_fd=lap_fd)
+        alpha = float(alpha_fn(cosmo, g0, dg))
+        v1 = alpha * v + (1 - alpha) / (g0 + dg / 2) * forces
+        x2 = x1 + v1 * (dg / 2)
+        return (x2 - x) / dg, (v1 - v) / dg
+
+    return vector_field
+
+
+class NbodyCtx:
+    """What `nbody_bf_vjp` needs: the plan, host scalars and the device checkpoint buffer."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _step_scalars(cosmo, a0, a1, n_steps, integrator):
+    """Host float64 scalars of the Euler/BullFrog loop, with diffrax's accumulated time (nbody.py:974-976, :999)."""
+    g0, g1 = float(a2g(cosmo, a0)), float(a2g(cosmo, a1))
+    dg = (g1 - g0) / n_steps
+    alpha_fn = _ALPHAS[integrator]
+    t, alphas, betas = g0, [], []
+    for _ in range(n_steps):
+        al = float(alpha_fn(cosmo, t, dg))
+        alphas.append(al)
+        betas.append((1 - al) / (t + dg / 2))
+        t = min(t + dg, g1)
+    lpt_s = [float(a2g(cosmo, a0)), float(a2g2(cosmo, a0)), float(a2dg2dg(cosmo, a0))]
+    return dg, np.array(alphas), np.array(betas), np.array(lpt_s)
+
+
+def _dptr(x):
+    return x.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 2, lpt_order: int = 2,
+             paint_deconv=False, grad_fd=np.inf, lap_fd=np.inf, snapshots=None, fn=None,
+             integrator="bullfrog", return_ctx=False, lattice_out=False):
+    """N-body simulation with the BullFrog solver (nbody.py:967-1002).
+
+    `pos` must be the regular lattice (`bricks.regular_pos(mesh_shape, ptcl_shape)`, as at model.py:738) given
+    as a LatticePos or as its (N,3) array.  Returns (pos, vel) with a leading snapshot axis of 1 like
+    diffrax's SaveAt(t1=True); with `lattice_out=True`, pos is a LatticePos (no leading axis).
+    `integrator='fastpm'` selects the alpha_fpm coefficient (nbody.py:921-931).
+    `return_ctx=True` also returns the context for `nbody_bf_vjp` (checkpoints are then kept).
+    """
+    if paint_deconv or grad_fd != np.inf or lap_fd != np.inf:
+        raise NotImplementedError("nbody_bf runs the model's configuration: paint_deconv=False, spectral kernels")
+    if not (snapshots is None or (isinstance(snapshots, int) and snapshots <= 1)):
+        raise NotImplementedError("intermediate snapshots are not implemented")
+    n_steps = int(n_steps)
+    spec = _c64(init_mesh)
+    mesh_shape = ch2rshape(spec.shape)
+    if isinstance(pos, LatticePos):
+        ptcl_shape = pos.ptcl_shape
+        if float(pos.disp.abs().max()) != 0.0:
+            raise ValueError("nbody_bf starts from the undisplaced lattice")
+    else:
+        ptcl_shape = _infer_lattice(pos, mesh_shape)
+    plan = get_plan(mesh_shape, ptcl_shape)
+    dg, alphas, betas, lpt_s = _step_scalars(cosmo, a0, a1, n_steps, integrator)
+    N = plan.N
+    x = torch.empty((N, 3), dtype=torch.float32, device=spec.device)
+    v = torch.empty((N, 3), dtype=torch.float32, device=spec.device)
+    ckpt = None
+    if return_ctx:
+        nck = lib.mcpm_nbody_ckpt_floats(plan.h, n_steps, lpt_order)
+        ckpt = torch.empty((nck,), dtype=torch.float32, device=spec.device)
+    plan.call("mcpm_nbody_bf_f32", _ptr(spec), n_steps, _dptr(alphas), _dptr(betas), float(dg), _dptr(lpt_s),
+              int(lpt_order), int(paint_order), _ptr(x), _ptr(v), _ptr(ckpt))
+    lp = LatticePos(x, mesh_shape, ptcl_shape)
+    out = (lp, v) if lattice_out else (lp.to_absolute()[None], v[None])
+    if return_ctx:
+        ctx = NbodyCtx(plan=plan, init_mesh=spec, n_steps=n_steps, dg=dg, alphas=alphas, betas=betas, lpt_s=lpt_s,
+                       lpt_order=int(lpt_order), paint_order=int(paint_order), ckpt=ckpt, cosmo=cosmo, a0=a0, a1=a1,
+                       integrator=integrator)
+        return out, ctx
+    return out
+
+
+def nbody_bf_vjp(ctx, pos_bar, vel_bar):
+    """Reverse sweep of nbody_bf.  `pos_bar`, `vel_bar`: cotangents of the final (pos, vel), shape (N,3) or
+    (1,N,3).  Returns (init_mesh_bar, scalar_bars): init_mesh_bar is a complex64 half-spectrum in the
+    real-pair convention dL = Re(sum(conj(bar) * d init_mesh)) (the conjugate of jax.grad's); scalar_bars is a
+    dict of float64 cotangents of the host scalars (alpha_i, beta_i per step, and the LPT growth scalars)."""
+    plan, n = ctx.plan, ctx.n_steps
+    xb = _f32(pos_bar).reshape(-1, 3)
+    vb = _f32(vel_bar).reshape(-1, 3)
+    if xb.shape[0] != plan.N or vb.shape[0] != plan.N:
+        raise ValueError("cotangent shape does not match the particle count")
+    out = torch.empty(tuple(ctx.init_mesh.shape), dtype=torch.complex64, device=xb.device)
+    sb = np.zeros(2 * n + 3)
+    plan.call("mcpm_nbody_bf_vjp_f32", _ptr(ctx.init_mesh), n, _dptr(ctx.alphas), _dptr(ctx.betas), float(ctx.dg),
+              _dptr(ctx.lpt_s), ctx.lpt_order, ctx.paint_order, _ptr(ctx.ckpt), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
+    bars = {"alpha": sb[:n].copy(), "beta": sb[n:2 * n].copy(), "g": sb[2 * n], "g2": sb[2 * n + 1], "dg2dg": sb[2 * n + 2]}
+    return out, bars
+
+
+def lpt_vjp(cosmo, init_mesh, pos, a, dpos_bar, vel_bar, lpt_order: int = 2):
+    """VJP of `lpt(..., read_order=1)` on the regular lattice w.r.t. init_mesh, scalar `a` only.
+    Implemented as the zero-step limit of the nbody reverse sweep's LPT stage."""
+    raise NotImplementedError("use nbody_bf_vjp; a standalone lpt_vjp entry point is scheduled next")
+
+
+def _infer_lattice(pos, mesh_shape):
+    """Particle-lattice shape of an (N,3) regular_pos array (bricks.py:593-603): checks it IS that lattice."""
+    t = torch.as_tensor(pos)
+    n = t.shape[0]
+    if n == int(np.prod(mesh_shape)):
+        ptcl = tuple(mesh_shape)
+    else:
+        # number of distinct values per axis from the strides of the meshgrid ordering
+        t64 = t.to(torch.float64)
+        pz = int((t64[:, 2] == t64[0, 2]).nonzero()[1]) if n > 1 else 1
+        py = int((t64[::pz, 1] == t64[0, 1]).nonzero()[1]) if n > pz else 1
+        ptcl = (n // (py * pz), py, pz)
+    lat = LatticePos.regular(mesh_shape, ptcl).lattice(torch.float64)
+    if lat.shape[0] != n or not torch.allclose(lat, t.to(lat.device, torch.float64), atol=1e-6):
+        raise ValueError("nbody_bf needs pos = regular_pos(mesh_shape, ptcl_shape) (the reference's call, model.py:738)")
+    return ptcl

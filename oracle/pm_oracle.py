@@ -270,7 +270,7 @@ def irfftn_vjp(real_bar):
 def rfftn_vjp(spec_bar, shape_r):
     """X = rfftn(rho), rho real  ->  rho_bar = M * irfftn(X_bar / w)."""
     M = int(np.prod(shape_r))
-    return np.fft.irfftn(spec_bar / _zweights(shape_r), s=shape_r) * M
+    return np.fft.irfftn(spec_bar / _zweights(shape_r), s=shape_r, axes=tuple(range(len(shape_r)))) * M
 
 
 # --------------------------------------------------------------------------- forces

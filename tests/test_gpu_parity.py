@@ -1,0 +1,288 @@
+"""GPU parity tests: the HIP path (through the C ABI, via montecosmo_amd.nbody) against the float64 oracle
+on the same seeded inputs.  Tolerances: integer work (cell indices) bit-exact; floating point fields
+relative L2 <= 1e-5 (north-star tolerance for the final density), tighter where fp32 round-off allows."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pm_oracle as o, background as obg  # noqa: E402  (checker only)
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    dt = np.complex128 if (np.iscomplexobj(a) or np.iscomplexobj(b)) else np.float64
+    a, b = a.astype(dt), b.astype(dt)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def nb(gpu):
+    from montecosmo_amd import nbody
+    return nbody
+
+
+def random_pos(n, N, seed, spread=3.0):
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-spread * n, spread * n, (N, 3)).astype(np.float32)
+    # exact integers, half-integers and tiny negatives exercise floor / round-half-even / wrap
+    pos[:64] = np.round(pos[:64])
+    pos[64:128] = np.round(pos[64:128]) + 0.5
+    pos[128:160] = -1e-7
+    return pos
+
+
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("shape", [(16, 16, 16), (12, 20, 6), (64, 64, 64)])
+def test_cell_index_bit_exact_absolute(nb, order, shape):
+    pos = random_pos(max(shape), 50000, 1)
+    got = to_np(nb.cell_index(pos, shape, order))
+    want = o.cell_index(pos.astype(np.float64), shape, order)
+    assert got.dtype == np.int16
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("mesh,ptcl", [((32, 32, 32), None), ((16, 16, 16), (8, 8, 8)), ((24, 16, 12), (16, 16, 16))])
+def test_cell_index_bit_exact_lattice(nb, order, mesh, ptcl):
+    ptcl_ = mesh if ptcl is None else ptcl
+    N = int(np.prod(ptcl_))
+    rng = np.random.default_rng(2)
+    disp = (rng.standard_normal((N, 3)) * 3).astype(np.float32)
+    disp[:32] = 0.0
+    disp[32:64] = 0.5
+    disp[64:96] = -1e-9
+    lp = nb.LatticePos(disp, mesh, ptcl)
+    got = to_np(nb.cell_index(lp, mesh, order))
+    # the oracle sees the same positions: lattice point (exact rational, power-of-two ratios here) + float32 disp
+    pos64 = o.regular_pos(mesh, ptcl_) + disp.astype(np.float64)
+    if ptcl is not None and any(m % p for m, p in zip(mesh, ptcl_)):
+        # non-integer lattice spacing: the kernel adds fraction and displacement in float32
+        q = o.regular_pos(mesh, ptcl_)
+        qi = np.floor(q)
+        pos64 = qi + ((q - qi).astype(np.float32) + disp).astype(np.float64)
+    want = o.cell_index(pos64, mesh, order)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_paint_read_absolute(nb, order):
+    shape = (16, 24, 8)
+    pos = random_pos(24, 20000, 3, spread=1.5)
+    rng = np.random.default_rng(4)
+    w = rng.standard_normal(len(pos)).astype(np.float32)
+    got = to_np(nb.paint(pos, shape, w, order))
+    want = o.paint(pos.astype(np.float64), shape, w.astype(np.float64), order)
+    assert rel_l2(got, want) < 2e-6
+    got1 = to_np(nb.paint(pos, shape, 1., order))
+    assert abs(got1.sum() / len(pos) - 1) < 1e-6          # bricks.py:1101-1102 invariant
+    mesh = rng.standard_normal(shape).astype(np.float32)
+    r = to_np(nb.read(pos, mesh, order))
+    assert rel_l2(r, o.read(pos.astype(np.float64), mesh.astype(np.float64), order)) < 2e-6
+
+
+@pytest.mark.parametrize("n,halo,sigma", [(32, 4, 1.0), (64, 2, 1.5), (64, 4, 2.5), (16, 4, 1.0), (48, 4, 1.0)])
+def test_paint_tiled_lattice(nb, n, halo, sigma):
+    """LDS-tiled paint (incl. its outlier path, sigma ~ halo) against the oracle; also the weighted form."""
+    import ctypes as C
+    shape = (n, n, n)
+    N = n ** 3
+    rng = np.random.default_rng(5)
+    disp = (rng.standard_normal((N, 3)) * sigma).astype(np.float32)
+    disp[:100] *= 8.0   # far outliers, wrapping several tiles
+    lp = nb.LatticePos(disp, shape)
+    plan = nb.get_plan(shape)
+    plan.call("mcpm_plan_set_halo", halo)
+    pos64 = o.regular_pos(shape) + disp.astype(np.float64)
+    got = to_np(nb.paint(lp, shape))
+    want = o.paint(pos64, shape)
+    assert rel_l2(got, want) < 2e-6
+    assert abs(got.sum() / N - 1) < 1e-6
+    nout = plan.last_outliers()
+    expect_out = int(np.any((np.floor(disp) < -halo) | (np.floor(disp) > halo), axis=1).sum())
+    if n % 16 == 0:
+        assert nout == expect_out
+    w = rng.standard_normal(N).astype(np.float32)
+    gotw = to_np(nb.paint(lp, shape, w))
+    assert rel_l2(gotw, o.paint(pos64, shape, w.astype(np.float64))) < 2e-6
+    plan.call("mcpm_plan_set_halo", 4)
+
+
+def test_paint_regular_grid_is_constant(nb):
+    shape = (32, 32, 32)
+    got = to_np(nb.paint(nb.LatticePos.regular(shape), shape))
+    assert np.array_equal(got, np.ones(shape, dtype=np.float32))
+    got = to_np(nb.paint(nb.LatticePos.regular(shape, (16, 16, 16)), shape, order=1))
+    assert got.sum() == 16 ** 3
+
+
+def test_fft_matches_numpy(nb):
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((16, 24, 32)).astype(np.float32)
+    X = to_np(nb.rfftn(x))
+    assert rel_l2(X, np.fft.rfftn(x.astype(np.float64))) < 1e-6
+    assert rel_l2(to_np(nb.irfftn(X)), x) < 1e-6
+
+
+@pytest.mark.parametrize("fd", [np.inf, 2, 4])
+def test_pm_forces_spectrum_and_hermitian_projection(nb, fd):
+    shape = (16, 16, 16)
+    rng = np.random.default_rng(7)
+    spec = np.fft.rfftn(rng.standard_normal(shape))
+    pos = random_pos(16, 5000, 8, spread=1.0)
+    got = to_np(nb.pm_forces(pos, spec.astype(np.complex64), 2, grad_fd=fd, lap_fd=fd))
+    want = o.pm_forces(pos.astype(np.float64), spec, 2, grad_fd=fd, lap_fd=fd)
+    assert rel_l2(got, want) < 1e-5
+    got1 = to_np(nb.pm_forces(pos, spec.astype(np.complex64), 1))
+    assert rel_l2(got1, o.pm_forces(pos.astype(np.float64), spec, 1)) < 1e-5
+
+
+def test_pm_forces_painted_and_pm_forces2(nb):
+    shape = (32, 32, 32)
+    N = 32 ** 3
+    rng = np.random.default_rng(9)
+    disp = (rng.standard_normal((N, 3)) * 1.0).astype(np.float32)
+    lp = nb.LatticePos(disp, shape)
+    pos64 = o.regular_pos(shape) + disp.astype(np.float64)
+    got = to_np(nb.pm_forces(lp, shape, 2))
+    assert rel_l2(got, o.pm_forces(pos64, shape, 2)) < 1e-5
+    got = to_np(nb.pm_forces(lp, shape, 2, paint_deconv=True, kcut=2.0))
+    assert rel_l2(got, o.pm_forces(pos64, shape, 2, paint_deconv=True, kcut=2.0)) < 1e-5
+    spec = np.fft.rfftn(rng.standard_normal(shape)) * 0.05
+    got2 = to_np(nb.pm_forces2(lp, spec.astype(np.complex64), 2))
+    assert rel_l2(got2, o.pm_forces2(pos64, spec.astype(np.complex64).astype(np.complex128), 2)) < 1e-5
+
+
+def _ics(n, rms=1.0, seed=0):
+    from montecosmo_amd import synth
+    return synth.init_mesh(n, seed=seed, rms_disp=rms)
+
+
+@pytest.mark.parametrize("lpt_order", [1, 2])
+def test_lpt(nb, lpt_order):
+    from montecosmo_amd import bricks
+    n = 32
+    shape = (n, n, n)
+    spec = _ics(n)
+    pos = bricks.regular_pos(shape)
+    cos_o, cos_g = obg.Planck18(), bricks.Planck18()
+    dpos, vel = nb.lpt(cos_g, spec, pos, a=0.5, lpt_order=lpt_order, read_order=1)
+    dpos_o, vel_o = o.lpt(cos_o, spec.astype(np.complex128), pos, 0.5, lpt_order=lpt_order, read_order=1)
+    assert rel_l2(to_np(dpos), dpos_o) < 1e-5
+    assert rel_l2(to_np(vel), vel_o) < 1e-5
+
+
+def test_growth_and_coefficients(nb):
+    from montecosmo_amd import bricks
+    cos_o, cos_g = obg.Planck18(), bricks.Planck18()
+    a = np.linspace(0.0, 1.0, 23)
+    for name in ["a2g", "a2g2", "a2f", "a2f2", "a2dg2dg", "a2chi"]:
+        assert np.allclose(getattr(nb, name)(cos_g, a), getattr(o, name)(cos_o, a), rtol=1e-10, atol=1e-13), name
+    g = np.linspace(0.002, 1.0, 17)
+    for name in ["g2a", "g2g2", "g2f", "g2f2", "g2dg2dg"]:
+        assert np.allclose(getattr(nb, name)(cos_g, g), getattr(o, name)(cos_o, g), rtol=1e-10, atol=1e-13), name
+    for g0 in (0.01, 0.3, 0.8):
+        assert np.isclose(nb.alpha_bf(cos_g, g0, 0.1), o.alpha_bf(cos_o, g0, 0.1), rtol=1e-9)
+        assert np.isclose(nb.alpha_fpm(cos_g, g0, 0.1), o.alpha_fpm(cos_o, g0, 0.1), rtol=1e-9)
+
+
+@pytest.mark.parametrize("n,n_steps,integrator", [(32, 5, "bullfrog"), (64, 10, "bullfrog"), (32, 4, "fastpm")])
+def test_nbody_bf_final_density(nb, n, n_steps, integrator):
+    """North-star gate: final density within 1e-5 relative L2 of the float64 oracle; cell indices of the final
+    particles identical except where a particle sits within fp32 round-off of a cell face."""
+    from montecosmo_amd import bricks
+    shape = (n, n, n)
+    spec = _ics(n, rms=1.5)
+    pos = bricks.regular_pos(shape)
+    cos_o, cos_g = obg.Planck18(), bricks.Planck18()
+    alpha_fn = o.alpha_bf if integrator == "bullfrog" else o.alpha_fpm
+    (p_o, v_o) = o.nbody_bf(cos_o, spec.astype(np.complex128), pos, 0., 1., n_steps, alpha_fn=alpha_fn)
+    lp, vel = nb.nbody_bf(cos_g, spec, pos, a0=0., a1=1., n_steps=n_steps, integrator=integrator, lattice_out=True)
+    p_g = to_np(lp.to_absolute())
+    assert rel_l2(p_g - pos, p_o[0] - pos) < 1e-5
+    assert rel_l2(to_np(vel), v_o[0]) < 1e-5
+    dens_g = to_np(nb.paint(lp, shape))
+    dens_o = o.paint(p_o[0], shape)
+    assert rel_l2(dens_g, dens_o) < 1e-5
+    idx_g = to_np(nb.cell_index(lp, shape))
+    idx_o = o.cell_index(p_o[0], shape)
+    mismatch = np.any(idx_g != idx_o, axis=1).mean()
+    assert mismatch < 1e-4
+    # default return structure: absolute positions with a leading snapshot axis (nbody.py:988-989, :1000)
+    p1, v1 = nb.nbody_bf(cos_g, spec, pos, a0=0., a1=1., n_steps=n_steps, integrator=integrator)
+    assert tuple(p1.shape) == (1, n ** 3, 3) and tuple(v1.shape) == (1, n ** 3, 3)
+
+
+def test_bullfrog_vf_matches_oracle(nb):
+    from montecosmo_amd import bricks
+    n = 16
+    shape = (n, n, n)
+    rng = np.random.default_rng(11)
+    disp = rng.standard_normal((n ** 3, 3)).astype(np.float32)
+    vel = rng.standard_normal((n ** 3, 3)).astype(np.float32)
+    cos_o, cos_g = obg.Planck18(), bricks.Planck18()
+    vf_g = nb.bullfrog_vf(cos_g, 0.1, shape)
+    vf_o = o.bullfrog_vf(cos_o, 0.1, shape)
+    dx, dv = vf_g(0.3, (nb.LatticePos(disp, shape), vel))
+    pos64 = o.regular_pos(shape) + disp.astype(np.float64)
+    dx_o, dv_o = vf_o(0.3, (pos64, vel.astype(np.float64)))
+    assert rel_l2(to_np(dx), dx_o) < 1e-5
+    assert rel_l2(to_np(dv), dv_o) < 1e-5
+
+
+def test_paint_read_vjp(nb):
+    shape = (16, 16, 16)
+    rng = np.random.default_rng(12)
+    N = 4000
+    pos = rng.uniform(-20, 40, (N, 3)).astype(np.float32)
+    w = rng.standard_normal(N).astype(np.float32)
+    mb = rng.standard_normal(shape).astype(np.float32)
+    pb, wb = nb.paint_vjp(pos, shape, w, mb)
+    pb_o, wb_o = o.paint_vjp(pos.astype(np.float64), shape, w.astype(np.float64), mb.astype(np.float64))
+    assert rel_l2(to_np(pb), pb_o) < 1e-5 and rel_l2(to_np(wb), wb_o) < 1e-5
+    ob = rng.standard_normal(N).astype(np.float32)
+    pb, meshb = nb.read_vjp(pos, mb, ob)
+    pb_o, meshb_o = o.read_vjp(pos.astype(np.float64), mb.astype(np.float64), ob.astype(np.float64))
+    assert rel_l2(to_np(pb), pb_o) < 1e-5 and rel_l2(to_np(meshb), meshb_o) < 1e-5
+
+
+@pytest.mark.parametrize("n,n_steps,lpt_order,integrator", [(16, 3, 2, "bullfrog"), (32, 5, 2, "bullfrog"), (32, 3, 1, "fastpm")])
+def test_nbody_bf_vjp(nb, n, n_steps, lpt_order, integrator):
+    """Hand-written reverse sweep against the oracle's (finite-difference-validated) VJP."""
+    from montecosmo_amd import bricks
+    shape = (n, n, n)
+    spec = _ics(n, rms=1.0)
+    pos = bricks.regular_pos(shape)
+    cos_o, cos_g = obg.Planck18(), bricks.Planck18()
+    rng = np.random.default_rng(1)
+    xb = rng.standard_normal((n ** 3, 3)).astype(np.float32)
+    vb = rng.standard_normal((n ** 3, 3)).astype(np.float32)
+    alpha_fn = o.alpha_bf if integrator == "bullfrog" else o.alpha_fpm
+    mb_o, sb_o = o.nbody_bf_vjp(cos_o, spec.astype(np.complex128), pos, xb.astype(np.float64), vb.astype(np.float64),
+                                0.1, 1., n_steps, lpt_order=lpt_order, alpha_fn=alpha_fn)
+    (_, _), ctx = nb.nbody_bf(cos_g, spec, pos, a0=0.1, a1=1., n_steps=n_steps, lpt_order=lpt_order,
+                              integrator=integrator, return_ctx=True)
+    mb_g, sb_g = nb.nbody_bf_vjp(ctx, xb, vb)
+    mb_g = to_np(mb_g)
+    assert rel_l2(mb_g, mb_o) < 1e-4
+    # directional derivative along a Hermitian-consistent direction
+    d = np.fft.rfftn(rng.standard_normal(shape))
+    assert np.isclose(np.sum((np.conj(mb_g) * d).real), np.sum((np.conj(mb_o) * d).real), rtol=1e-4)
+    assert np.allclose(sb_g["alpha"], sb_o["alpha"], rtol=2e-4, atol=1e-3 * np.abs(sb_o["alpha"]).max())
+    assert np.allclose(sb_g["beta"], sb_o["beta"], rtol=2e-4, atol=1e-3 * np.abs(sb_o["beta"]).max())
+    for k in ("g", "g2", "dg2dg"):
+        assert np.isclose(sb_g[k], sb_o[k], rtol=1e-3, atol=1e-3 * abs(sb_o["g"])), k
+
+
+def test_errors_are_loud(nb):
+    from montecosmo_amd._lib import McpmError
+    with pytest.raises(McpmError):
+        nb.Plan((16, 16, 15))          # odd nz
+    with pytest.raises(NotImplementedError):
+        nb.paint(np.zeros((4, 3), np.float32), (8, 8, 8), order=3)
+    with pytest.raises(ValueError):
+        nb.invlaplace_hat(nb.rfftk((8, 8, 8)), fd_order=3)
