@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Benchmark of the PM hot path on MI355X (contract: see DESIGN.md "Measurement").
+
+Metric (BASELINE.json): PM forward+adjoint steps per second.  One "step" = one BullFrog drift-kick-drift
+step (CIC paint -> R2C -> k-space -> 3 C2R -> fused read+kick+drift) plus its hand-written adjoint, fp32,
+N = n^3 particles on an n^3 mesh, synthetic inputs of SURVEY.md 8(d).  The timed region runs K forward steps
+(writing checkpoints) followed by their K adjoint steps, with every input resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mesh n]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU.  Until the slab-decomposed FFT lands the ranks
+run independent replicas (the reference's own multi-device mode: independent chains, script.py:13-20), so
+scaling is "weak" and no collective is on the data path.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+B_PER_CELL_CYCLE = 100.0         # paint -> Poisson -> read force cycle
+B_PER_CELL_STEP = 492.0          # forward + adjoint DKD step
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mesh", type=int, default=int(os.environ.get("MCPM_BENCH_MESH", "512")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-mesh", type=int, default=128)
+    return ap.parse_args()
+
+
+class Runner:
+    """K forward steps + K adjoint steps through the step-level C ABI, on pre-allocated HBM buffers."""
+
+    def __init__(self, n, K, device):
+        from montecosmo_amd import nbody, bricks, synth
+        self.nbody = nbody
+        self.n, self.K = n, K
+        shape = (n, n, n)
+        self.plan = nbody.get_plan(shape)
+        N, M = self.plan.N, self.plan.M
+        self.N, self.M = N, M
+        cosmo = bricks.Planck18()
+        self.dg, self.alphas, self.betas, self.lpt_s = nbody._step_scalars(cosmo, 0.0, 1.0, K, "bullfrog")
+        spec = synth.init_mesh(n, seed=0, rms_disp=2.0)
+        self.spec = torch.from_numpy(spec).to(device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.states = torch.empty((K + 1, 2, N, 3), **f32)       # (x'_i, v_i) checkpoints
+        self.fmesh = torch.empty((K, 3, n, n, n), **f32)          # force meshes per step
+        rng = np.random.default_rng(1)
+        self.pos_bar = torch.from_numpy(rng.standard_normal((N, 3), dtype=np.float32)).to(device)
+        self.vel_bar = torch.from_numpy(rng.standard_normal((N, 3), dtype=np.float32)).to(device)
+        self.xb = torch.empty((N, 3), **f32)
+        self.vb = torch.empty((N, 3), **f32)
+        self.sbar = torch.zeros((2 * K,), dtype=torch.float64, device=device)
+        self.init_state()
+
+    def p(self, t):
+        return C.c_void_p(t.data_ptr())
+
+    def init_state(self):
+        """LPT initial conditions + first half drift (untimed set-up of the step loop)."""
+        x, v = self.states[0, 0], self.states[0, 1]
+        self.plan.call("mcpm_lpt_f32", self.p(self.spec), 2, float(self.lpt_s[0]), float(self.lpt_s[1]), float(self.lpt_s[2]),
+                       0, 0, self.p(x), self.p(v))
+        self.plan.call("mcpm_drift_f32", self.p(x), self.p(v), self.N, float(self.dg / 2), self.p(x))
+
+    def forward(self, steps):
+        K = self.K
+        for i in range(steps):
+            tau = self.dg / 2 if i == K - 1 else self.dg
+            self.plan.call("mcpm_bullfrog_step_f32", self.p(self.states[i, 0]), self.p(self.states[i, 1]),
+                           float(self.alphas[i]), float(self.betas[i]), float(tau), 2, self.p(self.fmesh[i]),
+                           self.p(self.states[i + 1, 0]), self.p(self.states[i + 1, 1]))
+
+    def backward(self, steps):
+        K = self.K
+        self.xb.copy_(self.pos_bar)
+        self.vb.copy_(self.vel_bar)
+        for i in reversed(range(steps)):
+            tau = self.dg / 2 if i == K - 1 else self.dg
+            self.plan.call("mcpm_bullfrog_step_vjp_f32", self.p(self.states[i, 0]), self.p(self.states[i, 1]),
+                           self.p(self.fmesh[i]), float(self.alphas[i]), float(self.betas[i]), float(tau), 2,
+                           self.p(self.xb), self.p(self.vb), C.c_void_p(self.sbar.data_ptr() + 8 * i),
+                           C.c_void_p(self.sbar.data_ptr() + 8 * (K + i)))
+
+    def run(self, steps):
+        self.forward(steps)
+        self.backward(steps)
+
+    def profile(self):
+        """Per-stage HIP-event timings of one more pass over the same K steps (events on the plan's stream)."""
+        from montecosmo_amd._lib import lib
+        self.plan.call("mcpm_plan_profile", 1)
+        self.forward(self.K)
+        fwd = self._read_profile()
+        self.backward(self.K)
+        bwd = self._read_profile()
+        self.plan.call("mcpm_plan_profile", 0)
+        names = [lib.mcpm_stage_name(i).decode() for i in range(len(fwd[0]))]
+        return names, fwd, bwd
+
+    def _read_profile(self):
+        from montecosmo_amd._lib import lib
+        nmax = 16
+        ms = (C.c_double * nmax)()
+        by = (C.c_double * nmax)()
+        calls = (C.c_int64 * nmax)()
+        ns = lib.mcpm_plan_profile_read(self.plan.h, nmax, ms, by, calls)
+        assert ns > 0
+        return list(ms)[:ns], list(by)[:ns], list(calls)[:ns]
+
+
+def cpu_baseline(n_cpu, n_gpu):
+    """The numpy float64 oracle (a port of the reference's algorithm; the JAX reference itself cannot run here)
+    timed on one forward+adjoint DKD step at n_cpu^3, scaled by cell count to the benchmark mesh."""
+    from oracle import pm_oracle as o
+    shape = (n_cpu,) * 3
+    N = n_cpu ** 3
+    rng = np.random.default_rng(0)
+    pos = o.regular_pos(shape) + rng.standard_normal((N, 3))
+    vel = rng.standard_normal((N, 3))
+    xb, vb = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
+    t0 = time.perf_counter()
+    o.dkd_vjp(pos, vel, xb, vb, 0.1, 0.5, 0.3, shape)
+    dt = time.perf_counter() - t0
+    scale = (n_gpu / n_cpu) ** 3
+    return {"value": 1.0 / (dt * scale), "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": f"1 forward+adjoint DKD step of the numpy float64 oracle at {n_cpu}^3 took {dt:.2f} s on 1 thread "
+                      f"(host has {os.cpu_count()} cores); scaled by cell count x{scale:.0f} to {n_gpu}^3"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group(backend="nccl", device_id=device)
+    K, W, n = args.steps, args.warmup, args.mesh
+
+    r = Runner(n, K, device)
+    w = W
+    while w > 0:                       # W untimed warm-up steps (rocFFT plans, code objects, caches)
+        r.run(min(w, K))
+        w -= min(w, K)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    r.run(K)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        M = float(n) ** 3
+        steps_per_s = world * K / dt
+        names, fwd, bwd = r.profile()
+        stages = {}
+        for i, nm in enumerate(names):
+            ms = fwd[0][i] + bwd[0][i]
+            calls = fwd[2][i] + bwd[2][i]
+            by = fwd[1][i] + bwd[1][i]
+            if calls:
+                stages[nm] = {"ms_total": round(ms, 3), "launches": calls, "ms_per_launch": round(ms / calls, 4),
+                              "algorithmic_GBps": round(by / (ms * 1e-3) / 1e9, 1)}
+        dom = max(stages, key=lambda k: stages[k]["ms_total"])
+        fwd_ms = sum(fwd[0])
+        bwd_ms = sum(bwd[0])
+        # force cycle = paint + R2C + k-space + 3 C2R + read(+kick+drift) of the forward pass
+        cyc_ms = sum(fwd[0][names.index(k)] for k in ("paint", "fft_r2c", "kspace", "fft_c2r", "kick_drift")) / K
+        step_ms = (fwd_ms + bwd_ms) / K
+        out = {
+            "metric": "PM forward+adjoint steps/sec", "value": round(steps_per_s, 3), "unit": "steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n}^3 mesh, {n}^3 particles, {K}-step BullFrog forward+VJP, CIC, 2LPT start (untimed), "
+                                   f"rms displacement 2 cells; " + ("single GPU" if world == 1 else f"{world} independent replicas"),
+                       "mesh": n, "n_steps": K, "parallelism": "replicas" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(stages[dom]["algorithmic_GBps"] / HBM_PEAK_GBS, 4), "traffic": None},
+            "force_cycle": {"ms": round(cyc_ms, 4), "algorithmic_GBps": round(B_PER_CELL_CYCLE * M / (cyc_ms * 1e-3) / 1e9, 1),
+                            "frac_of_hbm_peak": round(B_PER_CELL_CYCLE * M / (cyc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "fwd_adj_step": {"ms_events": round(step_ms, 4), "algorithmic_GBps": round(B_PER_CELL_STEP * M / (step_ms * 1e-3) / 1e9, 1),
+                             "frac_of_hbm_peak": round(B_PER_CELL_STEP * M / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "stages": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_mesh, n)
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,14 @@ int mcpm_plan_last_outliers(mcpm_plan *plan, int64_t *count);
 /* Tuning knob: halo radius (cells) of the LDS-tiled paint; displacements beyond it take the outlier path. */
 int mcpm_plan_set_halo(mcpm_plan *plan, int halo);
 
+/* Optional per-stage profile: HIP events on the plan's stream around every leaf stage (paint, FFTs, k-space,
+   read, fused particle kernels).  mcpm_plan_profile_read synchronises, fills up to nmax entries of
+   accumulated milliseconds / algorithmic bytes (SURVEY.md 8d accounting) / launch counts per stage, resets the
+   record and returns the number of stages (negative on error).  mcpm_stage_name(i) names stage i. */
+int mcpm_plan_profile(mcpm_plan *plan, int enable);
+int mcpm_plan_profile_read(mcpm_plan *plan, int nmax, double *ms, double *bytes, int64_t *calls);
+const char *mcpm_stage_name(int stage);
+
 /* ---- FFT (replaces jnp.fft.rfftn / irfftn at nbody.py:589,603,620,627,630) ------------------ */
 int mcpm_fft_r2c(mcpm_plan *plan, const float *real, float *spec, int batch);
 /* Unnormalised (M x irfftn); `spec` is destroyed. */
@@ -135,6 +143,16 @@ int mcpm_kick_drift_f32(mcpm_plan *plan, const float *pos_in, const float *vel_i
                         float *vel_out);
 /* lpt (nbody.py:634-667) on the plan's particle lattice, read_order = 1, scalar a:
    dpos = g F1 - g2 F2, vel = F1 - dg2dg F2 (lpt_order 2) from the half-spectrum init_mesh. */
+/* One BullFrog/FastPM step in the fused form x' -> paint -> forces -> v1 = alpha v + beta F(x'), x1 = x' + v1 tau
+   (kick nbody.py:933-938 between the two half drifts nbody.py:946-950, adjacent half drifts merged).
+   force_meshes (3 meshes, may be NULL -> plan scratch) receives the step's force meshes for the adjoint. */
+int mcpm_bullfrog_step_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in, double alpha, double beta,
+                           double tau, int paint_order, float *force_meshes, float *pos_out, float *vel_out);
+/* Adjoint of that step: pos_bar / vel_bar (cotangents of the step's outputs) are updated in place to the
+   cotangents of its inputs; alpha_bar / beta_bar are DEVICE double accumulators (may be NULL). */
+int mcpm_bullfrog_step_vjp_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in, const float *force_meshes,
+                               double alpha, double beta, double tau, int paint_order, float *pos_bar,
+                               float *vel_bar, double *alpha_bar, double *beta_bar);
 int mcpm_lpt_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg,
                  int lap_fd, int grad_fd, float *dpos, float *vel);
 /* nbody_bf (nbody.py:967-1002), snapshots=None: LPT start at a0 then n_steps drift-kick-drift steps of size

@@ -46,6 +46,11 @@ SIGNATURES = {
     "mcpm_drift_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_float, _f32p]),
     "mcpm_kick_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_float, C.c_float, _f32p]),
     "mcpm_kick_drift_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_float, C.c_float, C.c_float, _f32p, _f32p]),
+    "mcpm_plan_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "mcpm_plan_profile_read": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p, C.POINTER(C.c_int64)]),
+    "mcpm_stage_name": (C.c_char_p, [C.c_int]),
+    "mcpm_bullfrog_step_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, _f32p]),
+    "mcpm_bullfrog_step_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, C.c_void_p, C.c_void_p]),
     "mcpm_lpt_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _f32p, _f32p]),
     "mcpm_nbody_bf_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f64p, C.c_double, _f64p, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
     "mcpm_nbody_ckpt_floats": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),

@@ -172,6 +172,7 @@ static inline void lattice_launch(const Geom &g, dim3 &grid, dim3 &block) {
 }
 
 static int axpby(mcpm_plan *p, const float *x, const float *y, int64_t n, float a, float b, float *out) {
+    StageTimer st_(p, ST_AXPY, 12.0 * n);
     unsigned nb = (unsigned)((n + 255) / 256);
     axpby_kernel<<<nb, 256, 0, p->stream>>>(x, y, n, a, b, out);
     MCPM_LAUNCH_CHECK(p, "axpby_kernel");
@@ -192,6 +193,12 @@ static int spec_to_delta2(mcpm_plan *p, const float *spec, int lap_fd, int grad_
     MCPM_TRY(mcpm_fft_c2r(p, p->spec, p->fmesh, 6));
     MCPM_TRY(mcpm_hessian_combine_f32(p, p->fmesh, p->rho));
     MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
+    return MCPM_OK;
+}
+
+static int ensure_pscratch(mcpm_plan *p) {
+    if (!p->pscratch && hipMalloc((void **)&p->pscratch, sizeof(float) * 9 * p->Np) != hipSuccess)
+        return mcpm_fail(p, MCPM_E_NOMEM, "adjoint particle scratch");
     return MCPM_OK;
 }
 
@@ -235,14 +242,62 @@ int mcpm_lpt_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, float g, f
     dim3 grid, block;
     lattice_launch(p->g, grid, block);
     MCPM_TRY(spec_to_force_meshes(p, init_mesh, lap_fd, grad_fd, 0.f, 0, p->fmesh));
-    lpt_accum_kernel<<<grid, block, 0, p->stream>>>(p->g, p->fmesh, p->M, g, 1.f, 1, dpos, vel);
+    {
+        StageTimer st_(p, ST_LPT, 12.0 * p->M + 24.0 * p->Np);
+        lpt_accum_kernel<<<grid, block, 0, p->stream>>>(p->g, p->fmesh, p->M, g, 1.f, 1, dpos, vel);
+    }
     MCPM_LAUNCH_CHECK(p, "lpt_accum_kernel");
     if (lpt_order == 2) {
         MCPM_TRY(spec_to_delta2(p, init_mesh, lap_fd, grad_fd));
         MCPM_TRY(spec_to_force_meshes(p, p->spec1, lap_fd, grad_fd, 0.f, 0, p->fmesh));
+        StageTimer st_(p, ST_LPT, 12.0 * p->M + 48.0 * p->Np);
         lpt_accum_kernel<<<grid, block, 0, p->stream>>>(p->g, p->fmesh, p->M, -g2, -dg2dg, 0, dpos, vel);
         MCPM_LAUNCH_CHECK(p, "lpt_accum_kernel");
     }
+    return MCPM_OK;
+}
+
+int mcpm_bullfrog_step_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, double alpha, double beta, double tau,
+                           int paint_order, float *force_meshes, float *pos_out, float *vel_out) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, pos_in && vel_in && pos_out && vel_out, MCPM_E_ARG, "mcpm_bullfrog_step_f32: null buffer");
+    float *fm = force_meshes ? force_meshes : p->fmesh;
+    MCPM_TRY(mcpm_paint_f32(p, pos_in, p->Np, MCPM_POS_LATTICE, nullptr, 1, 1.f, paint_order, p->rho, 0));
+    MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
+    MCPM_TRY(spec_to_force_meshes(p, p->spec1, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, fm));
+    MCPM_TRY(mcpm_kick_drift_f32(p, pos_in, vel_in, p->Np, MCPM_POS_LATTICE, fm, paint_order, (float)alpha, (float)beta,
+                                 (float)tau, pos_out, vel_out));
+    return MCPM_OK;
+}
+
+int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes,
+                               double alpha, double beta, double tau, int paint_order, float *pos_bar, float *vel_bar,
+                               double *alpha_bar, double *beta_bar) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, pos_in && vel_in && force_meshes && pos_bar && vel_bar, MCPM_E_ARG, "mcpm_bullfrog_step_vjp_f32: null buffer");
+    MCPM_REQUIRE(p, paint_order == 1 || paint_order == 2, MCPM_E_ORDER, "mcpm_bullfrog_step_vjp_f32: paint_order must be 1 or 2");
+    MCPM_TRY(ensure_pscratch(p));
+    const int64_t N = p->Np, M = p->M;
+    float *Fb = p->pscratch + 6 * N;
+    const float a = (float)alpha, b = (float)beta, t = (float)tau;
+    // force cotangent F_bar = beta (v_bar + tau x_bar), scattered onto three meshes (adjoint of read)
+    MCPM_TRY(axpby(p, vel_bar, pos_bar, 3 * N, b, b * t, Fb));
+    for (int c = 0; c < 3; ++c)
+        MCPM_TRY(mcpm_paint_f32(p, pos_in, N, MCPM_POS_LATTICE, Fb + c, 3, 0.f, paint_order, p->fmesh + c * M, 0));
+    // adjoint of 3 C2R + k-space + R2C: rho_bar = C2R( (1/M) sum_c conj(m_c) R2C(f_bar_c) )
+    MCPM_TRY(mcpm_fft_r2c(p, p->fmesh, p->spec, 3));
+    MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, p->spec1, 1.f / (float)M, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 0, 1, 0));
+    MCPM_TRY(mcpm_fft_c2r(p, p->spec1, p->rho, 1));
+    dim3 grid, block;
+    lattice_launch(p->g, grid, block);
+    StageTimer st_(p, ST_STEPADJ, 72.0 * N + 16.0 * M);
+    if (paint_order == 2)
+        step_adjoint_kernel<2><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, p->rho, M, a, b,
+                                                              t, alpha_bar, beta_bar);
+    else
+        step_adjoint_kernel<1><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, p->rho, M, a, b,
+                                                              t, alpha_bar, beta_bar);
+    MCPM_LAUNCH_CHECK(p, "step_adjoint_kernel");
     return MCPM_OK;
 }
 
@@ -268,14 +323,10 @@ int mcpm_nbody_bf_f32(mcpm_plan *p, const float *init_mesh, int n_steps, const d
                           MCPM_FD_INF, MCPM_FD_INF, x, v));
     MCPM_TRY(mcpm_drift_f32(p, x, v, N, (float)(dg / 2), x));
     for (int i = 0; i < n_steps; ++i) {
-        float *fm = ckpt ? force_m(i) : p->fmesh;
-        MCPM_TRY(mcpm_paint_f32(p, x, N, MCPM_POS_LATTICE, nullptr, 1, 1.f, paint_order, p->rho, 0));
-        MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
-        MCPM_TRY(spec_to_force_meshes(p, p->spec1, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, fm));
         const bool last = (i == n_steps - 1);
         float *xn = (ckpt && !last) ? state_x(i + 1) : pos_out, *vn = (ckpt && !last) ? state_v(i + 1) : vel_out;
-        MCPM_TRY(mcpm_kick_drift_f32(p, x, v, N, MCPM_POS_LATTICE, fm, paint_order, (float)alpha[i], (float)beta[i],
-                                     (float)(last ? dg / 2 : dg), xn, vn));
+        MCPM_TRY(mcpm_bullfrog_step_f32(p, x, v, alpha[i], beta[i], last ? dg / 2 : dg, paint_order,
+                                        ckpt ? force_m(i) : nullptr, xn, vn));
         x = xn;
         v = vn;
     }
@@ -292,11 +343,8 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     MCPM_REQUIRE(p, paint_order == 1 || paint_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: paint_order must be 1 or 2");
     MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: lpt_order must be 1 or 2");
     const int64_t N = p->Np, M = p->M;
-    if (!p->pscratch) {
-        if (hipMalloc((void **)&p->pscratch, sizeof(float) * 9 * N) != hipSuccess)
-            return mcpm_fail(p, MCPM_E_NOMEM, "adjoint particle scratch");
-    }
-    float *xb = p->pscratch, *vb = p->pscratch + 3 * N, *Fb = p->pscratch + 6 * N;
+    MCPM_TRY(ensure_pscratch(p));
+    float *xb = p->pscratch, *vb = p->pscratch + 3 * N;
     auto state_x = [&](int i) { return ckpt + (int64_t)i * 6 * N; };
     auto state_v = [&](int i) { return ckpt + (int64_t)i * 6 * N + 3 * N; };
     auto force_m = [&](int i) { return ckpt + (int64_t)n_steps * 6 * N + (int64_t)i * 3 * M; };
@@ -306,24 +354,10 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     dim3 grid, block;
     lattice_launch(p->g, grid, block);
     const float invM = 1.f / (float)M;
-    for (int i = n_steps - 1; i >= 0; --i) {
-        const float tau = (float)((i == n_steps - 1) ? dg / 2 : dg), a = (float)alpha[i], b = (float)beta[i];
-        // force cotangent F_bar = beta (v_bar + tau x_bar), scattered onto three meshes (adjoint of read)
-        MCPM_TRY(axpby(p, vb, xb, 3 * N, b, b * tau, Fb));
-        for (int c = 0; c < 3; ++c)
-            MCPM_TRY(mcpm_paint_f32(p, state_x(i), N, MCPM_POS_LATTICE, Fb + c, 3, 0.f, paint_order, p->fmesh + c * M, 0));
-        // adjoint of 3 C2R + k-space + R2C: rho_bar = C2R( (1/M) sum_c conj(m_c) R2C(f_bar_c) )
-        MCPM_TRY(mcpm_fft_r2c(p, p->fmesh, p->spec, 3));
-        MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, p->spec1, invM, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 0, 1, 0));
-        MCPM_TRY(mcpm_fft_c2r(p, p->spec1, p->rho, 1));
-        if (paint_order == 2)
-            step_adjoint_kernel<2><<<grid, block, 0, p->stream>>>(p->g, state_x(i), state_v(i), xb, vb, force_m(i), p->rho, M, a,
-                                                                  b, tau, p->reduce + i, p->reduce + n_steps + i);
-        else
-            step_adjoint_kernel<1><<<grid, block, 0, p->stream>>>(p->g, state_x(i), state_v(i), xb, vb, force_m(i), p->rho, M, a,
-                                                                  b, tau, p->reduce + i, p->reduce + n_steps + i);
-        MCPM_LAUNCH_CHECK(p, "step_adjoint_kernel");
-    }
+    for (int i = n_steps - 1; i >= 0; --i)
+        MCPM_TRY(mcpm_bullfrog_step_vjp_f32(p, state_x(i), state_v(i), force_m(i), alpha[i], beta[i],
+                                            (i == n_steps - 1) ? dg / 2 : dg, paint_order, xb, vb, p->reduce + i,
+                                            p->reduce + n_steps + i));
     // initial half drift x'_0 = x_0 + v_0 dg/2
     MCPM_TRY(axpby(p, vb, xb, 3 * N, 1.f, (float)(dg / 2), vb));
 

@@ -233,6 +233,7 @@ int mcpm_kspace_force_f32(mcpm_plan *p, const float *in, float *out3, float scal
     MCPM_REQUIRE(p, in && out3, MCPM_E_ARG, "mcpm_kspace_force_f32: null buffer");
     MCPM_REQUIRE(p, fd_ok(lap_fd) && fd_ok(grad_fd), MCPM_E_ORDER, "finite-difference order must be 0 (inf), 2 or 4");
     KArgs a{p->g, scale, kcut, deconv_order, 0, 1, 0};
+    StageTimer st_(p, ST_KSPACE, 32.0 * p->Mh);
     unsigned nb = (unsigned)((p->Mh + 255) / 256);
     DISPATCH_FD(lap_fd, grad_fd, kspace_force_kernel, <<<nb, 256, 0, p->stream>>>(a, (const float2 *)in, (float2 *)out3, p->Mh));
     MCPM_LAUNCH_CHECK(p, "kspace_force_kernel");
@@ -245,6 +246,7 @@ int mcpm_kspace_force_vjp_f32(mcpm_plan *p, const float *in3, float *out, float 
     MCPM_REQUIRE(p, in3 && out, MCPM_E_ARG, "mcpm_kspace_force_vjp_f32: null buffer");
     MCPM_REQUIRE(p, fd_ok(lap_fd) && fd_ok(grad_fd), MCPM_E_ORDER, "finite-difference order must be 0 (inf), 2 or 4");
     KArgs a{p->g, scale, kcut, deconv_order, zweights, hermitian, accumulate};
+    StageTimer st_(p, ST_KSPACE, (accumulate ? 40.0 : 32.0) * p->Mh);
     unsigned nb = (unsigned)((p->Mh + 255) / 256);
     DISPATCH_FD(lap_fd, grad_fd, kspace_force_vjp_kernel, <<<nb, 256, 0, p->stream>>>(a, (const float2 *)in3, (float2 *)out, p->Mh));
     MCPM_LAUNCH_CHECK(p, "kspace_force_vjp_kernel");
@@ -256,6 +258,7 @@ int mcpm_kspace_hessian_f32(mcpm_plan *p, const float *in, float *out6, float sc
     MCPM_REQUIRE(p, in && out6, MCPM_E_ARG, "mcpm_kspace_hessian_f32: null buffer");
     MCPM_REQUIRE(p, fd_ok(lap_fd) && fd_ok(grad_fd), MCPM_E_ORDER, "finite-difference order must be 0 (inf), 2 or 4");
     KArgs a{p->g, scale, 0.f, 0, 0, 1, 0};
+    StageTimer st_(p, ST_KSPACE, 56.0 * p->Mh);
     unsigned nb = (unsigned)((p->Mh + 255) / 256);
     DISPATCH_FD(lap_fd, grad_fd, kspace_hessian_kernel, <<<nb, 256, 0, p->stream>>>(a, (const float2 *)in, (float2 *)out6, p->Mh));
     MCPM_LAUNCH_CHECK(p, "kspace_hessian_kernel");
@@ -268,6 +271,7 @@ int mcpm_kspace_hessian_vjp_f32(mcpm_plan *p, const float *in6, float *out, floa
     MCPM_REQUIRE(p, in6 && out, MCPM_E_ARG, "mcpm_kspace_hessian_vjp_f32: null buffer");
     MCPM_REQUIRE(p, fd_ok(lap_fd) && fd_ok(grad_fd), MCPM_E_ORDER, "finite-difference order must be 0 (inf), 2 or 4");
     KArgs a{p->g, scale, 0.f, 0, zweights, 0, accumulate};
+    StageTimer st_(p, ST_KSPACE, (accumulate ? 64.0 : 56.0) * p->Mh);
     unsigned nb = (unsigned)((p->Mh + 255) / 256);
     DISPATCH_FD(lap_fd, grad_fd, kspace_hessian_vjp_kernel, <<<nb, 256, 0, p->stream>>>(a, (const float2 *)in6, (float2 *)out, p->Mh));
     MCPM_LAUNCH_CHECK(p, "kspace_hessian_vjp_kernel");
@@ -277,6 +281,7 @@ int mcpm_kspace_hessian_vjp_f32(mcpm_plan *p, const float *in6, float *out, floa
 int mcpm_hessian_combine_f32(mcpm_plan *p, const float *hess6, float *delta2) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, hess6 && delta2, MCPM_E_ARG, "mcpm_hessian_combine_f32: null buffer");
+    StageTimer st_(p, ST_LPT, 28.0 * p->M);
     unsigned nb = (unsigned)((p->M + 255) / 256);
     hessian_combine_kernel<<<nb, 256, 0, p->stream>>>(hess6, p->M, delta2);
     MCPM_LAUNCH_CHECK(p, "hessian_combine_kernel");
@@ -286,6 +291,7 @@ int mcpm_hessian_combine_f32(mcpm_plan *p, const float *hess6, float *delta2) {
 int mcpm_hessian_combine_vjp_f32(mcpm_plan *p, const float *hess6, const float *delta2_bar, float *hess6_bar) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, hess6 && delta2_bar && hess6_bar, MCPM_E_ARG, "mcpm_hessian_combine_vjp_f32: null buffer");
+    StageTimer st_(p, ST_LPT, 52.0 * p->M);
     unsigned nb = (unsigned)((p->M + 255) / 256);
     hessian_combine_vjp_kernel<<<nb, 256, 0, p->stream>>>(hess6, delta2_bar, p->M, hess6_bar);
     MCPM_LAUNCH_CHECK(p, "hessian_combine_vjp_kernel");

@@ -7,10 +7,31 @@
 #include <cstdio>
 #include <map>
 #include <string>
+#include <vector>
 
 #include "../../include/mcpm.h"
 
 #define MCPM_NREDUCE 1024
+
+// Stages of the path, for the optional per-stage HIP-event profile (mcpm_plan_profile*).
+enum McpmStage {
+    ST_PAINT = 0,   // paint_tile_kernel + paint_outlier_kernel, or paint_atomic_kernel
+    ST_R2C,         // rocFFT real forward
+    ST_C2R,         // rocFFT real inverse
+    ST_KSPACE,      // k-space force / hessian kernels and their adjoints
+    ST_READ,        // read / read_vjp / paint_vjp gathers
+    ST_KICKDRIFT,   // fused read + kick + drift
+    ST_STEPADJ,     // fused adjoint particle kernel
+    ST_AXPY,        // drift / kick / cotangent axpy
+    ST_LPT,         // lattice kernels of lpt and its adjoint, hessian combine
+    ST_NSTAGES
+};
+
+struct StageRec {
+    hipEvent_t e0, e1;
+    int stage;
+    double bytes;
+};
 
 // Mesh + particle-lattice geometry handed to kernels by value.
 struct Geom {
@@ -43,7 +64,42 @@ struct mcpm_plan {
     double *reduce;  // device accumulators for scalar cotangents (MCPM_NREDUCE doubles)
     float *pscratch; // 9*Np floats, allocated on first VJP (adjoint state + force cotangent)
 
+    // optional profile: HIP events recorded on the plan's stream around every leaf stage
+    int profiling;
+    std::vector<StageRec> recs;
+    std::vector<hipEvent_t> event_pool;
+
     std::string err;
+};
+
+// RAII stage bracket: records two events on the plan's stream when profiling is on.
+struct StageTimer {
+    mcpm_plan *p;
+    StageRec r;
+    bool on;
+    StageTimer(mcpm_plan *plan, int stage, double bytes) : p(plan), on(plan && plan->profiling) {
+        if (!on) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!p->event_pool.empty()) {
+                e = p->event_pool.back();
+                p->event_pool.pop_back();
+            } else {
+                (void)hipEventCreate(&e);
+            }
+            return e;
+        };
+        r.e0 = get();
+        r.e1 = get();
+        r.stage = stage;
+        r.bytes = bytes;
+        (void)hipEventRecord(r.e0, p->stream);
+    }
+    ~StageTimer() {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, p->stream);
+        p->recs.push_back(r);
+    }
 };
 
 extern thread_local std::string g_mcpm_create_error;

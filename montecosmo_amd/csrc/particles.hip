@@ -318,7 +318,7 @@ static bool try_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int6
     const int H = p->halo;
     if (g.nx < H + 1 || g.ny < H + 1 || g.nz < H + 1) return false;
     if (((uintptr_t)mesh) & 15) return false;
-    hipMemsetAsync(p->outlier_count, 0, sizeof(int), p->stream);
+    (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int), p->stream);
     const bool z64 = (g.nz % 64 == 0);
     if (z64) {
         switch (H) {
@@ -359,6 +359,7 @@ int mcpm_paint_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const fl
     MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_paint_f32"));
     MCPM_REQUIRE(p, mesh != nullptr, MCPM_E_ARG, "mcpm_paint_f32: null mesh");
     if (weights && wstride < 1) return mcpm_fail(p, MCPM_E_ARG, "mcpm_paint_f32: wstride must be >= 1");
+    StageTimer st_(p, ST_PAINT, (weights ? 16.0 : 12.0) * n + (accumulate ? 8.0 : 4.0) * p->M);
     if (mode == MCPM_POS_LATTICE && order == 2 && n > 0 && try_paint_tiled(p, pos, weights, wstride, wscalar, mesh, accumulate)) {
         MCPM_LAUNCH_CHECK(p, "paint_tile_kernel");
         return MCPM_OK;
@@ -379,6 +380,7 @@ int mcpm_read_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const flo
     MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_read_f32"));
     MCPM_REQUIRE(p, meshes && out, MCPM_E_ARG, "mcpm_read_f32: null buffer");
     MCPM_REQUIRE(p, ncomp == 1 || ncomp == 3, MCPM_E_ARG, "mcpm_read_f32: ncomp must be 1 or 3");
+    StageTimer st_(p, ST_READ, 12.0 * n + 4.0 * ncomp * (p->M + n));
     if (n == 0) return MCPM_OK;
     dim3 grid, block;
     if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
@@ -396,6 +398,7 @@ int mcpm_read_vjp_pos_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, c
     MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_read_vjp_pos_f32"));
     MCPM_REQUIRE(p, meshes && out_bar && pos_bar, MCPM_E_ARG, "mcpm_read_vjp_pos_f32: null buffer");
     MCPM_REQUIRE(p, ncomp == 1 || ncomp == 3, MCPM_E_ARG, "mcpm_read_vjp_pos_f32: ncomp must be 1 or 3");
+    StageTimer st_(p, ST_READ, 24.0 * n + 4.0 * ncomp * (p->M + n));
     if (n == 0) return MCPM_OK;
     dim3 grid, block;
     if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
@@ -415,6 +418,7 @@ int mcpm_paint_vjp_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, cons
     MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_paint_vjp_f32"));
     MCPM_REQUIRE(p, mesh_bar && pos_bar, MCPM_E_ARG, "mcpm_paint_vjp_f32: null buffer");
     if (weights && wstride < 1) return mcpm_fail(p, MCPM_E_ARG, "mcpm_paint_vjp_f32: wstride must be >= 1");
+    StageTimer st_(p, ST_READ, 28.0 * n + 4.0 * p->M);
     if (n == 0) return MCPM_OK;
     dim3 grid, block;
     if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
@@ -430,6 +434,7 @@ int mcpm_paint_vjp_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, cons
 int mcpm_drift_f32(mcpm_plan *p, const float *pos_in, const float *vel, int64_t n, float dt, float *pos_out) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, pos_in && vel && pos_out && n >= 0, MCPM_E_ARG, "mcpm_drift_f32: bad argument");
+    StageTimer st_(p, ST_AXPY, 36.0 * n);
     if (n == 0) return MCPM_OK;
     dim3 grid, block;
     flat_launch(3 * n, grid, block);
@@ -442,6 +447,7 @@ int mcpm_kick_f32(mcpm_plan *p, const float *vel_in, const float *forces, int64_
                   float *vel_out) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, vel_in && forces && vel_out && n >= 0, MCPM_E_ARG, "mcpm_kick_f32: bad argument");
+    StageTimer st_(p, ST_AXPY, 36.0 * n);
     if (n == 0) return MCPM_OK;
     dim3 grid, block;
     flat_launch(3 * n, grid, block);
@@ -455,6 +461,7 @@ int mcpm_kick_drift_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, 
                         float *vel_out) {
     MCPM_TRY(check_particles(p, pos_in, n, mode, order, "mcpm_kick_drift_f32"));
     MCPM_REQUIRE(p, vel_in && meshes3 && pos_out && vel_out, MCPM_E_ARG, "mcpm_kick_drift_f32: null buffer");
+    StageTimer st_(p, ST_KICKDRIFT, 48.0 * n + 12.0 * p->M);
     if (n == 0) return MCPM_OK;
     dim3 grid, block;
     if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);

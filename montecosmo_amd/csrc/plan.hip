@@ -66,6 +66,7 @@ int mcpm_plan_create(int nx, int ny, int nz, int px, int py, int pz, void *strea
     p->outliers = p->outlier_count = nullptr;
     p->reduce = nullptr;
     p->pscratch = nullptr;
+    p->profiling = 0;
     std::call_once(g_rocfft_once, [] { rocfft_setup(); });
     hipError_t e = hipSuccess;
     auto alloc = [&](void **ptr, size_t bytes) {
@@ -83,28 +84,33 @@ int mcpm_plan_create(int nx, int ny, int nz, int px, int py, int pz, void *strea
         mcpm_plan_destroy(p);
         return mcpm_fail(nullptr, MCPM_E_NOMEM, msg);
     }
-    hipMemsetAsync(p->outlier_count, 0, sizeof(int) * 2, p->stream);
+    (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int) * 2, p->stream);
     *out = p;
     return MCPM_OK;
 }
 
 int mcpm_plan_destroy(mcpm_plan *p) {
     if (!p) return MCPM_OK;
-    hipStreamSynchronize(p->stream);
+    (void)hipStreamSynchronize(p->stream);
+    for (auto &r : p->recs) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    for (auto &e : p->event_pool) (void)hipEventDestroy(e);
     for (auto &kv : p->r2c) rocfft_plan_destroy(kv.second);
     for (auto &kv : p->c2r) rocfft_plan_destroy(kv.second);
     for (auto &kv : p->r2c_info) rocfft_execution_info_destroy(kv.second);
     for (auto &kv : p->c2r_info) rocfft_execution_info_destroy(kv.second);
-    for (auto &kv : p->r2c_work) hipFree(kv.second);
-    for (auto &kv : p->c2r_work) hipFree(kv.second);
-    hipFree(p->rho);
-    hipFree(p->spec);
-    hipFree(p->fmesh);
-    hipFree(p->spec1);
-    hipFree(p->outliers);
-    hipFree(p->outlier_count);
-    hipFree(p->reduce);
-    hipFree(p->pscratch);
+    for (auto &kv : p->r2c_work) (void)hipFree(kv.second);
+    for (auto &kv : p->c2r_work) (void)hipFree(kv.second);
+    (void)hipFree(p->rho);
+    (void)hipFree(p->spec);
+    (void)hipFree(p->fmesh);
+    (void)hipFree(p->spec1);
+    (void)hipFree(p->outliers);
+    (void)hipFree(p->outlier_count);
+    (void)hipFree(p->reduce);
+    (void)hipFree(p->pscratch);
     delete p;
     return MCPM_OK;
 }
@@ -125,6 +131,40 @@ int mcpm_plan_last_outliers(mcpm_plan *p, int64_t *count) {
     return MCPM_OK;
 }
 
+static const char *k_stage_names[ST_NSTAGES] = {"paint", "fft_r2c", "fft_c2r", "kspace", "read", "kick_drift",
+                                                 "step_adjoint", "axpy", "lpt_lattice"};
+
+const char *mcpm_stage_name(int stage) { return (stage >= 0 && stage < ST_NSTAGES) ? k_stage_names[stage] : ""; }
+
+int mcpm_plan_profile(mcpm_plan *p, int enable) {
+    if (!p) return MCPM_E_ARG;
+    p->profiling = enable ? 1 : 0;
+    return MCPM_OK;
+}
+
+int mcpm_plan_profile_read(mcpm_plan *p, int nmax, double *ms, double *bytes, int64_t *calls) {
+    if (!p || !ms || !bytes || !calls) return MCPM_E_ARG;
+    MCPM_HIP(p, hipStreamSynchronize(p->stream));
+    for (int i = 0; i < nmax; ++i) {
+        ms[i] = 0.;
+        bytes[i] = 0.;
+        calls[i] = 0;
+    }
+    for (auto &r : p->recs) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.e0, r.e1);
+        if (r.stage < nmax) {
+            ms[r.stage] += t;
+            bytes[r.stage] += r.bytes;
+            calls[r.stage] += 1;
+        }
+        p->event_pool.push_back(r.e0);
+        p->event_pool.push_back(r.e1);
+    }
+    p->recs.clear();
+    return ST_NSTAGES;
+}
+
 int mcpm_plan_force_meshes(mcpm_plan *p, float **meshes3) {
     if (!p || !meshes3) return MCPM_E_ARG;
     *meshes3 = p->fmesh;
@@ -135,6 +175,7 @@ int mcpm_fft_r2c(mcpm_plan *p, const float *real, float *spec, int batch) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, real && spec && batch >= 1, MCPM_E_ARG, "mcpm_fft_r2c: null buffer or batch < 1");
     MCPM_TRY(make_fft(p, true, batch));
+    StageTimer st_(p, ST_R2C, (double)batch * (4.0 * p->M + 8.0 * p->Mh));
     void *in[1] = {(void *)real};
     void *out[1] = {(void *)spec};
     rocfft_status st = rocfft_execute(p->r2c[batch], in, out, p->r2c_info[batch]);
@@ -146,6 +187,7 @@ int mcpm_fft_c2r(mcpm_plan *p, float *spec, float *real, int batch) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, real && spec && batch >= 1, MCPM_E_ARG, "mcpm_fft_c2r: null buffer or batch < 1");
     MCPM_TRY(make_fft(p, false, batch));
+    StageTimer st_(p, ST_C2R, (double)batch * (4.0 * p->M + 8.0 * p->Mh));
     void *in[1] = {(void *)spec};
     void *out[1] = {(void *)real};
     rocfft_status st = rocfft_execute(p->c2r[batch], in, out, p->c2r_info[batch]);
