@@ -70,7 +70,31 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// block-reduce two doubles and add them to out[0], out[1]
+#define MCPM_NSLOT 1024
+
+// sum the MCPM_NSLOT partial slots of the step adjoint into the two accumulators
+__global__ __launch_bounds__(MCPM_NSLOT) void reduce_slots_kernel(const double *__restrict__ slots, double *out0, double *out1) {
+    __shared__ double sh[2][MCPM_NSLOT / 64];
+    double a = wave_sum(slots[threadIdx.x]), b = wave_sum(slots[MCPM_NSLOT + threadIdx.x]);
+    int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) {
+        sh[0][w] = a;
+        sh[1][w] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sa = 0., sb = 0.;
+        for (int i = 0; i < MCPM_NSLOT / 64; ++i) {
+            sa += sh[0][i];
+            sb += sh[1][i];
+        }
+        if (out0) *out0 += sa;
+        if (out1) *out1 += sb;
+    }
+}
+
+// block-reduce two doubles and atomically add them to *out0, *out1.  Callers with many blocks pass per-slot
+// addresses: half a million blocks adding to ONE address serialise at the memory-side atomic unit.
 __device__ __forceinline__ void block_add2(double a, double b, double *out0, double *out1) {
     __shared__ double sh[2][4];
     a = wave_sum(a);
@@ -122,7 +146,7 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
                                                            float *__restrict__ xb, float *__restrict__ vb,
                                                            const float *__restrict__ fm, const float *__restrict__ rho_bar,
                                                            int64_t M, float alpha, float beta, float tau,
-                                                           double *alpha_bar, double *beta_bar) {
+                                                           double *slots) {
     PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
     double ra = 0., rb = 0.;
     if (pi.valid) {
@@ -155,7 +179,8 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
         store3(xb, pi.i, xbi);
         store3(vb, pi.i, P3{alpha * vt.x, alpha * vt.y, alpha * vt.z});
     }
-    block_add2(ra, rb, alpha_bar, beta_bar);
+    const int slot = blockIdx.x % MCPM_NSLOT;
+    block_add2(ra, rb, slots + slot, slots + MCPM_NSLOT + slot);
 }
 
 __global__ void axpby_kernel(const float *__restrict__ x, const float *__restrict__ y, int64_t n, float a, float b,
@@ -291,13 +316,19 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *v
     dim3 grid, block;
     lattice_launch(p->g, grid, block);
     StageTimer st_(p, ST_STEPADJ, 72.0 * N + 16.0 * M);
+    double *slots = p->reduce + (MCPM_NREDUCE - 2 * MCPM_NSLOT);
+    MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 2 * MCPM_NSLOT, p->stream));
     if (paint_order == 2)
         step_adjoint_kernel<2><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, p->rho, M, a, b,
-                                                              t, alpha_bar, beta_bar);
+                                                              t, slots);
     else
         step_adjoint_kernel<1><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, p->rho, M, a, b,
-                                                              t, alpha_bar, beta_bar);
+                                                              t, slots);
     MCPM_LAUNCH_CHECK(p, "step_adjoint_kernel");
+    if (alpha_bar || beta_bar) {
+        reduce_slots_kernel<<<1, MCPM_NSLOT, 0, p->stream>>>(slots, alpha_bar, beta_bar);
+        MCPM_LAUNCH_CHECK(p, "reduce_slots_kernel");
+    }
     return MCPM_OK;
 }
 
@@ -339,7 +370,7 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, init_mesh && alpha && beta && lpt_scalars && ckpt && pos_bar && vel_bar && init_mesh_bar, MCPM_E_ARG,
                  "mcpm_nbody_bf_vjp_f32: null argument");
-    MCPM_REQUIRE(p, n_steps >= 1 && 2 * n_steps + 3 <= MCPM_NREDUCE, MCPM_E_ARG, "mcpm_nbody_bf_vjp_f32: bad n_steps");
+    MCPM_REQUIRE(p, n_steps >= 1 && 2 * n_steps + 3 <= MCPM_NREDUCE - 2 * MCPM_NSLOT, MCPM_E_ARG, "mcpm_nbody_bf_vjp_f32: bad n_steps");
     MCPM_REQUIRE(p, paint_order == 1 || paint_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: paint_order must be 1 or 2");
     MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: lpt_order must be 1 or 2");
     const int64_t N = p->Np, M = p->M;

@@ -11,7 +11,7 @@
 
 #include "../../include/mcpm.h"
 
-#define MCPM_NREDUCE 1024
+#define MCPM_NREDUCE 4096
 
 // Stages of the path, for the optional per-stage HIP-event profile (mcpm_plan_profile*).
 enum McpmStage {
@@ -48,6 +48,7 @@ struct mcpm_plan {
     int64_t Mh;  // nx*ny*nzh
     int64_t Np;  // px*py*pz
     int halo;    // halo radius of the tiled paint
+    int paint_variant;  // threads/unroll variant of the tiled paint (tuning)
 
     // rocFFT plans keyed by batch
     std::map<int, rocfft_plan> r2c, c2r;

@@ -58,14 +58,18 @@ __global__ __launch_bounds__(256) void paint_atomic_kernel(Geom g, const float *
 
 // ------------------------------------------------------------------------------------------------
 // tiled paint (lattice displacements, lattice == mesh, CIC)
-template <int BX, int BY, int BZ, int H, bool WEIGHTED>
-__global__ __launch_bounds__(256) void paint_tile_kernel(Geom g, const float *__restrict__ disp,
-                                                         const float *__restrict__ w, int64_t wstride, float wscalar,
-                                                         float *__restrict__ mesh, int accumulate,
-                                                         int *__restrict__ outliers, int *__restrict__ ocount) {
+// THREADS x U particle loads are issued before any is consumed: the pull loop is otherwise bound by load
+// latency (one 12-byte load in flight per thread moves < 1 TB/s chip-wide).
+template <int BX, int BY, int BZ, int H, bool WEIGHTED, int THREADS, int U>
+__global__ __launch_bounds__(THREADS) void paint_tile_kernel(Geom g, const float *__restrict__ disp,
+                                                             const float *__restrict__ w, int64_t wstride, float wscalar,
+                                                             float *__restrict__ mesh, int accumulate,
+                                                             int *__restrict__ outliers, int *__restrict__ ocount) {
     constexpr int WX = BX + 2 * H + 1, WY = BY + 2 * H + 1, WZ = BZ + 2 * H + 1, NW = WX * WY * WZ;
     constexpr int NT = BX * BY * BZ;
-    __shared__ float tile[NT];
+    // double accumulators: on gfx950 LDS ds_add_f64 sustains ~4-5 lanes/clk/CU, ds_add_f32 only ~0.3
+    // (tools/lds_atomic_bench.hip), and the sums become insensitive to arrival order at fp32 output precision.
+    __shared__ double tile[NT];
 
     // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
     // run of tiles so that neighbouring tiles, which re-read each other's halo particles, share L2.
@@ -75,62 +79,85 @@ __global__ __launch_bounds__(256) void paint_tile_kernel(Geom g, const float *__
     const int tz = t % ntz, tt = t / ntz, ty = tt % nty, tx = tt / nty;
     const int x0 = tx * BX, y0 = ty * BY, z0 = tz * BZ;
 
-    float4 *tile4 = reinterpret_cast<float4 *>(tile);
-    for (int i = threadIdx.x; i < NT / 4; i += 256) tile4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    double2 *tile2 = reinterpret_cast<double2 *>(tile);
+    for (int i = threadIdx.x; i < NT / 2; i += THREADS) tile2[i] = make_double2(0., 0.);
     __syncthreads();
 
-    for (int j = threadIdx.x; j < NW; j += 256) {
-        const int jz = j % WZ, r = j / WZ, jy = r % WY, jx = r / WY;
-        const int rx = jx - (H + 1), ry = jy - (H + 1), rz = jz - (H + 1);  // lattice point relative to the tile
-        int gx = x0 + rx, gy = y0 + ry, gz = z0 + rz;
-        gx += gx < 0 ? g.nx : 0;
-        gx -= gx >= g.nx ? g.nx : 0;
-        gy += gy < 0 ? g.ny : 0;
-        gy -= gy >= g.ny ? g.ny : 0;
-        gz += gz < 0 ? g.nz : 0;
-        gz -= gz >= g.nz ? g.nz : 0;
-        const int64_t gi = ((int64_t)gx * g.ny + gy) * g.nz + gz;
-        const P3 d = load3(disp, gi);
-        const float fx = floorf(d.x), fy = floorf(d.y), fz = floorf(d.z);
-        // outliers: |floor(d)| > H on any axis (NaN compares false everywhere -> treated as outlier)
-        const bool inl = fx >= (float)-H && fx <= (float)H && fy >= (float)-H && fy <= (float)H && fz >= (float)-H &&
-                         fz <= (float)H;
-        if (!inl) {
-            const bool home = (unsigned)rx < (unsigned)BX && (unsigned)ry < (unsigned)BY && (unsigned)rz < (unsigned)BZ;
-            if (home) {
-                int k = atomicAdd(ocount, 1);
-                outliers[k] = (int)gi;
+    for (int j0 = threadIdx.x; j0 < NW; j0 += THREADS * U) {
+        P3 d[U];
+        float wt[U];
+        int rxs[U], rys[U], rzs[U], gis[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * THREADS;
+            const bool ok = j < NW;
+            const int jz = j % WZ, r = j / WZ, jy = r % WY, jx = r / WY;
+            const int rx = jx - (H + 1), ry = jy - (H + 1), rz = jz - (H + 1);  // lattice point relative to the tile
+            int gx = x0 + rx, gy = y0 + ry, gz = z0 + rz;
+            gx += gx < 0 ? g.nx : 0;
+            gx -= gx >= g.nx ? g.nx : 0;
+            gy += gy < 0 ? g.ny : 0;
+            gy -= gy >= g.ny ? g.ny : 0;
+            gz += gz < 0 ? g.nz : 0;
+            gz -= gz >= g.nz ? g.nz : 0;
+            const int gi = ok ? (gx * g.ny + gy) * g.nz + gz : -1;
+            rxs[u] = rx;
+            rys[u] = ry;
+            rzs[u] = rz;
+            gis[u] = gi;
+            if (ok) {
+                d[u] = load3(disp, gi);
+                wt[u] = WEIGHTED ? w[(int64_t)gi * wstride] : wscalar;
+            } else {
+                d[u] = P3{0.f, 0.f, 0.f};
+                wt[u] = 0.f;
             }
-            continue;
         }
-        const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
-        if (cx < -1 || cx >= BX || cy < -1 || cy >= BY || cz < -1 || cz >= BZ) continue;
-        const float tx1 = d.x - fx, ty1 = d.y - fy, tz1 = d.z - fz;
-        const float wt = WEIGHTED ? w[gi * wstride] : wscalar;
-        const float kx[2] = {1.f - tx1, tx1}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int x = cx + a;
-            if ((unsigned)x >= (unsigned)BX) continue;
+        for (int u = 0; u < U; ++u) {
+            if (gis[u] < 0) continue;
+            const int rx = rxs[u], ry = rys[u], rz = rzs[u];
+            const float fx = floorf(d[u].x), fy = floorf(d[u].y), fz = floorf(d[u].z);
+            // outliers: |floor(d)| > H on any axis (NaN compares false everywhere -> treated as outlier)
+            const bool inl = fx >= (float)-H && fx <= (float)H && fy >= (float)-H && fy <= (float)H && fz >= (float)-H &&
+                             fz <= (float)H;
+            if (!inl) {
+                const bool home = (unsigned)rx < (unsigned)BX && (unsigned)ry < (unsigned)BY && (unsigned)rz < (unsigned)BZ;
+                if (home) {
+                    int k = atomicAdd(ocount, 1);
+                    outliers[k] = gis[u];
+                }
+                continue;
+            }
+            const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
+            if (cx < -1 || cx >= BX || cy < -1 || cy >= BY || cz < -1 || cz >= BZ) continue;
+            const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
+            const float kx[2] = {1.f - tx1, tx1}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                const int y = cy + bb;
-                if ((unsigned)y >= (unsigned)BY) continue;
-                const float wxy = wt * kx[a] * ky[bb];
-                float *row = tile + (x * BY + y) * BZ;
+            for (int a = 0; a < 2; ++a) {
+                const int x = cx + a;
+                if ((unsigned)x >= (unsigned)BX) continue;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int z = cz + e;
-                    if ((unsigned)z < (unsigned)BZ) atomicAdd(row + z, wxy * kz[e]);
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int y = cy + bb;
+                    if ((unsigned)y >= (unsigned)BY) continue;
+                    const float wxy = wt[u] * kx[a] * ky[bb];
+                    double *row = tile + (x * BY + y) * BZ;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int z = cz + e;
+                        if ((unsigned)z < (unsigned)BZ) atomicAdd(row + z, (double)(wxy * kz[e]));
+                    }
                 }
             }
         }
     }
     __syncthreads();
 
-    for (int i = threadIdx.x; i < NT / 4; i += 256) {
+    for (int i = threadIdx.x; i < NT / 4; i += THREADS) {
         const int lz = (i % (BZ / 4)) * 4, r = i / (BZ / 4), ly = r % BY, lx = r / BY;
-        float4 v = tile4[i];
+        const double2 lo = tile2[2 * i], hi = tile2[2 * i + 1];
+        float4 v = make_float4((float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y);
         float4 *dst = reinterpret_cast<float4 *>(mesh + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz);
         if (accumulate) {
             float4 o = *dst;
@@ -296,17 +323,35 @@ static int check_particles(mcpm_plan *p, const void *pos, int64_t n, int mode, i
         }                                                  \
     } while (0)
 
-template <int BX, int BY, int BZ, int H>
+template <int BX, int BY, int BZ, int H, int THREADS, int U>
 static void launch_tile(mcpm_plan *p, const float *pos, const float *w, int64_t wstride, float wscalar, float *mesh,
                         int accumulate) {
     const Geom &g = p->g;
     unsigned nb = (unsigned)((g.nx / BX) * (g.ny / BY) * (g.nz / BZ));
     if (w)
-        paint_tile_kernel<BX, BY, BZ, H, true><<<nb, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate,
-                                                                          p->outliers, p->outlier_count);
+        paint_tile_kernel<BX, BY, BZ, H, true, THREADS, U><<<nb, THREADS, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate,
+                                                                                          p->outliers, p->outlier_count);
     else
-        paint_tile_kernel<BX, BY, BZ, H, false><<<nb, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate,
-                                                                           p->outliers, p->outlier_count);
+        paint_tile_kernel<BX, BY, BZ, H, false, THREADS, U><<<nb, THREADS, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate,
+                                                                                           p->outliers, p->outlier_count);
+}
+
+template <int BZ, int H>
+static void launch_tile_variant(mcpm_plan *p, const float *pos, const float *w, int64_t wstride, float wscalar, float *mesh,
+                                int accumulate) {
+    if (BZ == 64) {
+        switch (p->paint_variant) {
+            case 1: launch_tile<16, 16, 32, H, 512, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 2: launch_tile<16, 16, 32, H, 512, 2>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 3: launch_tile<16, 16, 32, H, 256, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 4: launch_tile<16, 16, 64, H, 1024, 2>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 5: launch_tile<16, 16, 64, H, 1024, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 6: launch_tile<16, 16, 64, H, 512, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            default: launch_tile<16, 16, 64, H, 1024, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+        }
+    } else {
+        launch_tile<16, 16, 16, H, 256, 4>(p, pos, w, wstride, wscalar, mesh, accumulate);
+    }
 }
 
 // Tiled paint if the geometry allows; returns false if the caller must use the generic path.
@@ -322,17 +367,17 @@ static bool try_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int6
     const bool z64 = (g.nz % 64 == 0);
     if (z64) {
         switch (H) {
-            case 1: launch_tile<16, 16, 64, 1>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
-            case 2: launch_tile<16, 16, 64, 2>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
-            case 4: launch_tile<16, 16, 64, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
-            default: launch_tile<16, 16, 64, 6>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 1: launch_tile_variant<64, 1>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 2: launch_tile_variant<64, 2>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 4: launch_tile_variant<64, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            default: launch_tile_variant<64, 6>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
         }
     } else {
         switch (H) {
-            case 1: launch_tile<16, 16, 16, 1>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
-            case 2: launch_tile<16, 16, 16, 2>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
-            case 4: launch_tile<16, 16, 16, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
-            default: launch_tile<16, 16, 16, 6>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 1: launch_tile_variant<16, 1>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 2: launch_tile_variant<16, 2>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 4: launch_tile_variant<16, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            default: launch_tile_variant<16, 6>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
         }
     }
     paint_outlier_kernel<<<256, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->outliers, p->outlier_count);

@@ -62,6 +62,8 @@ int mcpm_plan_create(int nx, int ny, int nz, int px, int py, int pz, void *strea
     p->Mh = (int64_t)nx * ny * p->g.nzh;
     p->Np = (int64_t)px * py * pz;
     p->halo = 4;
+    p->paint_variant = 0;
+    if (const char *e = getenv("MCPM_PAINT_VARIANT")) p->paint_variant = atoi(e);
     p->rho = p->spec = p->fmesh = p->spec1 = nullptr;
     p->outliers = p->outlier_count = nullptr;
     p->reduce = nullptr;
