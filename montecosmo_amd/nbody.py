@@ -559,7 +559,7 @@ def _step_scalars(cosmo, a0, a1, n_steps, integrator):
         al = float(alpha_fn(cosmo, t, dg))
         alphas.append(al)
         betas.append((1 - al) / (t + dg / 2))
-        t = min(t + dg, g1)
+        t = g1 if t + dg > g1 - 1e-10 else t + dg   # diffrax snaps the last step onto t1
     lpt_s = [float(a2g(cosmo, a0)), float(a2g2(cosmo, a0)), float(a2dg2dg(cosmo, a0))]
     return dg, np.array(alphas), np.array(betas), np.array(lpt_s)
 

@@ -583,10 +583,12 @@ def bullfrog_vf(cosmo, dg, mesh_shape, paint_order=2, paint_deconv=False, grad_f
 
 
 def euler_times(g0, g1, dg, n_steps):
-    """diffrax Euler/ConstantStepSize time grid: t accumulates by +dg, clipped to g1."""
+    """diffrax==0.5.0 ConstantStepSize time grid: t accumulates by +dg and a step that lands within 1e-10
+    (float64 tolerance of diffrax's `_clip_to_end`) of g1, or beyond it, is snapped to g1."""
     ts = [g0]
     for _ in range(n_steps):
-        ts.append(min(ts[-1] + dg, g1))
+        tn = ts[-1] + dg
+        ts.append(g1 if tn > g1 - 1e-10 else tn)
     return ts
 
 

@@ -1,0 +1,192 @@
+"""Pins the oracle (the CPU restatement of the reference algorithm) with the analytic known answers of
+SURVEY.md 8(c) items 1-7 and with the single numeric datum the reference's own tests hold for this path
+(tests_old/valid_fastpm.ipynb:747-749).  The reference cannot run here (jax not installed)."""
+import numpy as np
+import pytest
+
+from oracle import pm_oracle as o, background as obg
+
+
+@pytest.fixture(scope="module")
+def rng():
+    return np.random.default_rng(0)
+
+
+def test_paint_conserves_mass_and_regular_grid_is_flat(rng):
+    """Item 1: paint of N unit-weight particles sums to N (bricks.py:1101-1102); regular grid -> constant N/M."""
+    shape = (8, 10, 12)
+    pos = rng.uniform(-30, 30, (5000, 3))
+    for order in (1, 2, 3, 4):
+        assert np.isclose(o.paint(pos, shape, order=order).sum(), 5000, rtol=1e-12)
+    assert np.allclose(o.paint(o.regular_pos(shape), shape), 1.0)
+    assert np.allclose(o.paint(o.regular_pos(shape, (16, 20, 24)), shape), 8.0)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
+def test_paint_read_are_adjoint(rng, order):
+    """Item 2: <paint(w), m> = <w, read(m)>."""
+    shape = (6, 8, 10)
+    pos = rng.uniform(-10, 20, (700, 3))
+    w, m = rng.standard_normal(700), rng.standard_normal(shape)
+    assert np.isclose(np.sum(o.paint(pos, shape, w, order) * m), np.sum(w * o.read(pos, m, order)), rtol=1e-12)
+
+
+def test_index_semantics():
+    """floor for CIC, round-half-even for NGP, Python modulo wrap, int16 (nbody.py:369-377)."""
+    pos = np.array([[-0.5, 0.5, 1.5], [2.5, -1e-9, 7.999], [8.0, -8.0, 16.25]])
+    assert o.cell_index(pos, (8, 8, 8), 2).tolist() == [[7, 0, 1], [2, 7, 7], [0, 0, 0]]
+    assert o.cell_index(pos, (8, 8, 8), 1).tolist() == [[0, 0, 2], [2, 0, 0], [0, 0, 0]]
+    assert o.cell_index(pos, (8, 8, 8), 2).dtype == np.int16
+
+
+def test_plane_wave_force():
+    """Item 3: density eps cos(k.x) on the mesh -> force eps (k/k^2) sin(k.x), read at lattice points (NGP)."""
+    n, eps = 16, 1e-3
+    shape = (n, n, n)
+    kv = 2 * np.pi * np.array([2, 0, 1]) / n
+    x = o.regular_pos(shape)
+    delta = eps * np.cos(x @ kv).reshape(shape)
+    F = o.pm_forces(x, np.fft.rfftn(delta), read_order=1)
+    # pot = -delta/k^2 ; F = -grad pot = -(k/k^2) eps sin(k.x) * (-1)... sign follows nbody.py:597-603
+    want = -eps * np.sin(x @ kv)[:, None] * kv[None, :] / (kv @ kv) * -1
+    assert np.allclose(F, -want, atol=1e-15) or np.allclose(F, want, atol=1e-15)
+    # F = -grad(phi) with laplace(phi) = delta
+    phi = -delta.reshape(-1) / (kv @ kv)
+    grad_phi = -eps * np.sin(x @ kv)[:, None] * kv[None, :] * (-1 / (kv @ kv))
+    assert np.allclose(F, -grad_phi, atol=1e-15)
+
+
+def test_irfftn_discards_non_hermitian_part(rng):
+    """The Hermitian projection that the HIP k-space kernels apply explicitly is what numpy's irfftn does
+    implicitly on the kz = 0 / Nyquist planes (see montecosmo_amd/csrc/kspace.hip)."""
+    shape = (8, 8, 8)
+    spec = np.fft.rfftn(rng.standard_normal(shape))
+    kvec = o.rfftk(shape)
+    for c in range(3):
+        mult = -o.gradient_hat(kvec, c) * o.invlaplace_hat(kvec)
+        full = np.broadcast_to(mult, spec.shape).copy()
+        proj = full.copy()
+        nyq = [np.arange(8) == 4, np.arange(8) == 4, np.arange(5) == 4]
+        special = np.zeros(5, bool)
+        special[[0, 4]] = True
+        mask = np.zeros(spec.shape, bool)
+        idx = [slice(None)] * 3
+        sel = np.ix_(*[nyq[c] if a == c else np.ones(s, bool) for a, s in enumerate(spec.shape)])
+        mask[sel] = True
+        mask &= special[None, None, :]
+        proj[mask] = 0
+        assert np.allclose(np.fft.irfftn(full * spec), np.fft.irfftn(proj * spec), atol=1e-14)
+
+
+def test_eds_growth_closed_forms():
+    """Item 4: Einstein-de Sitter: D = a, f = 1, f2 = 2, D2 ~ a^2, and the integrator coefficients."""
+    eds = obg.Cosmology(Omega_c=1.0, Omega_b=0.0)
+    a = np.array([0.01, 0.1, 0.5, 1.0])
+    assert np.allclose(o.a2g(eds, a), a, rtol=1e-6)
+    assert np.allclose(o.a2f(eds, a), 1.0, rtol=1e-5)
+    assert np.allclose(o.a2f2(eds, a), 2.0, rtol=1e-5)
+    assert np.allclose(o.a2g2(eds, a), -3 / 7 * a ** 2, rtol=2e-3)
+    # FastPM coefficient in EdS: E a^2 g f = a^(-3/2) a^2 a = a^(3/2)
+    assert np.isclose(o.alpha_fpm(eds, 0.25, 0.5), (0.25 / 0.75) ** 1.5, rtol=1e-3)
+    assert 0 < o.alpha_bf(eds, 0.25, 0.5) < 1
+
+
+def test_planck18_growth_matches_reference_notebook():
+    """Item 7: tests_old/valid_fastpm.ipynb:747-749 prints [1, 0.429, 0.522, 0.454] for Planck18 at a = 1
+    ([D, 3/7 D2/D, D f, 3/7 D2 f2 / D] / D with the JaxPM growth that nbody.py:679-748 follows)."""
+    c = obg.Planck18()
+    g, g2, f, f2 = o.a2g(c, 1.), o.a2g2(c, 1.), o.a2f(c, 1.), o.a2f2(c, 1.)
+    got = [g, -g2 / g, g * f, -g2 * f2 / g]
+    assert np.allclose(np.round(got, 3), [1.0, 0.429, 0.522, 0.454])
+    assert np.isclose(o.a2g(c, 0.0), o.growth_table(c)["g"][0])     # a0 = 0 is table-clamped, not 0
+
+
+def test_zeldovich_plane_wave():
+    """Item 5: a single plane wave before shell crossing: PM stepping stays on x = q + D psi(q) to integrator
+    and CIC-force accuracy (1-D collapse, amplitude well below shell crossing).  A floor-based CIC paint of a
+    one-particle-per-cell lattice is a backward difference, i.e. the mesh force is the Zel'dovich one shifted by
+    half a cell: relative L2 error ~ k/2 = 0.098 at this wavelength, which bounds the agreement."""
+    n = 32
+    shape = (n, n, n)
+    cosmo = obg.Planck18()
+    q = o.regular_pos(shape)
+    k = 2 * np.pi / n
+    amp = 0.3                       # D=1 displacement amplitude in cells; shell crossing at amp*k = 1
+    delta = (amp * k * np.cos(k * q[:, 0])).reshape(shape)   # delta = -div psi, psi = -amp sin(kx)... sign by lpt
+    spec = np.fft.rfftn(delta)
+    dpos1, _ = o.lpt(cosmo, spec, q, 1.0, lpt_order=1, read_order=1)
+    (p, v) = o.nbody_bf(cosmo, spec, q, a0=0.1, a1=1.0, n_steps=8)
+    disp = p[0] - q
+    assert np.abs(disp[:, 1:]).max() < 1e-10                 # motion stays 1-D
+    assert np.linalg.norm(disp[:, 0] - dpos1[:, 0]) / np.linalg.norm(dpos1[:, 0]) < 0.11
+
+
+def test_vjps_match_finite_differences(rng):
+    """Item 6: hand-derived VJPs vs central finite differences of the same oracle."""
+    n = 8
+    shape = (n, n, n)
+    N = 200
+    pos = rng.uniform(-3, 12, (N, 3))
+    R = rng.standard_normal((N, 3))
+    d = rng.standard_normal((N, 3))
+    eps = 1e-6
+    L = lambda p: np.sum(o.pm_forces(p, shape) * R)
+    pb, _ = o.pm_forces_vjp(pos, shape, R)
+    assert np.isclose((L(pos + eps * d) - L(pos - eps * d)) / (2 * eps), np.sum(pb * d), rtol=1e-6)
+    X = np.fft.rfftn(rng.standard_normal(shape))
+    dX = rng.standard_normal(X.shape) + 1j * rng.standard_normal(X.shape)
+    for fwd, vjp in ((o.pm_forces, o.pm_forces_vjp), (o.pm_forces2, o.pm_forces2_vjp)):
+        L = lambda X: np.sum(fwd(pos, X) * R)
+        _, mb = vjp(pos, X, R)
+        assert np.isclose((L(X + eps * dX) - L(X - eps * dX)) / (2 * eps), np.sum((np.conj(mb) * dX).real), rtol=1e-6)
+    # paint / read
+    w, mbar = rng.standard_normal(N), rng.standard_normal(shape)
+    L = lambda p: np.sum(o.paint(p, shape, w) * mbar)
+    assert np.isclose((L(pos + eps * d) - L(pos - eps * d)) / (2 * eps), np.sum(o.paint_vjp(pos, shape, w, mbar)[0] * d), rtol=1e-6)
+    mesh, ob = rng.standard_normal(shape), rng.standard_normal(N)
+    L = lambda p: np.sum(o.read(p, mesh) * ob)
+    assert np.isclose((L(pos + eps * d) - L(pos - eps * d)) / (2 * eps), np.sum(o.read_vjp(pos, mesh, ob)[0] * d), rtol=1e-6)
+
+
+@pytest.mark.parametrize("alpha_fn", [o.alpha_bf, o.alpha_fpm])
+def test_nbody_vjp_matches_finite_differences(rng, alpha_fn):
+    n = 8
+    shape = (n, n, n)
+    cosmo = obg.Planck18()
+    pos = o.regular_pos(shape)
+    X = np.fft.rfftn(rng.standard_normal(shape)) * 0.3
+    Rx, Rv = rng.standard_normal((n ** 3, 3)), rng.standard_normal((n ** 3, 3))
+
+    def L(X):
+        p, v = o.nbody_bf(cosmo, X, pos, a0=0.1, a1=1., n_steps=3, alpha_fn=alpha_fn)
+        return np.sum(p[0] * Rx) + np.sum(v[0] * Rv)
+
+    mb, sb = o.nbody_bf_vjp(cosmo, X, pos, Rx, Rv, a0=0.1, a1=1., n_steps=3, alpha_fn=alpha_fn)
+    dX = rng.standard_normal(X.shape) + 1j * rng.standard_normal(X.shape)
+    eps = 1e-6
+    assert np.isclose((L(X + eps * dX) - L(X - eps * dX)) / (2 * eps), np.sum((np.conj(mb) * dX).real), rtol=1e-6)
+
+
+def test_euler_time_grid_is_diffrax_like():
+    ts = o.euler_times(0.1, 1.0, 0.09, 10)
+    assert ts[0] == 0.1 and ts[-1] == 1.0 and len(ts) == 11
+    assert all(t1 > t0 for t0, t1 in zip(ts, ts[1:]))
+
+
+def test_oracle_reproduces_golden_fixtures():
+    """The committed fixtures are what the oracle produces (guards accidental oracle drift)."""
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(here, "nbody_16.npz"))
+    n, n_steps, a0 = int(g["n"]), int(g["n_steps"]), float(g["a0"])
+    shape = (n, n, n)
+    cosmo = obg.Planck18()
+    pos = o.regular_pos(shape)
+    p, v = o.nbody_bf(cosmo, g["init_mesh"].astype(np.complex128), pos, a0, 1.0, n_steps)
+    assert np.allclose(p[0] - pos, g["final_disp"], rtol=0, atol=1e-12)
+    assert np.array_equal(o.cell_index(p[0], shape), g["final_cell"])
+    pr = np.load(os.path.join(here, "paint_read.npz"))
+    shape = tuple(int(s) for s in pr["shape"])
+    for order in (1, 2):
+        assert np.array_equal(o.cell_index(pr["pos"].astype(np.float64), shape, order), pr[f"cell_{order}"])
+        assert np.allclose(o.paint(pr["pos"].astype(np.float64), shape, pr["weights"].astype(np.float64), order), pr[f"paint_{order}"])
