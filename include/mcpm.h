@@ -117,6 +117,13 @@ int mcpm_kspace_hessian_vjp_f32(mcpm_plan *plan, const float *spec_in6, float *s
 int mcpm_hessian_combine_f32(mcpm_plan *plan, const float *hess6, float *delta2);
 int mcpm_hessian_combine_vjp_f32(mcpm_plan *plan, const float *hess6, const float *delta2_bar, float *hess6_bar);
 
+/* Poisson solve on meshes (nbody.py:589, :596-603 with fd_order = inf): three real force meshes
+   irfftn(-(i k_c)(-1/k^2) rfftn(rho)) from a real density mesh, and the adjoint (three real cotangent meshes ->
+   rho_bar).  Power-of-two meshes run the hand-written five-pass FFT with the k-space multiply fused into the
+   x pass (fftpm.hip); other sizes run rocFFT + the k-space kernels.  fm3 / fbar3: three contiguous meshes. */
+int mcpm_force_meshes_f32(mcpm_plan *plan, const float *rho, float *fm3);
+int mcpm_force_meshes_vjp_f32(mcpm_plan *plan, const float *fbar3, float *rho_bar);
+
 /* ---- forces (nbody.py:583-631) -------------------------------------------------------------- */
 /* pm_forces with mesh = shape tuple: paint -> R2C -> k-space -> 3 C2R -> read; forces[N][3].
    Leaves the three force meshes in the plan (mcpm_plan_force_meshes). */

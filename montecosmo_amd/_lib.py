@@ -39,6 +39,8 @@ SIGNATURES = {
     "mcpm_kspace_hessian_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mcpm_hessian_combine_f32": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "mcpm_hessian_combine_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p]),
+    "mcpm_force_meshes_f32": (C.c_int, [C.c_void_p, _f32p, _f32p]),
+    "mcpm_force_meshes_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "mcpm_pm_forces_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f32p]),
     "mcpm_pm_forces_spec_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f32p]),
     "mcpm_pm_forces2_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),

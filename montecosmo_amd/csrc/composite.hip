@@ -229,13 +229,35 @@ static int ensure_pscratch(mcpm_plan *p) {
 
 extern "C" {
 
+int mcpm_force_meshes_f32(mcpm_plan *p, const float *rho, float *fm3) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, rho && fm3, MCPM_E_ARG, "mcpm_force_meshes_f32: null buffer");
+    if (mcpm_fftpm_supported(p)) return mcpm_fftpm_force_meshes(p, rho, fm3);
+    MCPM_TRY(mcpm_fft_r2c(p, rho, p->spec1, 1));
+    return spec_to_force_meshes(p, p->spec1, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, fm3);
+}
+
+int mcpm_force_meshes_vjp_f32(mcpm_plan *p, const float *fbar3, float *rho_bar) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, fbar3 && rho_bar, MCPM_E_ARG, "mcpm_force_meshes_vjp_f32: null buffer");
+    if (mcpm_fftpm_supported(p)) return mcpm_fftpm_force_meshes_vjp(p, fbar3, rho_bar);
+    // rho_bar = C2R( (1/M) sum_c conj(m_c) R2C(f_bar_c) )
+    MCPM_TRY(mcpm_fft_r2c(p, fbar3, p->spec, 3));
+    MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, p->spec1, 1.f / (float)p->M, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 0, 1, 0));
+    return mcpm_fft_c2r(p, p->spec1, rho_bar, 1);
+}
+
 int mcpm_pm_forces_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, int order, int paint_deconv, int lap_fd,
                        int grad_fd, float kcut, float *forces) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, forces != nullptr, MCPM_E_ARG, "mcpm_pm_forces_f32: null output");
     MCPM_TRY(mcpm_paint_f32(p, pos, n, mode, nullptr, 1, 1.f, order, p->rho, 0));
-    MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
-    MCPM_TRY(spec_to_force_meshes(p, p->spec1, lap_fd, grad_fd, kcut, paint_deconv ? order : 0, p->fmesh));
+    if (!paint_deconv && lap_fd == MCPM_FD_INF && grad_fd == MCPM_FD_INF && kcut <= 0.f) {
+        MCPM_TRY(mcpm_force_meshes_f32(p, p->rho, p->fmesh));
+    } else {
+        MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
+        MCPM_TRY(spec_to_force_meshes(p, p->spec1, lap_fd, grad_fd, kcut, paint_deconv ? order : 0, p->fmesh));
+    }
     MCPM_TRY(mcpm_read_f32(p, pos, n, mode, p->fmesh, 3, order, forces));
     return MCPM_OK;
 }
@@ -288,8 +310,7 @@ int mcpm_bullfrog_step_f32(mcpm_plan *p, const float *pos_in, const float *vel_i
     MCPM_REQUIRE(p, pos_in && vel_in && pos_out && vel_out, MCPM_E_ARG, "mcpm_bullfrog_step_f32: null buffer");
     float *fm = force_meshes ? force_meshes : p->fmesh;
     MCPM_TRY(mcpm_paint_f32(p, pos_in, p->Np, MCPM_POS_LATTICE, nullptr, 1, 1.f, paint_order, p->rho, 0));
-    MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
-    MCPM_TRY(spec_to_force_meshes(p, p->spec1, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, fm));
+    MCPM_TRY(mcpm_force_meshes_f32(p, p->rho, fm));
     MCPM_TRY(mcpm_kick_drift_f32(p, pos_in, vel_in, p->Np, MCPM_POS_LATTICE, fm, paint_order, (float)alpha, (float)beta,
                                  (float)tau, pos_out, vel_out));
     return MCPM_OK;
@@ -310,9 +331,7 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *v
     for (int c = 0; c < 3; ++c)
         MCPM_TRY(mcpm_paint_f32(p, pos_in, N, MCPM_POS_LATTICE, Fb + c, 3, 0.f, paint_order, p->fmesh + c * M, 0));
     // adjoint of 3 C2R + k-space + R2C: rho_bar = C2R( (1/M) sum_c conj(m_c) R2C(f_bar_c) )
-    MCPM_TRY(mcpm_fft_r2c(p, p->fmesh, p->spec, 3));
-    MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, p->spec1, 1.f / (float)M, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 0, 1, 0));
-    MCPM_TRY(mcpm_fft_c2r(p, p->spec1, p->rho, 1));
+    MCPM_TRY(mcpm_force_meshes_vjp_f32(p, p->fmesh, p->rho));
     dim3 grid, block;
     lattice_launch(p->g, grid, block);
     StageTimer st_(p, ST_STEPADJ, 72.0 * N + 16.0 * M);

@@ -1,0 +1,480 @@
+// Hand-written FFT Poisson solve of libmcpm.so for gfx950: real density -> three real force meshes, and its
+// adjoint, in five HBM passes instead of rocFFT's twelve plus a k-space kernel:
+//
+//     z R2C  ->  y column FFT  ->  [x column FFT . k-space multiply . inverse x column FFT] (1 -> 3 spectra)
+//            ->  3 x inverse y column FFT  ->  3 x z C2R
+//
+// Replaces `rfftn` / `invlaplace_hat * gradient_hat` / 3 x `irfftn` of montecosmo/nbody.py:589-603 (and the
+// transpose chain for the VJP).  Power-of-two axes 64..1024 only; other sizes use the rocFFT path (plan.hip).
+//
+// Building block `fft_line`: a length-N complex Stockham FFT held 8 points per thread (T = N/8 threads per
+// line), radix-8 stages exchanged through LDS, an optional last radix-2/4 stage.  Input and output share one
+// register layout (thread u holds points u + T*m), so a forward and an inverse transform chain without
+// reshuffling -- that is what lets the k-space multiply sit between them in registers.
+//   * z passes: lines are contiguous; two real lines ride one complex FFT (a + i b), split / merged with the
+//     Hermitian mirror through LDS.
+//   * y / x passes: a workgroup owns 16 adjacent kz columns of one (x or y) plane so every global access is a
+//     128-byte row segment; lines sit "line-fastest" in LDS, which keeps the exchanges bank-conflict free.
+// Spectra live in a padded internal layout [nx][ny][nzp], nzp = nz/2 + 16, so that those segments are aligned.
+#include "mcpm_internal.h"
+
+typedef float2 cf;
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// multiply by exp(SIGN * i * pi/2): SIGN = -1 (forward) -> -i, +1 (inverse) -> +i
+template <int SIGN>
+__device__ __forceinline__ cf mul_i(cf a) {
+    return SIGN < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+
+template <int SIGN>
+__device__ __forceinline__ void fft4(cf &a0, cf &a1, cf &a2, cf &a3) {
+    cf t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_i<SIGN>(csub(a1, a3));
+    a0 = cadd(t0, t2);
+    a2 = csub(t0, t2);
+    a1 = cadd(t1, t3);
+    a3 = csub(t1, t3);
+}
+
+// in-place radix-8 DFT: v[k] <- sum_n v[n] exp(SIGN 2 pi i n k / 8)
+template <int SIGN>
+__device__ __forceinline__ void fft8(cf (&v)[8]) {
+    cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    fft4<SIGN>(e0, e1, e2, e3);
+    fft4<SIGN>(o0, o1, o2, o3);
+    const float h = 0.70710678118654752f;
+    // w8^1 = (1 + SIGN i)/sqrt2, w8^2 = SIGN i, w8^3 = (-1 + SIGN i)/sqrt2
+    cf w1 = SIGN < 0 ? make_float2(h * (o1.x + o1.y), h * (o1.y - o1.x)) : make_float2(h * (o1.x - o1.y), h * (o1.y + o1.x));
+    cf w2 = mul_i<SIGN>(o2);
+    cf w3 = SIGN < 0 ? make_float2(h * (o3.y - o3.x), -h * (o3.x + o3.y)) : make_float2(-h * (o3.x + o3.y), h * (o3.x - o3.y));
+    v[0] = cadd(e0, o0);
+    v[4] = csub(e0, o0);
+    v[1] = cadd(e1, w1);
+    v[5] = csub(e1, w1);
+    v[2] = cadd(e2, w2);
+    v[6] = csub(e2, w2);
+    v[3] = cadd(e3, w3);
+    v[7] = csub(e3, w3);
+}
+
+// LDS addressing of a tile of LINES lines of N points.  `e` is the point index; each exchange skews it by
+// (e / S) * S2 (S = size of the sub-transform that READS the exchange) to spread the strided reads over banks.
+template <int N, int LINES, bool LINE_FASTEST>
+struct Tile {
+    static constexpr int NP = N + N / 8 + 8;  // padded points per line
+    static constexpr int FLOATS2 = NP * LINES;
+    int l;
+    __device__ __forceinline__ int operator()(int e_padded) const {
+        return LINE_FASTEST ? e_padded * LINES + l : l * NP + e_padded;
+    }
+};
+
+template <int N>
+struct FftShape {
+    static constexpr int T = N / 8;
+    static constexpr int NST8 = (N == 64 || N == 128 || N == 256) ? 2 : 3;
+    static constexpr int P8 = NST8 == 2 ? 64 : 512;
+    static constexpr int RL = N / P8;  // last radix: 1 (none), 2 or 4
+    static_assert(N == 64 || N == 128 || N == 256 || N == 512 || N == 1024, "unsupported FFT length");
+};
+
+// Length-N FFT of one line.  In: v[m] = x[u + T m].  Out: v[m] = X[u + T m].  W[j] = exp(-2 pi i j / N).
+// Every thread of the workgroup must call it (it synchronises the workgroup).
+template <int N, int SIGN, class TILE>
+__device__ __forceinline__ void fft_line(cf (&v)[8], cf *lds, const cf *__restrict__ W, int u, const TILE &tile) {
+    constexpr int T = FftShape<N>::T, NST8 = FftShape<N>::NST8, RL = FftShape<N>::RL;
+    int P = 1, S = N;
+#pragma unroll
+    for (int s = 0; s < NST8; ++s) {
+        const int S2 = S / 8;
+        const int K = u / S2, n2 = u - K * S2;
+        fft8<SIGN>(v);
+        if (S2 > 1) {
+            cf w1 = W[n2 * P];
+            if (SIGN > 0) w1.y = -w1.y;
+            const cf w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+            v[1] = cmul(v[1], w1);
+            v[2] = cmul(v[2], w2);
+            v[3] = cmul(v[3], w3);
+            v[4] = cmul(v[4], w4);
+            v[5] = cmul(v[5], cmul(w4, w1));
+            v[6] = cmul(v[6], cmul(w4, w2));
+            v[7] = cmul(v[7], cmul(w4, w3));
+        }
+        const bool final_stage = (s == NST8 - 1) && (RL == 1);
+        if (!final_stage) {
+            // exchange: outputs at e = (K + P k) S2 + n2; next stage (sub-size S2) reads e = K' S2 + n1 (S2/R') + n2'
+            const int Snext = S2;
+            const int S2next = (s == NST8 - 1) ? 1 : S2 / 8;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = (K + P * k) * S2 + n2;
+                // the small last radix reads with stride RL: skew by one point per 32 instead
+                lds[tile((s == NST8 - 1) ? e + (e >> 5) : e + (e / Snext) * S2next)] = v[k];
+            }
+            __syncthreads();
+            if (s < NST8 - 1) {
+                const int Kn = u / S2next, n2n = u - Kn * S2next;
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1) {
+                    const int e = Kn * Snext + n1 * S2next + n2n;
+                    v[n1] = lds[tile(e + (e / Snext) * S2next)];
+                }
+            }
+        }
+        P *= 8;
+        S = S2;
+    }
+    if (RL > 1) {
+        // last stage, radix RL: thread u owns butterflies K = u + T j; inputs e = K RL + n1; outputs X[K + P k]
+        constexpr int NB = 8 / (RL > 1 ? RL : 8);
+        cf x[8];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int n1 = 0; n1 < RL; ++n1) {
+                const int e = (u + T * j) * RL + n1;
+                x[j * RL + n1] = lds[tile(e + (e >> 5))];
+            }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (RL == 2) {
+                cf a = x[2 * j], b = x[2 * j + 1];
+                v[j] = cadd(a, b);
+                v[j + NB] = csub(a, b);
+            } else {
+                cf a0 = x[4 * j], a1 = x[4 * j + 1], a2 = x[4 * j + 2], a3 = x[4 * j + 3];
+                fft4<SIGN>(a0, a1, a2, a3);
+                v[j] = a0;
+                v[j + NB] = a1;
+                v[j + 2 * NB] = a2;
+                v[j + 3 * NB] = a3;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// z passes: contiguous lines, two real lines per complex transform
+struct FGeom {
+    int nx, ny, nz, nzh, nzp;  // nzp: padded complex pitch of the internal spectra
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void zfwd_kernel(FGeom g, const float *__restrict__ real, cf *__restrict__ spec,
+                                                   const cf *__restrict__ W, int64_t npairs) {
+    constexpr int T = FftShape<N>::T, PAIRS = 256 / T;
+    typedef Tile<N, PAIRS, false> TL;
+    __shared__ cf lds[TL::FLOATS2];
+    const int pl = threadIdx.x / T, u = threadIdx.x - pl * T;
+    const int64_t pair = (int64_t)blockIdx.x * PAIRS + pl;
+    const bool ok = pair < npairs;
+    const float *a = real + (2 * pair) * N, *b = a + N;
+    cf v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = ok ? make_float2(a[u + T * m], b[u + T * m]) : make_float2(0.f, 0.f);
+    TL tile{pl};
+    fft_line<N, -1>(v, lds, W, u, tile);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) lds[tile(u + T * m)] = v[m];
+    __syncthreads();
+    if (!ok) return;
+    cf *oa = spec + (2 * pair) * g.nzp, *ob = oa + g.nzp;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int k = u + T * m;
+        const cf z = v[m], zm = lds[tile((N - k) & (N - 1))];
+        oa[k] = make_float2(0.5f * (z.x + zm.x), 0.5f * (z.y - zm.y));
+        ob[k] = make_float2(0.5f * (z.y + zm.y), 0.5f * (zm.x - z.x));
+    }
+    if (u == 0) {  // Nyquist: Z[N/2] is its own mirror
+        const cf z = v[4];
+        oa[N / 2] = make_float2(z.x, 0.f);
+        ob[N / 2] = make_float2(z.y, 0.f);
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void zinv_kernel(FGeom g, const cf *__restrict__ spec, float *__restrict__ real,
+                                                   const cf *__restrict__ W, int64_t npairs) {
+    constexpr int T = FftShape<N>::T, PAIRS = 256 / T;
+    typedef Tile<N, PAIRS, false> TL;
+    __shared__ cf lds[TL::FLOATS2];
+    const int pl = threadIdx.x / T, u = threadIdx.x - pl * T;
+    const int64_t pair = (int64_t)blockIdx.x * PAIRS + pl;
+    const bool ok = pair < npairs;
+    const cf *ia = spec + (2 * pair) * g.nzp, *ib = ia + g.nzp;
+    TL tile{pl};
+    // Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k]); imaginary parts of k = 0 and N/2 are ignored (c2r)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int k = u + T * m;
+        cf A = ok ? ia[k] : make_float2(0.f, 0.f), B = ok ? ib[k] : make_float2(0.f, 0.f);
+        if (k == 0) {
+            lds[tile(0)] = make_float2(A.x, B.x);
+        } else {
+            lds[tile(k)] = make_float2(A.x - B.y, A.y + B.x);
+            lds[tile(N - k)] = make_float2(A.x + B.y, B.x - A.y);
+        }
+    }
+    if (u == 0) {
+        cf A = ok ? ia[N / 2] : make_float2(0.f, 0.f), B = ok ? ib[N / 2] : make_float2(0.f, 0.f);
+        lds[tile(N / 2)] = make_float2(A.x, B.x);
+    }
+    __syncthreads();
+    cf v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = lds[tile(u + T * m)];
+    fft_line<N, +1>(v, lds, W, u, tile);
+    if (!ok) return;
+    float *a = real + (2 * pair) * N, *b = a + N;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        a[u + T * m] = v[m].x;
+        b[u + T * m] = v[m].y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column passes (y or x): 16 adjacent kz columns per workgroup
+template <int N>
+struct ColShape {
+    static constexpr int T = FftShape<N>::T;
+    static constexpr int LINES = (1024 / T) < 16 ? (1024 / T) : 16;
+    static constexpr int THREADS = T * LINES;
+};
+
+// in-place FFT along y for every (batch, x, kz): element (y, kz) of plane p at spec[(p ny + y) nzp + kz]
+template <int N, int SIGN>
+__global__ __launch_bounds__(ColShape<N>::THREADS) void ycol_kernel(FGeom g, cf *__restrict__ spec, const cf *__restrict__ W) {
+    constexpr int T = ColShape<N>::T, LINES = ColShape<N>::LINES;
+    typedef Tile<N, LINES, true> TL;
+    __shared__ cf lds[TL::FLOATS2];
+    const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
+    const int kz = blockIdx.x * LINES + l;
+    const bool ok = kz < g.nzh;
+    cf *base = spec + (int64_t)blockIdx.y * N * g.nzp + kz;
+    cf v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = ok ? base[(int64_t)(u + T * m) * g.nzp] : make_float2(0.f, 0.f);
+    TL tile{l};
+    fft_line<N, SIGN>(v, lds, W, u, tile);
+    if (!ok) return;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) base[(int64_t)(u + T * m) * g.nzp] = v[m];
+}
+
+// k-space multipliers (nbody.py:109-163 with fd_order = inf), wavevectors from indices
+#define MCPM_TWO_PI 6.283185307179586f
+__device__ __forceinline__ float kfreq_i(int i, int n) {
+    int s = (i < (n + 1) / 2) ? i : i - n;
+    return MCPM_TWO_PI * (float)s / (float)n;
+}
+
+struct KMul {
+    float s[3];  // out_c = s_c * (-i) * in  (s_c = k_c * (-1/k^2) * scale, Hermitian-projected)
+};
+__device__ __forceinline__ KMul force_mult(const FGeom &g, int ix, int iy, int iz, float scale) {
+    const float kx = kfreq_i(ix, g.nx), ky = kfreq_i(iy, g.ny), kz = MCPM_TWO_PI * (float)iz / (float)g.nz;
+    const float kk = kx * kx + ky * ky + kz * kz;
+    const float L = kk == 0.f ? 0.f : -scale / kk;
+    const bool special = (iz == 0) || (iz == g.nz / 2);
+    KMul m;
+    m.s[0] = (special && ix == g.nx / 2) ? 0.f : kx * L;
+    m.s[1] = (special && iy == g.ny / 2) ? 0.f : ky * L;
+    m.s[2] = (iz == g.nz / 2) ? 0.f : kz * L;
+    return m;
+}
+
+// MODE 0: in (1 spectrum) -> forward x FFT -> x (-(i k_c))(-1/k^2) scale -> inverse x FFT -> out (3 spectra)
+// MODE 1: in (3 spectra) -> forward x FFT -> sum_c conj(multiplier_c) -> inverse x FFT -> out (1 spectrum)
+// element (x, y, kz) at [(x ny + y) nzp + kz]; spectra are `sstride` complex apart.
+template <int N, int MODE>
+__global__ __launch_bounds__(ColShape<N>::THREADS) void xfused_kernel(FGeom g, const cf *__restrict__ in, cf *__restrict__ out,
+                                                                      int64_t sstride, float scale, const cf *__restrict__ W) {
+    constexpr int T = ColShape<N>::T, LINES = ColShape<N>::LINES;
+    typedef Tile<N, LINES, true> TL;
+    __shared__ cf lds[TL::FLOATS2];
+    const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
+    const int kz = blockIdx.x * LINES + l, iy = blockIdx.y;
+    const bool ok = kz < g.nzh;
+    const int64_t off0 = (int64_t)iy * g.nzp + kz, xs = (int64_t)g.ny * g.nzp;
+    TL tile{l};
+    if (MODE == 0) {
+        cf v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = ok ? in[off0 + (u + T * m) * xs] : make_float2(0.f, 0.f);
+        fft_line<N, -1>(v, lds, W, u, tile);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            cf w[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const KMul km = force_mult(g, u + T * m, iy, kz, scale);
+                w[m] = make_float2(km.s[c] * v[m].y, -km.s[c] * v[m].x);  // (a + i b)(-i s)
+            }
+            fft_line<N, +1>(w, lds, W, u, tile);
+            if (ok) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) out[c * sstride + off0 + (u + T * m) * xs] = w[m];
+            }
+        }
+    } else {
+        cf acc[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            cf v[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = ok ? in[c * sstride + off0 + (u + T * m) * xs] : make_float2(0.f, 0.f);
+            fft_line<N, -1>(v, lds, W, u, tile);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const KMul km = force_mult(g, u + T * m, iy, kz, scale);
+                acc[m].x += -km.s[c] * v[m].y;  // (a + i b)(+i s)
+                acc[m].y += km.s[c] * v[m].x;
+            }
+        }
+        fft_line<N, +1>(acc, lds, W, u, tile);
+        if (ok) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) out[off0 + (u + T * m) * xs] = acc[m];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+static bool pow2_ok(int n) { return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024; }
+
+bool mcpm_fftpm_supported(const mcpm_plan *p) {
+    if (getenv("MCPM_DISABLE_FFTPM")) return false;
+    return pow2_ok(p->g.nx) && pow2_ok(p->g.ny) && pow2_ok(p->g.nz);
+}
+
+static int ensure_twiddles(mcpm_plan *p) {
+    if (p->tw[0]) return MCPM_OK;
+    const int dims[3] = {p->g.nx, p->g.ny, p->g.nz};
+    for (int a = 0; a < 3; ++a) {
+        const int n = dims[a];
+        std::vector<float> h(2 * (size_t)n);
+        for (int j = 0; j < n; ++j) {
+            const double ang = -2.0 * 3.14159265358979323846 * j / n;
+            h[2 * j] = (float)cos(ang);
+            h[2 * j + 1] = (float)sin(ang);
+        }
+        if (hipMalloc((void **)&p->tw[a], sizeof(float) * 2 * n) != hipSuccess) return mcpm_fail(p, MCPM_E_NOMEM, "twiddle table");
+        MCPM_HIP(p, hipMemcpy(p->tw[a], h.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+    }
+    return MCPM_OK;
+}
+
+static FGeom fgeom(const mcpm_plan *p) { return FGeom{p->g.nx, p->g.ny, p->g.nz, p->g.nzh, p->g.nz / 2 + 16}; }
+
+#define DISPATCH_N(n, CALL)                  \
+    switch (n) {                             \
+        case 64: CALL(64); break;            \
+        case 128: CALL(128); break;          \
+        case 256: CALL(256); break;          \
+        case 512: CALL(512); break;          \
+        default: CALL(1024); break;          \
+    }
+
+static int z_forward(mcpm_plan *p, const float *real, cf *spec, int batch) {
+    const FGeom g = fgeom(p);
+    const int64_t npairs = (int64_t)batch * g.nx * g.ny / 2;
+    StageTimer st_(p, ST_R2C, (double)batch * (4.0 * p->M + 8.0 * p->Mh) / 3.0);
+#define CALL(NN)                                                                                                   \
+    {                                                                                                              \
+        constexpr int PAIRS = 256 / (NN / 8);                                                                      \
+        zfwd_kernel<NN><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, real, spec, (const cf *)p->tw[2], npairs); \
+    }
+    DISPATCH_N(g.nz, CALL)
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "zfwd_kernel");
+    return MCPM_OK;
+}
+
+static int z_inverse(mcpm_plan *p, const cf *spec, float *real, int batch) {
+    const FGeom g = fgeom(p);
+    const int64_t npairs = (int64_t)batch * g.nx * g.ny / 2;
+    StageTimer st_(p, ST_C2R, (double)batch * (4.0 * p->M + 8.0 * p->Mh) / 3.0);
+#define CALL(NN)                                                                                                   \
+    {                                                                                                              \
+        constexpr int PAIRS = 256 / (NN / 8);                                                                      \
+        zinv_kernel<NN><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, spec, real, (const cf *)p->tw[2], npairs); \
+    }
+    DISPATCH_N(g.nz, CALL)
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "zinv_kernel");
+    return MCPM_OK;
+}
+
+static int y_columns(mcpm_plan *p, cf *spec, int batch, int sign) {
+    const FGeom g = fgeom(p);
+    StageTimer st_(p, sign < 0 ? ST_R2C : ST_C2R, (double)batch * (4.0 * p->M + 8.0 * p->Mh) / 3.0);
+#define CALL(NN)                                                                                       \
+    {                                                                                                  \
+        constexpr int LINES = ColShape<NN>::LINES, TH = ColShape<NN>::THREADS;                         \
+        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)(batch * g.nx));                  \
+        if (sign < 0) ycol_kernel<NN, -1><<<grid, TH, 0, p->stream>>>(g, spec, (const cf *)p->tw[1]);  \
+        else ycol_kernel<NN, +1><<<grid, TH, 0, p->stream>>>(g, spec, (const cf *)p->tw[1]);           \
+    }
+    DISPATCH_N(g.ny, CALL)
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "ycol_kernel");
+    return MCPM_OK;
+}
+
+static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
+    const FGeom g = fgeom(p);
+    const int64_t sstride = (int64_t)g.nx * g.ny * g.nzp;
+    const float scale = 1.f / (float)p->M;
+    // one forward + one inverse x pass of (1 + 3) spectra and the k-space multiply
+    StageTimer st_(p, ST_KSPACE, 32.0 * p->Mh + 4.0 * (4.0 * p->M + 8.0 * p->Mh) / 3.0);
+#define CALL(NN)                                                                                              \
+    {                                                                                                         \
+        constexpr int LINES = ColShape<NN>::LINES, TH = ColShape<NN>::THREADS;                                \
+        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)g.ny);                                   \
+        if (mode == 0) xfused_kernel<NN, 0><<<grid, TH, 0, p->stream>>>(g, in, out, sstride, scale, (const cf *)p->tw[0]); \
+        else xfused_kernel<NN, 1><<<grid, TH, 0, p->stream>>>(g, in, out, sstride, scale, (const cf *)p->tw[0]);           \
+    }
+    DISPATCH_N(g.nx, CALL)
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "xfused_kernel");
+    return MCPM_OK;
+}
+
+// rho (real mesh) -> three force meshes irfftn(-(i k_c)(-1/k^2) rfftn(rho))
+int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3) {
+    MCPM_TRY(ensure_twiddles(p));
+    const FGeom g = fgeom(p);
+    const int64_t ss = (int64_t)g.nx * g.ny * g.nzp;
+    cf *s0 = (cf *)p->spec, *s123 = s0 + ss;
+    MCPM_TRY(z_forward(p, rho, s0, 1));
+    MCPM_TRY(y_columns(p, s0, 1, -1));
+    MCPM_TRY(x_fused(p, s0, s123, 0));
+    MCPM_TRY(y_columns(p, s123, 3, +1));
+    MCPM_TRY(z_inverse(p, s123, fm3, 3));
+    return MCPM_OK;
+}
+
+// adjoint: three real cotangent meshes -> rho_bar = irfftn(sum_c conj(multiplier_c) rfftn(f_bar_c))
+int mcpm_fftpm_force_meshes_vjp(mcpm_plan *p, const float *fbar3, float *rho_bar) {
+    MCPM_TRY(ensure_twiddles(p));
+    const FGeom g = fgeom(p);
+    const int64_t ss = (int64_t)g.nx * g.ny * g.nzp;
+    cf *s0 = (cf *)p->spec, *s123 = s0 + ss;
+    MCPM_TRY(z_forward(p, fbar3, s123, 3));
+    MCPM_TRY(y_columns(p, s123, 3, -1));
+    MCPM_TRY(x_fused(p, s123, s0, 1));
+    MCPM_TRY(y_columns(p, s0, 1, +1));
+    MCPM_TRY(z_inverse(p, s0, rho_bar, 1));
+    return MCPM_OK;
+}

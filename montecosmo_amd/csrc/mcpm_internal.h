@@ -64,6 +64,7 @@ struct mcpm_plan {
     int *outlier_count;  // device counter (2 ints: live counter, copy of last)
     double *reduce;  // device accumulators for scalar cotangents (MCPM_NREDUCE doubles)
     float *pscratch; // 9*Np floats, allocated on first VJP (adjoint state + force cotangent)
+    float *tw[3];    // twiddle tables exp(-2 pi i j / n) of the hand-written FFT, per axis (x, y, z)
 
     // optional profile: HIP events recorded on the plan's stream around every leaf stage
     int profiling;
@@ -106,6 +107,11 @@ struct StageTimer {
 extern thread_local std::string g_mcpm_create_error;
 
 int mcpm_fail(mcpm_plan *plan, int code, const std::string &msg);
+
+// hand-written FFT Poisson solve (fftpm.hip); power-of-two axes only
+bool mcpm_fftpm_supported(const mcpm_plan *p);
+int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3);
+int mcpm_fftpm_force_meshes_vjp(mcpm_plan *p, const float *fbar3, float *rho_bar);
 
 #define MCPM_HIP(plan, expr)                                                                         \
     do {                                                                                             \
