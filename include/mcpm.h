@@ -56,6 +56,11 @@ typedef struct mcpm_plan mcpm_plan;
 /* ---- plan ------------------------------------------------------------------------------------ */
 /* mesh (nx,ny,nz), particle lattice (px,py,pz), HIP stream (hipStream_t, may be NULL). */
 int mcpm_plan_create(int nx, int ny, int nz, int px, int py, int pz, void *stream, mcpm_plan **plan);
+/* x-slab plan for rank `rank` of `nranks`: (nx,ny,nz) is the GLOBAL mesh; this rank owns mesh
+   planes [rank*nx/nranks, (rank+1)*nx/nranks) and the lattice particles of those planes (Lagrangian ownership:
+   particles never migrate).  Particle kernels then work on the ghost-extended local mesh
+   (nx/nranks + 2*ghost, ny, nz), non-periodic in x; ghost planes are exchanged by the host (montecosmo_amd/dist.py). */
+int mcpm_plan_create_slab(int nx, int ny, int nz, int nranks, int rank, int ghost, void *stream, mcpm_plan **plan);
 int mcpm_plan_destroy(mcpm_plan *plan);
 const char *mcpm_last_error(const mcpm_plan *plan); /* plan may be NULL: last error of a failed create */
 const char *mcpm_version(void);
@@ -124,6 +129,21 @@ int mcpm_hessian_combine_vjp_f32(mcpm_plan *plan, const float *hess6, const floa
 int mcpm_force_meshes_f32(mcpm_plan *plan, const float *rho, float *fm3);
 int mcpm_force_meshes_vjp_f32(mcpm_plan *plan, const float *fbar3, float *rho_bar);
 
+/* Pass-level entry points of the same solve for slab plans: the host (montecosmo_amd/dist.py) places an all-to-all
+   between the y and the x pass.  Spectra are complex64 in the internal padded layout, mcpm_slab_spec_elems()
+   complex per spectrum = (nx/ranks) * ny * (nz/2 + 16).
+     zfwd  : `batch` real meshes of nx/ranks planes (mesh b at real + b*real_bstride floats) -> `batch` spectra
+     ycol  : FFT along y (sign -1 forward / +1 inverse); *_packed = all-to-all layout
+             [dest rank][plane][y_local][nzp], plain = [plane][y][nzp]
+     xfused: mode 0: one spectrum [x][y_local][nzp] -> x FFT, k-space force multiply, inverse x FFT -> three
+             spectra [dest rank][c][x_local][y_local][nzp]; mode 1 is the adjoint (three in that layout -> one)
+     zinv  : `batch` spectra -> `batch` real meshes (unnormalised; the 1/M sits in xfused). */
+int64_t mcpm_slab_spec_elems(const mcpm_plan *plan);
+int mcpm_slab_zfwd(mcpm_plan *plan, const float *real, int64_t real_bstride, float *spec, int batch);
+int mcpm_slab_ycol(mcpm_plan *plan, const float *in, float *out, int batch, int sign, int in_packed, int out_packed);
+int mcpm_slab_xfused(mcpm_plan *plan, const float *in, float *out, int mode);
+int mcpm_slab_zinv(mcpm_plan *plan, const float *spec, float *real, int64_t real_bstride, int batch);
+
 /* ---- forces (nbody.py:583-631) -------------------------------------------------------------- */
 /* pm_forces with mesh = shape tuple: paint -> R2C -> k-space -> 3 C2R -> read; forces[N][3].
    Leaves the three force meshes in the plan (mcpm_plan_force_meshes). */
@@ -160,8 +180,18 @@ int mcpm_bullfrog_step_f32(mcpm_plan *plan, const float *pos_in, const float *ve
 int mcpm_bullfrog_step_vjp_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in, const float *force_meshes,
                                double alpha, double beta, double tau, int paint_order, float *pos_bar,
                                float *vel_bar, double *alpha_bar, double *beta_bar);
+/* The particle half of that adjoint alone (fused gradient gather of the three force meshes and of rho_bar, kick /
+   drift adjoints, scalar cotangents); used by the slab path, where the host exchanges ghost planes in between. */
+int mcpm_step_adjoint_particles_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in,
+                                    const float *force_meshes, const float *rho_bar, double alpha, double beta,
+                                    double tau, int paint_order, float *pos_bar, float *vel_bar, double *alpha_bar,
+                                    double *beta_bar);
 int mcpm_lpt_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg,
                  int lap_fd, int grad_fd, float *dpos, float *vel);
+/* VJP of mcpm_lpt_f32 w.r.t. init_mesh (real-pair convention, irfftn multiplicity weights included) and the three
+   growth scalars: scalar_bars = {g_bar, g2_bar, dg2dg_bar} (host, may be NULL; forces a stream sync when given). */
+int mcpm_lpt_vjp_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, const double *lpt_scalars,
+                     const float *dpos_bar, const float *vel_bar, float *init_mesh_bar, double *scalar_bars);
 /* nbody_bf (nbody.py:967-1002), snapshots=None: LPT start at a0 then n_steps drift-kick-drift steps of size
    dg in growth-factor time.  alpha[i] and beta[i] = (1-alpha_i)/(g_i + dg/2) are host float64 arrays computed
    from the growth tables (alpha_bf nbody.py:907-919 or alpha_fpm :921-931, evaluated at the accumulated Euler

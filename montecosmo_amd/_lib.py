@@ -21,6 +21,7 @@ _f64p = C.POINTER(C.c_double)
 # name -> (restype, argtypes); mirrors include/mcpm.h one to one
 SIGNATURES = {
     "mcpm_plan_create": (C.c_int, [C.c_int] * 6 + [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mcpm_plan_create_slab": (C.c_int, [C.c_int] * 6 + [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mcpm_plan_destroy": (C.c_int, [C.c_void_p]),
     "mcpm_last_error": (C.c_char_p, [C.c_void_p]),
     "mcpm_version": (C.c_char_p, []),
@@ -41,6 +42,11 @@ SIGNATURES = {
     "mcpm_hessian_combine_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p]),
     "mcpm_force_meshes_f32": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "mcpm_force_meshes_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p]),
+    "mcpm_slab_spec_elems": (C.c_int64, [C.c_void_p]),
+    "mcpm_slab_zfwd": (C.c_int, [C.c_void_p, _f32p, C.c_int64, _f32p, C.c_int]),
+    "mcpm_slab_ycol": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mcpm_slab_xfused": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int]),
+    "mcpm_slab_zinv": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int]),
     "mcpm_pm_forces_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f32p]),
     "mcpm_pm_forces_spec_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f32p]),
     "mcpm_pm_forces2_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
@@ -53,6 +59,8 @@ SIGNATURES = {
     "mcpm_stage_name": (C.c_char_p, [C.c_int]),
     "mcpm_bullfrog_step_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, _f32p]),
     "mcpm_bullfrog_step_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, C.c_void_p, C.c_void_p]),
+    "mcpm_step_adjoint_particles_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, C.c_void_p, C.c_void_p]),
+    "mcpm_lpt_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f32p, _f32p, _f32p, _f64p]),
     "mcpm_lpt_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _f32p, _f32p]),
     "mcpm_nbody_bf_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f64p, C.c_double, _f64p, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
     "mcpm_nbody_ckpt_floats": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),

@@ -22,7 +22,7 @@ __device__ __forceinline__ int lattice_ngp(int ip, int n, int p, int same) {
 }
 
 __device__ __forceinline__ int64_t lattice_cell(const Geom &g, const PIdx &pi) {
-    int cx = lattice_ngp(pi.ipx, g.nx, g.px, g.same_lattice);
+    int cx = lattice_ngp(pi.ipx, g.nx, g.px, g.same_lattice) + g.xoff;
     int cy = lattice_ngp(pi.ipy, g.ny, g.py, g.same_lattice);
     int cz = lattice_ngp(pi.ipz, g.nz, g.pz, g.same_lattice);
     return ((int64_t)cx * g.ny + cy) * g.nz + cz;
@@ -227,6 +227,42 @@ static int ensure_pscratch(mcpm_plan *p) {
     return MCPM_OK;
 }
 
+// Adjoint of lpt at the lattice (read_order = 1): cotangents (xb, vb) of (dpos, vel) -> init_mesh_bar (real-pair
+// convention) and three DEVICE double accumulators sb = {g_bar, -g2_bar, -dg2dg_bar} (added to, not reset).
+static int lpt_vjp_device(mcpm_plan *p, const float *init_mesh, int lpt_order, const double *lpt_scalars, const float *xb,
+                          const float *vb, float *init_mesh_bar, double *sb) {
+    const int64_t M = p->M;
+    const float invM = 1.f / (float)M;
+    dim3 grid, block;
+    lattice_launch(p->g, grid, block);
+    const float g = (float)lpt_scalars[0], g2 = (float)lpt_scalars[1], c2 = (float)lpt_scalars[2];
+    MCPM_TRY(spec_to_force_meshes(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, p->fmesh));
+    lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, p->fmesh, M, xb, nullptr, sb + 0, nullptr);
+    MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
+    if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(p->fmesh, 0, sizeof(float) * 3 * M, p->stream));
+    lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, g, 1.f, p->fmesh, M);
+    MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
+    MCPM_TRY(mcpm_fft_r2c(p, p->fmesh, p->spec, 3));
+    MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, init_mesh_bar, invM, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 1, 0, 0));
+    if (lpt_order == 2) {
+        float *h = p->fmesh, *f2 = p->fmesh + 6 * M;
+        MCPM_TRY(spec_to_delta2(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF));             // h in fmesh[0:6], delta2_k in spec1
+        MCPM_TRY(spec_to_force_meshes(p, p->spec1, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, f2));  // F2 meshes
+        lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, f2, M, xb, vb, sb + 1, sb + 2);  // negated on the host
+        MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
+        if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(f2, 0, sizeof(float) * 3 * M, p->stream));
+        lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, -g2, -c2, f2, M);
+        MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
+        MCPM_TRY(mcpm_fft_r2c(p, f2, p->spec, 3));
+        MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, p->spec1, invM, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 0, 1, 0));
+        MCPM_TRY(mcpm_fft_c2r(p, p->spec1, p->rho, 1));                               // delta2_bar
+        MCPM_TRY(mcpm_hessian_combine_vjp_f32(p, h, p->rho, h));                      // in place: h -> h_bar
+        MCPM_TRY(mcpm_fft_r2c(p, h, p->spec, 6));
+        MCPM_TRY(mcpm_kspace_hessian_vjp_f32(p, p->spec, init_mesh_bar, invM, MCPM_FD_INF, MCPM_FD_INF, 1, 1));
+    }
+    return MCPM_OK;
+}
+
 extern "C" {
 
 int mcpm_force_meshes_f32(mcpm_plan *p, const float *rho, float *fm3) {
@@ -332,21 +368,50 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *v
         MCPM_TRY(mcpm_paint_f32(p, pos_in, N, MCPM_POS_LATTICE, Fb + c, 3, 0.f, paint_order, p->fmesh + c * M, 0));
     // adjoint of 3 C2R + k-space + R2C: rho_bar = C2R( (1/M) sum_c conj(m_c) R2C(f_bar_c) )
     MCPM_TRY(mcpm_force_meshes_vjp_f32(p, p->fmesh, p->rho));
+    return mcpm_step_adjoint_particles_f32(p, pos_in, vel_in, force_meshes, p->rho, alpha, beta, tau, paint_order, pos_bar,
+                                           vel_bar, alpha_bar, beta_bar);
+}
+
+int mcpm_step_adjoint_particles_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes,
+                                    const float *rho_bar, double alpha, double beta, double tau, int paint_order,
+                                    float *pos_bar, float *vel_bar, double *alpha_bar, double *beta_bar) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, pos_in && vel_in && force_meshes && rho_bar && pos_bar && vel_bar, MCPM_E_ARG,
+                 "mcpm_step_adjoint_particles_f32: null buffer");
+    MCPM_REQUIRE(p, paint_order == 1 || paint_order == 2, MCPM_E_ORDER, "mcpm_step_adjoint_particles_f32: paint_order must be 1 or 2");
+    const int64_t N = p->Np, M = p->M;
+    const float a = (float)alpha, b = (float)beta, t = (float)tau;
     dim3 grid, block;
     lattice_launch(p->g, grid, block);
     StageTimer st_(p, ST_STEPADJ, 72.0 * N + 16.0 * M);
     double *slots = p->reduce + (MCPM_NREDUCE - 2 * MCPM_NSLOT);
     MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 2 * MCPM_NSLOT, p->stream));
     if (paint_order == 2)
-        step_adjoint_kernel<2><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, p->rho, M, a, b,
+        step_adjoint_kernel<2><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b,
                                                               t, slots);
     else
-        step_adjoint_kernel<1><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, p->rho, M, a, b,
+        step_adjoint_kernel<1><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b,
                                                               t, slots);
     MCPM_LAUNCH_CHECK(p, "step_adjoint_kernel");
     if (alpha_bar || beta_bar) {
         reduce_slots_kernel<<<1, MCPM_NSLOT, 0, p->stream>>>(slots, alpha_bar, beta_bar);
         MCPM_LAUNCH_CHECK(p, "reduce_slots_kernel");
+    }
+    return MCPM_OK;
+}
+
+int mcpm_lpt_vjp_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, const double *lpt_scalars, const float *dpos_bar,
+                     const float *vel_bar, float *init_mesh_bar, double *scalar_bars) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, init_mesh && lpt_scalars && dpos_bar && vel_bar && init_mesh_bar, MCPM_E_ARG, "mcpm_lpt_vjp_f32: null argument");
+    MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_lpt_vjp_f32: lpt_order must be 1 or 2");
+    MCPM_HIP(p, hipMemsetAsync(p->reduce, 0, sizeof(double) * 3, p->stream));
+    MCPM_TRY(lpt_vjp_device(p, init_mesh, lpt_order, lpt_scalars, dpos_bar, vel_bar, init_mesh_bar, p->reduce));
+    if (scalar_bars) {
+        MCPM_HIP(p, hipMemcpyAsync(scalar_bars, p->reduce, sizeof(double) * 3, hipMemcpyDeviceToHost, p->stream));
+        MCPM_HIP(p, hipStreamSynchronize(p->stream));
+        scalar_bars[1] = -scalar_bars[1];
+        scalar_bars[2] = -scalar_bars[2];
     }
     return MCPM_OK;
 }
@@ -401,9 +466,6 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     MCPM_HIP(p, hipMemcpyAsync(xb, pos_bar, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, p->stream));
     MCPM_HIP(p, hipMemcpyAsync(vb, vel_bar, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, p->stream));
     MCPM_HIP(p, hipMemsetAsync(p->reduce, 0, sizeof(double) * (2 * n_steps + 3), p->stream));
-    dim3 grid, block;
-    lattice_launch(p->g, grid, block);
-    const float invM = 1.f / (float)M;
     for (int i = n_steps - 1; i >= 0; --i)
         MCPM_TRY(mcpm_bullfrog_step_vjp_f32(p, state_x(i), state_v(i), force_m(i), alpha[i], beta[i],
                                             (i == n_steps - 1) ? dg / 2 : dg, paint_order, xb, vb, p->reduce + i,
@@ -412,32 +474,7 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     MCPM_TRY(axpby(p, vb, xb, 3 * N, 1.f, (float)(dg / 2), vb));
 
     // ---- adjoint of lpt (nbody.py:634-667) at the lattice, read_order = 1
-    const float g = (float)lpt_scalars[0], g2 = (float)lpt_scalars[1], c2 = (float)lpt_scalars[2];
-    double *sb = p->reduce + 2 * n_steps;
-    MCPM_TRY(spec_to_force_meshes(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, p->fmesh));
-    lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, p->fmesh, M, xb, nullptr, sb + 0, nullptr);
-    MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
-    if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(p->fmesh, 0, sizeof(float) * 3 * M, p->stream));
-    lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, g, 1.f, p->fmesh, M);
-    MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
-    MCPM_TRY(mcpm_fft_r2c(p, p->fmesh, p->spec, 3));
-    MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, init_mesh_bar, invM, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 1, 0, 0));
-    if (lpt_order == 2) {
-        float *h = p->fmesh, *f2 = p->fmesh + 6 * M;
-        MCPM_TRY(spec_to_delta2(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF));             // h in fmesh[0:6], delta2_k in spec1
-        MCPM_TRY(spec_to_force_meshes(p, p->spec1, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, f2));  // F2 meshes
-        lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, f2, M, xb, vb, sb + 1, sb + 2);  // negated on the host
-        MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
-        if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(f2, 0, sizeof(float) * 3 * M, p->stream));
-        lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, -g2, -c2, f2, M);
-        MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
-        MCPM_TRY(mcpm_fft_r2c(p, f2, p->spec, 3));
-        MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, p->spec1, invM, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 0, 1, 0));
-        MCPM_TRY(mcpm_fft_c2r(p, p->spec1, p->rho, 1));                               // delta2_bar
-        MCPM_TRY(mcpm_hessian_combine_vjp_f32(p, h, p->rho, h));                      // in place: h -> h_bar
-        MCPM_TRY(mcpm_fft_r2c(p, h, p->spec, 6));
-        MCPM_TRY(mcpm_kspace_hessian_vjp_f32(p, p->spec, init_mesh_bar, invM, MCPM_FD_INF, MCPM_FD_INF, 1, 1));
-    }
+    MCPM_TRY(lpt_vjp_device(p, init_mesh, lpt_order, lpt_scalars, xb, vb, init_mesh_bar, p->reduce + 2 * n_steps));
     if (scalar_bars) {
         MCPM_HIP(p, hipMemcpyAsync(scalar_bars, p->reduce, sizeof(double) * (2 * n_steps + 3), hipMemcpyDeviceToHost, p->stream));
         MCPM_HIP(p, hipStreamSynchronize(p->stream));

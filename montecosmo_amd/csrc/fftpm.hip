@@ -161,19 +161,36 @@ __device__ __forceinline__ void fft_line(cf (&v)[8], cf *lds, const cf *__restri
 // ------------------------------------------------------------------------------------------------
 // z passes: contiguous lines, two real lines per complex transform
 struct FGeom {
-    int nx, ny, nz, nzh, nzp;  // nzp: padded complex pitch of the internal spectra
+    int nx, ny, nz, nzh, nzp;  // GLOBAL mesh; nzp: padded complex pitch of the internal spectra
+};
+// batched z lines: mesh b starts at real + b*real_bstride (floats) / spec + b*spec_bstride (complex); `lines` per mesh
+struct ZBatch {
+    int64_t lines, real_bstride, spec_bstride;
+};
+// y-line addressing of a column pass: point y of plane p sits at p*PS + (y / YB)*SB + (y % YB)*nzp (complex).
+// Plain layout [plane][y][nzp]: YB = ny, SB = 0.  All-to-all packed layout [dest][plane][y_local][nzp]: YB = ny/ranks.
+struct YLayout {
+    int64_t PS, SB;
+    int YB;
+};
+// x-line addressing of the fused pass.  One-spectrum side: [x][yl][nzp] (NYL rows per x).  Three-spectra side:
+// (x / XB)*SBx + c*SC + ((x % XB)*NYL + yl)*nzp  (single GPU: XB = nx; slabs: [src/dest rank][c][xl][yl][nzp]).
+struct XLayout {
+    int NYL, iy0, XB;
+    int64_t SBx, SC;
 };
 
 template <int N>
 __global__ __launch_bounds__(256) void zfwd_kernel(FGeom g, const float *__restrict__ real, cf *__restrict__ spec,
-                                                   const cf *__restrict__ W, int64_t npairs) {
+                                                   const cf *__restrict__ W, int64_t npairs, ZBatch zb) {
     constexpr int T = FftShape<N>::T, PAIRS = 256 / T;
     typedef Tile<N, PAIRS, false> TL;
     __shared__ cf lds[TL::FLOATS2];
     const int pl = threadIdx.x / T, u = threadIdx.x - pl * T;
     const int64_t pair = (int64_t)blockIdx.x * PAIRS + pl;
     const bool ok = pair < npairs;
-    const float *a = real + (2 * pair) * N, *b = a + N;
+    const int64_t line = 2 * pair, bi = line / zb.lines, lm = line - bi * zb.lines;
+    const float *a = real + bi * zb.real_bstride + lm * N, *b = a + N;
     cf v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = ok ? make_float2(a[u + T * m], b[u + T * m]) : make_float2(0.f, 0.f);
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(256) void zfwd_kernel(FGeom g, const float *__restr
     for (int m = 0; m < 8; ++m) lds[tile(u + T * m)] = v[m];
     __syncthreads();
     if (!ok) return;
-    cf *oa = spec + (2 * pair) * g.nzp, *ob = oa + g.nzp;
+    cf *oa = spec + bi * zb.spec_bstride + lm * g.nzp, *ob = oa + g.nzp;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int k = u + T * m;
@@ -201,14 +218,15 @@ __global__ __launch_bounds__(256) void zfwd_kernel(FGeom g, const float *__restr
 
 template <int N>
 __global__ __launch_bounds__(256) void zinv_kernel(FGeom g, const cf *__restrict__ spec, float *__restrict__ real,
-                                                   const cf *__restrict__ W, int64_t npairs) {
+                                                   const cf *__restrict__ W, int64_t npairs, ZBatch zb) {
     constexpr int T = FftShape<N>::T, PAIRS = 256 / T;
     typedef Tile<N, PAIRS, false> TL;
     __shared__ cf lds[TL::FLOATS2];
     const int pl = threadIdx.x / T, u = threadIdx.x - pl * T;
     const int64_t pair = (int64_t)blockIdx.x * PAIRS + pl;
     const bool ok = pair < npairs;
-    const cf *ia = spec + (2 * pair) * g.nzp, *ib = ia + g.nzp;
+    const int64_t line = 2 * pair, bi = line / zb.lines, lm = line - bi * zb.lines;
+    const cf *ia = spec + bi * zb.spec_bstride + lm * g.nzp, *ib = ia + g.nzp;
     TL tile{pl};
     // Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k]); imaginary parts of k = 0 and N/2 are ignored (c2r)
 #pragma unroll
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(256) void zinv_kernel(FGeom g, const cf *__restrict
     for (int m = 0; m < 8; ++m) v[m] = lds[tile(u + T * m)];
     fft_line<N, +1>(v, lds, W, u, tile);
     if (!ok) return;
-    float *a = real + (2 * pair) * N, *b = a + N;
+    float *a = real + bi * zb.real_bstride + lm * N, *b = a + N;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         a[u + T * m] = v[m].x;
@@ -249,24 +267,32 @@ struct ColShape {
     static constexpr int THREADS = T * LINES;
 };
 
-// in-place FFT along y for every (batch, x, kz): element (y, kz) of plane p at spec[(p ny + y) nzp + kz]
+// FFT along y for every (plane, kz); in == out allowed when both layouts are equal
 template <int N, int SIGN>
-__global__ __launch_bounds__(ColShape<N>::THREADS) void ycol_kernel(FGeom g, cf *__restrict__ spec, const cf *__restrict__ W) {
+__global__ __launch_bounds__(ColShape<N>::THREADS) void ycol_kernel(FGeom g, const cf *__restrict__ in, cf *__restrict__ out,
+                                                                    YLayout li, YLayout lo, const cf *__restrict__ W) {
     constexpr int T = ColShape<N>::T, LINES = ColShape<N>::LINES;
     typedef Tile<N, LINES, true> TL;
     __shared__ cf lds[TL::FLOATS2];
     const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
     const int kz = blockIdx.x * LINES + l;
     const bool ok = kz < g.nzh;
-    cf *base = spec + (int64_t)blockIdx.y * N * g.nzp + kz;
+    const cf *ib = in + (int64_t)blockIdx.y * li.PS + kz;
+    cf *ob = out + (int64_t)blockIdx.y * lo.PS + kz;
     cf v[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = ok ? base[(int64_t)(u + T * m) * g.nzp] : make_float2(0.f, 0.f);
+    for (int m = 0; m < 8; ++m) {
+        const int y = u + T * m, yb = y / li.YB;
+        v[m] = ok ? ib[yb * li.SB + (int64_t)(y - yb * li.YB) * g.nzp] : make_float2(0.f, 0.f);
+    }
     TL tile{l};
     fft_line<N, SIGN>(v, lds, W, u, tile);
     if (!ok) return;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) base[(int64_t)(u + T * m) * g.nzp] = v[m];
+    for (int m = 0; m < 8; ++m) {
+        const int y = u + T * m, yb = y / lo.YB;
+        ob[yb * lo.SB + (int64_t)(y - yb * lo.YB) * g.nzp] = v[m];
+    }
 }
 
 // k-space multipliers (nbody.py:109-163 with fd_order = inf), wavevectors from indices
@@ -296,14 +322,18 @@ __device__ __forceinline__ KMul force_mult(const FGeom &g, int ix, int iy, int i
 // element (x, y, kz) at [(x ny + y) nzp + kz]; spectra are `sstride` complex apart.
 template <int N, int MODE>
 __global__ __launch_bounds__(ColShape<N>::THREADS) void xfused_kernel(FGeom g, const cf *__restrict__ in, cf *__restrict__ out,
-                                                                      int64_t sstride, float scale, const cf *__restrict__ W) {
+                                                                      XLayout xl, float scale, const cf *__restrict__ W) {
     constexpr int T = ColShape<N>::T, LINES = ColShape<N>::LINES;
     typedef Tile<N, LINES, true> TL;
     __shared__ cf lds[TL::FLOATS2];
     const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
-    const int kz = blockIdx.x * LINES + l, iy = blockIdx.y;
+    const int kz = blockIdx.x * LINES + l, yl = blockIdx.y, iy = xl.iy0 + yl;
     const bool ok = kz < g.nzh;
-    const int64_t off0 = (int64_t)iy * g.nzp + kz, xs = (int64_t)g.ny * g.nzp;
+    const int64_t off0 = (int64_t)yl * g.nzp + kz, xs = (int64_t)xl.NYL * g.nzp;
+    auto a3 = [&](int c, int x) {  // three-spectra side
+        const int xb = x / xl.XB;
+        return xb * xl.SBx + c * xl.SC + (int64_t)(x - xb * xl.XB) * xs + off0;
+    };
     TL tile{l};
     if (MODE == 0) {
         cf v[8];
@@ -321,7 +351,7 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xfused_kernel(FGeom g, c
             fft_line<N, +1>(w, lds, W, u, tile);
             if (ok) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) out[c * sstride + off0 + (u + T * m) * xs] = w[m];
+                for (int m = 0; m < 8; ++m) out[a3(c, u + T * m)] = w[m];
             }
         }
     } else {
@@ -332,7 +362,7 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xfused_kernel(FGeom g, c
         for (int c = 0; c < 3; ++c) {
             cf v[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = ok ? in[c * sstride + off0 + (u + T * m) * xs] : make_float2(0.f, 0.f);
+            for (int m = 0; m < 8; ++m) v[m] = ok ? in[a3(c, u + T * m)] : make_float2(0.f, 0.f);
             fft_line<N, -1>(v, lds, W, u, tile);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
@@ -355,12 +385,12 @@ static bool pow2_ok(int n) { return n == 64 || n == 128 || n == 256 || n == 512 
 
 bool mcpm_fftpm_supported(const mcpm_plan *p) {
     if (getenv("MCPM_DISABLE_FFTPM")) return false;
-    return pow2_ok(p->g.nx) && pow2_ok(p->g.ny) && pow2_ok(p->g.nz);
+    return pow2_ok(p->nx_global) && pow2_ok(p->g.ny) && pow2_ok(p->g.nz);
 }
 
 static int ensure_twiddles(mcpm_plan *p) {
     if (p->tw[0]) return MCPM_OK;
-    const int dims[3] = {p->g.nx, p->g.ny, p->g.nz};
+    const int dims[3] = {p->nx_global, p->g.ny, p->g.nz};
     for (int a = 0; a < 3; ++a) {
         const int n = dims[a];
         std::vector<float> h(2 * (size_t)n);
@@ -375,7 +405,12 @@ static int ensure_twiddles(mcpm_plan *p) {
     return MCPM_OK;
 }
 
-static FGeom fgeom(const mcpm_plan *p) { return FGeom{p->g.nx, p->g.ny, p->g.nz, p->g.nzh, p->g.nz / 2 + 16}; }
+static FGeom fgeom(const mcpm_plan *p) { return FGeom{p->nx_global, p->g.ny, p->g.nz, p->g.nzh, p->g.nz / 2 + 16}; }
+// one local spectrum: nxl planes x ny x nzp complex
+static int64_t spec_elems(const mcpm_plan *p) { return (int64_t)p->nxl * p->g.ny * (p->g.nz / 2 + 16); }
+static double pass_bytes(const mcpm_plan *p, int batch) {  // algorithmic share of one pass of a 3-pass transform
+    return (double)batch * (4.0 * p->nxl * p->g.ny * p->g.nz + 8.0 * p->nxl * p->g.ny * p->g.nzh) / 3.0;
+}
 
 #define DISPATCH_N(n, CALL)                  \
     switch (n) {                             \
@@ -386,14 +421,15 @@ static FGeom fgeom(const mcpm_plan *p) { return FGeom{p->g.nx, p->g.ny, p->g.nz,
         default: CALL(1024); break;          \
     }
 
-static int z_forward(mcpm_plan *p, const float *real, cf *spec, int batch) {
+static int z_forward(mcpm_plan *p, const float *real, int64_t real_bstride, cf *spec, int batch) {
     const FGeom g = fgeom(p);
-    const int64_t npairs = (int64_t)batch * g.nx * g.ny / 2;
-    StageTimer st_(p, ST_R2C, (double)batch * (4.0 * p->M + 8.0 * p->Mh) / 3.0);
+    const ZBatch zb{(int64_t)p->nxl * g.ny, real_bstride, spec_elems(p)};
+    const int64_t npairs = (int64_t)batch * zb.lines / 2;
+    StageTimer st_(p, ST_R2C, pass_bytes(p, batch));
 #define CALL(NN)                                                                                                   \
     {                                                                                                              \
         constexpr int PAIRS = 256 / (NN / 8);                                                                      \
-        zfwd_kernel<NN><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, real, spec, (const cf *)p->tw[2], npairs); \
+        zfwd_kernel<NN><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, real, spec, (const cf *)p->tw[2], npairs, zb); \
     }
     DISPATCH_N(g.nz, CALL)
 #undef CALL
@@ -401,14 +437,15 @@ static int z_forward(mcpm_plan *p, const float *real, cf *spec, int batch) {
     return MCPM_OK;
 }
 
-static int z_inverse(mcpm_plan *p, const cf *spec, float *real, int batch) {
+static int z_inverse(mcpm_plan *p, const cf *spec, float *real, int64_t real_bstride, int batch) {
     const FGeom g = fgeom(p);
-    const int64_t npairs = (int64_t)batch * g.nx * g.ny / 2;
-    StageTimer st_(p, ST_C2R, (double)batch * (4.0 * p->M + 8.0 * p->Mh) / 3.0);
+    const ZBatch zb{(int64_t)p->nxl * g.ny, real_bstride, spec_elems(p)};
+    const int64_t npairs = (int64_t)batch * zb.lines / 2;
+    StageTimer st_(p, ST_C2R, pass_bytes(p, batch));
 #define CALL(NN)                                                                                                   \
     {                                                                                                              \
         constexpr int PAIRS = 256 / (NN / 8);                                                                      \
-        zinv_kernel<NN><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, spec, real, (const cf *)p->tw[2], npairs); \
+        zinv_kernel<NN><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, spec, real, (const cf *)p->tw[2], npairs, zb); \
     }
     DISPATCH_N(g.nz, CALL)
 #undef CALL
@@ -416,15 +453,24 @@ static int z_inverse(mcpm_plan *p, const cf *spec, float *real, int batch) {
     return MCPM_OK;
 }
 
-static int y_columns(mcpm_plan *p, cf *spec, int batch, int sign) {
+// packed = all-to-all layout [dest rank][plane (batch*nxl)][y_local][nzp]
+static YLayout ylayout(const mcpm_plan *p, int batch, bool packed) {
+    const int64_t nzp = p->g.nz / 2 + 16;
+    if (!packed) return YLayout{(int64_t)p->g.ny * nzp, 0, p->g.ny};
+    const int nyl = p->g.ny / p->nranks;
+    return YLayout{(int64_t)nyl * nzp, (int64_t)batch * p->nxl * nyl * nzp, nyl};
+}
+
+static int y_columns(mcpm_plan *p, const cf *in, cf *out, int batch, int sign, bool in_packed, bool out_packed) {
     const FGeom g = fgeom(p);
-    StageTimer st_(p, sign < 0 ? ST_R2C : ST_C2R, (double)batch * (4.0 * p->M + 8.0 * p->Mh) / 3.0);
+    const YLayout li = ylayout(p, batch, in_packed), lo = ylayout(p, batch, out_packed);
+    StageTimer st_(p, sign < 0 ? ST_R2C : ST_C2R, pass_bytes(p, batch));
 #define CALL(NN)                                                                                       \
     {                                                                                                  \
         constexpr int LINES = ColShape<NN>::LINES, TH = ColShape<NN>::THREADS;                         \
-        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)(batch * g.nx));                  \
-        if (sign < 0) ycol_kernel<NN, -1><<<grid, TH, 0, p->stream>>>(g, spec, (const cf *)p->tw[1]);  \
-        else ycol_kernel<NN, +1><<<grid, TH, 0, p->stream>>>(g, spec, (const cf *)p->tw[1]);           \
+        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)(batch * p->nxl));                \
+        if (sign < 0) ycol_kernel<NN, -1><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1]);  \
+        else ycol_kernel<NN, +1><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1]);           \
     }
     DISPATCH_N(g.ny, CALL)
 #undef CALL
@@ -432,18 +478,21 @@ static int y_columns(mcpm_plan *p, cf *spec, int batch, int sign) {
     return MCPM_OK;
 }
 
+// x pass over the y rows this rank holds after the transpose (all of them on one GPU)
 static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
     const FGeom g = fgeom(p);
-    const int64_t sstride = (int64_t)g.nx * g.ny * g.nzp;
-    const float scale = 1.f / (float)p->M;
+    const int nyl = g.ny / p->nranks;
+    const int64_t blk = (int64_t)p->nxl * nyl * g.nzp;  // one rank's block of one spectrum
+    const XLayout xl{nyl, p->rank * nyl, p->nxl, 3 * blk, blk};
+    const float scale = 1.f / ((float)g.nx * (float)g.ny * (float)g.nz);
     // one forward + one inverse x pass of (1 + 3) spectra and the k-space multiply
-    StageTimer st_(p, ST_KSPACE, 32.0 * p->Mh + 4.0 * (4.0 * p->M + 8.0 * p->Mh) / 3.0);
+    StageTimer st_(p, ST_KSPACE, (32.0 * p->nxl * g.ny * g.nzh) + 4.0 * pass_bytes(p, 1));
 #define CALL(NN)                                                                                              \
     {                                                                                                         \
         constexpr int LINES = ColShape<NN>::LINES, TH = ColShape<NN>::THREADS;                                \
-        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)g.ny);                                   \
-        if (mode == 0) xfused_kernel<NN, 0><<<grid, TH, 0, p->stream>>>(g, in, out, sstride, scale, (const cf *)p->tw[0]); \
-        else xfused_kernel<NN, 1><<<grid, TH, 0, p->stream>>>(g, in, out, sstride, scale, (const cf *)p->tw[0]);           \
+        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)nyl);                                    \
+        if (mode == 0) xfused_kernel<NN, 0><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]); \
+        else xfused_kernel<NN, 1><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]);           \
     }
     DISPATCH_N(g.nx, CALL)
 #undef CALL
@@ -451,30 +500,68 @@ static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
     return MCPM_OK;
 }
 
-// rho (real mesh) -> three force meshes irfftn(-(i k_c)(-1/k^2) rfftn(rho))
+// rho (real mesh) -> three force meshes irfftn(-(i k_c)(-1/k^2) rfftn(rho)); single-GPU plans
 int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3) {
     MCPM_TRY(ensure_twiddles(p));
-    const FGeom g = fgeom(p);
-    const int64_t ss = (int64_t)g.nx * g.ny * g.nzp;
+    const int64_t ss = spec_elems(p);
     cf *s0 = (cf *)p->spec, *s123 = s0 + ss;
-    MCPM_TRY(z_forward(p, rho, s0, 1));
-    MCPM_TRY(y_columns(p, s0, 1, -1));
+    MCPM_TRY(z_forward(p, rho, p->M, s0, 1));
+    MCPM_TRY(y_columns(p, s0, s0, 1, -1, false, false));
     MCPM_TRY(x_fused(p, s0, s123, 0));
-    MCPM_TRY(y_columns(p, s123, 3, +1));
-    MCPM_TRY(z_inverse(p, s123, fm3, 3));
+    MCPM_TRY(y_columns(p, s123, s123, 3, +1, false, false));
+    MCPM_TRY(z_inverse(p, s123, fm3, p->M, 3));
     return MCPM_OK;
 }
 
 // adjoint: three real cotangent meshes -> rho_bar = irfftn(sum_c conj(multiplier_c) rfftn(f_bar_c))
 int mcpm_fftpm_force_meshes_vjp(mcpm_plan *p, const float *fbar3, float *rho_bar) {
     MCPM_TRY(ensure_twiddles(p));
-    const FGeom g = fgeom(p);
-    const int64_t ss = (int64_t)g.nx * g.ny * g.nzp;
+    const int64_t ss = spec_elems(p);
     cf *s0 = (cf *)p->spec, *s123 = s0 + ss;
-    MCPM_TRY(z_forward(p, fbar3, s123, 3));
-    MCPM_TRY(y_columns(p, s123, 3, -1));
+    MCPM_TRY(z_forward(p, fbar3, p->M, s123, 3));
+    MCPM_TRY(y_columns(p, s123, s123, 3, -1, false, false));
     MCPM_TRY(x_fused(p, s123, s0, 1));
-    MCPM_TRY(y_columns(p, s0, 1, +1));
-    MCPM_TRY(z_inverse(p, s0, rho_bar, 1));
+    MCPM_TRY(y_columns(p, s0, s0, 1, +1, false, false));
+    MCPM_TRY(z_inverse(p, s0, rho_bar, p->M, 1));
     return MCPM_OK;
 }
+
+// ---- pass-level entry points for the slab-decomposed solve (the all-to-all between them is the host's) ----------
+extern "C" {
+
+int64_t mcpm_slab_spec_elems(const mcpm_plan *p) { return p ? spec_elems(p) : 0; }
+
+int mcpm_slab_zfwd(mcpm_plan *p, const float *real, int64_t real_bstride, float *spec, int batch) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, real && spec && batch >= 1, MCPM_E_ARG, "mcpm_slab_zfwd: bad argument");
+    MCPM_REQUIRE(p, mcpm_fftpm_supported(p), MCPM_E_UNSUPPORTED, "slab FFT needs power-of-two axes in [64, 1024]");
+    MCPM_TRY(ensure_twiddles(p));
+    return z_forward(p, real, real_bstride, (cf *)spec, batch);
+}
+
+int mcpm_slab_zinv(mcpm_plan *p, const float *spec, float *real, int64_t real_bstride, int batch) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, real && spec && batch >= 1, MCPM_E_ARG, "mcpm_slab_zinv: bad argument");
+    MCPM_REQUIRE(p, mcpm_fftpm_supported(p), MCPM_E_UNSUPPORTED, "slab FFT needs power-of-two axes in [64, 1024]");
+    MCPM_TRY(ensure_twiddles(p));
+    return z_inverse(p, (const cf *)spec, real, real_bstride, batch);
+}
+
+int mcpm_slab_ycol(mcpm_plan *p, const float *in, float *out, int batch, int sign, int in_packed, int out_packed) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, in && out && batch >= 1 && (sign == 1 || sign == -1), MCPM_E_ARG, "mcpm_slab_ycol: bad argument");
+    MCPM_REQUIRE(p, in != out || in_packed == out_packed, MCPM_E_ARG, "mcpm_slab_ycol: in-place needs equal layouts");
+    MCPM_REQUIRE(p, mcpm_fftpm_supported(p), MCPM_E_UNSUPPORTED, "slab FFT needs power-of-two axes in [64, 1024]");
+    MCPM_TRY(ensure_twiddles(p));
+    return y_columns(p, (const cf *)in, (cf *)out, batch, sign, in_packed != 0, out_packed != 0);
+}
+
+int mcpm_slab_xfused(mcpm_plan *p, const float *in, float *out, int mode) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, in && out && in != out && (mode == 0 || mode == 1), MCPM_E_ARG, "mcpm_slab_xfused: bad argument");
+    MCPM_REQUIRE(p, mcpm_fftpm_supported(p), MCPM_E_UNSUPPORTED, "slab FFT needs power-of-two axes in [64, 1024]");
+    MCPM_TRY(ensure_twiddles(p));
+    return x_fused(p, (const cf *)in, (cf *)out, mode);
+}
+
+}  // extern "C"

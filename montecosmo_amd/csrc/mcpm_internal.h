@@ -38,7 +38,9 @@ struct Geom {
     int nx, ny, nz;   // mesh
     int px, py, pz;   // particle lattice (regular_pos(mesh, ptcl))
     int nzh;          // nz/2 + 1
-    int same_lattice; // px==nx && py==ny && pz==nz
+    int same_lattice; // px==nx && py==ny && pz==nz (unit lattice spacing)
+    int xoff;         // slab mode: mesh plane of lattice plane 0 (= ghost width); 0 otherwise
+    int xslab;        // slab mode: x is NOT periodic on this (ghost-extended) mesh
 };
 
 struct mcpm_plan {
@@ -49,6 +51,8 @@ struct mcpm_plan {
     int64_t Np;  // px*py*pz
     int halo;    // halo radius of the tiled paint
     int paint_variant;  // threads/unroll variant of the tiled paint (tuning)
+    // x-slab decomposition (mcpm_plan_create_slab): this rank owns global planes [rank*nxl, (rank+1)*nxl)
+    int nranks, rank, ghost, nx_global, nxl;
 
     // rocFFT plans keyed by batch
     std::map<int, rocfft_plan> r2c, c2r;

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void cell_index_kernel(Geom g, const float *__
     int c[3];
     float f[3];
     locate<MODE, ORDER>(g, pi, d, c, f);
-    idx[3 * pi.i + 0] = (int16_t)wrapi(c[0], g.nx);
+    idx[3 * pi.i + 0] = (int16_t)(g.xslab ? c[0] : wrapi(c[0], g.nx));
     idx[3 * pi.i + 1] = (int16_t)wrapi(c[1], g.ny);
     idx[3 * pi.i + 2] = (int16_t)wrapi(c[2], g.nz);
 }
@@ -90,16 +90,23 @@ __global__ __launch_bounds__(THREADS) void paint_tile_kernel(Geom g, const float
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u * THREADS;
-            const bool ok = j < NW;
+            bool ok = j < NW;
             const int jz = j % WZ, r = j / WZ, jy = r % WY, jx = r / WY;
             const int rx = jx - (H + 1), ry = jy - (H + 1), rz = jz - (H + 1);  // lattice point relative to the tile
             int gx = x0 + rx, gy = y0 + ry, gz = z0 + rz;
-            gx += gx < 0 ? g.nx : 0;
-            gx -= gx >= g.nx ? g.nx : 0;
+            bool inx = true;
+            if (g.xslab) {  // ghost-extended slab: lattice planes are mesh planes [xoff, xoff + px), no wrap
+                gx -= g.xoff;
+                inx = (unsigned)gx < (unsigned)g.px;
+            } else {
+                gx += gx < 0 ? g.nx : 0;
+                gx -= gx >= g.nx ? g.nx : 0;
+            }
             gy += gy < 0 ? g.ny : 0;
             gy -= gy >= g.ny ? g.ny : 0;
             gz += gz < 0 ? g.nz : 0;
             gz -= gz >= g.nz ? g.nz : 0;
+            ok = ok && inx;
             const int gi = ok ? (gx * g.ny + gy) * g.nz + gz : -1;
             rxs[u] = rx;
             rys[u] = ry;

@@ -66,14 +66,21 @@ template <int MODE>
 __device__ __forceinline__ PIdx particle_index(const Geom &g, int64_t n) {
     PIdx r;
     if (MODE == MCPM_POS_LATTICE) {
-        int cpr = (g.pz + blockDim.x - 1) / blockDim.x;
-        int row = blockIdx.x / cpr;
-        int chunk = blockIdx.x - row * cpr;
+        // Block -> (lattice row, z chunk).  Two locality remaps, speed only:
+        //  * blocks b, b+8, ... share an XCD (and its L2): give each XCD a contiguous run of virtual blocks;
+        //  * within the run, 8 consecutive x planes of one (y, z chunk) come first, so that the mesh rows a
+        //    CIC stencil shares between x and x+1 (and y, y+1 of the next blocks) are re-read from L2.
+        const int cpr = (g.pz + blockDim.x - 1) / blockDim.x;
+        const unsigned nb = gridDim.x, b = blockIdx.x;
+        const unsigned vb = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+        const unsigned XB = (g.px % 8 == 0) ? 8 : 1;
+        const unsigned xi = vb % XB, r1 = vb / XB;
+        const unsigned chunk = r1 % cpr, r2 = r1 / cpr;
+        r.ipy = r2 % g.py;
+        r.ipx = (r2 / g.py) * XB + xi;
         r.ipz = chunk * blockDim.x + threadIdx.x;
-        r.ipx = row / g.py;
-        r.ipy = row - r.ipx * g.py;
         r.valid = r.ipz < g.pz;
-        r.i = (int64_t)row * g.pz + r.ipz;
+        r.i = ((int64_t)r.ipx * g.py + r.ipy) * g.pz + r.ipz;
     } else {
         r.i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         r.ipx = r.ipy = r.ipz = 0;
@@ -89,6 +96,7 @@ __device__ __forceinline__ void locate(const Geom &g, const PIdx &pi, P3 d, int 
     float fx = 0.f, fy = 0.f, fz = 0.f;
     if (MODE == MCPM_POS_LATTICE) {
         lattice_q(pi.ipx, g.nx, g.px, g.same_lattice, qx, fx);
+        qx += g.xoff;  // slab mode: lattice plane 0 sits at mesh plane `ghost`
         lattice_q(pi.ipy, g.ny, g.py, g.same_lattice, qy, fy);
         lattice_q(pi.ipz, g.nz, g.pz, g.same_lattice, qz, fz);
     }
@@ -103,7 +111,10 @@ struct Stencil {
     int64_t xo[2], yo[2];
     int zo[2];
     __device__ __forceinline__ Stencil(const Geom &g, const int (&c)[3]) {
-        int x0 = wrapi(c[0], g.nx), y0 = wrapi(c[1], g.ny), z0 = wrapi(c[2], g.nz);
+        // slab mode: x is not periodic on the ghost-extended mesh; clamp (only particles displaced beyond the
+        // ghost width are affected, see DESIGN.md "Multi-GPU")
+        int x0 = g.xslab ? min(max(c[0], 0), g.nx - ORDER) : wrapi(c[0], g.nx);
+        int y0 = wrapi(c[1], g.ny), z0 = wrapi(c[2], g.nz);
         xo[0] = (int64_t)x0 * g.ny * g.nz;
         yo[0] = (int64_t)y0 * g.nz;
         zo[0] = z0;
@@ -132,10 +143,26 @@ __device__ __forceinline__ void interp(const float *__restrict__ m, const Stenci
         gx = gy = gz = 0.f;
         return;
     }
-    float v000 = m[s.xo[0] + s.yo[0] + s.zo[0]], v001 = m[s.xo[0] + s.yo[0] + s.zo[1]];
-    float v010 = m[s.xo[0] + s.yo[1] + s.zo[0]], v011 = m[s.xo[0] + s.yo[1] + s.zo[1]];
-    float v100 = m[s.xo[1] + s.yo[0] + s.zo[0]], v101 = m[s.xo[1] + s.yo[0] + s.zo[1]];
-    float v110 = m[s.xo[1] + s.yo[1] + s.zo[0]], v111 = m[s.xo[1] + s.yo[1] + s.zo[1]];
+    // z and z+1 are adjacent in memory: one 8-byte gather per (x, y) corner instead of two 4-byte ones (the
+    // gathers are bound by address processing, not bytes).  At the periodic wrap (z = nz-1, z+1 = 0) the pair
+    // is read one cell lower and the z = 0 cell separately.
+    struct __attribute__((packed, aligned(4))) F2 {
+        float a, b;
+    };
+    const bool wrap = s.zo[1] != s.zo[0] + 1;
+    const int zc = wrap ? s.zo[0] - 1 : s.zo[0];
+    const F2 p00 = *reinterpret_cast<const F2 *>(m + s.xo[0] + s.yo[0] + zc);
+    const F2 p01 = *reinterpret_cast<const F2 *>(m + s.xo[0] + s.yo[1] + zc);
+    const F2 p10 = *reinterpret_cast<const F2 *>(m + s.xo[1] + s.yo[0] + zc);
+    const F2 p11 = *reinterpret_cast<const F2 *>(m + s.xo[1] + s.yo[1] + zc);
+    float v000 = wrap ? p00.b : p00.a, v001 = p00.b, v010 = wrap ? p01.b : p01.a, v011 = p01.b;
+    float v100 = wrap ? p10.b : p10.a, v101 = p10.b, v110 = wrap ? p11.b : p11.a, v111 = p11.b;
+    if (wrap) {
+        v001 = m[s.xo[0] + s.yo[0] + s.zo[1]];
+        v011 = m[s.xo[0] + s.yo[1] + s.zo[1]];
+        v101 = m[s.xo[1] + s.yo[0] + s.zo[1]];
+        v111 = m[s.xo[1] + s.yo[1] + s.zo[1]];
+    }
     float ax = 1.f - f[0], bx = f[0], ay = 1.f - f[1], by = f[1], az = 1.f - f[2], bz = f[2];
     // collapse z, then y, then x
     float v00 = az * v000 + bz * v001, v01 = az * v010 + bz * v011;

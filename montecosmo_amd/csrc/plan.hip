@@ -47,16 +47,44 @@ const char *mcpm_version(void) { return "mcpm 0.1 (gfx950)"; }
 
 const char *mcpm_last_error(const mcpm_plan *plan) { return plan ? plan->err.c_str() : g_mcpm_create_error.c_str(); }
 
+static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int nranks, int rank, int ghost, void *stream,
+                            mcpm_plan **out);
+
 int mcpm_plan_create(int nx, int ny, int nz, int px, int py, int pz, void *stream, mcpm_plan **out) {
+    return plan_create_impl(nx, ny, nz, px, py, pz, 1, 0, 0, stream, out);
+}
+
+int mcpm_plan_create_slab(int nx, int ny, int nz, int nranks, int rank, int ghost, void *stream, mcpm_plan **out) {
     if (!out) return mcpm_fail(nullptr, MCPM_E_ARG, "plan output pointer is null");
     *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return mcpm_fail(nullptr, MCPM_E_ARG, "bad rank / nranks");
+    if (nx % nranks || ny % nranks) return mcpm_fail(nullptr, MCPM_E_SHAPE, "nx and ny must be divisible by the number of ranks");
+    const int nxl = nx / nranks;
+    if (ghost < 5 || ghost > nxl) return mcpm_fail(nullptr, MCPM_E_ARG, "ghost width must be in [5, nx/nranks]");
+    return plan_create_impl(nx, ny, nz, nxl, ny, nz, nranks, rank, ghost, stream, out);
+}
+
+// nranks == 1, ghost == 0: ordinary periodic plan.  Otherwise (slab): (nx, ny, nz) is the GLOBAL mesh, the local
+// mesh is the ghost-extended slab (nx/nranks + 2 ghost, ny, nz) and the lattice (px, py, pz) = (nx/nranks, ny, nz).
+static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int nranks, int rank, int ghost, void *stream,
+                            mcpm_plan **out) {
+    if (!out) return mcpm_fail(nullptr, MCPM_E_ARG, "plan output pointer is null");
+    *out = nullptr;
+    const bool slab = ghost > 0;
+    const int nx_global = nx;
+    if (slab) nx = px + 2 * ghost;
     if (nx < 2 || ny < 2 || nz < 2 || (nz & 1)) return mcpm_fail(nullptr, MCPM_E_SHAPE, "mesh dims must be >= 2 and nz even");
     if (nx > 32766 || ny > 32766 || nz > 32766) return mcpm_fail(nullptr, MCPM_E_SHAPE, "mesh side must stay below 32767 (int16 index math)");
     if (px < 1 || py < 1 || pz < 1) return mcpm_fail(nullptr, MCPM_E_SHAPE, "particle lattice dims must be >= 1");
     if ((int64_t)px * py * pz >= (int64_t)1 << 31) return mcpm_fail(nullptr, MCPM_E_SHAPE, "more than 2^31 particles per plan");
     mcpm_plan *p = new (std::nothrow) mcpm_plan();
     if (!p) return mcpm_fail(nullptr, MCPM_E_NOMEM, "host allocation");
-    p->g = Geom{nx, ny, nz, px, py, pz, nz / 2 + 1, (px == nx && py == ny && pz == nz) ? 1 : 0};
+    p->g = Geom{nx, ny, nz, px, py, pz, nz / 2 + 1, ((slab || px == nx) && py == ny && pz == nz) ? 1 : 0, slab ? ghost : 0, slab ? 1 : 0};
+    p->nranks = nranks;
+    p->rank = rank;
+    p->ghost = ghost;
+    p->nx_global = nx_global;
+    p->nxl = slab ? px : nx;
     p->stream = (hipStream_t)stream;
     p->M = (int64_t)nx * ny * nz;
     p->Mh = (int64_t)nx * ny * p->g.nzh;

@@ -1,0 +1,276 @@
+"""
+x-slab decomposition of the PM step over the GPUs of one node (no counterpart in the reference,
+whose only multi-device mode is independent chains, script.py:13-20).
+
+Decomposition (one process per GPU, `torch.distributed`, backend "nccl" = RCCL over xGMI):
+  * rank r owns mesh planes [r nx/P, (r+1) nx/P) and -- Lagrangian ownership -- the lattice particles of those
+    planes.  Particles are stored as displacements from their lattice point, so they NEVER migrate; what
+    crosses slab boundaries is mass, through `ghost` extra planes on each side of the local mesh.
+  * paint -> ghost planes added into the neighbours' interiors (point-to-point send/recv);
+    FFT: local z and y passes -> ONE all-to-all (x <-> y transpose, written directly in transposed order by the
+    y pass) -> fused x pass (x FFT . k-space . inverse x FFT) -> one all-to-all back -> local y, z passes;
+    read: interior planes sent to the neighbours' ghosts (point-to-point), then the fused read+kick+drift.
+  The all-to-all is used for the FFT transpose only; ghost planes are point-to-point.
+The adjoint mirrors it (3 weighted paints + ghost add, 3 forward / 1 inverse transform, ghost fill, fused
+adjoint particle kernel); scalar cotangents are all-reduced once at the end.
+
+The LPT start (13 FFTs, once per log-prob) is computed redundantly on every rank with the single-GPU plan in
+round 1; distributing it is listed under DESIGN.md "next".
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import nbody
+from ._lib import lib, check, POS_LATTICE
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class LocalComm:
+    """Single-rank communicator: every exchange is a local copy (used to validate the slab code path itself)."""
+    world, rank = 1, 0
+
+    def all_to_all(self, out, inp):
+        out.copy_(inp)
+
+    def neighbour_exchange(self, to_left, to_right, from_left, from_right):
+        from_right.copy_(to_left)   # my left neighbour is me: what I send left arrives "from the right"
+        from_left.copy_(to_right)
+
+    def all_reduce_sum(self, t):
+        return t
+
+    def all_gather_cat(self, t):
+        return t
+
+
+class TorchComm:
+    """torch.distributed communicator.  With the "gloo" backend (CPU tests, or several ranks sharing one GPU in
+    the single-GPU test box) device tensors are staged through host memory; with "nccl" (RCCL) they are used
+    in place."""
+
+    def __init__(self, group=None):
+        import torch.distributed as td
+        self.td, self.group = td, group
+        self.world, self.rank = td.get_world_size(group), td.get_rank(group)
+        self.stage = td.get_backend(group) == "gloo"
+
+    def _h(self, t):
+        return t.cpu() if (self.stage and t.is_cuda) else t
+
+    def all_to_all(self, out, inp):
+        if self.stage and inp.is_cuda:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            self.td.all_to_all_single(o.view(torch.float32) if o.is_complex() else o,
+                                      (inp.cpu().view(torch.float32) if inp.is_complex() else inp.cpu()), group=self.group)
+            out.copy_(o)
+        else:
+            vo = torch.view_as_real(out) if out.is_complex() else out
+            vi = torch.view_as_real(inp) if inp.is_complex() else inp
+            self.td.all_to_all_single(vo, vi, group=self.group)
+
+    def neighbour_exchange(self, to_left, to_right, from_left, from_right):
+        td, P, r = self.td, self.world, self.rank
+        left, right = (r - 1) % P, (r + 1) % P
+        sl, sr = self._h(to_left), self._h(to_right)
+        rl = torch.empty(from_left.shape, dtype=from_left.dtype) if (self.stage and from_left.is_cuda) else from_left
+        rr = torch.empty(from_right.shape, dtype=from_right.dtype) if (self.stage and from_right.is_cuda) else from_right
+        # with two ranks both messages go to the same peer: my first send (to the left) must meet the peer's first
+        # receive, which is therefore its "from the right"
+        ops = [td.P2POp(td.isend, sl, left, self.group), td.P2POp(td.isend, sr, right, self.group),
+               td.P2POp(td.irecv, rr, right, self.group), td.P2POp(td.irecv, rl, left, self.group)]
+        for w in td.batch_isend_irecv(ops):
+            w.wait()
+        if rl is not from_left:
+            from_left.copy_(rl)
+        if rr is not from_right:
+            from_right.copy_(rr)
+
+    def all_reduce_sum(self, t):
+        h = self._h(t).clone()
+        self.td.all_reduce(h, group=self.group)
+        return h.to(t.device)
+
+    def all_gather_cat(self, t):
+        h = self._h(t).contiguous()
+        outs = [torch.empty_like(h) for _ in range(self.world)]
+        self.td.all_gather(outs, h, group=self.group)
+        return torch.cat(outs, dim=0).to(t.device)
+
+
+class HaloMixin:
+    """Ghost-plane algebra of an x-slab (needs self.comm, self.G, self.nxl); meshes are (..., nxl + 2G, ny, nz)."""
+
+    def halo_add(self, ext):
+        """Adds my ghost planes into the neighbours' interiors (after a paint)."""
+        G, nxl = self.G, self.nxl
+        lo = ext[..., :G, :, :].contiguous()
+        hi = ext[..., G + nxl:, :, :].contiguous()
+        from_l, from_r = torch.empty_like(hi), torch.empty_like(lo)
+        self.comm.neighbour_exchange(lo, hi, from_l, from_r)
+        ext[..., G:2 * G, :, :] += from_l          # the left neighbour's high ghost = my lowest interior planes
+        ext[..., nxl:nxl + G, :, :] += from_r      # the right neighbour's low ghost = my highest interior planes
+
+    def halo_fill(self, ext):
+        """Fills my ghost planes from the neighbours' interiors (before a read)."""
+        G, nxl = self.G, self.nxl
+        to_l = ext[..., G:2 * G, :, :].contiguous()          # becomes the left neighbour's high ghost
+        to_r = ext[..., nxl:nxl + G, :, :].contiguous()      # becomes the right neighbour's low ghost
+        from_l, from_r = torch.empty_like(to_r), torch.empty_like(to_l)
+        self.comm.neighbour_exchange(to_l, to_r, from_l, from_r)
+        ext[..., :G, :, :] = from_l
+        ext[..., G + nxl:, :, :] = from_r
+
+
+class SlabPM(HaloMixin):
+    """Slab-decomposed PM stepper for one rank."""
+
+    def __init__(self, mesh_shape, comm=None, ghost=16, device=None):
+        self.comm = comm if comm is not None else LocalComm()
+        P, r = self.comm.world, self.comm.rank
+        nx, ny, nz = (int(s) for s in mesh_shape)
+        if nx % P or ny % P:
+            raise ValueError("nx and ny must be divisible by the number of ranks")
+        self.shape, self.P, self.rank = (nx, ny, nz), P, r
+        self.nxl, self.nyl, self.G = nx // P, ny // P, int(ghost)
+        self.nxe = self.nxl + 2 * self.G
+        self.device = device if device is not None else nbody._device()
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        check(lib.mcpm_plan_create_slab(nx, ny, nz, P, r, self.G, C.c_void_p(self.stream.cuda_stream), C.byref(h)), None,
+              "mcpm_plan_create_slab")
+        self.h = h
+        self.Nl = self.nxl * ny * nz                   # local particles
+        self.Me = self.nxe * ny * nz                   # ghost-extended local mesh
+        self.plane = ny * nz
+        ss = lib.mcpm_slab_spec_elems(h)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        c64 = dict(dtype=torch.complex64, device=self.device)
+        self.rho = torch.zeros((self.nxe, ny, nz), **f32)
+        self.f3 = torch.zeros((3, self.nxe, ny, nz), **f32)
+        self.s1a, self.s1b = torch.empty(ss, **c64), torch.empty(ss, **c64)
+        self.s3a, self.s3b = torch.empty(3 * ss, **c64), torch.empty(3 * ss, **c64)
+        self.Fb = torch.empty((self.Nl, 3), **f32)
+        self.sbar = None
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and lib is not None:
+            lib.mcpm_plan_destroy(h)
+
+    def call(self, name, *args):
+        check(getattr(lib, name)(self.h, *args), self.h, name)
+
+    def _interior(self, ext, c=None):
+        base = ext if c is None else ext[c]
+        return C.c_void_p(base.data_ptr() + 4 * self.G * self.plane)
+
+    # ---- Poisson solve on slabs ----------------------------------------------------------------------------
+    def force_meshes(self, rho_ext, f3_ext):
+        """Interior of rho_ext (ghosts already added) -> interiors of the three force meshes f3_ext."""
+        self.call("mcpm_slab_zfwd", self._interior(rho_ext), self.Me, _p(self.s1a), 1)
+        self.call("mcpm_slab_ycol", _p(self.s1a), _p(self.s1b), 1, -1, 0, 1)          # plain -> transposed order
+        self.comm.all_to_all(self.s1a, self.s1b)                                     # x <-> y transpose
+        self.call("mcpm_slab_xfused", _p(self.s1a), _p(self.s3a), 0)
+        self.comm.all_to_all(self.s3b, self.s3a)
+        self.call("mcpm_slab_ycol", _p(self.s3b), _p(self.s3a), 3, +1, 1, 0)
+        self.call("mcpm_slab_zinv", _p(self.s3a), self._interior(f3_ext, 0), self.Me, 3)
+
+    def force_meshes_vjp(self, fbar3_ext, rhobar_ext):
+        self.call("mcpm_slab_zfwd", self._interior(fbar3_ext, 0), self.Me, _p(self.s3a), 3)
+        self.call("mcpm_slab_ycol", _p(self.s3a), _p(self.s3b), 3, -1, 0, 1)
+        self.comm.all_to_all(self.s3a, self.s3b)
+        self.call("mcpm_slab_xfused", _p(self.s3a), _p(self.s1a), 1)
+        self.comm.all_to_all(self.s1b, self.s1a)
+        self.call("mcpm_slab_ycol", _p(self.s1b), _p(self.s1a), 1, +1, 1, 0)
+        self.call("mcpm_slab_zinv", _p(self.s1a), self._interior(rhobar_ext), self.Me, 1)
+
+    # ---- one BullFrog step and its adjoint -----------------------------------------------------------------
+    def step(self, x, v, alpha, beta, tau, f3_out, x_out, v_out, paint_order=2):
+        """x, v: (Nl,3) local state; f3_out: (3, nxe, ny, nz) receives the ghost-filled force meshes."""
+        self.call("mcpm_paint_f32", _p(x), self.Nl, POS_LATTICE, None, 1, 1.0, paint_order, _p(self.rho), 0)
+        self.halo_add(self.rho)
+        self.force_meshes(self.rho, f3_out)
+        self.halo_fill(f3_out)
+        self.call("mcpm_kick_drift_f32", _p(x), _p(v), self.Nl, POS_LATTICE, _p(f3_out), paint_order, float(alpha),
+                  float(beta), float(tau), _p(x_out), _p(v_out))
+
+    def step_vjp(self, x, v, f3, alpha, beta, tau, xb, vb, abar_ptr, bbar_ptr, paint_order=2):
+        """Adjoint of `step`: xb, vb (cotangents of its outputs) are updated in place."""
+        self.call("mcpm_kick_f32", _p(vb), _p(xb), self.Nl, float(beta), float(beta * tau), _p(self.Fb))
+        for c in range(3):
+            self.call("mcpm_paint_f32", _p(x), self.Nl, POS_LATTICE, C.c_void_p(self.Fb.data_ptr() + 4 * c), 3, 0.0,
+                      paint_order, _p(self.f3[c]), 0)
+        self.halo_add(self.f3)
+        self.force_meshes_vjp(self.f3, self.rho)
+        self.halo_fill(self.rho)
+        self.call("mcpm_step_adjoint_particles_f32", _p(x), _p(v), _p(f3), _p(self.rho), float(alpha), float(beta),
+                  float(tau), paint_order, _p(xb), _p(vb), abar_ptr, bbar_ptr)
+
+
+class SlabCtx:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def nbody_bf_slab(cosmo, init_mesh, a0=0., a1=1., n_steps=5, paint_order=2, lpt_order=2, comm=None, ghost=16,
+                  integrator="bullfrog", return_ctx=False, slab=None):
+    """Slab-decomposed `nbody_bf` (nbody.py:967-1002).  `init_mesh` is the full half-spectrum, replicated on every
+    rank.  Returns this rank's (disp, vel), each (N/P, 3): displacement from the lattice and velocity of the
+    particles whose lattice plane lies in the rank's slab (rows [r N/P, (r+1) N/P) of the global arrays)."""
+    spec = nbody._c64(init_mesh)
+    shape = nbody.ch2rshape(spec.shape)
+    pm = slab if slab is not None else SlabPM(shape, comm, ghost)
+    n_steps = int(n_steps)
+    dg, alphas, betas, lpt_s = nbody._step_scalars(cosmo, a0, a1, n_steps, integrator)
+    # LPT start, redundantly on the full mesh (round 1), then this rank's slab of particles
+    full = nbody.get_plan(shape)
+    dpos = torch.empty((full.N, 3), dtype=torch.float32, device=spec.device)
+    vel = torch.empty((full.N, 3), dtype=torch.float32, device=spec.device)
+    full.call("mcpm_lpt_f32", _p(spec), int(lpt_order), float(lpt_s[0]), float(lpt_s[1]), float(lpt_s[2]), 0, 0, _p(dpos), _p(vel))
+    lo, hi = pm.rank * pm.Nl, (pm.rank + 1) * pm.Nl
+    K = n_steps
+    states = torch.empty((K + 1, 2, pm.Nl, 3), dtype=torch.float32, device=spec.device)
+    f3s = torch.zeros((K, 3, pm.nxe) + shape[1:], dtype=torch.float32, device=spec.device) if return_ctx else None
+    states[0, 0] = dpos[lo:hi] + vel[lo:hi] * (dg / 2)
+    states[0, 1] = vel[lo:hi]
+    del dpos, vel
+    for i in range(K):
+        tau = dg / 2 if i == K - 1 else dg
+        pm.step(states[i, 0], states[i, 1], alphas[i], betas[i], tau, f3s[i] if return_ctx else pm.f3,
+                states[i + 1, 0], states[i + 1, 1], paint_order)
+    out = (states[K, 0], states[K, 1])
+    if return_ctx:
+        return out, SlabCtx(pm=pm, spec=spec, states=states, f3s=f3s, dg=dg, alphas=alphas, betas=betas, lpt_s=lpt_s,
+                            n_steps=K, lpt_order=int(lpt_order), paint_order=int(paint_order))
+    return out
+
+
+def nbody_bf_slab_vjp(ctx, disp_bar, vel_bar):
+    """Reverse sweep.  disp_bar, vel_bar: this rank's (N/P, 3) cotangents.  Returns (init_mesh_bar, scalar_bars) with
+    the full init_mesh_bar on every rank (real-pair convention) and the scalar cotangents summed over ranks."""
+    pm, K = ctx.pm, ctx.n_steps
+    dev = ctx.spec.device
+    xb = nbody._f32(disp_bar, (pm.Nl, 3)).clone()
+    vb = nbody._f32(vel_bar, (pm.Nl, 3)).clone()
+    sbar = torch.zeros(2 * K, dtype=torch.float64, device=dev)
+    for i in reversed(range(K)):
+        tau = ctx.dg / 2 if i == K - 1 else ctx.dg
+        pm.step_vjp(ctx.states[i, 0], ctx.states[i, 1], ctx.f3s[i], ctx.alphas[i], ctx.betas[i], tau, xb, vb,
+                    C.c_void_p(sbar.data_ptr() + 8 * i), C.c_void_p(sbar.data_ptr() + 8 * (K + i)), ctx.paint_order)
+    vb += xb * (ctx.dg / 2)                      # initial half drift x'_0 = x_0 + v_0 dg/2
+    sbar = pm.comm.all_reduce_sum(sbar).cpu().numpy()
+    # LPT adjoint on the gathered cotangents, redundantly on every rank (round 1)
+    xb_all, vb_all = pm.comm.all_gather_cat(xb), pm.comm.all_gather_cat(vb)
+    full = nbody.get_plan(pm.shape)
+    out = torch.empty(tuple(ctx.spec.shape), dtype=torch.complex64, device=dev)
+    ls = np.zeros(3)
+    full.call("mcpm_lpt_vjp_f32", _p(ctx.spec), ctx.lpt_order, nbody._dptr(ctx.lpt_s), _p(xb_all), _p(vb_all), _p(out),
+              nbody._dptr(ls))
+    return out, {"alpha": sbar[:K].copy(), "beta": sbar[K:].copy(), "g": ls[0], "g2": ls[1], "dg2dg": ls[2]}

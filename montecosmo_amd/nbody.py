@@ -632,9 +632,18 @@ def nbody_bf_vjp(ctx, pos_bar, vel_bar):
 
 
 def lpt_vjp(cosmo, init_mesh, pos, a, dpos_bar, vel_bar, lpt_order: int = 2):
-    """VJP of `lpt(..., read_order=1)` on the regular lattice w.r.t. init_mesh, scalar `a` only.
-    Implemented as the zero-step limit of the nbody reverse sweep's LPT stage."""
-    raise NotImplementedError("use nbody_bf_vjp; a standalone lpt_vjp entry point is scheduled next")
+    """VJP of `lpt(..., read_order=1)` on the regular lattice w.r.t. init_mesh (half-spectrum) for scalar `a`.
+    Returns (init_mesh_bar, {'g','g2','dg2dg'} scalar cotangents)."""
+    spec = _c64(init_mesh)
+    mesh_shape = ch2rshape(spec.shape)
+    ptcl_shape = pos.ptcl_shape if isinstance(pos, LatticePos) else _infer_lattice(pos, mesh_shape)
+    plan = get_plan(mesh_shape, ptcl_shape)
+    xb, vb = _f32(dpos_bar, (plan.N, 3)), _f32(vel_bar, (plan.N, 3))
+    sc = np.array([float(a2g(cosmo, a)), float(a2g2(cosmo, a)), float(a2dg2dg(cosmo, a))])
+    out = torch.empty(tuple(spec.shape), dtype=torch.complex64, device=spec.device)
+    sb = np.zeros(3)
+    plan.call("mcpm_lpt_vjp_f32", _ptr(spec), int(lpt_order), _dptr(sc), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
+    return out, {"g": sb[0], "g2": sb[1], "dg2dg": sb[2]}
 
 
 def _infer_lattice(pos, mesh_shape):

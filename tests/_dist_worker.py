@@ -1,0 +1,106 @@
+"""Worker bodies for the multi-process slab tests (spawned with torch.multiprocessing)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _init(rank, world, port):
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    return td
+
+
+def cpu_comm_worker(rank, world, port, out_dir):
+    """gloo / CPU: communicator primitives and the ghost-plane algebra against a serial numpy model."""
+    import torch
+    td = _init(rank, world, port)
+    from montecosmo_amd.dist import TorchComm, HaloMixin
+    comm = TorchComm()
+    nx, ny, nz, G = 8 * world, 4, 6, 3
+    nxl = nx // world
+    rng = np.random.default_rng(0)                      # same global field on every rank
+
+    class Halo(HaloMixin):
+        pass
+
+    h = Halo()
+    h.comm, h.G, h.nxl = comm, G, nxl
+    # halo_fill: ghosts must equal the periodic neighbours' planes of the global mesh
+    glob = rng.standard_normal((2, nx, ny, nz)).astype(np.float32)
+    ext = torch.zeros((2, nxl + 2 * G, ny, nz))
+    ext[:, G:G + nxl] = torch.from_numpy(glob[:, rank * nxl:(rank + 1) * nxl])
+    h.halo_fill(ext)
+    idx = np.arange(rank * nxl - G, (rank + 1) * nxl + G) % nx
+    assert np.array_equal(ext.numpy(), glob[:, idx]), "halo_fill"
+    # halo_add: every rank paints an extended slab; the sum over ranks of the unfolded slabs is the global mesh
+    ext_all = rng.standard_normal((world, nxl + 2 * G, ny, nz)).astype(np.float32)
+    want = np.zeros((nx, ny, nz), np.float64)
+    for r in range(world):
+        ii = np.arange(r * nxl - G, (r + 1) * nxl + G) % nx
+        np.add.at(want, ii, ext_all[r].astype(np.float64))
+    mine = torch.from_numpy(ext_all[rank].copy())
+    h.halo_add(mine)
+    got = mine[G:G + nxl].numpy()
+    assert np.allclose(got, want[rank * nxl:(rank + 1) * nxl], atol=1e-5), "halo_add"
+    # all_to_all in the packed transpose layout: [dest][xl][yl][k] -> [x][yl][k]
+    nyl, nk = 2, 3
+    full = rng.standard_normal((nx, nyl * world, nk)).astype(np.float32)          # global [x][y][k]
+    mine = full[rank * nxl:(rank + 1) * nxl]                                     # my x planes, all y
+    send = np.stack([mine[:, d * nyl:(d + 1) * nyl] for d in range(world)])       # [d][xl][yl][k]
+    recv = torch.empty(send.shape)
+    comm.all_to_all(recv, torch.from_numpy(send.copy()))
+    assert np.array_equal(recv.numpy().reshape(nx, nyl, nk), full[:, rank * nyl:(rank + 1) * nyl]), "all_to_all transpose"
+    # complex payloads travel as float pairs
+    cs = torch.from_numpy((send + 1j * send).astype(np.complex64).reshape(-1).copy())
+    cr = torch.empty_like(cs)
+    comm.all_to_all(cr, cs)
+    assert np.array_equal(cr.numpy().real.reshape(nx, nyl, nk), full[:, rank * nyl:(rank + 1) * nyl])
+    t = comm.all_reduce_sum(torch.tensor([float(rank + 1)], dtype=torch.float64))
+    assert float(t) == world * (world + 1) / 2
+    g = comm.all_gather_cat(torch.full((2, 3), float(rank)))
+    assert g.shape == (2 * world, 3) and float(g[2 * rank, 0]) == rank
+    td.barrier()
+    td.destroy_process_group()
+    open(os.path.join(out_dir, f"ok_{rank}"), "w").write("ok")
+
+
+def gpu_slab_worker(rank, world, port, out_dir, n, n_steps):
+    """Several ranks sharing cuda:0 (gloo, staged through the host): the slab path against the single-GPU path."""
+    import torch
+    td = _init(rank, world, port)
+    torch.cuda.set_device(0)
+    from montecosmo_amd import nbody, bricks, synth, dist
+    shape = (n, n, n)
+    spec = synth.init_mesh(n, seed=3, rms_disp=1.5)
+    cosmo = bricks.Planck18()
+    comm = dist.TorchComm()
+    (d, v), ctx = dist.nbody_bf_slab(cosmo, spec, a0=0.1, a1=1.0, n_steps=n_steps, comm=comm, ghost=8, return_ctx=True)
+    rng = np.random.default_rng(5)
+    xb = rng.standard_normal((n ** 3, 3)).astype(np.float32)
+    vb = rng.standard_normal((n ** 3, 3)).astype(np.float32)
+    Nl = n ** 3 // world
+    mb, sb = dist.nbody_bf_slab_vjp(ctx, xb[rank * Nl:(rank + 1) * Nl], vb[rank * Nl:(rank + 1) * Nl])
+    d_all, v_all = comm.all_gather_cat(d), comm.all_gather_cat(v)
+    if rank == 0:
+        (lp, v1), c1 = nbody.nbody_bf(cosmo, spec, nbody.LatticePos.regular(shape), a0=0.1, a1=1.0, n_steps=n_steps,
+                                      return_ctx=True, lattice_out=True)
+        mb1, sb1 = nbody.nbody_bf_vjp(c1, xb, vb)
+
+        def rel(a, b):
+            a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+            return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+        res = {"disp": rel(d_all, lp.disp), "vel": rel(v_all, v1), "grad": rel(mb, mb1),
+               "alpha": float(np.abs(sb["alpha"] - sb1["alpha"]).max() / np.abs(sb1["alpha"]).max()),
+               "beta": float(np.abs(sb["beta"] - sb1["beta"]).max() / np.abs(sb1["beta"]).max())}
+        import json
+        json.dump(res, open(os.path.join(out_dir, "result.json"), "w"))
+    td.barrier()
+    td.destroy_process_group()
