@@ -8,9 +8,10 @@ N = n^3 particles on an n^3 mesh, synthetic inputs of SURVEY.md 8(d).  The timed
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mesh n]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU.  Until the slab-decomposed FFT lands the ranks
-run independent replicas (the reference's own multi-device mode: independent chains, script.py:13-20), so
-scaling is "weak" and no collective is on the data path.
+N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL): the SAME mesh is x-slab decomposed over the
+ranks (montecosmo_amd/dist.py: ghost planes point-to-point, one all-to-all per FFT transpose), so the total work
+is fixed and scaling is "strong".  `--replicas` instead runs N independent copies (the reference's own
+multi-device mode: independent chains, script.py:13-20; "weak", no collective on the data path).
 """
 import argparse
 import ctypes as C
@@ -38,6 +39,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mesh", type=int, default=int(os.environ.get("MCPM_BENCH_MESH", "512")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: independent replicas instead of slabs")
+    ap.add_argument("--ghost", type=int, default=8)
     ap.add_argument("--cpu-mesh", type=int, default=128)
     return ap.parse_args()
 
@@ -124,6 +127,80 @@ class Runner:
         return list(ms)[:ns], list(by)[:ns], list(calls)[:ns]
 
 
+class SlabRunner:
+    """The same K forward + K adjoint steps on an x-slab of the mesh (one rank of N)."""
+
+    def __init__(self, n, K, device, ghost):
+        from montecosmo_amd import nbody, bricks, synth, dist
+        self.n, self.K = n, K
+        shape = (n, n, n)
+        self.comm = dist.TorchComm()
+        self.pm = dist.SlabPM(shape, self.comm, ghost, device)
+        pm = self.pm
+        cosmo = bricks.Planck18()
+        self.dg, self.alphas, self.betas, self.lpt_s = nbody._step_scalars(cosmo, 0.0, 1.0, K, "bullfrog")
+        spec = torch.from_numpy(synth.init_mesh(n, seed=0, rms_disp=2.0)).to(device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.states = torch.empty((K + 1, 2, pm.Nl, 3), **f32)
+        self.f3s = torch.zeros((K, 3, pm.nxe, n, n), **f32)
+        # LPT start (untimed set-up), redundantly on the full mesh, then this rank's slab of particles
+        full = nbody.get_plan(shape)
+        dpos, vel = torch.empty((full.N, 3), **f32), torch.empty((full.N, 3), **f32)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        full.call("mcpm_lpt_f32", p(spec), 2, float(self.lpt_s[0]), float(self.lpt_s[1]), float(self.lpt_s[2]), 0, 0, p(dpos), p(vel))
+        lo, hi = pm.rank * pm.Nl, (pm.rank + 1) * pm.Nl
+        self.states[0, 0] = dpos[lo:hi] + vel[lo:hi] * (self.dg / 2)
+        self.states[0, 1] = vel[lo:hi]
+        del dpos, vel, full, spec
+        nbody.clear_plans()
+        torch.cuda.empty_cache()
+        rng = np.random.default_rng(1 + pm.rank)
+        self.pos_bar = torch.from_numpy(rng.standard_normal((pm.Nl, 3), dtype=np.float32)).to(device)
+        self.vel_bar = torch.from_numpy(rng.standard_normal((pm.Nl, 3), dtype=np.float32)).to(device)
+        self.xb, self.vb = torch.empty((pm.Nl, 3), **f32), torch.empty((pm.Nl, 3), **f32)
+        self.sbar = torch.zeros((2 * K,), dtype=torch.float64, device=device)
+
+    def forward(self, steps):
+        K = self.K
+        for i in range(steps):
+            tau = self.dg / 2 if i == K - 1 else self.dg
+            self.pm.step(self.states[i, 0], self.states[i, 1], self.alphas[i], self.betas[i], tau, self.f3s[i],
+                         self.states[i + 1, 0], self.states[i + 1, 1])
+
+    def backward(self, steps):
+        K = self.K
+        self.xb.copy_(self.pos_bar)
+        self.vb.copy_(self.vel_bar)
+        for i in reversed(range(steps)):
+            tau = self.dg / 2 if i == K - 1 else self.dg
+            self.pm.step_vjp(self.states[i, 0], self.states[i, 1], self.f3s[i], self.alphas[i], self.betas[i], tau,
+                             self.xb, self.vb, C.c_void_p(self.sbar.data_ptr() + 8 * i),
+                             C.c_void_p(self.sbar.data_ptr() + 8 * (K + i)))
+
+    def run(self, steps):
+        self.forward(steps)
+        self.backward(steps)
+
+    def profile(self):
+        from montecosmo_amd._lib import lib
+        self.pm.call("mcpm_plan_profile", 1)
+        self.forward(self.K)
+        fwd = self._read_profile()
+        self.backward(self.K)
+        bwd = self._read_profile()
+        self.pm.call("mcpm_plan_profile", 0)
+        names = [lib.mcpm_stage_name(i).decode() for i in range(len(fwd[0]))]
+        return names, fwd, bwd
+
+    def _read_profile(self):
+        from montecosmo_amd._lib import lib
+        nmax = 16
+        ms, by, calls = (C.c_double * nmax)(), (C.c_double * nmax)(), (C.c_int64 * nmax)()
+        ns = lib.mcpm_plan_profile_read(self.pm.h, nmax, ms, by, calls)
+        assert ns > 0
+        return list(ms)[:ns], list(by)[:ns], list(calls)[:ns]
+
+
 def cpu_baseline(n_cpu, n_gpu):
     """The numpy float64 oracle (a port of the reference's algorithm; the JAX reference itself cannot run here)
     timed on one forward+adjoint DKD step at n_cpu^3, scaled by cell count to the benchmark mesh."""
@@ -149,14 +226,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank % ndev)
+    device = torch.device("cuda", local_rank % ndev)
     if dist:
         import torch.distributed as td
-        td.init_process_group(backend="nccl", device_id=device)
+        # RCCL ("nccl") on a real multi-GPU node; MCPM_BENCH_BACKEND=gloo only rehearses the script with several
+        # ranks sharing one GPU (collectives staged through the host) and is never a measurement
+        backend = os.environ.get("MCPM_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            td.init_process_group(backend="nccl", device_id=device)
+        else:
+            td.init_process_group(backend=backend)
     K, W, n = args.steps, args.warmup, args.mesh
 
-    r = Runner(n, K, device)
+    slab = dist and not args.replicas
+    r = SlabRunner(n, K, device, args.ghost) if slab else Runner(n, K, device)
     w = W
     while w > 0:                       # W untimed warm-up steps (rocFFT plans, code objects, caches)
         r.run(min(w, K))
@@ -173,15 +258,16 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if td.get_backend() == "nccl" else "cpu")
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
 
     out = None
+    prof = r.profile() if (slab or rank == 0) else None     # slabbed: collective, every rank takes part
     if rank == 0:
-        M = float(n) ** 3
-        steps_per_s = world * K / dt
-        names, fwd, bwd = r.profile()
+        M = float(n) ** 3          # whole mesh: stage times below are rank 0's, which holds 1/world of it when slabbed
+        steps_per_s = (1 if slab else world) * K / dt
+        names, fwd, bwd = prof
         stages = {}
         for i, nm in enumerate(names):
             ms = fwd[0][i] + bwd[0][i]
@@ -194,23 +280,29 @@ def main():
         fwd_ms = sum(fwd[0])
         bwd_ms = sum(bwd[0])
         # force cycle = paint + R2C + k-space + 3 C2R + read(+kick+drift) of the forward pass
+        Mloc = M / world if slab else M    # cells whose stages rank 0 timed
         cyc_ms = sum(fwd[0][names.index(k)] for k in ("paint", "fft_r2c", "kspace", "fft_c2r", "kick_drift")) / K
         step_ms = (fwd_ms + bwd_ms) / K
         out = {
             "metric": "PM forward+adjoint steps/sec", "value": round(steps_per_s, 3), "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if slab else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}^3 mesh, {n}^3 particles, {K}-step BullFrog forward+VJP, CIC, 2LPT start (untimed), "
-                                   f"rms displacement 2 cells; " + ("single GPU" if world == 1 else f"{world} independent replicas"),
-                       "mesh": n, "n_steps": K, "parallelism": "replicas" if world > 1 else "single"},
+                                   f"rms displacement 2 cells; " + ("single GPU" if world == 1 else
+                                                                    (f"x-slab decomposed over {world} GPUs (ghost {args.ghost} planes, RCCL all-to-all FFT transpose)"
+                                                                     if slab else f"{world} independent replicas")),
+                       "mesh": n, "n_steps": K, "parallelism": "single" if world == 1 else (f"slab{world}" if slab else f"replicas{world}")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(stages[dom]["algorithmic_GBps"] / HBM_PEAK_GBS, 4), "traffic": None},
-            "force_cycle": {"ms": round(cyc_ms, 4), "algorithmic_GBps": round(B_PER_CELL_CYCLE * M / (cyc_ms * 1e-3) / 1e9, 1),
-                            "frac_of_hbm_peak": round(B_PER_CELL_CYCLE * M / (cyc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "fwd_adj_step": {"ms_events": round(step_ms, 4), "algorithmic_GBps": round(B_PER_CELL_STEP * M / (step_ms * 1e-3) / 1e9, 1),
-                             "frac_of_hbm_peak": round(B_PER_CELL_STEP * M / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "force_cycle": {"ms": round(cyc_ms, 4), "algorithmic_GBps": round(B_PER_CELL_CYCLE * Mloc / (cyc_ms * 1e-3) / 1e9, 1),
+                            "frac_of_hbm_peak": round(B_PER_CELL_CYCLE * Mloc / (cyc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "fwd_adj_step": {"ms_events": round(step_ms, 4), "algorithmic_GBps": round(B_PER_CELL_STEP * Mloc / (step_ms * 1e-3) / 1e9, 1),
+                             "frac_of_hbm_peak": round(B_PER_CELL_STEP * Mloc / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "stages": stages,
         }
+        if slab:
+            out["comm_and_host_ms_per_step"] = round(dt / K * 1e3 - step_ms, 3)   # wall minus rank-0 kernel stages
+            out["deposits_beyond_ghost_rank0"] = r.pm.out_of_ghost()                # must be 0
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_mesh, n)
     if dist:

@@ -61,6 +61,9 @@ int mcpm_plan_create(int nx, int ny, int nz, int px, int py, int pz, void *strea
    particles never migrate).  Particle kernels then work on the ghost-extended local mesh
    (nx/nranks + 2*ghost, ny, nz), non-periodic in x; ghost planes are exchanged by the host (montecosmo_amd/dist.py). */
 int mcpm_plan_create_slab(int nx, int ny, int nz, int nranks, int rank, int ghost, void *stream, mcpm_plan **plan);
+/* Slab plans: cumulative number of particle deposits that fell beyond the ghost planes (clamped to the edge); a
+   non-zero count means `ghost` is too small for the displacements (host sync). */
+int mcpm_plan_slab_oob(mcpm_plan *plan, int64_t *count);
 int mcpm_plan_destroy(mcpm_plan *plan);
 const char *mcpm_last_error(const mcpm_plan *plan); /* plan may be NULL: last error of a failed create */
 const char *mcpm_version(void);

@@ -22,6 +22,7 @@ _f64p = C.POINTER(C.c_double)
 SIGNATURES = {
     "mcpm_plan_create": (C.c_int, [C.c_int] * 6 + [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mcpm_plan_create_slab": (C.c_int, [C.c_int] * 6 + [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mcpm_plan_slab_oob": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mcpm_plan_destroy": (C.c_int, [C.c_void_p]),
     "mcpm_last_error": (C.c_char_p, [C.c_void_p]),
     "mcpm_version": (C.c_char_p, []),

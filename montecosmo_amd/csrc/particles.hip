@@ -34,13 +34,14 @@ __global__ __launch_bounds__(256) void cell_index_kernel(Geom g, const float *__
 template <int MODE, int ORDER>
 __global__ __launch_bounds__(256) void paint_atomic_kernel(Geom g, const float *__restrict__ pos, int64_t n,
                                                            const float *__restrict__ w, int64_t wstride,
-                                                           float wscalar, float *__restrict__ mesh) {
+                                                           float wscalar, float *__restrict__ mesh, int *__restrict__ oob) {
     PIdx pi = particle_index<MODE>(g, n);
     if (!pi.valid) return;
     P3 d = load3(pos, pi.i);
     int c[3];
     float f[3];
     locate<MODE, ORDER>(g, pi, d, c, f);
+    if (g.xslab && (c[0] < 0 || c[0] > g.nx - ORDER)) atomicAdd(oob, 1);  // beyond the ghost planes: clamped + counted
     float wt = w ? w[pi.i * wstride] : wscalar;
     Stencil<ORDER> s(g, c);
     if (ORDER == 1) {
@@ -197,6 +198,9 @@ __global__ __launch_bounds__(256) void paint_outlier_kernel(Geom g, const float 
         int c[3];
         float f[3];
         locate<MCPM_POS_LATTICE, 2>(g, pi, d, c, f);
+        // slab mode: a particle displaced beyond the ghost planes cannot be deposited on this rank; it is clamped
+        // to the edge and counted (mcpm_plan_slab_oob) so that the host can widen the ghost region
+        if (g.xslab && (c[0] < 0 || c[0] > g.nx - 2)) atomicAdd(ocount + 2, 1);
         const float wt = w ? w[(int64_t)gi * wstride] : wscalar;
         Stencil<2> s(g, c);
         const float kx[2] = {1.f - f[0], f[0]}, ky[2] = {1.f - f[1], f[1]}, kz[2] = {1.f - f[2], f[2]};
@@ -420,7 +424,7 @@ int mcpm_paint_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const fl
     if (n == 0) return MCPM_OK;
     dim3 grid, block;
     if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
-#define CALL(MO, OR) paint_atomic_kernel<MO, OR><<<grid, block, 0, p->stream>>>(p->g, pos, n, weights, wstride, wscalar, mesh)
+#define CALL(MO, OR) paint_atomic_kernel<MO, OR><<<grid, block, 0, p->stream>>>(p->g, pos, n, weights, wstride, wscalar, mesh, p->outlier_count + 2)
     DISPATCH_MODE_ORDER(mode, order, CALL);
 #undef CALL
     MCPM_LAUNCH_CHECK(p, "paint_atomic_kernel");

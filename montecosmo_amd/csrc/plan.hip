@@ -108,14 +108,14 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     alloc((void **)&p->fmesh, sizeof(float) * p->M * 9);
     alloc((void **)&p->spec1, sizeof(float) * 2 * p->Mh);
     alloc((void **)&p->outliers, sizeof(int) * p->Np);
-    alloc((void **)&p->outlier_count, sizeof(int) * 2);
+    alloc((void **)&p->outlier_count, sizeof(int) * 4);
     alloc((void **)&p->reduce, sizeof(double) * MCPM_NREDUCE);
     if (e != hipSuccess) {
         std::string msg = std::string("hipMalloc of plan scratch: ") + hipGetErrorString(e);
         mcpm_plan_destroy(p);
         return mcpm_fail(nullptr, MCPM_E_NOMEM, msg);
     }
-    (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int) * 2, p->stream);
+    (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int) * 4, p->stream);
     *out = p;
     return MCPM_OK;
 }
@@ -195,6 +195,15 @@ int mcpm_plan_profile_read(mcpm_plan *p, int nmax, double *ms, double *bytes, in
     }
     p->recs.clear();
     return ST_NSTAGES;
+}
+
+int mcpm_plan_slab_oob(mcpm_plan *p, int64_t *count) {
+    if (!p || !count) return MCPM_E_ARG;
+    int h = 0;
+    MCPM_HIP(p, hipMemcpyAsync(&h, p->outlier_count + 2, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    MCPM_HIP(p, hipStreamSynchronize(p->stream));
+    *count = h;
+    return MCPM_OK;
 }
 
 int mcpm_plan_force_meshes(mcpm_plan *p, float **meshes3) {

@@ -167,6 +167,12 @@ class SlabPM(HaloMixin):
     def call(self, name, *args):
         check(getattr(lib, name)(self.h, *args), self.h, name)
 
+    def out_of_ghost(self):
+        """Cumulative count of deposits that fell beyond this rank's ghost planes (must stay 0)."""
+        n = C.c_int64()
+        self.call("mcpm_plan_slab_oob", C.byref(n))
+        return n.value
+
     def _interior(self, ext, c=None):
         base = ext if c is None else ext[c]
         return C.c_void_p(base.data_ptr() + 4 * self.G * self.plane)

@@ -47,6 +47,7 @@ def test_slab_path_single_rank(gpu):
                                   return_ctx=True, lattice_out=True)
     rel = lambda a, b: float((a - b).norm() / b.norm())
     assert rel(d, lp.disp) < 2e-6 and rel(v, v1) < 2e-6
+    assert ctx.pm.out_of_ghost() == 0
     rng = np.random.default_rng(5)
     xb = rng.standard_normal((n ** 3, 3)).astype(np.float32)
     vb = rng.standard_normal((n ** 3, 3)).astype(np.float32)
@@ -65,3 +66,19 @@ def test_slab_path_multi_rank_shared_gpu(gpu, world):
     res = json.load(open(os.path.join(out, "result.json")))
     assert res["disp"] < 2e-6 and res["vel"] < 2e-6, res
     assert res["grad"] < 1e-5 and res["alpha"] < 1e-4 and res["beta"] < 1e-4, res
+
+
+@pytest.mark.gpu
+def test_too_small_ghost_is_detected(gpu):
+    """Deposits beyond the ghost planes are counted, so a too-narrow ghost region cannot pass silently."""
+    import ctypes as C
+    import torch
+    from montecosmo_amd import dist
+    from montecosmo_amd._lib import POS_LATTICE
+    pm = dist.SlabPM((64, 64, 64), ghost=5)
+    disp = torch.zeros((pm.Nl, 3), dtype=torch.float32, device="cuda")
+    disp[-10:, 0] = 9.5         # last lattice plane, pushed beyond the 5 ghost planes
+    disp[:10, 0] = -7.25        # first lattice plane, pushed below them
+    pm.call("mcpm_paint_f32", C.c_void_p(disp.data_ptr()), pm.Nl, POS_LATTICE, None, 1, 1.0, 2, C.c_void_p(pm.rho.data_ptr()), 0)
+    assert pm.out_of_ghost() == 20
+    assert abs(float(pm.rho.double().sum()) - pm.Nl) < 1e-3 * pm.Nl     # mass is clamped, not lost
