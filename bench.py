@@ -201,6 +201,19 @@ class SlabRunner:
         return list(ms)[:ns], list(by)[:ns], list(calls)[:ns]
 
 
+def pmc_traffic(stage, n):
+    """HBM-side bytes per launch of `stage`, from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under
+    profiles/ (separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 and as calibrated here
+    on axpy_kernel, whose byte count is known).  bench.py cannot collect PMC counters itself; null when the file
+    has no entry for this mesh."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        return d[str(n)][stage]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_cpu, n_gpu):
     """The numpy float64 oracle (a port of the reference's algorithm; the JAX reference itself cannot run here)
     timed on one forward+adjoint DKD step at n_cpu^3, scaled by cell count to the benchmark mesh."""
@@ -286,14 +299,15 @@ def main():
         out = {
             "metric": "PM forward+adjoint steps/sec", "value": round(steps_per_s, 3), "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong" if slab else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if args.replicas else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}^3 mesh, {n}^3 particles, {K}-step BullFrog forward+VJP, CIC, 2LPT start (untimed), "
                                    f"rms displacement 2 cells; " + ("single GPU" if world == 1 else
                                                                     (f"x-slab decomposed over {world} GPUs (ghost {args.ghost} planes, RCCL all-to-all FFT transpose)"
                                                                      if slab else f"{world} independent replicas")),
                        "mesh": n, "n_steps": K, "parallelism": "single" if world == 1 else (f"slab{world}" if slab else f"replicas{world}")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(stages[dom]["algorithmic_GBps"] / HBM_PEAK_GBS, 4), "traffic": None},
+                         "unit": "GB/s", "frac": round(stages[dom]["algorithmic_GBps"] / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(dom, n) if world == 1 else None},
             "force_cycle": {"ms": round(cyc_ms, 4), "algorithmic_GBps": round(B_PER_CELL_CYCLE * Mloc / (cyc_ms * 1e-3) / 1e9, 1),
                             "frac_of_hbm_peak": round(B_PER_CELL_CYCLE * Mloc / (cyc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "fwd_adj_step": {"ms_events": round(step_ms, 4), "algorithmic_GBps": round(B_PER_CELL_STEP * Mloc / (step_ms * 1e-3) / 1e9, 1),
