@@ -136,10 +136,11 @@ int mcpm_force_meshes_vjp_f32(mcpm_plan *plan, const float *fbar3, float *rho_ba
    between the y and the x pass.  Spectra are complex64 in the internal padded layout, mcpm_slab_spec_elems()
    complex per spectrum = (nx/ranks) * ny * (nz/2 + 16).
      zfwd  : `batch` real meshes of nx/ranks planes (mesh b at real + b*real_bstride floats) -> `batch` spectra
-     ycol  : FFT along y (sign -1 forward / +1 inverse); *_packed = all-to-all layout
-             [dest rank][plane][y_local][nzp], plain = [plane][y][nzp]
+     ycol  : FFT along y (sign -1 forward / +1 inverse) of `batch` spectra; *_packed = transposed-order layout
+             [c][dest rank][x_local][y_local][nzp] (what one all-to-all per spectrum exchanges), plain =
+             [c][x_local][y][nzp]
      xfused: mode 0: one spectrum [x][y_local][nzp] -> x FFT, k-space force multiply, inverse x FFT -> three
-             spectra [dest rank][c][x_local][y_local][nzp]; mode 1 is the adjoint (three in that layout -> one)
+             spectra [c][dest rank][x_local][y_local][nzp]; mode 1 is the adjoint (three in that layout -> one)
      zinv  : `batch` spectra -> `batch` real meshes (unnormalised; the 1/M sits in xfused). */
 int64_t mcpm_slab_spec_elems(const mcpm_plan *plan);
 int mcpm_slab_zfwd(mcpm_plan *plan, const float *real, int64_t real_bstride, float *spec, int batch);

@@ -167,14 +167,15 @@ struct FGeom {
 struct ZBatch {
     int64_t lines, real_bstride, spec_bstride;
 };
-// y-line addressing of a column pass: point y of plane p sits at p*PS + (y / YB)*SB + (y % YB)*nzp (complex).
-// Plain layout [plane][y][nzp]: YB = ny, SB = 0.  All-to-all packed layout [dest][plane][y_local][nzp]: YB = ny/ranks.
+// y-line addressing of a column pass: point y of x-plane xl of spectrum c sits at
+// c*BS + xl*PS + (y / YB)*SB + (y % YB)*nzp (complex).  Plain layout [c][xl][y][nzp]: YB = ny, SB = 0.
+// All-to-all (transposed-order) layout [c][dest rank][xl][y_local][nzp]: YB = ny/ranks, SB = one rank block.
 struct YLayout {
-    int64_t PS, SB;
-    int YB;
+    int64_t BS, PS, SB;
+    int YB, NXL;
 };
 // x-line addressing of the fused pass.  One-spectrum side: [x][yl][nzp] (NYL rows per x).  Three-spectra side:
-// (x / XB)*SBx + c*SC + ((x % XB)*NYL + yl)*nzp  (single GPU: XB = nx; slabs: [src/dest rank][c][xl][yl][nzp]).
+// c*SC + (x / XB)*SBx + ((x % XB)*NYL + yl)*nzp  (single GPU: XB = nx; slabs: [c][src/dest rank][xl][yl][nzp]).
 struct XLayout {
     int NYL, iy0, XB;
     int64_t SBx, SC;
@@ -277,8 +278,9 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol_kernel(FGeom g, con
     const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
     const int kz = blockIdx.x * LINES + l;
     const bool ok = kz < g.nzh;
-    const cf *ib = in + (int64_t)blockIdx.y * li.PS + kz;
-    cf *ob = out + (int64_t)blockIdx.y * lo.PS + kz;
+    const int pc = blockIdx.y / li.NXL, pxl = blockIdx.y - pc * li.NXL;
+    const cf *ib = in + pc * li.BS + pxl * li.PS + kz;
+    cf *ob = out + pc * lo.BS + pxl * lo.PS + kz;
     cf v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -453,17 +455,17 @@ static int z_inverse(mcpm_plan *p, const cf *spec, float *real, int64_t real_bst
     return MCPM_OK;
 }
 
-// packed = all-to-all layout [dest rank][plane (batch*nxl)][y_local][nzp]
-static YLayout ylayout(const mcpm_plan *p, int batch, bool packed) {
+// packed = all-to-all layout [c][dest rank][xl][y_local][nzp]; every spectrum is spec_elems() complex
+static YLayout ylayout(const mcpm_plan *p, bool packed) {
     const int64_t nzp = p->g.nz / 2 + 16;
-    if (!packed) return YLayout{(int64_t)p->g.ny * nzp, 0, p->g.ny};
+    if (!packed) return YLayout{spec_elems(p), (int64_t)p->g.ny * nzp, 0, p->g.ny, p->nxl};
     const int nyl = p->g.ny / p->nranks;
-    return YLayout{(int64_t)nyl * nzp, (int64_t)batch * p->nxl * nyl * nzp, nyl};
+    return YLayout{spec_elems(p), (int64_t)nyl * nzp, (int64_t)p->nxl * nyl * nzp, nyl, p->nxl};
 }
 
 static int y_columns(mcpm_plan *p, const cf *in, cf *out, int batch, int sign, bool in_packed, bool out_packed) {
     const FGeom g = fgeom(p);
-    const YLayout li = ylayout(p, batch, in_packed), lo = ylayout(p, batch, out_packed);
+    const YLayout li = ylayout(p, in_packed), lo = ylayout(p, out_packed);
     StageTimer st_(p, sign < 0 ? ST_R2C : ST_C2R, pass_bytes(p, batch));
 #define CALL(NN)                                                                                       \
     {                                                                                                  \
@@ -483,7 +485,7 @@ static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
     const FGeom g = fgeom(p);
     const int nyl = g.ny / p->nranks;
     const int64_t blk = (int64_t)p->nxl * nyl * g.nzp;  // one rank's block of one spectrum
-    const XLayout xl{nyl, p->rank * nyl, p->nxl, 3 * blk, blk};
+    const XLayout xl{nyl, p->rank * nyl, p->nxl, blk, (int64_t)p->nranks * blk};
     const float scale = 1.f / ((float)g.nx * (float)g.ny * (float)g.nz);
     // one forward + one inverse x pass of (1 + 3) spectra and the k-space multiply
     StageTimer st_(p, ST_KSPACE, (32.0 * p->nxl * g.ny * g.nzh) + 4.0 * pass_bytes(p, 1));

@@ -32,16 +32,36 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+class _Done:
+    """Handle of an exchange that has already completed."""
+
+    def wait(self):
+        pass
+
+
+class _Works:
+    def __init__(self, works, after=None):
+        self.works, self.after = works, after
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        if self.after:
+            self.after()
+
+
 class LocalComm:
     """Single-rank communicator: every exchange is a local copy (used to validate the slab code path itself)."""
     world, rank = 1, 0
 
-    def all_to_all(self, out, inp):
+    def all_to_all(self, out, inp, async_op=False):
         out.copy_(inp)
+        return _Done()
 
-    def neighbour_exchange(self, to_left, to_right, from_left, from_right):
+    def neighbour_exchange(self, to_left, to_right, from_left, from_right, async_op=False):
         from_right.copy_(to_left)   # my left neighbour is me: what I send left arrives "from the right"
         from_left.copy_(to_right)
+        return _Done()
 
     def all_reduce_sum(self, t):
         return t
@@ -64,18 +84,21 @@ class TorchComm:
     def _h(self, t):
         return t.cpu() if (self.stage and t.is_cuda) else t
 
-    def all_to_all(self, out, inp):
+    def all_to_all(self, out, inp, async_op=False):
+        """Equal-split all-to-all along dim 0.  With async_op the RCCL kernel runs on its own stream, ordered after
+        the work already enqueued on the current stream; `.wait()` orders the current stream after it."""
         if self.stage and inp.is_cuda:
             o = torch.empty(out.shape, dtype=out.dtype)
             self.td.all_to_all_single(o.view(torch.float32) if o.is_complex() else o,
                                       (inp.cpu().view(torch.float32) if inp.is_complex() else inp.cpu()), group=self.group)
             out.copy_(o)
-        else:
-            vo = torch.view_as_real(out) if out.is_complex() else out
-            vi = torch.view_as_real(inp) if inp.is_complex() else inp
-            self.td.all_to_all_single(vo, vi, group=self.group)
+            return _Done()
+        vo = torch.view_as_real(out) if out.is_complex() else out
+        vi = torch.view_as_real(inp) if inp.is_complex() else inp
+        w = self.td.all_to_all_single(vo, vi, group=self.group, async_op=async_op)
+        return _Works([w]) if async_op else _Done()
 
-    def neighbour_exchange(self, to_left, to_right, from_left, from_right):
+    def neighbour_exchange(self, to_left, to_right, from_left, from_right, async_op=False):
         td, P, r = self.td, self.world, self.rank
         left, right = (r - 1) % P, (r + 1) % P
         sl, sr = self._h(to_left), self._h(to_right)
@@ -85,12 +108,19 @@ class TorchComm:
         # receive, which is therefore its "from the right"
         ops = [td.P2POp(td.isend, sl, left, self.group), td.P2POp(td.isend, sr, right, self.group),
                td.P2POp(td.irecv, rr, right, self.group), td.P2POp(td.irecv, rl, left, self.group)]
-        for w in td.batch_isend_irecv(ops):
-            w.wait()
-        if rl is not from_left:
-            from_left.copy_(rl)
-        if rr is not from_right:
-            from_right.copy_(rr)
+        works = td.batch_isend_irecv(ops)
+
+        def finish():
+            if rl is not from_left:
+                from_left.copy_(rl)
+            if rr is not from_right:
+                from_right.copy_(rr)
+
+        h = _Works(works, finish)
+        if async_op and not self.stage:
+            return h
+        h.wait()
+        return _Done()
 
     def all_reduce_sum(self, t):
         h = self._h(t).clone()
@@ -117,15 +147,24 @@ class HaloMixin:
         ext[..., G:2 * G, :, :] += from_l          # the left neighbour's high ghost = my lowest interior planes
         ext[..., nxl:nxl + G, :, :] += from_r      # the right neighbour's low ghost = my highest interior planes
 
-    def halo_fill(self, ext):
-        """Fills my ghost planes from the neighbours' interiors (before a read)."""
+    def halo_fill(self, ext, async_op=False):
+        """Fills my ghost planes from the neighbours' interiors (before a read).  With async_op returns a handle
+        whose wait() completes the exchange and writes the ghosts (lets the next component's FFT passes overlap)."""
         G, nxl = self.G, self.nxl
         to_l = ext[..., G:2 * G, :, :].contiguous()          # becomes the left neighbour's high ghost
         to_r = ext[..., nxl:nxl + G, :, :].contiguous()      # becomes the right neighbour's low ghost
         from_l, from_r = torch.empty_like(to_r), torch.empty_like(to_l)
-        self.comm.neighbour_exchange(to_l, to_r, from_l, from_r)
-        ext[..., :G, :, :] = from_l
-        ext[..., G + nxl:, :, :] = from_r
+        h = self.comm.neighbour_exchange(to_l, to_r, from_l, from_r, async_op=async_op)
+
+        def finish():
+            h.wait()
+            ext[..., :G, :, :] = from_l
+            ext[..., G + nxl:, :, :] = from_r
+
+        if async_op:
+            return _Works([], finish)
+        finish()
+        return _Done()
 
 
 class SlabPM(HaloMixin):
@@ -149,7 +188,7 @@ class SlabPM(HaloMixin):
         self.Nl = self.nxl * ny * nz                   # local particles
         self.Me = self.nxe * ny * nz                   # ghost-extended local mesh
         self.plane = ny * nz
-        ss = lib.mcpm_slab_spec_elems(h)
+        ss = self.ss = lib.mcpm_slab_spec_elems(h)
         f32 = dict(dtype=torch.float32, device=self.device)
         c64 = dict(dtype=torch.complex64, device=self.device)
         self.rho = torch.zeros((self.nxe, ny, nz), **f32)
@@ -178,20 +217,42 @@ class SlabPM(HaloMixin):
         return C.c_void_p(base.data_ptr() + 4 * self.G * self.plane)
 
     # ---- Poisson solve on slabs ----------------------------------------------------------------------------
-    def force_meshes(self, rho_ext, f3_ext):
-        """Interior of rho_ext (ghosts already added) -> interiors of the three force meshes f3_ext."""
+    # Spectra buffers are component-major ([c][rank block][x_l][y_l][nzp]), so each force component is its own
+    # all-to-all; they are issued asynchronously and the per-component y / z passes (and ghost fills) of one
+    # component overlap the transfers of the next.
+    def _spec(self, buf, c):
+        return C.c_void_p(buf.data_ptr() + 8 * c * self.ss)
+
+    def force_meshes(self, rho_ext, f3_ext, fill_ghosts=True):
+        """Interior of rho_ext (ghosts already added) -> the three force meshes f3_ext (ghosts filled)."""
+        ss = self.ss
         self.call("mcpm_slab_zfwd", self._interior(rho_ext), self.Me, _p(self.s1a), 1)
         self.call("mcpm_slab_ycol", _p(self.s1a), _p(self.s1b), 1, -1, 0, 1)          # plain -> transposed order
         self.comm.all_to_all(self.s1a, self.s1b)                                     # x <-> y transpose
         self.call("mcpm_slab_xfused", _p(self.s1a), _p(self.s3a), 0)
-        self.comm.all_to_all(self.s3b, self.s3a)
-        self.call("mcpm_slab_ycol", _p(self.s3b), _p(self.s3a), 3, +1, 1, 0)
-        self.call("mcpm_slab_zinv", _p(self.s3a), self._interior(f3_ext, 0), self.Me, 3)
+        a2a = [self.comm.all_to_all(self.s3b[c * ss:(c + 1) * ss], self.s3a[c * ss:(c + 1) * ss], async_op=True)
+               for c in range(3)]
+        fills = []
+        for c in range(3):
+            a2a[c].wait()
+            self.call("mcpm_slab_ycol", self._spec(self.s3b, c), self._spec(self.s3a, c), 1, +1, 1, 0)
+            self.call("mcpm_slab_zinv", self._spec(self.s3a, c), self._interior(f3_ext, c), self.Me, 1)
+            if fill_ghosts:
+                fills.append(self.halo_fill(f3_ext[c], async_op=True))
+        for f in fills:
+            f.wait()
 
     def force_meshes_vjp(self, fbar3_ext, rhobar_ext):
-        self.call("mcpm_slab_zfwd", self._interior(fbar3_ext, 0), self.Me, _p(self.s3a), 3)
-        self.call("mcpm_slab_ycol", _p(self.s3a), _p(self.s3b), 3, -1, 0, 1)
-        self.comm.all_to_all(self.s3a, self.s3b)
+        ss = self.ss
+        a2a = []
+        for c in range(3):
+            self.call("mcpm_slab_zfwd", self._interior(fbar3_ext, c), self.Me, self._spec(self.s3a, c), 1)
+            self.call("mcpm_slab_ycol", self._spec(self.s3a, c), self._spec(self.s3b, c), 1, -1, 0, 1)
+            a2a.append(self.comm.all_to_all(self.s3a[c * ss:(c + 1) * ss], self.s3b[c * ss:(c + 1) * ss], async_op=True))
+        # s3a is both the z/y scratch of component c and the receive buffer of component c: the receive of c is
+        # ordered after the y pass that consumed it (same stream), and nothing touches it again before xfused
+        for h in a2a:
+            h.wait()
         self.call("mcpm_slab_xfused", _p(self.s3a), _p(self.s1a), 1)
         self.comm.all_to_all(self.s1b, self.s1a)
         self.call("mcpm_slab_ycol", _p(self.s1b), _p(self.s1a), 1, +1, 1, 0)
@@ -203,7 +264,6 @@ class SlabPM(HaloMixin):
         self.call("mcpm_paint_f32", _p(x), self.Nl, POS_LATTICE, None, 1, 1.0, paint_order, _p(self.rho), 0)
         self.halo_add(self.rho)
         self.force_meshes(self.rho, f3_out)
-        self.halo_fill(f3_out)
         self.call("mcpm_kick_drift_f32", _p(x), _p(v), self.Nl, POS_LATTICE, _p(f3_out), paint_order, float(alpha),
                   float(beta), float(tau), _p(x_out), _p(v_out))
 
