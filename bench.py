@@ -95,6 +95,8 @@ class Runner:
         self.vb.copy_(self.vel_bar)
         for i in reversed(range(steps)):
             tau = self.dg / 2 if i == K - 1 else self.dg
+            if i > 0:   # chain: this step's particle kernel also writes the force cotangent of step i-1
+                self.plan.call("mcpm_plan_hint_next_adjoint", float(self.betas[i - 1]), float(self.dg))
             self.plan.call("mcpm_bullfrog_step_vjp_f32", self.p(self.states[i, 0]), self.p(self.states[i, 1]),
                            self.p(self.fmesh[i]), float(self.alphas[i]), float(self.betas[i]), float(tau), 2,
                            self.p(self.xb), self.p(self.vb), C.c_void_p(self.sbar.data_ptr() + 8 * i),

@@ -93,6 +93,10 @@ int mcpm_cell_index(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, 
    accumulate = 0 overwrites mesh, 1 adds to it. */
 int mcpm_paint_f32(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, const float *weights,
                    int64_t wstride, float wscalar, int order, float *mesh, int accumulate);
+/* Three weighted paints in one pass: meshes3[c] (+)= paint(pos, weights = weights3[:, c]), c = 0..2 (the VJP of a
+   three-component read w.r.t. its meshes).  weights3 is float32 [N][3]; the three meshes are contiguous. */
+int mcpm_paint3_f32(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, const float *weights3, int order,
+                    float *meshes3, int accumulate);
 /* read (nbody.py:398-427) of `ncomp` contiguous meshes at once: out[p*ncomp + c]. */
 int mcpm_read_f32(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, const float *meshes,
                   int ncomp, int order, float *out);
@@ -184,6 +188,11 @@ int mcpm_bullfrog_step_f32(mcpm_plan *plan, const float *pos_in, const float *ve
 int mcpm_bullfrog_step_vjp_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in, const float *force_meshes,
                                double alpha, double beta, double tau, int paint_order, float *pos_bar,
                                float *vel_bar, double *alpha_bar, double *beta_bar);
+/* Optional chaining of consecutive adjoint steps: call this before the adjoint of step i with beta and tau of step
+   i-1; the particle kernel then also writes step i-1's force cotangent beta'(v_bar + tau' x_bar), and the next
+   mcpm_bullfrog_step_vjp_f32 call skips its own pass over the cotangents IF it is given the same pos_bar / vel_bar
+   pointers and exactly these scalars.  Only valid when the caller does not modify the cotangents in between. */
+int mcpm_plan_hint_next_adjoint(mcpm_plan *plan, double beta_next, double tau_next);
 /* The particle half of that adjoint alone (fused gradient gather of the three force meshes and of rho_bar, kick /
    drift adjoints, scalar cotangents); used by the slab path, where the host exchanges ghost planes in between. */
 int mcpm_step_adjoint_particles_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in,

@@ -32,6 +32,7 @@ SIGNATURES = {
     "mcpm_fft_c2r": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int]),
     "mcpm_cell_index": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "mcpm_paint_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int64, C.c_float, C.c_int, _f32p, C.c_int]),
+    "mcpm_paint3_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, _f32p, C.c_int]),
     "mcpm_read_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_int, _f32p]),
     "mcpm_paint_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int64, C.c_float, C.c_int, _f32p, _f32p, _f32p]),
     "mcpm_read_vjp_pos_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_int, _f32p, _f32p]),
@@ -60,6 +61,7 @@ SIGNATURES = {
     "mcpm_stage_name": (C.c_char_p, [C.c_int]),
     "mcpm_bullfrog_step_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, _f32p]),
     "mcpm_bullfrog_step_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, C.c_void_p, C.c_void_p]),
+    "mcpm_plan_hint_next_adjoint": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "mcpm_step_adjoint_particles_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, C.c_void_p, C.c_void_p]),
     "mcpm_lpt_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f32p, _f32p, _f32p, _f64p]),
     "mcpm_lpt_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _f32p, _f32p]),

@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
                                                            float *__restrict__ xb, float *__restrict__ vb,
                                                            const float *__restrict__ fm, const float *__restrict__ rho_bar,
                                                            int64_t M, float alpha, float beta, float tau,
-                                                           double *slots) {
+                                                           double *slots, float *__restrict__ fb_next, float beta_next,
+                                                           float tau_next) {
     PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
     double ra = 0., rb = 0.;
     if (pi.valid) {
@@ -176,8 +177,12 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
         }
         ra = (double)(vt.x * vi.x + vt.y * vi.y + vt.z * vi.z);
         rb = (double)(vt.x * F[0] + vt.y * F[1] + vt.z * F[2]);
+        const P3 vnew = {alpha * vt.x, alpha * vt.y, alpha * vt.z};
         store3(xb, pi.i, xbi);
-        store3(vb, pi.i, P3{alpha * vt.x, alpha * vt.y, alpha * vt.z});
+        store3(vb, pi.i, vnew);
+        if (fb_next)  // force cotangent of the PREVIOUS step, F_bar = beta' (v_bar + tau' x_bar)
+            store3(fb_next, pi.i, P3{beta_next * (vnew.x + tau_next * xbi.x), beta_next * (vnew.y + tau_next * xbi.y),
+                                     beta_next * (vnew.z + tau_next * xbi.z)});
     }
     const int slot = blockIdx.x % MCPM_NSLOT;
     block_add2(ra, rb, slots + slot, slots + MCPM_NSLOT + slot);
@@ -362,10 +367,12 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *v
     const int64_t N = p->Np, M = p->M;
     float *Fb = p->pscratch + 6 * N;
     const float a = (float)alpha, b = (float)beta, t = (float)tau;
-    // force cotangent F_bar = beta (v_bar + tau x_bar), scattered onto three meshes (adjoint of read)
-    MCPM_TRY(axpby(p, vel_bar, pos_bar, 3 * N, b, b * t, Fb));
-    for (int c = 0; c < 3; ++c)
-        MCPM_TRY(mcpm_paint_f32(p, pos_in, N, MCPM_POS_LATTICE, Fb + c, 3, 0.f, paint_order, p->fmesh + c * M, 0));
+    // force cotangent F_bar = beta (v_bar + tau x_bar), scattered onto three meshes (adjoint of read); already written
+    // by the previous call's particle kernel when the caller chained the steps (mcpm_plan_hint_next_adjoint)
+    if (!(p->fb_valid && p->fb_beta == b && p->fb_tau == t && p->fb_xb == pos_bar && p->fb_vb == vel_bar))
+        MCPM_TRY(axpby(p, vel_bar, pos_bar, 3 * N, b, b * t, Fb));
+    p->fb_valid = 0;
+    MCPM_TRY(mcpm_paint3_f32(p, pos_in, N, MCPM_POS_LATTICE, Fb, paint_order, p->fmesh, 0));
     // adjoint of 3 C2R + k-space + R2C: rho_bar = C2R( (1/M) sum_c conj(m_c) R2C(f_bar_c) )
     MCPM_TRY(mcpm_force_meshes_vjp_f32(p, p->fmesh, p->rho));
     return mcpm_step_adjoint_particles_f32(p, pos_in, vel_in, force_meshes, p->rho, alpha, beta, tau, paint_order, pos_bar,
@@ -384,14 +391,25 @@ int mcpm_step_adjoint_particles_f32(mcpm_plan *p, const float *pos_in, const flo
     dim3 grid, block;
     lattice_launch(p->g, grid, block);
     StageTimer st_(p, ST_STEPADJ, 72.0 * N + 16.0 * M);
+    float *fb_next = nullptr;
+    if (p->hint_set) {
+        MCPM_TRY(ensure_pscratch(p));
+        fb_next = p->pscratch + 6 * N;
+        p->fb_valid = 1;
+        p->fb_beta = p->hint_beta;
+        p->fb_tau = p->hint_tau;
+        p->fb_xb = pos_bar;
+        p->fb_vb = vel_bar;
+        p->hint_set = 0;
+    }
     double *slots = p->reduce + (MCPM_NREDUCE - 2 * MCPM_NSLOT);
     MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 2 * MCPM_NSLOT, p->stream));
     if (paint_order == 2)
         step_adjoint_kernel<2><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b,
-                                                              t, slots);
+                                                              t, slots, fb_next, p->hint_beta, p->hint_tau);
     else
         step_adjoint_kernel<1><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b,
-                                                              t, slots);
+                                                              t, slots, fb_next, p->hint_beta, p->hint_tau);
     MCPM_LAUNCH_CHECK(p, "step_adjoint_kernel");
     if (alpha_bar || beta_bar) {
         reduce_slots_kernel<<<1, MCPM_NSLOT, 0, p->stream>>>(slots, alpha_bar, beta_bar);
@@ -466,10 +484,13 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     MCPM_HIP(p, hipMemcpyAsync(xb, pos_bar, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, p->stream));
     MCPM_HIP(p, hipMemcpyAsync(vb, vel_bar, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, p->stream));
     MCPM_HIP(p, hipMemsetAsync(p->reduce, 0, sizeof(double) * (2 * n_steps + 3), p->stream));
-    for (int i = n_steps - 1; i >= 0; --i)
+    p->fb_valid = 0;
+    for (int i = n_steps - 1; i >= 0; --i) {
+        if (i > 0) MCPM_TRY(mcpm_plan_hint_next_adjoint(p, beta[i - 1], dg));
         MCPM_TRY(mcpm_bullfrog_step_vjp_f32(p, state_x(i), state_v(i), force_m(i), alpha[i], beta[i],
                                             (i == n_steps - 1) ? dg / 2 : dg, paint_order, xb, vb, p->reduce + i,
                                             p->reduce + n_steps + i));
+    }
     // initial half drift x'_0 = x_0 + v_0 dg/2
     MCPM_TRY(axpby(p, vb, xb, 3 * N, 1.f, (float)(dg / 2), vb));
 

@@ -51,6 +51,12 @@ struct mcpm_plan {
     int64_t Np;  // px*py*pz
     int halo;    // halo radius of the tiled paint
     int paint_variant;  // threads/unroll variant of the tiled paint (tuning)
+    int paint3_variant; // three-component tiled paint variant (tuning); < 0 disables it
+    // chaining of adjoint steps (mcpm_plan_hint_next_adjoint): the adjoint particle kernel of step i also writes the
+    // force cotangent F_bar of step i-1, saving one pass over the cotangents
+    int hint_set, fb_valid;
+    float hint_beta, hint_tau, fb_beta, fb_tau;
+    const void *fb_xb, *fb_vb;
     // x-slab decomposition (mcpm_plan_create_slab): this rank owns global planes [rank*nxl, (rank+1)*nxl)
     int nranks, rank, ghost, nx_global, nxl;
 

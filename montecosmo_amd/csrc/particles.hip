@@ -178,6 +178,160 @@ __global__ __launch_bounds__(THREADS) void paint_tile_kernel(Geom g, const float
     }
 }
 
+// Three weighted paints at once (the adjoint of a three-component read: weights[N][3] -> three meshes M apart).
+// Same pull scheme; the tile is 16x16x16 so that three f64 accumulators fit in LDS (96 KB).  One visit loads the
+// displacement and the three weights (12 + 12 bytes) and does the index / fraction arithmetic once.
+template <int B, int H, int THREADS, int U>
+__global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const float *__restrict__ disp,
+                                                              const float *__restrict__ w3, float *__restrict__ mesh,
+                                                              int64_t M, int accumulate, int *__restrict__ outliers,
+                                                              int *__restrict__ ocount) {
+    constexpr int W = B + 2 * H + 1, NW = W * W * W, NT = B * B * B;
+    __shared__ double tile[3 * NT];
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int t = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+    const int ntz = g.nz / B, nty = g.ny / B;
+    const int tz = t % ntz, tt = t / ntz, ty = tt % nty, tx = tt / nty;
+    const int x0 = tx * B, y0 = ty * B, z0 = tz * B;
+    double2 *tile2 = reinterpret_cast<double2 *>(tile);
+    for (int i = threadIdx.x; i < 3 * NT / 2; i += THREADS) tile2[i] = make_double2(0., 0.);
+    __syncthreads();
+
+    for (int j0 = threadIdx.x; j0 < NW; j0 += THREADS * U) {
+        P3 d[U], wt[U];
+        int rxs[U], rys[U], rzs[U], gis[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * THREADS;
+            bool ok = j < NW;
+            const int jz = j % W, r = j / W, jy = r % W, jx = r / W;
+            const int rx = jx - (H + 1), ry = jy - (H + 1), rz = jz - (H + 1);
+            int gx = x0 + rx, gy = y0 + ry, gz = z0 + rz;
+            bool inx = true;
+            if (g.xslab) {
+                gx -= g.xoff;
+                inx = (unsigned)gx < (unsigned)g.px;
+            } else {
+                gx += gx < 0 ? g.nx : 0;
+                gx -= gx >= g.nx ? g.nx : 0;
+            }
+            gy += gy < 0 ? g.ny : 0;
+            gy -= gy >= g.ny ? g.ny : 0;
+            gz += gz < 0 ? g.nz : 0;
+            gz -= gz >= g.nz ? g.nz : 0;
+            ok = ok && inx;
+            const int gi = ok ? (gx * g.ny + gy) * g.nz + gz : -1;
+            rxs[u] = rx;
+            rys[u] = ry;
+            rzs[u] = rz;
+            gis[u] = gi;
+            if (ok) {
+                d[u] = load3(disp, gi);
+                wt[u] = load3(w3, gi);
+            } else {
+                d[u] = P3{0.f, 0.f, 0.f};
+                wt[u] = P3{0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (gis[u] < 0) continue;
+            const int rx = rxs[u], ry = rys[u], rz = rzs[u];
+            const float fx = floorf(d[u].x), fy = floorf(d[u].y), fz = floorf(d[u].z);
+            const bool inl = fx >= (float)-H && fx <= (float)H && fy >= (float)-H && fy <= (float)H && fz >= (float)-H &&
+                             fz <= (float)H;
+            if (!inl) {
+                const bool home = (unsigned)rx < (unsigned)B && (unsigned)ry < (unsigned)B && (unsigned)rz < (unsigned)B;
+                if (home) {
+                    int k = atomicAdd(ocount, 1);
+                    outliers[k] = gis[u];
+                }
+                continue;
+            }
+            const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
+            if (cx < -1 || cx >= B || cy < -1 || cy >= B || cz < -1 || cz >= B) continue;
+            const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
+            const float kx[2] = {1.f - tx1, tx1}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int x = cx + a;
+                if ((unsigned)x >= (unsigned)B) continue;
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int y = cy + bb;
+                    if ((unsigned)y >= (unsigned)B) continue;
+                    const float kxy = kx[a] * ky[bb];
+                    double *row = tile + (x * B + y) * B;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int z = cz + e;
+                        if ((unsigned)z < (unsigned)B) {
+                            const float k = kxy * kz[e];
+                            atomicAdd(row + z, (double)(wt[u].x * k));
+                            atomicAdd(row + NT + z, (double)(wt[u].y * k));
+                            atomicAdd(row + 2 * NT + z, (double)(wt[u].z * k));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int i = threadIdx.x; i < 3 * NT / 4; i += THREADS) {
+        const int c = i / (NT / 4), ii = i - c * (NT / 4);
+        const int lz = (ii % (B / 4)) * 4, r = ii / (B / 4), ly = r % B, lx = r / B;
+        const double2 lo = tile2[2 * i], hi = tile2[2 * i + 1];
+        float4 v = make_float4((float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y);
+        float4 *dst = reinterpret_cast<float4 *>(mesh + c * M + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz);
+        if (accumulate) {
+            float4 o = *dst;
+            v.x += o.x;
+            v.y += o.y;
+            v.z += o.z;
+            v.w += o.w;
+        }
+        *dst = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void paint3_outlier_kernel(Geom g, const float *__restrict__ disp,
+                                                             const float *__restrict__ w3, float *__restrict__ mesh,
+                                                             int64_t M, const int *__restrict__ outliers,
+                                                             int *__restrict__ ocount) {
+    const int count = ocount[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ocount[1] = count;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        const int gi = outliers[k];
+        PIdx pi;
+        pi.i = gi;
+        pi.ipz = gi % g.nz;
+        const int r = gi / g.nz;
+        pi.ipy = r % g.ny;
+        pi.ipx = r / g.ny;
+        pi.valid = true;
+        const P3 d = load3(disp, gi), wt = load3(w3, gi);
+        int c[3];
+        float f[3];
+        locate<MCPM_POS_LATTICE, 2>(g, pi, d, c, f);
+        if (g.xslab && (c[0] < 0 || c[0] > g.nx - 2)) atomicAdd(ocount + 2, 1);
+        Stencil<2> s(g, c);
+        const float kx[2] = {1.f - f[0], f[0]}, ky[2] = {1.f - f[1], f[1]}, kz[2] = {1.f - f[2], f[2]};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float k = kx[a] * ky[b] * kz[e];
+                    float *m = mesh + s.xo[a] + s.yo[b] + s.zo[e];
+                    atomicAdd(m, wt.x * k);
+                    atomicAdd(m + M, wt.y * k);
+                    atomicAdd(m + 2 * M, wt.z * k);
+                }
+    }
+}
+
 // outliers of the tiled paint: global atomics, grid-stride over the device-side count
 __global__ __launch_bounds__(256) void paint_outlier_kernel(Geom g, const float *__restrict__ disp,
                                                             const float *__restrict__ w, int64_t wstride, float wscalar,
@@ -428,6 +582,43 @@ int mcpm_paint_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const fl
     DISPATCH_MODE_ORDER(mode, order, CALL);
 #undef CALL
     MCPM_LAUNCH_CHECK(p, "paint_atomic_kernel");
+    return MCPM_OK;
+}
+
+int mcpm_paint3_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *weights3, int order, float *meshes3,
+                    int accumulate) {
+    MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_paint3_f32"));
+    MCPM_REQUIRE(p, weights3 && meshes3, MCPM_E_ARG, "mcpm_paint3_f32: null buffer");
+    const Geom &g = p->g;
+    const int H = p->halo;
+    const bool tiled = mode == MCPM_POS_LATTICE && order == 2 && n > 0 && g.same_lattice && !(g.nx % 16) && !(g.ny % 16) &&
+                       !(g.nz % 16) && g.nx >= H + 1 && g.ny >= H + 1 && g.nz >= H + 1 && !(((uintptr_t)meshes3) & 15) &&
+                       !((p->M * 4) & 15) && p->paint3_variant >= 0;
+    if (!tiled) {
+        for (int c = 0; c < 3; ++c) MCPM_TRY(mcpm_paint_f32(p, pos, n, mode, weights3 + c, 3, 0.f, order, meshes3 + c * p->M, accumulate));
+        return MCPM_OK;
+    }
+    StageTimer st_(p, ST_PAINT, 24.0 * n + (accumulate ? 24.0 : 12.0) * p->M);
+    (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int), p->stream);
+    const unsigned nb = (unsigned)((g.nx / 16) * (g.ny / 16) * (g.nz / 16));
+#define CALL3(HH)                                                                                                             \
+    {                                                                                                                         \
+        if (p->paint3_variant == 1)                                                                                           \
+            paint3_tile_kernel<16, HH, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, p->outliers, p->outlier_count); \
+        else if (p->paint3_variant == 2)                                                                                      \
+            paint3_tile_kernel<16, HH, 1024, 4><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, p->outliers, p->outlier_count); \
+        else                                                                                                                  \
+            paint3_tile_kernel<16, HH, 1024, 2><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, p->outliers, p->outlier_count); \
+    }
+    switch (H) {
+        case 1: CALL3(1) break;
+        case 2: CALL3(2) break;
+        case 4: CALL3(4) break;
+        default: CALL3(6) break;
+    }
+#undef CALL3
+    paint3_outlier_kernel<<<256, 256, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, p->outliers, p->outlier_count);
+    MCPM_LAUNCH_CHECK(p, "paint3_tile_kernel");
     return MCPM_OK;
 }
 

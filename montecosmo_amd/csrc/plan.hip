@@ -92,6 +92,10 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->halo = 4;
     p->paint_variant = 0;
     if (const char *e = getenv("MCPM_PAINT_VARIANT")) p->paint_variant = atoi(e);
+    p->paint3_variant = 2;
+    p->hint_set = 0;
+    p->fb_valid = 0;
+    if (const char *e = getenv("MCPM_PAINT3_VARIANT")) p->paint3_variant = atoi(e);
     p->rho = p->spec = p->fmesh = p->spec1 = nullptr;
     p->outliers = p->outlier_count = nullptr;
     p->reduce = nullptr;
@@ -203,6 +207,14 @@ int mcpm_plan_slab_oob(mcpm_plan *p, int64_t *count) {
     MCPM_HIP(p, hipMemcpyAsync(&h, p->outlier_count + 2, sizeof(int), hipMemcpyDeviceToHost, p->stream));
     MCPM_HIP(p, hipStreamSynchronize(p->stream));
     *count = h;
+    return MCPM_OK;
+}
+
+int mcpm_plan_hint_next_adjoint(mcpm_plan *p, double beta_next, double tau_next) {
+    if (!p) return MCPM_E_ARG;
+    p->hint_beta = (float)beta_next;
+    p->hint_tau = (float)tau_next;
+    p->hint_set = 1;
     return MCPM_OK;
 }
 

@@ -270,9 +270,7 @@ class SlabPM(HaloMixin):
     def step_vjp(self, x, v, f3, alpha, beta, tau, xb, vb, abar_ptr, bbar_ptr, paint_order=2):
         """Adjoint of `step`: xb, vb (cotangents of its outputs) are updated in place."""
         self.call("mcpm_kick_f32", _p(vb), _p(xb), self.Nl, float(beta), float(beta * tau), _p(self.Fb))
-        for c in range(3):
-            self.call("mcpm_paint_f32", _p(x), self.Nl, POS_LATTICE, C.c_void_p(self.Fb.data_ptr() + 4 * c), 3, 0.0,
-                      paint_order, _p(self.f3[c]), 0)
+        self.call("mcpm_paint3_f32", _p(x), self.Nl, POS_LATTICE, _p(self.Fb), paint_order, _p(self.f3), 0)
         self.halo_add(self.f3)
         self.force_meshes_vjp(self.f3, self.rho)
         self.halo_fill(self.rho)

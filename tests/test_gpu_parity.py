@@ -286,3 +286,25 @@ def test_errors_are_loud(nb):
         nb.paint(np.zeros((4, 3), np.float32), (8, 8, 8), order=3)
     with pytest.raises(ValueError):
         nb.invlaplace_hat(nb.rfftk((8, 8, 8)), fd_order=3)
+
+
+@pytest.mark.parametrize("n,sigma", [(32, 1.0), (64, 2.0), (48, 1.0), (40, 1.0)])
+def test_paint3_matches_three_paints(nb, n, sigma):
+    """Three-component weighted paint (adjoint of a three-component read) against the oracle, incl. outliers and
+    the non-tiled fallback (n = 40)."""
+    import ctypes as C
+    import torch
+    shape = (n, n, n)
+    N = n ** 3
+    rng = np.random.default_rng(21)
+    disp = (rng.standard_normal((N, 3)) * sigma).astype(np.float32)
+    disp[:50] *= 6.0
+    w3 = rng.standard_normal((N, 3)).astype(np.float32)
+    lp = nb.LatticePos(disp, shape)
+    plan = nb.get_plan(shape)
+    out = torch.empty((3,) + shape, dtype=torch.float32, device="cuda")
+    wt = torch.from_numpy(w3).cuda()
+    plan.call("mcpm_paint3_f32", C.c_void_p(lp.disp.data_ptr()), N, 1, C.c_void_p(wt.data_ptr()), 2, C.c_void_p(out.data_ptr()), 0)
+    pos64 = o.regular_pos(shape) + disp.astype(np.float64)
+    for c in range(3):
+        assert rel_l2(to_np(out[c]), o.paint(pos64, shape, w3[:, c].astype(np.float64))) < 2e-6
