@@ -308,3 +308,40 @@ def test_paint3_matches_three_paints(nb, n, sigma):
     pos64 = o.regular_pos(shape) + disp.astype(np.float64)
     for c in range(3):
         assert rel_l2(to_np(out[c]), o.paint(pos64, shape, w3[:, c].astype(np.float64))) < 2e-6
+
+
+@pytest.mark.parametrize("mesh,ptcl", [((32, 32, 32), (16, 16, 16)), ((16, 32, 16), (32, 32, 32))])
+def test_nbody_bf_particle_lattice_differs_from_mesh(nb, mesh, ptcl):
+    """ptcl_shape != mesh_shape (model.py:738 with ptcl_oversamp != evol_oversamp): generic lattice path, forward
+    and gradient, against the oracle."""
+    from montecosmo_amd import bricks, synth
+    spec = synth.init_mesh(mesh, seed=4, rms_disp=1.0)
+    pos = bricks.regular_pos(mesh, ptcl)
+    cos_o, cos_g = obg.Planck18(), bricks.Planck18()
+    n_steps = 3
+    (p_o, v_o) = o.nbody_bf(cos_o, spec.astype(np.complex128), pos, 0.1, 1., n_steps)
+    (lp, vel), ctx = nb.nbody_bf(cos_g, spec, pos, a0=0.1, a1=1., n_steps=n_steps, lattice_out=True, return_ctx=True)
+    assert lp.ptcl_shape == tuple(ptcl)
+    assert rel_l2(to_np(lp.to_absolute()) - pos, p_o[0] - pos) < 1e-5
+    assert rel_l2(to_np(vel), v_o[0]) < 1e-5
+    rng = np.random.default_rng(2)
+    N = len(pos)
+    xb, vb = rng.standard_normal((N, 3)).astype(np.float32), rng.standard_normal((N, 3)).astype(np.float32)
+    mb_o, _ = o.nbody_bf_vjp(cos_o, spec.astype(np.complex128), pos, xb.astype(np.float64), vb.astype(np.float64), 0.1, 1., n_steps)
+    mb_g, _ = nb.nbody_bf_vjp(ctx, xb, vb)
+    assert rel_l2(to_np(mb_g), mb_o) < 1e-4
+
+
+def test_lpt_vjp_standalone(nb):
+    from montecosmo_amd import bricks, synth
+    n = 16
+    shape = (n, n, n)
+    spec = synth.init_mesh(n, seed=6, rms_disp=1.0)
+    pos = bricks.regular_pos(shape)
+    rng = np.random.default_rng(3)
+    xb, vb = rng.standard_normal((n ** 3, 3)), rng.standard_normal((n ** 3, 3))
+    mb_o, _, sb_o = o.lpt_vjp(obg.Planck18(), spec.astype(np.complex128), pos, 0.3, xb, vb, lpt_order=2, read_order=1)
+    mb_g, sb_g = nb.lpt_vjp(bricks.Planck18(), spec, pos, 0.3, xb.astype(np.float32), vb.astype(np.float32), lpt_order=2)
+    assert rel_l2(to_np(mb_g), mb_o) < 1e-5
+    for k in ("g", "g2", "dg2dg"):
+        assert np.isclose(sb_g[k], sb_o[k], rtol=1e-4, atol=1e-4 * abs(sb_o["g"])), k
