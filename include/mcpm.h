@@ -125,6 +125,12 @@ int mcpm_kspace_hessian_f32(mcpm_plan *plan, const float *spec_in, float *spec_o
                             int lap_fd, int grad_fd);
 int mcpm_kspace_hessian_vjp_f32(mcpm_plan *plan, const float *spec_in6, float *spec_out, float scale,
                                 int lap_fd, int grad_fd, int zweights, int accumulate);
+/* Elementwise half-spectrum operator of the observation-side painting (next row):
+   out (+)= scale * exp(i shift (kx+ky+kz)) / prod_a sinc(k_a/2pi)^deconv_order * in  -- the interlacing phase of
+   `interlace` (nbody.py:525) and the kernel deconvolution of `deconv_paint` (nbody.py:315-334).  conj = 1 conjugates
+   the phase and inv_zweights = 1 divides by the irfftn multiplicity (1,2,..,2,1): together the adjoint fed to a C2R. */
+int mcpm_kspace_phase_f32(mcpm_plan *plan, const float *in, float *out, float scale, float shift, int deconv_order,
+                          int conj, int inv_zweights, int accumulate);
 /* delta2 = sum_{i<j} h_ii h_jj - h_ij^2 from six contiguous real meshes (nbody.py:615-627). */
 int mcpm_hessian_combine_f32(mcpm_plan *plan, const float *hess6, float *delta2);
 int mcpm_hessian_combine_vjp_f32(mcpm_plan *plan, const float *hess6, const float *delta2_bar, float *hess6_bar);

@@ -40,6 +40,7 @@ SIGNATURES = {
     "mcpm_kspace_force_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mcpm_kspace_hessian_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_int, C.c_int]),
     "mcpm_kspace_hessian_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mcpm_kspace_phase_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mcpm_hessian_combine_f32": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "mcpm_hessian_combine_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p]),
     "mcpm_force_meshes_f32": (C.c_int, [C.c_void_p, _f32p, _f32p]),

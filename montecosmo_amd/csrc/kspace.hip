@@ -180,6 +180,42 @@ __global__ __launch_bounds__(256) void kspace_hessian_vjp_kernel(KArgs a, const 
     out[idx] = make_float2(re, im);
 }
 
+// out (+)= scale * exp(+-i shift (kx+ky+kz)) / prod_a sinc(k_a/2pi)^deconv [/ zw] * in
+// (interlacing phase nbody.py:525 and paint-kernel deconvolution nbody.py:315-334; conj / inverse multiplicity
+// weights give the adjoint used by nufft_vjp)
+__global__ __launch_bounds__(256) void kspace_phase_kernel(Geom g, float scale, float shift, int deconv, int conj, int inv_zw,
+                                                           int accumulate, const float2 *__restrict__ in,
+                                                           float2 *__restrict__ out, int64_t Mh) {
+    uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= Mh) return;
+    const int iz = idx % (uint32_t)g.nzh;
+    const uint32_t r = idx / (uint32_t)g.nzh;
+    const int iy = r % (uint32_t)g.ny, ix = r / (uint32_t)g.ny;
+    const float kx = kfreq(ix, g.nx), ky = kfreq(iy, g.ny), kz = TWO_PI * (float)iz / (float)g.nz;
+    float m = scale;
+    if (deconv > 0) {
+        const float sc = sincf_pi(kx) * sincf_pi(ky) * sincf_pi(kz);
+        float d = 1.f;
+        for (int i = 0; i < deconv; ++i) d *= sc;
+        m /= d;
+    }
+    if (inv_zw && !(iz == 0 || iz == g.nz / 2)) m *= 0.5f;
+    float c = 1.f, sn = 0.f;
+    if (shift != 0.f) {
+        const float ph = shift * (kx + ky + kz);
+        c = cosf(ph);
+        sn = conj ? -sinf(ph) : sinf(ph);
+    }
+    const float2 v = in[idx];
+    float re = m * (v.x * c - v.y * sn), im = m * (v.x * sn + v.y * c);
+    if (accumulate) {
+        const float2 o = out[idx];
+        re += o.x;
+        im += o.y;
+    }
+    out[idx] = make_float2(re, im);
+}
+
 // delta2 = h00*h11 + h22*(h00+h11) - h01^2 - h02^2 - h12^2 (running-sum order of nbody.py:615-627)
 __global__ __launch_bounds__(256) void hessian_combine_kernel(const float *__restrict__ h, int64_t M,
                                                               float *__restrict__ d2) {
@@ -275,6 +311,19 @@ int mcpm_kspace_hessian_vjp_f32(mcpm_plan *p, const float *in6, float *out, floa
     unsigned nb = (unsigned)((p->Mh + 255) / 256);
     DISPATCH_FD(lap_fd, grad_fd, kspace_hessian_vjp_kernel, <<<nb, 256, 0, p->stream>>>(a, (const float2 *)in6, (float2 *)out, p->Mh));
     MCPM_LAUNCH_CHECK(p, "kspace_hessian_vjp_kernel");
+    return MCPM_OK;
+}
+
+int mcpm_kspace_phase_f32(mcpm_plan *p, const float *in, float *out, float scale, float shift, int deconv_order, int conj,
+                          int inv_zweights, int accumulate) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, in && out, MCPM_E_ARG, "mcpm_kspace_phase_f32: null buffer");
+    MCPM_REQUIRE(p, deconv_order >= 0 && deconv_order <= 8, MCPM_E_ORDER, "mcpm_kspace_phase_f32: bad deconvolution order");
+    StageTimer st_(p, ST_KSPACE, (accumulate ? 24.0 : 16.0) * p->Mh);
+    unsigned nb = (unsigned)((p->Mh + 255) / 256);
+    kspace_phase_kernel<<<nb, 256, 0, p->stream>>>(p->g, scale, shift, deconv_order, conj, inv_zweights, accumulate,
+                                                   (const float2 *)in, (float2 *)out, p->Mh);
+    MCPM_LAUNCH_CHECK(p, "kspace_phase_kernel");
     return MCPM_OK;
 }
 

@@ -26,6 +26,7 @@ __all__ = [
     "paint", "read", "paint_vjp", "read_vjp", "pm_forces", "pm_forces2", "lpt", "lpt_vjp",
     "a2g", "a2g2", "a2f", "a2f2", "a2dg2dg", "g2a", "g2g2", "g2f", "g2f2", "g2dg2dg", "a2chi", "chi2a",
     "bullfrog_vf", "nbody_bf", "nbody_bf_vjp", "alpha_bf", "alpha_fpm", "LatticePos", "get_plan",
+    "deconv_paint", "interlace", "nufft", "nufft_vjp",
     "safe_div", "ch2rshape", "r2chshape", "scale_shape",
 ]
 
@@ -336,6 +337,89 @@ def irfftn(spec):
     out = torch.empty(shape, dtype=torch.float32, device=spec.device)
     plan.call("mcpm_fft_c2r", _ptr(spec), _ptr(out), 1)
     return out / plan.M
+
+
+# ------------------------------------------------------------------------------------------------
+# observation-side painting (nbody.py:315-334, :513-577): runs once per log-prob, outside the step loop
+def _shift_pos(pos, shift):
+    if isinstance(pos, LatticePos):
+        return LatticePos(pos.disp + shift, pos.mesh_shape, pos.ptcl_shape)
+    return _f32(pos) + shift
+
+
+def deconv_paint(mesh, order: int = 2, kernel_type='rectangular', oversamp=1.):
+    """Deconvolve the mesh by the paint kernel of given order (nbody.py:315-334); real or half-spectrum input."""
+    if kernel_type != 'rectangular':
+        raise NotImplementedError("only kernel_type='rectangular' is implemented on the HIP path")
+    t = torch.as_tensor(mesh)
+    if not t.is_complex():
+        spec = rfftn(t)
+        plan = get_plan(tuple(t.shape))
+        plan.call("mcpm_kspace_phase_f32", _ptr(spec), _ptr(spec), 1.0, 0.0, int(order), 0, 0, 0)
+        return irfftn(spec)
+    spec = _c64(t)
+    out = torch.empty_like(spec)
+    get_plan(ch2rshape(spec.shape)).call("mcpm_kspace_phase_f32", _ptr(spec), _ptr(out), 1.0, 0.0, int(order), 0, 0, 0)
+    return out
+
+
+def interlace(pos, shape: tuple, weights=1., paint_order: int = 2, interlace_order: int = 2, kernel_type='rectangular',
+              paint_oversamp: float = 1.):
+    """Equal-spacing interlacing (nbody.py:513-529): mean over shifts s = j/interlace_order of
+    rfftn(paint(pos + s)) * exp(i s (kx+ky+kz)).  Returns a half-spectrum."""
+    _check_kernel(kernel_type, paint_order)
+    shape = tuple(int(s) for s in shape)
+    plan = get_plan(shape, pos.ptcl_shape if isinstance(pos, LatticePos) else None)
+    out = torch.zeros(r2chshape(shape), dtype=torch.complex64, device=_device())
+    tmp = torch.empty_like(out)
+    for j in range(int(interlace_order)):
+        s = j / interlace_order
+        mesh = paint(_shift_pos(pos, s), shape, weights, paint_order)
+        plan.call("mcpm_fft_r2c", _ptr(mesh), _ptr(tmp), 1)
+        plan.call("mcpm_kspace_phase_f32", _ptr(tmp), _ptr(out), 1.0 / interlace_order, float(s), 0, 0, 0, 1)
+    return out
+
+
+def _nufft_shapes(final_shape, paint_shape):
+    final_shape = tuple(int(s) for s in final_shape)
+    if paint_shape is None:
+        return final_shape, final_shape
+    if isinstance(paint_shape, float):
+        return final_shape, scale_shape(final_shape, paint_shape)
+    return final_shape, tuple(int(s) for s in paint_shape)
+
+
+def nufft(pos, final_shape: tuple, paint_shape=None, weights=1., paint_order: int = 2, interlace_order: int = 2,
+          kernel_type='rectangular', paint_deconv=True):
+    """Non-uniform FFT with interlacing and kernel deconvolution (nbody.py:532-577).  `pos` in cell units of
+    `final_shape`.  A `paint_shape` different from `final_shape` needs `chreshape`, not implemented."""
+    final_shape, paint_shape = _nufft_shapes(final_shape, paint_shape)
+    if final_shape != paint_shape:
+        raise NotImplementedError("nufft with paint_shape != final_shape needs chreshape (next row)")
+    mesh = interlace(pos, paint_shape, weights, paint_order, interlace_order, kernel_type=kernel_type)
+    if paint_deconv:
+        mesh = deconv_paint(mesh, paint_order, kernel_type=kernel_type)
+    return mesh
+
+
+def nufft_vjp(pos, final_shape: tuple, weights, mesh_bar, paint_order: int = 2, interlace_order: int = 2, paint_deconv=True):
+    """VJP of nufft (paint_shape = final_shape) w.r.t. (pos, weights); mesh_bar is the half-spectrum cotangent in
+    the real-pair convention.  Returns (pos_bar (N,3), weights_bar)."""
+    shape = tuple(int(s) for s in final_shape)
+    mb = _c64(mesh_bar, r2chshape(shape))
+    plan = get_plan(shape, pos.ptcl_shape if isinstance(pos, LatticePos) else None)
+    tmp = torch.empty_like(mb)
+    real = torch.empty(shape, dtype=torch.float32, device=mb.device)
+    pos_bar, w_bar = None, None
+    for j in range(int(interlace_order)):
+        s = j / interlace_order
+        # adjoint of (x phase / deconv / interlace_order) then of rfftn: C2R(conj(mult) * bar / multiplicity)
+        plan.call("mcpm_kspace_phase_f32", _ptr(mb), _ptr(tmp), 1.0 / interlace_order, float(s), int(paint_order) if paint_deconv else 0, 1, 1, 0)
+        plan.call("mcpm_fft_c2r", _ptr(tmp), _ptr(real), 1)
+        pb, wb = paint_vjp(_shift_pos(pos, s), shape, weights, real, paint_order)
+        pos_bar = pb if pos_bar is None else pos_bar + pb
+        w_bar = wb if w_bar is None else w_bar + wb
+    return pos_bar, w_bar
 
 
 # ------------------------------------------------------------------------------------------------

@@ -250,6 +250,47 @@ def read_vjp(pos, mesh, out_bar, order=2):
     return pos_bar, mesh_bar
 
 
+# --------------------------------------------------------------------------- observation-side painting
+def deconv_paint(mesh, order=2):
+    """montecosmo/nbody.py:315-334 (kernel_type='rectangular')."""
+    if np.isrealobj(mesh):
+        kvec = rfftk(mesh.shape)
+        return np.fft.irfftn(np.fft.rfftn(mesh) / rectangular_hat(kvec, order), s=mesh.shape, axes=(0, 1, 2))
+    return mesh / rectangular_hat(rfftk(ch2rshape(mesh.shape)), order)
+
+
+def interlace(pos, shape, weights=1., paint_order=2, interlace_order=2):
+    """montecosmo/nbody.py:513-529"""
+    kvec = rfftk(shape)
+    mesh = np.zeros(r2chshape(shape), dtype=complex)
+    for shift in np.arange(interlace_order) / interlace_order:
+        m = paint(pos + shift, shape, weights, paint_order)
+        mesh = mesh + np.fft.rfftn(m) * np.exp(1j * shift * sum(kvec)) / interlace_order
+    return mesh
+
+
+def nufft(pos, final_shape, paint_shape=None, weights=1., paint_order=2, interlace_order=2, paint_deconv=True):
+    """montecosmo/nbody.py:532-577 for paint_shape == final_shape (no chreshape)."""
+    assert paint_shape is None or tuple(paint_shape) == tuple(final_shape)
+    mesh = interlace(pos, final_shape, weights, paint_order, interlace_order)
+    if paint_deconv:
+        mesh = deconv_paint(mesh, paint_order)
+    return mesh
+
+
+def nufft_vjp(pos, final_shape, weights, mesh_bar, paint_order=2, interlace_order=2, paint_deconv=True):
+    """VJP of nufft w.r.t. (pos, weights); mesh_bar in the real-pair convention."""
+    shape = tuple(final_shape)
+    kvec = rfftk(shape)
+    mult = 1.0 / rectangular_hat(kvec, paint_order) if paint_deconv else 1.0
+    pos_bar, w_bar = 0., 0.
+    for shift in np.arange(interlace_order) / interlace_order:
+        sb = mesh_bar * np.conj(mult * np.exp(1j * shift * sum(kvec)) / interlace_order)
+        pb, wb = paint_vjp(pos + shift, shape, weights, rfftn_vjp(sb, shape), paint_order)
+        pos_bar, w_bar = pos_bar + pb, w_bar + wb
+    return pos_bar, w_bar
+
+
 # --------------------------------------------------------------------------- FFT adjoints
 def _zweights(shape_r):
     """w = (1,2,...,2,1) along the half axis: multiplicity of each stored mode in irfftn."""
