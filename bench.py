@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--mesh", type=int, default=int(os.environ.get("MCPM_BENCH_MESH", "512")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent replicas instead of slabs")
+    ap.add_argument("--forward-only", action="store_true", help="time forward steps only (BASELINE config 2)")
     ap.add_argument("--ghost", type=int, default=8)
     ap.add_argument("--cpu-mesh", type=int, default=128)
     return ap.parse_args()
@@ -47,6 +48,8 @@ def parse():
 
 class Runner:
     """K forward steps + K adjoint steps through the step-level C ABI, on pre-allocated HBM buffers."""
+
+    forward_only = False
 
     def __init__(self, n, K, device):
         from montecosmo_amd import nbody, bricks, synth
@@ -104,7 +107,8 @@ class Runner:
 
     def run(self, steps):
         self.forward(steps)
-        self.backward(steps)
+        if not self.forward_only:
+            self.backward(steps)
 
     def profile(self):
         """Per-stage HIP-event timings of one more pass over the same K steps (events on the plan's stream)."""
@@ -112,7 +116,8 @@ class Runner:
         self.plan.call("mcpm_plan_profile", 1)
         self.forward(self.K)
         fwd = self._read_profile()
-        self.backward(self.K)
+        if not self.forward_only:
+            self.backward(self.K)
         bwd = self._read_profile()
         self.plan.call("mcpm_plan_profile", 0)
         names = [lib.mcpm_stage_name(i).decode() for i in range(len(fwd[0]))]
@@ -257,6 +262,9 @@ def main():
 
     slab = dist and not args.replicas
     r = SlabRunner(n, K, device, args.ghost) if slab else Runner(n, K, device)
+    if args.forward_only:
+        assert not slab, "--forward-only is a single-GPU configuration"
+        r.forward_only = True
     w = W
     while w > 0:                       # W untimed warm-up steps (rocFFT plans, code objects, caches)
         r.run(min(w, K))
@@ -299,10 +307,10 @@ def main():
         cyc_ms = sum(fwd[0][names.index(k)] for k in ("paint", "fft_r2c", "kspace", "fft_c2r", "kick_drift")) / K
         step_ms = (fwd_ms + bwd_ms) / K
         out = {
-            "metric": "PM forward+adjoint steps/sec", "value": round(steps_per_s, 3), "unit": "steps/s",
+            "metric": "PM forward steps/sec" if args.forward_only else "PM forward+adjoint steps/sec", "value": round(steps_per_s, 3), "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
             "higher_is_better": True, "scaling": "weak" if args.replicas else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n}^3 mesh, {n}^3 particles, {K}-step BullFrog forward+VJP, CIC, 2LPT start (untimed), "
+            "config": {"workload": f"{n}^3 mesh, {n}^3 particles, {K}-step BullFrog {'forward only' if args.forward_only else 'forward+VJP'}, CIC, 2LPT start (untimed), "
                                    f"rms displacement 2 cells; " + ("single GPU" if world == 1 else
                                                                     (f"x-slab decomposed over {world} GPUs (ghost {args.ghost} planes, RCCL all-to-all FFT transpose)"
                                                                      if slab else f"{world} independent replicas")),

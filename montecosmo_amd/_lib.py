@@ -75,6 +75,10 @@ SIGNATURES = {
 
 
 def _load():
+    if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
+        # a fresh checkout (the .so is git-ignored): build the HIP library in-tree once; there is still no fallback
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension is the product and there is no CPU fallback. "
