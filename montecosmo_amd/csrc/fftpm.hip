@@ -172,12 +172,12 @@ struct ZBatch {
 // All-to-all (transposed-order) layout [c][dest rank][xl][y_local][nzp]: YB = ny/ranks, SB = one rank block.
 struct YLayout {
     int64_t BS, PS, SB;
-    int YB, NXL;
+    int YB, NXL, lgYB;  // YB is a power of two
 };
 // x-line addressing of the fused pass.  One-spectrum side: [x][yl][nzp] (NYL rows per x).  Three-spectra side:
 // c*SC + (x / XB)*SBx + ((x % XB)*NYL + yl)*nzp  (single GPU: XB = nx; slabs: [c][src/dest rank][xl][yl][nzp]).
 struct XLayout {
-    int NYL, iy0, XB;
+    int NYL, iy0, XB, lgXB;  // XB is a power of two
     int64_t SBx, SC;
 };
 
@@ -284,16 +284,16 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol_kernel(FGeom g, con
     cf v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        const int y = u + T * m, yb = y / li.YB;
-        v[m] = ok ? ib[yb * li.SB + (int64_t)(y - yb * li.YB) * g.nzp] : make_float2(0.f, 0.f);
+        const int y = u + T * m, yb = y >> li.lgYB;
+        v[m] = ok ? ib[yb * li.SB + (int64_t)(y & (li.YB - 1)) * g.nzp] : make_float2(0.f, 0.f);
     }
     TL tile{l};
     fft_line<N, SIGN>(v, lds, W, u, tile);
     if (!ok) return;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        const int y = u + T * m, yb = y / lo.YB;
-        ob[yb * lo.SB + (int64_t)(y - yb * lo.YB) * g.nzp] = v[m];
+        const int y = u + T * m, yb = y >> lo.lgYB;
+        ob[yb * lo.SB + (int64_t)(y & (lo.YB - 1)) * g.nzp] = v[m];
     }
 }
 
@@ -304,24 +304,10 @@ __device__ __forceinline__ float kfreq_i(int i, int n) {
     return MCPM_TWO_PI * (float)s / (float)n;
 }
 
-struct KMul {
-    float s[3];  // out_c = s_c * (-i) * in  (s_c = k_c * (-1/k^2) * scale, Hermitian-projected)
-};
-__device__ __forceinline__ KMul force_mult(const FGeom &g, int ix, int iy, int iz, float scale) {
-    const float kx = kfreq_i(ix, g.nx), ky = kfreq_i(iy, g.ny), kz = MCPM_TWO_PI * (float)iz / (float)g.nz;
-    const float kk = kx * kx + ky * ky + kz * kz;
-    const float L = kk == 0.f ? 0.f : -scale / kk;
-    const bool special = (iz == 0) || (iz == g.nz / 2);
-    KMul m;
-    m.s[0] = (special && ix == g.nx / 2) ? 0.f : kx * L;
-    m.s[1] = (special && iy == g.ny / 2) ? 0.f : ky * L;
-    m.s[2] = (iz == g.nz / 2) ? 0.f : kz * L;
-    return m;
-}
-
 // MODE 0: in (1 spectrum) -> forward x FFT -> x (-(i k_c))(-1/k^2) scale -> inverse x FFT -> out (3 spectra)
 // MODE 1: in (3 spectra) -> forward x FFT -> sum_c conj(multiplier_c) -> inverse x FFT -> out (1 spectrum)
-// element (x, y, kz) at [(x ny + y) nzp + kz]; spectra are `sstride` complex apart.
+// The multiplier of component c at mode (kx, ky, kz) is s_c * (-i), s_c = k_c * (-scale/k^2), Hermitian-projected:
+// on the kz = 0 / Nyquist planes a component whose own index sits at Nyquist is dropped (kspace.hip header).
 template <int N, int MODE>
 __global__ __launch_bounds__(ColShape<N>::THREADS) void xfused_kernel(FGeom g, const cf *__restrict__ in, cf *__restrict__ out,
                                                                       XLayout xl, float scale, const cf *__restrict__ W) {
@@ -329,31 +315,45 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xfused_kernel(FGeom g, c
     typedef Tile<N, LINES, true> TL;
     __shared__ cf lds[TL::FLOATS2];
     const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
-    const int kz = blockIdx.x * LINES + l, yl = blockIdx.y, iy = xl.iy0 + yl;
-    const bool ok = kz < g.nzh;
-    const int64_t off0 = (int64_t)yl * g.nzp + kz, xs = (int64_t)xl.NYL * g.nzp;
-    auto a3 = [&](int c, int x) {  // three-spectra side
-        const int xb = x / xl.XB;
-        return xb * xl.SBx + c * xl.SC + (int64_t)(x - xb * xl.XB) * xs + off0;
-    };
+    const int kzi = blockIdx.x * LINES + l, yl = blockIdx.y, iy = xl.iy0 + yl;
+    const bool ok = kzi < g.nzh;
+    const uint32_t off0 = (uint32_t)yl * g.nzp + kzi, xs = (uint32_t)xl.NYL * g.nzp;
+    // element offsets (complex units, < 2^31): one-spectrum side and three-spectra side (without the c*SC term)
+    uint32_t o1[8], o3[8];
+    float sx[8], L[8];
+    const float ky = kfreq_i(iy, g.ny), kz = MCPM_TWO_PI * (float)kzi / (float)g.nz;
+    const bool special = (kzi == 0) || (kzi == g.nz / 2);
+    const float fy = (special && iy == g.ny / 2) ? 0.f : ky, fz = (kzi == g.nz / 2) ? 0.f : kz;
+    const float dkx = MCPM_TWO_PI / (float)N;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int x = u + T * m;
+        o1[m] = off0 + (uint32_t)x * xs;
+        o3[m] = (uint32_t)((x >> xl.lgXB) * xl.SBx) + (uint32_t)(x & (xl.XB - 1)) * xs + off0;
+        const float kx = dkx * (float)(x < N / 2 ? x : x - N);
+        const float kk = kx * kx + ky * ky + kz * kz;
+        L[m] = kk == 0.f ? 0.f : -scale * __frcp_rn(kk);
+        sx[m] = (special && x == N / 2) ? 0.f : kx * L[m];
+    }
     TL tile{l};
     if (MODE == 0) {
         cf v[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = ok ? in[off0 + (u + T * m) * xs] : make_float2(0.f, 0.f);
+        for (int m = 0; m < 8; ++m) v[m] = ok ? in[o1[m]] : make_float2(0.f, 0.f);
         fft_line<N, -1>(v, lds, W, u, tile);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             cf w[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                const KMul km = force_mult(g, u + T * m, iy, kz, scale);
-                w[m] = make_float2(km.s[c] * v[m].y, -km.s[c] * v[m].x);  // (a + i b)(-i s)
+                const float sc = c == 0 ? sx[m] : (c == 1 ? fy : fz) * L[m];
+                w[m] = make_float2(sc * v[m].y, -sc * v[m].x);  // (a + i b)(-i s)
             }
             fft_line<N, +1>(w, lds, W, u, tile);
             if (ok) {
+                cf *oc = out + c * xl.SC;
 #pragma unroll
-                for (int m = 0; m < 8; ++m) out[a3(c, u + T * m)] = w[m];
+                for (int m = 0; m < 8; ++m) oc[o3[m]] = w[m];
             }
         }
     } else {
@@ -363,20 +363,21 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xfused_kernel(FGeom g, c
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             cf v[8];
+            const cf *ic = in + c * xl.SC;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = ok ? in[a3(c, u + T * m)] : make_float2(0.f, 0.f);
+            for (int m = 0; m < 8; ++m) v[m] = ok ? ic[o3[m]] : make_float2(0.f, 0.f);
             fft_line<N, -1>(v, lds, W, u, tile);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                const KMul km = force_mult(g, u + T * m, iy, kz, scale);
-                acc[m].x += -km.s[c] * v[m].y;  // (a + i b)(+i s)
-                acc[m].y += km.s[c] * v[m].x;
+                const float sc = c == 0 ? sx[m] : (c == 1 ? fy : fz) * L[m];
+                acc[m].x += -sc * v[m].y;  // (a + i b)(+i s)
+                acc[m].y += sc * v[m].x;
             }
         }
         fft_line<N, +1>(acc, lds, W, u, tile);
         if (ok) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) out[off0 + (u + T * m) * xs] = acc[m];
+            for (int m = 0; m < 8; ++m) out[o1[m]] = acc[m];
         }
     }
 }
@@ -387,6 +388,7 @@ static bool pow2_ok(int n) { return n == 64 || n == 128 || n == 256 || n == 512 
 
 bool mcpm_fftpm_supported(const mcpm_plan *p) {
     if (getenv("MCPM_DISABLE_FFTPM")) return false;
+    if (p->nranks & (p->nranks - 1)) return false;  // slab blocks must stay powers of two (shift / mask indexing)
     return pow2_ok(p->nx_global) && pow2_ok(p->g.ny) && pow2_ok(p->g.nz);
 }
 
@@ -458,9 +460,10 @@ static int z_inverse(mcpm_plan *p, const cf *spec, float *real, int64_t real_bst
 // packed = all-to-all layout [c][dest rank][xl][y_local][nzp]; every spectrum is spec_elems() complex
 static YLayout ylayout(const mcpm_plan *p, bool packed) {
     const int64_t nzp = p->g.nz / 2 + 16;
-    if (!packed) return YLayout{spec_elems(p), (int64_t)p->g.ny * nzp, 0, p->g.ny, p->nxl};
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    if (!packed) return YLayout{spec_elems(p), (int64_t)p->g.ny * nzp, 0, p->g.ny, p->nxl, lg(p->g.ny)};
     const int nyl = p->g.ny / p->nranks;
-    return YLayout{spec_elems(p), (int64_t)nyl * nzp, (int64_t)p->nxl * nyl * nzp, nyl, p->nxl};
+    return YLayout{spec_elems(p), (int64_t)nyl * nzp, (int64_t)p->nxl * nyl * nzp, nyl, p->nxl, lg(nyl)};
 }
 
 static int y_columns(mcpm_plan *p, const cf *in, cf *out, int batch, int sign, bool in_packed, bool out_packed) {
@@ -485,7 +488,9 @@ static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
     const FGeom g = fgeom(p);
     const int nyl = g.ny / p->nranks;
     const int64_t blk = (int64_t)p->nxl * nyl * g.nzp;  // one rank's block of one spectrum
-    const XLayout xl{nyl, p->rank * nyl, p->nxl, blk, (int64_t)p->nranks * blk};
+    int lgxb = 0;
+    while ((1 << lgxb) < p->nxl) ++lgxb;
+    const XLayout xl{nyl, p->rank * nyl, p->nxl, lgxb, blk, (int64_t)p->nranks * blk};
     const float scale = 1.f / ((float)g.nx * (float)g.ny * (float)g.nz);
     // one forward + one inverse x pass of (1 + 3) spectra and the k-space multiply
     StageTimer st_(p, ST_KSPACE, (32.0 * p->nxl * g.ny * g.nzh) + 4.0 * pass_bytes(p, 1));

@@ -200,8 +200,11 @@ class SlabPM(HaloMixin):
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
-        if h and lib is not None:
-            lib.mcpm_plan_destroy(h)
+        try:
+            if h:
+                lib.mcpm_plan_destroy(h)
+        except Exception:  # interpreter shutdown
+            pass
 
     def call(self, name, *args):
         check(getattr(lib, name)(self.h, *args), self.h, name)

@@ -68,8 +68,11 @@ class Plan:
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
-        if h:
-            lib.mcpm_plan_destroy(h)
+        try:
+            if h:
+                lib.mcpm_plan_destroy(h)
+        except Exception:  # interpreter shutdown: the library handle may already be gone
+            pass
 
     def call(self, name, *args):
         check(getattr(lib, name)(self.h, *args), self.h, name)
