@@ -137,15 +137,24 @@ class TorchComm:
 class HaloMixin:
     """Ghost-plane algebra of an x-slab (needs self.comm, self.G, self.nxl); meshes are (..., nxl + 2G, ny, nz)."""
 
-    def halo_add(self, ext):
-        """Adds my ghost planes into the neighbours' interiors (after a paint)."""
+    def halo_add(self, ext, async_op=False):
+        """Adds my ghost planes into the neighbours' interiors (after a paint).  With async_op returns a handle
+        whose wait() completes the exchange and does the additions."""
         G, nxl = self.G, self.nxl
         lo = ext[..., :G, :, :].contiguous()
         hi = ext[..., G + nxl:, :, :].contiguous()
         from_l, from_r = torch.empty_like(hi), torch.empty_like(lo)
-        self.comm.neighbour_exchange(lo, hi, from_l, from_r)
-        ext[..., G:2 * G, :, :] += from_l          # the left neighbour's high ghost = my lowest interior planes
-        ext[..., nxl:nxl + G, :, :] += from_r      # the right neighbour's low ghost = my highest interior planes
+        h = self.comm.neighbour_exchange(lo, hi, from_l, from_r, async_op=async_op)
+
+        def finish():
+            h.wait()
+            ext[..., G:2 * G, :, :] += from_l          # the left neighbour's high ghost = my lowest interior planes
+            ext[..., nxl:nxl + G, :, :] += from_r      # the right neighbour's low ghost = my highest interior planes
+
+        if async_op:
+            return _Works([], finish)
+        finish()
+        return _Done()
 
     def halo_fill(self, ext, async_op=False):
         """Fills my ghost planes from the neighbours' interiors (before a read).  With async_op returns a handle
@@ -245,10 +254,13 @@ class SlabPM(HaloMixin):
         for f in fills:
             f.wait()
 
-    def force_meshes_vjp(self, fbar3_ext, rhobar_ext):
+    def force_meshes_vjp(self, fbar3_ext, rhobar_ext, ghost_adds=None):
+        """fbar3_ext: three cotangent meshes (ghosts added, or `ghost_adds[c]` handles still in flight)."""
         ss = self.ss
         a2a = []
         for c in range(3):
+            if ghost_adds is not None:
+                ghost_adds[c].wait()
             self.call("mcpm_slab_zfwd", self._interior(fbar3_ext, c), self.Me, self._spec(self.s3a, c), 1)
             self.call("mcpm_slab_ycol", self._spec(self.s3a, c), self._spec(self.s3b, c), 1, -1, 0, 1)
             a2a.append(self.comm.all_to_all(self.s3a[c * ss:(c + 1) * ss], self.s3b[c * ss:(c + 1) * ss], async_op=True))
@@ -274,8 +286,8 @@ class SlabPM(HaloMixin):
         """Adjoint of `step`: xb, vb (cotangents of its outputs) are updated in place."""
         self.call("mcpm_kick_f32", _p(vb), _p(xb), self.Nl, float(beta), float(beta * tau), _p(self.Fb))
         self.call("mcpm_paint3_f32", _p(x), self.Nl, POS_LATTICE, _p(self.Fb), paint_order, _p(self.f3), 0)
-        self.halo_add(self.f3)
-        self.force_meshes_vjp(self.f3, self.rho)
+        adds = [self.halo_add(self.f3[c], async_op=True) for c in range(3)]   # overlap with the z / y passes below
+        self.force_meshes_vjp(self.f3, self.rho, adds)
         self.halo_fill(self.rho)
         self.call("mcpm_step_adjoint_particles_f32", _p(x), _p(v), _p(f3), _p(self.rho), float(alpha), float(beta),
                   float(tau), paint_order, _p(xb), _p(vb), abar_ptr, bbar_ptr)
