@@ -512,7 +512,15 @@ static void launch_tile_variant(mcpm_plan *p, const float *pos, const float *w, 
             case 4: launch_tile<16, 16, 64, H, 1024, 2>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
             case 5: launch_tile<16, 16, 64, H, 1024, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
             case 6: launch_tile<16, 16, 64, H, 512, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
-            default: launch_tile<16, 16, 64, H, 1024, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 7: launch_tile<16, 16, 16, H, 256, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 8: launch_tile<16, 16, 32, H, 512, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 9: launch_tile<16, 16, 16, H, 512, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            default:
+                // 16^3 tiles (32 KB of f64, several workgroups per CU): the kernel is bound by the LDS f64 atomic rate,
+                // not by the 3.8x halo re-reads, so they tie the 16x16x64 tile at 512^3 and win on small meshes
+                // (64^3: 0.030 vs 0.051 ms), where few large tiles cannot fill the chip
+                launch_tile<16, 16, 16, H, 512, 4>(p, pos, w, wstride, wscalar, mesh, accumulate);
+                break;
         }
     } else {
         launch_tile<16, 16, 16, H, 256, 4>(p, pos, w, wstride, wscalar, mesh, accumulate);
