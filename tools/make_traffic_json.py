@@ -1,0 +1,51 @@
+"""Builds profiles/r01_pmc_traffic.json from two rocprofv3 PMC passes over bench.py (FETCH_SIZE, WRITE_SIZE).
+usage: python tools/make_traffic_json.py <fetch_dir> <write_dir> <mesh> <out.json> <per_kernel.txt>"""
+import collections, csv, glob, json, sys
+
+fetch_dir, write_dir, mesh, out_json, out_txt = sys.argv[1:6]
+stage_of = [("paint3_", "paint"), ("paint_tile_kernel", "paint"), ("paint_outlier_kernel", "paint"), ("paint_atomic_kernel", "paint"),
+            ("zfwd_kernel", "fft_r2c"), ("ycol_kernel<512, -1>", "fft_r2c"), ("ycol_kernel<256, -1>", "fft_r2c"),
+            ("ycol_kernel<512, 1>", "fft_c2r"), ("ycol_kernel<256, 1>", "fft_c2r"), ("zinv_kernel", "fft_c2r"),
+            ("xfused_kernel", "kspace"), ("kick_drift_kernel", "kick_drift"), ("step_adjoint_kernel", "step_adjoint"),
+            ("axpby_kernel", "axpy"), ("axpy_kernel", "axpy")]
+outlier_kernels = ("paint_outlier_kernel", "paint3_outlier_kernel")
+
+
+def stage(name):
+    for k, v in stage_of:
+        if k in name:
+            return v
+    return None
+
+
+tot = collections.defaultdict(lambda: {"fetch_kb": 0.0, "write_kb": 0.0, "launches": 0})
+per_kernel = collections.defaultdict(lambda: {"fetch_kb": [], "write_kb": []})
+for d, key in ((fetch_dir, "fetch_kb"), (write_dir, "write_kb")):
+    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    for r in csv.DictReader(open(f)):
+        nm, v = r["Kernel_Name"], float(r["Counter_Value"])
+        per_kernel[nm.split("(")[0]][key].append(v)
+        st = stage(nm)
+        if st:
+            tot[st][key] += v
+            if key == "fetch_kb" and not any(o in nm for o in outlier_kernels):
+                tot[st]["launches"] += 1
+out = {str(mesh): {}, "_method": (
+    "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu-baseline --warmup 0`; "
+    "counters are KB; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
+    "128-B requests as 64 B), calibrated here on axpy_kernel / lpt_accum_kernel whose byte counts are known; the counters sit "
+    "on the L2 fabric side, so Infinity-Cache hits are included. Per stage = sum over the stage's kernels / stage launches.")}
+for st, v in tot.items():
+    n = max(v["launches"], 1)
+    out[str(mesh)][st] = {"bytes_per_launch": round((2 * v["fetch_kb"] + v["write_kb"]) * 1024 / n),
+                          "fetch_bytes_per_launch": round(2 * v["fetch_kb"] * 1024 / n),
+                          "write_bytes_per_launch": round(v["write_kb"] * 1024 / n), "launches_profiled": n}
+json.dump(out, open(out_json, "w"), indent=1)
+with open(out_txt, "w") as fo:
+    fo.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per-kernel averages, raw KB (FETCH_SIZE not yet doubled)\n")
+    for k, v in sorted(per_kernel.items()):
+        if v["fetch_kb"]:
+            fo.write(f"{k[:90]:92s} n={len(v['fetch_kb']):4d} FETCH_SIZE_avg_KB={sum(v['fetch_kb'])/len(v['fetch_kb']):14.1f} "
+                     f"WRITE_SIZE_avg_KB={sum(v['write_kb'])/max(len(v['write_kb']),1):14.1f}\n")
+for st, v in out[str(mesh)].items():
+    print(st, {k: (f"{x/1e9:.2f} GB" if "bytes" in k else x) for k, x in v.items()})
