@@ -212,18 +212,37 @@ static int axpby(mcpm_plan *p, const float *x, const float *y, int64_t n, float 
 // spectrum -> three force meshes (C2R output buffer `fm`), using plan->spec as spectral scratch
 static int spec_to_force_meshes(mcpm_plan *p, const float *spec, int lap_fd, int grad_fd, float kcut, int deconv,
                                 float *fm) {
+    if (mcpm_fftpm_supported(p) && !p->g.xslab && lap_fd == MCPM_FD_INF && grad_fd == MCPM_FD_INF && kcut <= 0.f && !deconv &&
+        spec != p->spec && spec != p->spec1)
+        return mcpm_fftpm_spec_meshes(p, spec, fm, 3);
     MCPM_TRY(mcpm_kspace_force_f32(p, spec, p->spec, 1.f / (float)p->M, lap_fd, grad_fd, kcut, deconv));
     MCPM_TRY(mcpm_fft_c2r(p, p->spec, fm, 3));
     return MCPM_OK;
 }
 
 // half-spectrum -> delta2 spectrum in plan->spec1; leaves the six Hessian meshes in fmesh[0:6]
-static int spec_to_delta2(mcpm_plan *p, const float *spec, int lap_fd, int grad_fd) {
-    MCPM_TRY(mcpm_kspace_hessian_f32(p, spec, p->spec, 1.f / (float)p->M, lap_fd, grad_fd));
-    MCPM_TRY(mcpm_fft_c2r(p, p->spec, p->fmesh, 6));
+static bool spec_custom(const mcpm_plan *p, const float *spec, int lap_fd, int grad_fd) {
+    return mcpm_fftpm_supported(p) && !p->g.xslab && lap_fd == MCPM_FD_INF && grad_fd == MCPM_FD_INF && spec != p->spec &&
+           spec != p->spec1;
+}
+
+// half-spectrum -> delta2 (real, in plan->rho), Hessian meshes left in fmesh[0:6]
+static int spec_to_delta2_real(mcpm_plan *p, const float *spec, int lap_fd, int grad_fd) {
+    if (spec_custom(p, spec, lap_fd, grad_fd)) {
+        MCPM_TRY(mcpm_fftpm_spec_meshes(p, spec, p->fmesh, 6));
+    } else {
+        MCPM_TRY(mcpm_kspace_hessian_f32(p, spec, p->spec, 1.f / (float)p->M, lap_fd, grad_fd));
+        MCPM_TRY(mcpm_fft_c2r(p, p->spec, p->fmesh, 6));
+    }
     MCPM_TRY(mcpm_hessian_combine_f32(p, p->fmesh, p->rho));
-    MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
     return MCPM_OK;
+}
+
+// delta2 (plan->rho) -> its three force meshes
+static int delta2_to_force_meshes(mcpm_plan *p, int lap_fd, int grad_fd, float *fm) {
+    if (lap_fd == MCPM_FD_INF && grad_fd == MCPM_FD_INF) return mcpm_force_meshes_f32(p, p->rho, fm);
+    MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
+    return spec_to_force_meshes(p, p->spec1, lap_fd, grad_fd, 0.f, 0, fm);
 }
 
 static int ensure_pscratch(mcpm_plan *p) {
@@ -247,23 +266,30 @@ static int lpt_vjp_device(mcpm_plan *p, const float *init_mesh, int lpt_order, c
     if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(p->fmesh, 0, sizeof(float) * 3 * M, p->stream));
     lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, g, 1.f, p->fmesh, M);
     MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
-    MCPM_TRY(mcpm_fft_r2c(p, p->fmesh, p->spec, 3));
-    MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, init_mesh_bar, invM, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 1, 0, 0));
+    const bool custom = spec_custom(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF);
+    if (custom) {
+        MCPM_TRY(mcpm_fftpm_spec_meshes_vjp(p, p->fmesh, init_mesh_bar, 3));
+    } else {
+        MCPM_TRY(mcpm_fft_r2c(p, p->fmesh, p->spec, 3));
+        MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, init_mesh_bar, invM, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 1, 0, 0));
+    }
     if (lpt_order == 2) {
         float *h = p->fmesh, *f2 = p->fmesh + 6 * M;
-        MCPM_TRY(spec_to_delta2(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF));             // h in fmesh[0:6], delta2_k in spec1
-        MCPM_TRY(spec_to_force_meshes(p, p->spec1, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, f2));  // F2 meshes
+        MCPM_TRY(spec_to_delta2_real(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF));        // h in fmesh[0:6], delta2 in rho
+        MCPM_TRY(delta2_to_force_meshes(p, MCPM_FD_INF, MCPM_FD_INF, f2));            // F2 meshes
         lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, f2, M, xb, vb, sb + 1, sb + 2);  // negated on the host
         MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
         if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(f2, 0, sizeof(float) * 3 * M, p->stream));
         lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, -g2, -c2, f2, M);
         MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
-        MCPM_TRY(mcpm_fft_r2c(p, f2, p->spec, 3));
-        MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, p->spec1, invM, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 0, 1, 0));
-        MCPM_TRY(mcpm_fft_c2r(p, p->spec1, p->rho, 1));                               // delta2_bar
+        MCPM_TRY(mcpm_force_meshes_vjp_f32(p, f2, p->rho));                           // delta2_bar
         MCPM_TRY(mcpm_hessian_combine_vjp_f32(p, h, p->rho, h));                      // in place: h -> h_bar
-        MCPM_TRY(mcpm_fft_r2c(p, h, p->spec, 6));
-        MCPM_TRY(mcpm_kspace_hessian_vjp_f32(p, p->spec, init_mesh_bar, invM, MCPM_FD_INF, MCPM_FD_INF, 1, 1));
+        if (custom) {
+            MCPM_TRY(mcpm_fftpm_spec_meshes_vjp(p, h, init_mesh_bar, 6));
+        } else {
+            MCPM_TRY(mcpm_fft_r2c(p, h, p->spec, 6));
+            MCPM_TRY(mcpm_kspace_hessian_vjp_f32(p, p->spec, init_mesh_bar, invM, MCPM_FD_INF, MCPM_FD_INF, 1, 1));
+        }
     }
     return MCPM_OK;
 }
@@ -316,8 +342,8 @@ int mcpm_pm_forces2_f32(mcpm_plan *p, const float *spec, const float *pos, int64
                         int grad_fd, float *forces) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, spec && forces, MCPM_E_ARG, "mcpm_pm_forces2_f32: null buffer");
-    MCPM_TRY(spec_to_delta2(p, spec, lap_fd, grad_fd));
-    MCPM_TRY(spec_to_force_meshes(p, p->spec1, lap_fd, grad_fd, 0.f, 0, p->fmesh));
+    MCPM_TRY(spec_to_delta2_real(p, spec, lap_fd, grad_fd));
+    MCPM_TRY(delta2_to_force_meshes(p, lap_fd, grad_fd, p->fmesh));
     MCPM_TRY(mcpm_read_f32(p, pos, n, mode, p->fmesh, 3, order, forces));
     return MCPM_OK;
 }
@@ -336,8 +362,8 @@ int mcpm_lpt_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, float g, f
     }
     MCPM_LAUNCH_CHECK(p, "lpt_accum_kernel");
     if (lpt_order == 2) {
-        MCPM_TRY(spec_to_delta2(p, init_mesh, lap_fd, grad_fd));
-        MCPM_TRY(spec_to_force_meshes(p, p->spec1, lap_fd, grad_fd, 0.f, 0, p->fmesh));
+        MCPM_TRY(spec_to_delta2_real(p, init_mesh, lap_fd, grad_fd));
+        MCPM_TRY(delta2_to_force_meshes(p, lap_fd, grad_fd, p->fmesh));
         StageTimer st_(p, ST_LPT, 12.0 * p->M + 48.0 * p->Np);
         lpt_accum_kernel<<<grid, block, 0, p->stream>>>(p->g, p->fmesh, p->M, -g2, -dg2dg, 0, dpos, vel);
         MCPM_LAUNCH_CHECK(p, "lpt_accum_kernel");

@@ -382,6 +382,116 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xfused_kernel(FGeom g, c
     }
 }
 
+// Spectrum-side variants of the x pass, for lpt and its adjoint (nbody.py:611-667): the input (or output) is a
+// half-spectrum in the caller's plain layout [x][ny][nz/2+1], already (or still) in k-space along x, so one of the
+// two x transforms disappears.
+//   MODE 2: spectrum -> x (-(i k_c))(-1/k^2) scale -> inverse x FFT -> 3 spectra          (pm_forces on a spectrum)
+//   MODE 3: spectrum -> x (i k_a)(i k_b)(-1/k^2) scale -> inverse x FFT -> 6 spectra     (Hessian, ab = 00 01 02 11 12 22)
+//   MODE 4: 3 spectra -> forward x FFT -> sum_c conj(mult_c) * zw -> spectrum            (VJP of MODE 2)
+//   MODE 5: 6 spectra -> forward x FFT -> sum_ab mult_ab * zw -> spectrum += ...         (VJP of MODE 3, accumulates)
+// MODE 2/3 feed a C2R, so their multipliers are Hermitian-projected; MODE 4/5 return the exact cotangent of the numpy
+// function: un-projected multipliers times the irfftn multiplicity zw = (1,2,..,2,1) (kspace.hip header).
+template <int N, int MODE>
+__global__ __launch_bounds__(ColShape<N>::THREADS) void xspec_kernel(FGeom g, const cf *__restrict__ in, cf *__restrict__ out,
+                                                                     XLayout xl, float scale, const cf *__restrict__ W) {
+    constexpr int T = ColShape<N>::T, LINES = ColShape<N>::LINES;
+    constexpr int NC = (MODE == 2 || MODE == 4) ? 3 : 6;
+    constexpr bool PROJECT = (MODE == 2 || MODE == 3);
+    typedef Tile<N, LINES, true> TL;
+    __shared__ cf lds[TL::FLOATS2];
+    const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
+    const int kzi = blockIdx.x * LINES + l, yl = blockIdx.y, iy = xl.iy0 + yl;
+    const bool ok = kzi < g.nzh;
+    const uint32_t off0 = (uint32_t)yl * g.nzp + kzi, xs = (uint32_t)xl.NYL * g.nzp;
+    uint32_t os[8], o3[8];
+    float kx[8], L[8];
+    const float ky = kfreq_i(iy, g.ny), kz = MCPM_TWO_PI * (float)kzi / (float)g.nz;
+    const bool special = (kzi == 0) || (kzi == g.nz / 2);
+    const bool nyq_y = iy == g.ny / 2, nyq_z = kzi == g.nz / 2;
+    const float zw = special ? 1.f : 2.f;
+    const float dkx = MCPM_TWO_PI / (float)N;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int x = u + T * m;
+        os[m] = ((uint32_t)x * g.ny + iy) * g.nzh + kzi;  // caller's plain layout
+        o3[m] = (uint32_t)((x >> xl.lgXB) * xl.SBx) + (uint32_t)(x & (xl.XB - 1)) * xs + off0;
+        kx[m] = dkx * (float)(x < N / 2 ? x : x - N);
+        const float kk = kx[m] * kx[m] + ky * ky + kz * kz;
+        L[m] = kk == 0.f ? 0.f : -scale * __frcp_rn(kk);
+    }
+    // real factor of component c at point m: force: s_c = k_c L (multiplier -i s_c); hessian: h_ab = -k_a k_b L
+    auto factor = [&](int c, int m) -> float {
+        const bool nyq_x = (u + T * m) == N / 2;
+        if (NC == 3) {
+            const float k = c == 0 ? kx[m] : (c == 1 ? ky : kz);
+            const bool nq = c == 0 ? nyq_x : (c == 1 ? nyq_y : nyq_z);
+            if (PROJECT && nq && (special || c == 2)) return 0.f;
+            return k * L[m];
+        }
+        const int a = c < 3 ? 0 : (c < 5 ? 1 : 2), b = c < 3 ? c : (c < 5 ? c - 2 : 2);
+        const float ka = a == 0 ? kx[m] : (a == 1 ? ky : kz), kb = b == 0 ? kx[m] : (b == 1 ? ky : kz);
+        const bool na = a == 0 ? nyq_x : (a == 1 ? nyq_y : nyq_z), nb2 = b == 0 ? nyq_x : (b == 1 ? nyq_y : nyq_z);
+        if (PROJECT && special && (na != nb2)) return 0.f;
+        return -ka * kb * L[m];
+    };
+    TL tile{l};
+    if (MODE == 2 || MODE == 3) {
+        cf v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = ok ? in[os[m]] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            cf w[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float f = factor(c, m);
+                w[m] = NC == 3 ? make_float2(f * v[m].y, -f * v[m].x) : make_float2(f * v[m].x, f * v[m].y);
+            }
+            fft_line<N, +1>(w, lds, W, u, tile);
+            if (ok) {
+                cf *oc = out + c * xl.SC;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) oc[o3[m]] = w[m];
+            }
+        }
+    } else {
+        cf acc[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            cf v[8];
+            const cf *ic = in + c * xl.SC;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = ok ? ic[o3[m]] : make_float2(0.f, 0.f);
+            fft_line<N, -1>(v, lds, W, u, tile);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float f = factor(c, m) * zw;
+                if (NC == 3) {  // conj(-i s) = +i s
+                    acc[m].x += -f * v[m].y;
+                    acc[m].y += f * v[m].x;
+                } else {
+                    acc[m].x += f * v[m].x;
+                    acc[m].y += f * v[m].y;
+                }
+            }
+        }
+        if (ok) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                cf r = acc[m];
+                if (MODE == 5) {
+                    const cf o = out[os[m]];
+                    r.x += o.x;
+                    r.y += o.y;
+                }
+                out[os[m]] = r;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 static bool pow2_ok(int n) { return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024; }
@@ -507,6 +617,53 @@ static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
     return MCPM_OK;
 }
 
+// spectrum-side x pass (modes 2..5 of xspec_kernel); `spec` is the caller's plain half-spectrum, `multi` the 3 or 6
+// internal spectra
+static int x_spec(mcpm_plan *p, const cf *in, cf *out, int mode) {
+    const FGeom g = fgeom(p);
+    const int nyl = g.ny / p->nranks;
+    const int64_t blk = (int64_t)p->nxl * nyl * g.nzp;
+    int lgxb = 0;
+    while ((1 << lgxb) < p->nxl) ++lgxb;
+    const XLayout xl{nyl, p->rank * nyl, p->nxl, lgxb, blk, (int64_t)p->nranks * blk};
+    const float scale = 1.f / ((float)g.nx * (float)g.ny * (float)g.nz);
+    const int nc = (mode == 2 || mode == 4) ? 3 : 6;
+    StageTimer st_(p, ST_KSPACE, 8.0 * (nc + 1) * p->nxl * g.ny * g.nzh + nc * pass_bytes(p, 1));
+#define CALL(NN)                                                                                              \
+    {                                                                                                         \
+        constexpr int LINES = ColShape<NN>::LINES, TH = ColShape<NN>::THREADS;                                \
+        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)nyl);                                    \
+        const cf *tw = (const cf *)p->tw[0];                                                                  \
+        if (mode == 2) xspec_kernel<NN, 2><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, tw);            \
+        else if (mode == 3) xspec_kernel<NN, 3><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, tw);       \
+        else if (mode == 4) xspec_kernel<NN, 4><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, tw);       \
+        else xspec_kernel<NN, 5><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, tw);                      \
+    }
+    DISPATCH_N(g.nx, CALL)
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "xspec_kernel");
+    return MCPM_OK;
+}
+
+// half-spectrum (plain layout) -> three force meshes / six Hessian meshes, and the adjoints; single-GPU plans
+int mcpm_fftpm_spec_meshes(mcpm_plan *p, const float *spec, float *meshes, int nc) {
+    MCPM_TRY(ensure_twiddles(p));
+    cf *s = (cf *)p->spec + spec_elems(p);
+    MCPM_TRY(x_spec(p, (const cf *)spec, s, nc == 3 ? 2 : 3));
+    MCPM_TRY(y_columns(p, s, s, nc, +1, false, false));
+    MCPM_TRY(z_inverse(p, s, meshes, p->M, nc));
+    return MCPM_OK;
+}
+
+int mcpm_fftpm_spec_meshes_vjp(mcpm_plan *p, const float *meshes_bar, float *spec_bar, int nc) {
+    MCPM_TRY(ensure_twiddles(p));
+    cf *s = (cf *)p->spec + spec_elems(p);
+    MCPM_TRY(z_forward(p, meshes_bar, p->M, s, nc));
+    MCPM_TRY(y_columns(p, s, s, nc, -1, false, false));
+    MCPM_TRY(x_spec(p, s, (cf *)spec_bar, nc == 3 ? 4 : 5));
+    return MCPM_OK;
+}
+
 // rho (real mesh) -> three force meshes irfftn(-(i k_c)(-1/k^2) rfftn(rho)); single-GPU plans
 int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3) {
     MCPM_TRY(ensure_twiddles(p));
@@ -565,9 +722,10 @@ int mcpm_slab_ycol(mcpm_plan *p, const float *in, float *out, int batch, int sig
 
 int mcpm_slab_xfused(mcpm_plan *p, const float *in, float *out, int mode) {
     if (!p) return MCPM_E_ARG;
-    MCPM_REQUIRE(p, in && out && in != out && (mode == 0 || mode == 1), MCPM_E_ARG, "mcpm_slab_xfused: bad argument");
+    MCPM_REQUIRE(p, in && out && in != out && mode >= 0 && mode <= 5, MCPM_E_ARG, "mcpm_slab_xfused: bad argument");
     MCPM_REQUIRE(p, mcpm_fftpm_supported(p), MCPM_E_UNSUPPORTED, "slab FFT needs power-of-two axes in [64, 1024]");
     MCPM_TRY(ensure_twiddles(p));
+    if (mode >= 2) return x_spec(p, (const cf *)in, (cf *)out, mode);
     return x_fused(p, (const cf *)in, (cf *)out, mode);
 }
 

@@ -122,6 +122,10 @@ int mcpm_fail(mcpm_plan *plan, int code, const std::string &msg);
 bool mcpm_fftpm_supported(const mcpm_plan *p);
 int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3);
 int mcpm_fftpm_force_meshes_vjp(mcpm_plan *p, const float *fbar3, float *rho_bar);
+// plain half-spectrum -> nc = 3 force meshes or nc = 6 Hessian meshes (00 01 02 11 12 22), and the adjoints
+// (spec_bar overwritten for nc = 3, accumulated into for nc = 6)
+int mcpm_fftpm_spec_meshes(mcpm_plan *p, const float *spec, float *meshes, int nc);
+int mcpm_fftpm_spec_meshes_vjp(mcpm_plan *p, const float *meshes_bar, float *spec_bar, int nc);
 
 #define MCPM_HIP(plan, expr)                                                                         \
     do {                                                                                             \

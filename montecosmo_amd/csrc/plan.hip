@@ -108,7 +108,10 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
         if (e == hipSuccess) e = hipMalloc(ptr, bytes);
     };
     alloc((void **)&p->rho, sizeof(float) * p->M);
-    alloc((void **)&p->spec, sizeof(float) * 2 * p->Mh * 6);
+    {   // 6 plain half-spectra (rocFFT path) or 1 + 6 spectra in the padded layout of the hand-written FFT
+        const size_t plain = (size_t)p->Mh * 6, padded = (size_t)nx * ny * (nz / 2 + 16) * 7;
+        alloc((void **)&p->spec, sizeof(float) * 2 * (plain > padded ? plain : padded));
+    }
     alloc((void **)&p->fmesh, sizeof(float) * p->M * 9);
     alloc((void **)&p->spec1, sizeof(float) * 2 * p->Mh);
     alloc((void **)&p->outliers, sizeof(int) * p->Np);

@@ -250,7 +250,8 @@ def test_paint_read_vjp(nb):
     assert rel_l2(to_np(pb), pb_o) < 1e-5 and rel_l2(to_np(meshb), meshb_o) < 1e-5
 
 
-@pytest.mark.parametrize("n,n_steps,lpt_order,integrator", [(16, 3, 2, "bullfrog"), (32, 5, 2, "bullfrog"), (32, 3, 1, "fastpm")])
+@pytest.mark.parametrize("n,n_steps,lpt_order,integrator", [(16, 3, 2, "bullfrog"), (32, 5, 2, "bullfrog"), (32, 3, 1, "fastpm"),
+                                                            (64, 2, 2, "bullfrog")])  # 64: hand-written FFT incl. the lpt adjoint
 def test_nbody_bf_vjp(nb, n, n_steps, lpt_order, integrator):
     """Hand-written reverse sweep against the oracle's (finite-difference-validated) VJP."""
     from montecosmo_amd import bricks
