@@ -150,16 +150,10 @@ class SlabRunner:
         f32 = dict(dtype=torch.float32, device=device)
         self.states = torch.empty((K + 1, 2, pm.Nl, 3), **f32)
         self.f3s = torch.zeros((K, 3, pm.nxe, n, n), **f32)
-        # LPT start (untimed set-up), redundantly on the full mesh, then this rank's slab of particles
-        full = nbody.get_plan(shape)
-        dpos, vel = torch.empty((full.N, 3), **f32), torch.empty((full.N, 3), **f32)
-        p = lambda t: C.c_void_p(t.data_ptr())
-        full.call("mcpm_lpt_f32", p(spec), 2, float(self.lpt_s[0]), float(self.lpt_s[1]), float(self.lpt_s[2]), 0, 0, p(dpos), p(vel))
-        lo, hi = pm.rank * pm.Nl, (pm.rank + 1) * pm.Nl
-        self.states[0, 0] = dpos[lo:hi] + vel[lo:hi] * (self.dg / 2)
-        self.states[0, 1] = vel[lo:hi]
-        del dpos, vel, full, spec
-        nbody.clear_plans()
+        # slab-decomposed LPT start (untimed set-up) + first half drift
+        pm.lpt(spec, 2, self.lpt_s[0], self.lpt_s[1], self.lpt_s[2], self.states[0, 0], self.states[0, 1])
+        self.states[0, 0] += self.states[0, 1] * (self.dg / 2)
+        del spec
         torch.cuda.empty_cache()
         rng = np.random.default_rng(1 + pm.rank)
         self.pos_bar = torch.from_numpy(rng.standard_normal((pm.Nl, 3), dtype=np.float32)).to(device)

@@ -150,7 +150,11 @@ int mcpm_force_meshes_vjp_f32(mcpm_plan *plan, const float *fbar3, float *rho_ba
              [c][dest rank][x_local][y_local][nzp] (what one all-to-all per spectrum exchanges), plain =
              [c][x_local][y][nzp]
      xfused: mode 0: one spectrum [x][y_local][nzp] -> x FFT, k-space force multiply, inverse x FFT -> three
-             spectra [c][dest rank][x_local][y_local][nzp]; mode 1 is the adjoint (three in that layout -> one)
+             spectra [c][dest rank][x_local][y_local][nzp]; mode 1 is the adjoint (three in that layout -> one).
+             Modes 2..5 are the spectrum-side variants of lpt: the single spectrum is the caller's FULL plain
+             half-spectrum [nx][ny][nz/2+1] (this rank touches its y rows only) and one x transform disappears:
+             2: spectrum -> 3 force spectra, 3: spectrum -> 6 Hessian spectra (00 01 02 11 12 22),
+             4: 3 -> spectrum cotangent (overwrites the rank's rows), 5: 6 -> spectrum cotangent (accumulates)
      zinv  : `batch` spectra -> `batch` real meshes (unnormalised; the 1/M sits in xfused). */
 int64_t mcpm_slab_spec_elems(const mcpm_plan *plan);
 int mcpm_slab_zfwd(mcpm_plan *plan, const float *real, int64_t real_bstride, float *spec, int batch);
@@ -207,6 +211,13 @@ int mcpm_step_adjoint_particles_f32(mcpm_plan *plan, const float *pos_in, const 
                                     double *beta_bar);
 int mcpm_lpt_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg,
                  int lap_fd, int grad_fd, float *dpos, float *vel);
+/* Lattice-point pieces of lpt (read_order = 1 at pos = regular_pos, nbody.py:984-985), exposed for the slab path:
+     lpt_accum      : dpos = (init ? 0 : dpos) + ad * F(q_i), vel likewise with av; F from three contiguous meshes
+     lattice_scatter: its adjoint, meshes3[c][cell(q_i)] (+)= a * xb[i][c] + b * vb[i][c]
+     lattice_dot    : out2[0] += sum_i a_i . F(q_i), out2[1] += sum_i b_i . F(q_i)   (DEVICE doubles; a or b may be NULL) */
+int mcpm_lpt_accum_f32(mcpm_plan *plan, const float *meshes3, float ad, float av, int init, float *dpos, float *vel);
+int mcpm_lattice_scatter_f32(mcpm_plan *plan, const float *xb, const float *vb, float a, float b, float *meshes3);
+int mcpm_lattice_dot_f32(mcpm_plan *plan, const float *meshes3, const float *a, const float *b, double *out2);
 /* VJP of mcpm_lpt_f32 w.r.t. init_mesh (real-pair convention, irfftn multiplicity weights included) and the three
    growth scalars: scalar_bars = {g_bar, g2_bar, dg2dg_bar} (host, may be NULL; forces a stream sync when given). */
 int mcpm_lpt_vjp_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, const double *lpt_scalars,

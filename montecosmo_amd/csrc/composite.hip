@@ -348,6 +348,40 @@ int mcpm_pm_forces2_f32(mcpm_plan *p, const float *spec, const float *pos, int64
     return MCPM_OK;
 }
 
+int mcpm_lpt_accum_f32(mcpm_plan *p, const float *meshes3, float ad, float av, int init, float *dpos, float *vel) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, meshes3 && dpos && vel, MCPM_E_ARG, "mcpm_lpt_accum_f32: null buffer");
+    dim3 grid, block;
+    lattice_launch(p->g, grid, block);
+    StageTimer st_(p, ST_LPT, 12.0 * p->M + (init ? 24.0 : 48.0) * p->Np);
+    lpt_accum_kernel<<<grid, block, 0, p->stream>>>(p->g, meshes3, p->M, ad, av, init, dpos, vel);
+    MCPM_LAUNCH_CHECK(p, "lpt_accum_kernel");
+    return MCPM_OK;
+}
+
+int mcpm_lattice_scatter_f32(mcpm_plan *p, const float *xb, const float *vb, float a, float b, float *meshes3) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, xb && vb && meshes3, MCPM_E_ARG, "mcpm_lattice_scatter_f32: null buffer");
+    dim3 grid, block;
+    lattice_launch(p->g, grid, block);
+    if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(meshes3, 0, sizeof(float) * 3 * p->M, p->stream));
+    StageTimer st_(p, ST_LPT, 12.0 * p->M + 24.0 * p->Np);
+    lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, a, b, meshes3, p->M);
+    MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
+    return MCPM_OK;
+}
+
+int mcpm_lattice_dot_f32(mcpm_plan *p, const float *meshes3, const float *a, const float *b, double *out2) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, meshes3 && out2 && (a || b), MCPM_E_ARG, "mcpm_lattice_dot_f32: null buffer");
+    dim3 grid, block;
+    lattice_launch(p->g, grid, block);
+    StageTimer st_(p, ST_LPT, 12.0 * p->M + 24.0 * p->Np);
+    lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, meshes3, p->M, a, b, a ? out2 : nullptr, b ? out2 + 1 : nullptr);
+    MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
+    return MCPM_OK;
+}
+
 int mcpm_lpt_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg, int lap_fd,
                  int grad_fd, float *dpos, float *vel) {
     if (!p) return MCPM_E_ARG;

@@ -14,8 +14,9 @@ Decomposition (one process per GPU, `torch.distributed`, backend "nccl" = RCCL o
 The adjoint mirrors it (3 weighted paints + ghost add, 3 forward / 1 inverse transform, ghost fill, fused
 adjoint particle kernel); scalar cotangents are all-reduced once at the end.
 
-The LPT start (13 FFTs, once per log-prob) is computed redundantly on every rank with the single-GPU plan in
-round 1; distributing it is listed under DESIGN.md "next".
+The LPT start and its adjoint are slab-decomposed as well (`SlabPM.lpt`, `SlabPM.lpt_vjp`): the replicated initial
+half-spectrum is already in k-space, so each rank runs the spectrum-side x pass on its y rows, and the same
+all-to-all / y / z passes follow; the init_mesh cotangent is assembled with one all-reduce.
 """
 from __future__ import annotations
 
@@ -123,6 +124,8 @@ class TorchComm:
         return _Done()
 
     def all_reduce_sum(self, t):
+        if t.is_complex():
+            return torch.view_as_complex(self.all_reduce_sum(torch.view_as_real(t)))
         h = self._h(t).clone()
         self.td.all_reduce(h, group=self.group)
         return h.to(t.device)
@@ -203,7 +206,9 @@ class SlabPM(HaloMixin):
         self.rho = torch.zeros((self.nxe, ny, nz), **f32)
         self.f3 = torch.zeros((3, self.nxe, ny, nz), **f32)
         self.s1a, self.s1b = torch.empty(ss, **c64), torch.empty(ss, **c64)
-        self.s3a, self.s3b = torch.empty(3 * ss, **c64), torch.empty(3 * ss, **c64)
+        self.s6a, self.s6b = torch.empty(6 * ss, **c64), torch.empty(6 * ss, **c64)     # lpt: 6 Hessian spectra
+        self.s3a, self.s3b = self.s6a[:3 * ss], self.s6b[:3 * ss]
+        self.h6 = None                                                                # (6, nxe, ny, nz), allocated by lpt
         self.Fb = torch.empty((self.Nl, 3), **f32)
         self.sbar = None
 
@@ -273,6 +278,69 @@ class SlabPM(HaloMixin):
         self.call("mcpm_slab_ycol", _p(self.s1b), _p(self.s1a), 1, +1, 1, 0)
         self.call("mcpm_slab_zinv", _p(self.s1a), self._interior(rhobar_ext), self.Me, 1)
 
+    # ---- lpt on slabs (nbody.py:634-667 at the lattice, read_order = 1) -------------------------------------
+    def spec_to_meshes(self, spec_full, out_ext, nc):
+        """Replicated plain half-spectrum -> nc = 3 force meshes or nc = 6 Hessian meshes (interiors of out_ext[c])."""
+        ss = self.ss
+        self.call("mcpm_slab_xfused", _p(spec_full), _p(self.s6a), 2 if nc == 3 else 3)
+        a2a = [self.comm.all_to_all(self.s6b[c * ss:(c + 1) * ss], self.s6a[c * ss:(c + 1) * ss], async_op=True)
+               for c in range(nc)]
+        for c in range(nc):
+            a2a[c].wait()
+            self.call("mcpm_slab_ycol", self._spec(self.s6b, c), self._spec(self.s6a, c), 1, +1, 1, 0)
+            self.call("mcpm_slab_zinv", self._spec(self.s6a, c), self._interior(out_ext, c), self.Me, 1)
+
+    def meshes_to_spec_bar(self, meshes_ext, spec_bar_full, nc):
+        """Adjoint of spec_to_meshes: writes (nc = 3) or accumulates (nc = 6) this rank's y rows of spec_bar_full."""
+        ss = self.ss
+        a2a = []
+        for c in range(nc):
+            self.call("mcpm_slab_zfwd", self._interior(meshes_ext, c), self.Me, self._spec(self.s6a, c), 1)
+            self.call("mcpm_slab_ycol", self._spec(self.s6a, c), self._spec(self.s6b, c), 1, -1, 0, 1)
+            a2a.append(self.comm.all_to_all(self.s6a[c * ss:(c + 1) * ss], self.s6b[c * ss:(c + 1) * ss], async_op=True))
+        for h in a2a:
+            h.wait()
+        self.call("mcpm_slab_xfused", _p(self.s6a), _p(spec_bar_full), 4 if nc == 3 else 5)
+
+    def _h6(self):
+        if self.h6 is None:
+            self.h6 = torch.zeros((6, self.nxe) + self.shape[1:], dtype=torch.float32, device=self.device)
+        return self.h6
+
+    def lpt(self, spec, lpt_order, g, g2, dg2dg, dpos, vel):
+        """dpos, vel (Nl,3) of this rank's particles from the replicated half-spectrum `spec`."""
+        self.spec_to_meshes(spec, self.f3, 3)
+        self.call("mcpm_lpt_accum_f32", _p(self.f3), float(g), 1.0, 1, _p(dpos), _p(vel))
+        if lpt_order == 2:
+            h6 = self._h6()
+            self.spec_to_meshes(spec, h6, 6)
+            self.call("mcpm_hessian_combine_f32", _p(h6), _p(self.rho))
+            self.force_meshes(self.rho, self.f3, fill_ghosts=False)
+            self.call("mcpm_lpt_accum_f32", _p(self.f3), -float(g2), -float(dg2dg), 0, _p(dpos), _p(vel))
+
+    def lpt_vjp(self, spec, lpt_order, g, g2, dg2dg, xb, vb):
+        """Cotangents (xb, vb) of this rank's (dpos, vel) -> (init_mesh_bar, [g_bar, g2_bar, dg2dg_bar]), both
+        already summed over ranks (init_mesh_bar is the full half-spectrum on every rank)."""
+        out = torch.zeros(tuple(spec.shape), dtype=torch.complex64, device=spec.device)
+        sbar = torch.zeros(3, dtype=torch.float64, device=spec.device)
+        self.spec_to_meshes(spec, self.f3, 3)
+        self.call("mcpm_lattice_dot_f32", _p(self.f3), _p(xb), None, _p(sbar))
+        self.call("mcpm_lattice_scatter_f32", _p(xb), _p(vb), float(g), 1.0, _p(self.f3))
+        self.meshes_to_spec_bar(self.f3, out, 3)
+        if lpt_order == 2:
+            h6 = self._h6()
+            self.spec_to_meshes(spec, h6, 6)
+            self.call("mcpm_hessian_combine_f32", _p(h6), _p(self.rho))
+            self.force_meshes(self.rho, self.f3, fill_ghosts=False)
+            self.call("mcpm_lattice_dot_f32", _p(self.f3), _p(xb), _p(vb), C.c_void_p(sbar.data_ptr() + 8))
+            self.call("mcpm_lattice_scatter_f32", _p(xb), _p(vb), -float(g2), -float(dg2dg), _p(self.f3))
+            self.force_meshes_vjp(self.f3, self.rho)
+            self.call("mcpm_hessian_combine_vjp_f32", _p(h6), _p(self.rho), _p(h6))
+            self.meshes_to_spec_bar(h6, out, 6)
+        out = self.comm.all_reduce_sum(out)
+        sb = self.comm.all_reduce_sum(sbar).cpu().numpy()
+        return out, np.array([sb[0], -sb[1], -sb[2]])
+
     # ---- one BullFrog step and its adjoint -----------------------------------------------------------------
     def step(self, x, v, alpha, beta, tau, f3_out, x_out, v_out, paint_order=2):
         """x, v: (Nl,3) local state; f3_out: (3, nxe, ny, nz) receives the ghost-filled force meshes."""
@@ -308,18 +376,11 @@ def nbody_bf_slab(cosmo, init_mesh, a0=0., a1=1., n_steps=5, paint_order=2, lpt_
     pm = slab if slab is not None else SlabPM(shape, comm, ghost)
     n_steps = int(n_steps)
     dg, alphas, betas, lpt_s = nbody._step_scalars(cosmo, a0, a1, n_steps, integrator)
-    # LPT start, redundantly on the full mesh (round 1), then this rank's slab of particles
-    full = nbody.get_plan(shape)
-    dpos = torch.empty((full.N, 3), dtype=torch.float32, device=spec.device)
-    vel = torch.empty((full.N, 3), dtype=torch.float32, device=spec.device)
-    full.call("mcpm_lpt_f32", _p(spec), int(lpt_order), float(lpt_s[0]), float(lpt_s[1]), float(lpt_s[2]), 0, 0, _p(dpos), _p(vel))
-    lo, hi = pm.rank * pm.Nl, (pm.rank + 1) * pm.Nl
     K = n_steps
     states = torch.empty((K + 1, 2, pm.Nl, 3), dtype=torch.float32, device=spec.device)
     f3s = torch.zeros((K, 3, pm.nxe) + shape[1:], dtype=torch.float32, device=spec.device) if return_ctx else None
-    states[0, 0] = dpos[lo:hi] + vel[lo:hi] * (dg / 2)
-    states[0, 1] = vel[lo:hi]
-    del dpos, vel
+    pm.lpt(spec, int(lpt_order), lpt_s[0], lpt_s[1], lpt_s[2], states[0, 0], states[0, 1])      # slab-decomposed LPT start
+    states[0, 0] += states[0, 1] * (dg / 2)
     for i in range(K):
         tau = dg / 2 if i == K - 1 else dg
         pm.step(states[i, 0], states[i, 1], alphas[i], betas[i], tau, f3s[i] if return_ctx else pm.f3,
@@ -345,11 +406,5 @@ def nbody_bf_slab_vjp(ctx, disp_bar, vel_bar):
                     C.c_void_p(sbar.data_ptr() + 8 * i), C.c_void_p(sbar.data_ptr() + 8 * (K + i)), ctx.paint_order)
     vb += xb * (ctx.dg / 2)                      # initial half drift x'_0 = x_0 + v_0 dg/2
     sbar = pm.comm.all_reduce_sum(sbar).cpu().numpy()
-    # LPT adjoint on the gathered cotangents, redundantly on every rank (round 1)
-    xb_all, vb_all = pm.comm.all_gather_cat(xb), pm.comm.all_gather_cat(vb)
-    full = nbody.get_plan(pm.shape)
-    out = torch.empty(tuple(ctx.spec.shape), dtype=torch.complex64, device=dev)
-    ls = np.zeros(3)
-    full.call("mcpm_lpt_vjp_f32", _p(ctx.spec), ctx.lpt_order, nbody._dptr(ctx.lpt_s), _p(xb_all), _p(vb_all), _p(out),
-              nbody._dptr(ls))
+    out, ls = pm.lpt_vjp(ctx.spec, ctx.lpt_order, ctx.lpt_s[0], ctx.lpt_s[1], ctx.lpt_s[2], xb, vb)
     return out, {"alpha": sbar[:K].copy(), "beta": sbar[K:].copy(), "g": ls[0], "g2": ls[1], "dg2dg": ls[2]}

@@ -99,7 +99,8 @@ def gpu_slab_worker(rank, world, port, out_dir, n, n_steps):
 
         res = {"disp": rel(d_all, lp.disp), "vel": rel(v_all, v1), "grad": rel(mb, mb1),
                "alpha": float(np.abs(sb["alpha"] - sb1["alpha"]).max() / np.abs(sb1["alpha"]).max()),
-               "beta": float(np.abs(sb["beta"] - sb1["beta"]).max() / np.abs(sb1["beta"]).max())}
+               "beta": float(np.abs(sb["beta"] - sb1["beta"]).max() / np.abs(sb1["beta"]).max()),
+               "lpt_scalars": float(max(abs(sb[k] - sb1[k]) for k in ("g", "g2", "dg2dg")) / abs(sb1["g"]))}
         import json
         json.dump(res, open(os.path.join(out_dir, "result.json"), "w"))
     td.barrier()

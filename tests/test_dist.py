@@ -56,6 +56,8 @@ def test_slab_path_single_rank(gpu):
     assert rel(mb, mb1) < 1e-5
     assert np.allclose(sb["alpha"], sb1["alpha"], rtol=1e-4, atol=1e-4 * np.abs(sb1["alpha"]).max())
     assert np.allclose(sb["beta"], sb1["beta"], rtol=1e-4, atol=1e-4 * np.abs(sb1["beta"]).max())
+    for k in ("g", "g2", "dg2dg"):
+        assert np.isclose(sb[k], sb1[k], rtol=1e-4, atol=1e-4 * abs(sb1["g"])), k
 
 
 @pytest.mark.gpu
@@ -65,7 +67,7 @@ def test_slab_path_multi_rank_shared_gpu(gpu, world):
     out = _spawn(gpu_slab_worker, world, 64, 3)
     res = json.load(open(os.path.join(out, "result.json")))
     assert res["disp"] < 2e-6 and res["vel"] < 2e-6, res
-    assert res["grad"] < 1e-5 and res["alpha"] < 1e-4 and res["beta"] < 1e-4, res
+    assert res["grad"] < 1e-5 and res["alpha"] < 1e-4 and res["beta"] < 1e-4 and res["lpt_scalars"] < 1e-4, res
 
 
 @pytest.mark.gpu
