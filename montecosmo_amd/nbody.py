@@ -668,8 +668,8 @@ def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 
     """
     if paint_deconv or grad_fd != np.inf or lap_fd != np.inf:
         raise NotImplementedError("nbody_bf runs the model's configuration: paint_deconv=False, spectral kernels")
-    if not (snapshots is None or (isinstance(snapshots, int) and snapshots <= 1)):
-        raise NotImplementedError("intermediate snapshots are not implemented")
+    if fn is not None:
+        raise NotImplementedError("only the default save function (the state itself) is implemented")
     n_steps = int(n_steps)
     spec = _c64(init_mesh)
     mesh_shape = ch2rshape(spec.shape)
@@ -685,19 +685,55 @@ def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 
     x = torch.empty((N, 3), dtype=torch.float32, device=spec.device)
     v = torch.empty((N, 3), dtype=torch.float32, device=spec.device)
     ckpt = None
-    if return_ctx:
+    want_snaps = not (snapshots is None or (isinstance(snapshots, int) and snapshots <= 1))
+    if return_ctx or want_snaps:
         nck = lib.mcpm_nbody_ckpt_floats(plan.h, n_steps, lpt_order)
         ckpt = torch.empty((nck,), dtype=torch.float32, device=spec.device)
     plan.call("mcpm_nbody_bf_f32", _ptr(spec), n_steps, _dptr(alphas), _dptr(betas), float(dg), _dptr(lpt_s),
               int(lpt_order), int(paint_order), _ptr(x), _ptr(v), _ptr(ckpt))
     lp = LatticePos(x, mesh_shape, ptcl_shape)
-    out = (lp, v) if lattice_out else (lp.to_absolute()[None], v[None])
+    if want_snaps:
+        if lattice_out:
+            raise NotImplementedError("snapshots are returned as absolute positions")
+        out = _snapshots(cosmo, snapshots, a0, a1, n_steps, dg, ckpt, N, lp, v)
+    else:
+        out = (lp, v) if lattice_out else (lp.to_absolute()[None], v[None])
     if return_ctx:
         ctx = NbodyCtx(plan=plan, init_mesh=spec, n_steps=n_steps, dg=dg, alphas=alphas, betas=betas, lpt_s=lpt_s,
                        lpt_order=int(lpt_order), paint_order=int(paint_order), ckpt=ckpt, cosmo=cosmo, a0=a0, a1=a1,
                        integrator=integrator)
         return out, ctx
     return out
+
+
+def _snapshots(cosmo, snapshots, a0, a1, n_steps, dg, ckpt, N, lp_final, v_final):
+    """diffrax SaveAt(ts=...) on the Euler solution (nbody.py:990-997): linear interpolation between the step states.
+    Step state i is rebuilt from the checkpoint (x'_i - v_i dg/2, v_i); the last one is the returned state."""
+    g0, g1 = float(a2g(cosmo, a0)), float(a2g(cosmo, a1))
+    if isinstance(snapshots, int):
+        ts = np.linspace(g0, g1, snapshots)
+    else:
+        ts = np.atleast_1d(a2g(cosmo, np.asarray(snapshots, dtype=np.float64)))
+    tgrid = [g0]
+    for _ in range(n_steps):
+        tgrid.append(g1 if tgrid[-1] + dg > g1 - 1e-10 else tgrid[-1] + dg)
+    lat = lp_final.lattice(torch.float64)
+
+    def state(i):
+        if i == n_steps:
+            return lp_final.disp.double(), v_final.double()
+        xs = ckpt[i * 6 * N: i * 6 * N + 3 * N].view(N, 3).double()
+        vs = ckpt[i * 6 * N + 3 * N: (i + 1) * 6 * N].view(N, 3).double()
+        return xs - vs * (dg / 2), vs
+
+    pos_out, vel_out = [], []
+    for t in ts:
+        i = int(np.clip(np.searchsorted(tgrid, t, side="right") - 1, 0, n_steps - 1))
+        th = (t - tgrid[i]) / (tgrid[i + 1] - tgrid[i])
+        (x0, v0), (x1, v1) = state(i), state(i + 1)
+        pos_out.append(lat + x0 + (x1 - x0) * th)
+        vel_out.append((v0 + (v1 - v0) * th).float())
+    return torch.stack(pos_out), torch.stack(vel_out)
 
 
 def nbody_bf_vjp(ctx, pos_bar, vel_bar):

@@ -635,8 +635,9 @@ def euler_times(g0, g1, dg, n_steps):
 
 def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order=2, lpt_order=2, paint_deconv=False,
              grad_fd=np.inf, lap_fd=np.inf, snapshots=None, alpha_fn=alpha_bf, return_traj=False):
-    """nbody.py:967-1002 with snapshots=None (SaveAt(t1=True) -> leading axis of 1)."""
-    assert snapshots is None or (isinstance(snapshots, int) and snapshots <= 1)
+    """nbody.py:967-1002.  snapshots=None -> SaveAt(t1=True) (leading axis of 1); an int > 1 -> SaveAt(ts=linspace(g0,
+    g1, n)); a list of scale factors -> SaveAt(ts=a2g(list)): diffrax interpolates the Euler solution linearly
+    between step states."""
     n_steps = int(n_steps)
     g0 = float(a2g(cosmo, a0))
     g1 = float(a2g(cosmo, a1))
@@ -652,7 +653,17 @@ def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order=2, lpt_
         dt = ts[i + 1] - ts[i]
         state = tuple(y + v * dt for y, v in zip(state, d))
         traj.append(state)
-    out = (state[0][None], state[1][None])
+    if snapshots is None or (isinstance(snapshots, int) and snapshots <= 1):
+        out = (state[0][None], state[1][None])
+    else:
+        tq = np.linspace(g0, g1, snapshots) if isinstance(snapshots, int) else np.atleast_1d(a2g(cosmo, np.asarray(snapshots, dtype=float)))
+        ps, vs = [], []
+        for t in tq:
+            i = int(np.clip(np.searchsorted(ts, t, side="right") - 1, 0, n_steps - 1))
+            th = (t - ts[i]) / (ts[i + 1] - ts[i])
+            ps.append(traj[i][0] + (traj[i + 1][0] - traj[i][0]) * th)
+            vs.append(traj[i][1] + (traj[i + 1][1] - traj[i][1]) * th)
+        out = (np.stack(ps), np.stack(vs))
     return (out, traj, ts, dg) if return_traj else out
 
 

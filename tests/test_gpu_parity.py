@@ -346,3 +346,18 @@ def test_lpt_vjp_standalone(nb):
     assert rel_l2(to_np(mb_g), mb_o) < 1e-5
     for k in ("g", "g2", "dg2dg"):
         assert np.isclose(sb_g[k], sb_o[k], rtol=1e-4, atol=1e-4 * abs(sb_o["g"])), k
+
+
+@pytest.mark.parametrize("snapshots", [3, [0.3, 0.55, 1.0]])
+def test_nbody_bf_snapshots(nb, snapshots):
+    """SaveAt(ts=...) (nbody.py:990-997): linear interpolation of the Euler solution between steps."""
+    from montecosmo_amd import bricks
+    n = 16
+    shape = (n, n, n)
+    spec = _ics(n, rms=1.0)
+    pos = bricks.regular_pos(shape)
+    p_o, v_o = o.nbody_bf(obg.Planck18(), spec.astype(np.complex128), pos, 0.1, 1., 4, snapshots=snapshots)
+    p_g, v_g = nb.nbody_bf(bricks.Planck18(), spec, pos, a0=0.1, a1=1., n_steps=4, snapshots=snapshots)
+    assert tuple(p_g.shape) == p_o.shape == (3, n ** 3, 3) and tuple(v_g.shape) == v_o.shape
+    assert rel_l2(to_np(p_g) - pos, p_o - pos) < 1e-5
+    assert rel_l2(to_np(v_g), v_o) < 1e-5
