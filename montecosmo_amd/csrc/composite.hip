@@ -422,7 +422,7 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *v
                                double *alpha_bar, double *beta_bar) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, pos_in && vel_in && force_meshes && pos_bar && vel_bar, MCPM_E_ARG, "mcpm_bullfrog_step_vjp_f32: null buffer");
-    MCPM_REQUIRE(p, paint_order == 1 || paint_order == 2, MCPM_E_ORDER, "mcpm_bullfrog_step_vjp_f32: paint_order must be 1 or 2");
+    MCPM_REQUIRE(p, paint_order >= 1 && paint_order <= 4, MCPM_E_ORDER, "mcpm_bullfrog_step_vjp_f32: paint_order must be 1..4");
     MCPM_TRY(ensure_pscratch(p));
     const int64_t N = p->Np, M = p->M;
     float *Fb = p->pscratch + 6 * N;
@@ -445,7 +445,7 @@ int mcpm_step_adjoint_particles_f32(mcpm_plan *p, const float *pos_in, const flo
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, pos_in && vel_in && force_meshes && rho_bar && pos_bar && vel_bar, MCPM_E_ARG,
                  "mcpm_step_adjoint_particles_f32: null buffer");
-    MCPM_REQUIRE(p, paint_order == 1 || paint_order == 2, MCPM_E_ORDER, "mcpm_step_adjoint_particles_f32: paint_order must be 1 or 2");
+    MCPM_REQUIRE(p, paint_order >= 1 && paint_order <= 4, MCPM_E_ORDER, "mcpm_step_adjoint_particles_f32: paint_order must be 1..4");
     const int64_t N = p->Np, M = p->M;
     const float a = (float)alpha, b = (float)beta, t = (float)tau;
     dim3 grid, block;
@@ -464,12 +464,14 @@ int mcpm_step_adjoint_particles_f32(mcpm_plan *p, const float *pos_in, const flo
     }
     double *slots = p->reduce + (MCPM_NREDUCE - 2 * MCPM_NSLOT);
     MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 2 * MCPM_NSLOT, p->stream));
-    if (paint_order == 2)
-        step_adjoint_kernel<2><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b,
-                                                              t, slots, fb_next, p->hint_beta, p->hint_tau);
-    else
-        step_adjoint_kernel<1><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b,
-                                                              t, slots, fb_next, p->hint_beta, p->hint_tau);
+#define ADJ(OR)                                                                                                                   \
+    step_adjoint_kernel<OR><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
+                                                           slots, fb_next, p->hint_beta, p->hint_tau)
+    if (paint_order == 2) ADJ(2);
+    else if (paint_order == 1) ADJ(1);
+    else if (paint_order == 3) ADJ(3);
+    else ADJ(4);
+#undef ADJ
     MCPM_LAUNCH_CHECK(p, "step_adjoint_kernel");
     if (alpha_bar || beta_bar) {
         reduce_slots_kernel<<<1, MCPM_NSLOT, 0, p->stream>>>(slots, alpha_bar, beta_bar);
@@ -506,7 +508,7 @@ int mcpm_nbody_bf_f32(mcpm_plan *p, const float *init_mesh, int n_steps, const d
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, init_mesh && alpha && beta && lpt_scalars && pos_out && vel_out, MCPM_E_ARG, "mcpm_nbody_bf_f32: null argument");
     MCPM_REQUIRE(p, n_steps >= 1, MCPM_E_ARG, "mcpm_nbody_bf_f32: n_steps must be >= 1");
-    MCPM_REQUIRE(p, paint_order == 1 || paint_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_f32: paint_order must be 1 or 2");
+    MCPM_REQUIRE(p, paint_order >= 1 && paint_order <= 4, MCPM_E_ORDER, "mcpm_nbody_bf_f32: paint_order must be 1..4");
     const int64_t N = p->Np, M = p->M;
     auto state_x = [&](int i) { return ckpt + (int64_t)i * 6 * N; };
     auto state_v = [&](int i) { return ckpt + (int64_t)i * 6 * N + 3 * N; };
@@ -533,7 +535,7 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     MCPM_REQUIRE(p, init_mesh && alpha && beta && lpt_scalars && ckpt && pos_bar && vel_bar && init_mesh_bar, MCPM_E_ARG,
                  "mcpm_nbody_bf_vjp_f32: null argument");
     MCPM_REQUIRE(p, n_steps >= 1 && 2 * n_steps + 3 <= MCPM_NREDUCE - 2 * MCPM_NSLOT, MCPM_E_ARG, "mcpm_nbody_bf_vjp_f32: bad n_steps");
-    MCPM_REQUIRE(p, paint_order == 1 || paint_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: paint_order must be 1 or 2");
+    MCPM_REQUIRE(p, paint_order >= 1 && paint_order <= 4, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: paint_order must be 1..4");
     MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: lpt_order must be 1 or 2");
     const int64_t N = p->Np, M = p->M;
     MCPM_TRY(ensure_pscratch(p));

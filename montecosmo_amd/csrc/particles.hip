@@ -48,6 +48,20 @@ __global__ __launch_bounds__(256) void paint_atomic_kernel(Geom g, const float *
         atomicAdd(mesh + s.xo[0] + s.yo[0] + s.zo[0], wt);
         return;
     }
+    if (ORDER >= 3) {
+        constexpr int NPG = ORDER < 3 ? 3 : ORDER;
+        float wx[NPG], wy[NPG], wz[NPG], dd[NPG];
+        axis_weights<NPG, false>(f[0], wx, dd);
+        axis_weights<NPG, false>(f[1], wy, dd);
+        axis_weights<NPG, false>(f[2], wz, dd);
+#pragma unroll
+        for (int a = 0; a < NPG; ++a)
+#pragma unroll
+            for (int b = 0; b < NPG; ++b)
+#pragma unroll
+                for (int e = 0; e < NPG; ++e) atomicAdd(mesh + s.xo[a] + s.yo[b] + s.zo[e], wt * wx[a] * wy[b] * wz[e]);
+        return;
+    }
     float kx[2] = {1.f - f[0], f[0]}, ky[2] = {1.f - f[1], f[1]}, kz[2] = {1.f - f[2], f[2]};
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -467,7 +481,7 @@ static int check_particles(mcpm_plan *p, const void *pos, int64_t n, int mode, i
     MCPM_REQUIRE(p, mode == MCPM_POS_ABSOLUTE || mode == MCPM_POS_LATTICE, MCPM_E_ARG, std::string(who) + ": bad pos_mode");
     MCPM_REQUIRE(p, mode != MCPM_POS_LATTICE || n == p->Np, MCPM_E_SHAPE,
                  std::string(who) + ": MCPM_POS_LATTICE needs n == px*py*pz");
-    MCPM_REQUIRE(p, order == 1 || order == 2, MCPM_E_ORDER, std::string(who) + ": only orders 1 (NGP) and 2 (CIC) are implemented");
+    MCPM_REQUIRE(p, order >= 1 && order <= 4, MCPM_E_ORDER, std::string(who) + ": assignment order must be 1 (NGP), 2 (CIC), 3 (TSC) or 4 (PCS)");
     return MCPM_OK;
 }
 
@@ -476,14 +490,22 @@ static int check_particles(mcpm_plan *p, const void *pos, int64_t n, int mode, i
         if (mode == MCPM_POS_LATTICE) {                    \
             if (order == 2) {                              \
                 CALL(MCPM_POS_LATTICE, 2);                 \
-            } else {                                       \
+            } else if (order == 1) {                       \
                 CALL(MCPM_POS_LATTICE, 1);                 \
+            } else if (order == 3) {                       \
+                CALL(MCPM_POS_LATTICE, 3);                 \
+            } else {                                       \
+                CALL(MCPM_POS_LATTICE, 4);                 \
             }                                              \
         } else {                                           \
             if (order == 2) {                              \
                 CALL(MCPM_POS_ABSOLUTE, 2);                \
-            } else {                                       \
+            } else if (order == 1) {                       \
                 CALL(MCPM_POS_ABSOLUTE, 1);                \
+            } else if (order == 3) {                       \
+                CALL(MCPM_POS_ABSOLUTE, 3);                \
+            } else {                                       \
+                CALL(MCPM_POS_ABSOLUTE, 4);                \
             }                                              \
         }                                                  \
     } while (0)

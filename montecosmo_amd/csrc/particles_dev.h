@@ -36,21 +36,39 @@ __device__ __forceinline__ void lattice_q(int ip, int n, int p, int same, int &q
     }
 }
 
-// Base cell (unwrapped) and fraction along one axis.  t = qf + d is the coordinate relative to qi.
-// ORDER 2: c = qi + floor(t), f = t - floor(t) in [0,1].
-// ORDER 1: c = round-half-even(qi + t), f unused (0).
+// Base cell id0 (unwrapped, before the stencil shift) and offset f = pos - id0 along one axis (nbody.py:375).
+// t = qf + d is the coordinate relative to qi.
+// even ORDER (2 CIC, 4 PCS): id0 = floor, f in [0,1].   odd ORDER (1 NGP, 3 TSC): id0 = round-half-even, f in [-1/2,1/2].
 template <int ORDER>
 __device__ __forceinline__ void axis_cell(int qi, float t, int &c, float &f) {
     float fl = floorf(t);
     float fr = t - fl;
     int b = qi + (int)fl;
-    if (ORDER == 2) {
+    if (ORDER % 2 == 0) {
         c = b;
         f = fr;
     } else {
-        c = b + ((fr > 0.5f || (fr == 0.5f && (b & 1))) ? 1 : 0);
-        f = 0.f;
+        const int up = (fr > 0.5f || (fr == 0.5f && (b & 1))) ? 1 : 0;
+        c = b + up;
+        f = ORDER == 1 ? 0.f : fr - (float)up;
     }
+}
+
+// 1-D assignment kernels of nbody.py:239-246 at s = idx - pos, and d/dpos K(idx - pos) = -k'(|s|) sign(s)
+// (sign(0) = 0, as jax differentiates |s|).
+template <int ORDER>
+__device__ __forceinline__ float kern(float s) {
+    const float u = fabsf(s);
+    if (ORDER == 3) return u <= 0.5f ? 0.75f - u * u : 0.5f * (1.5f - u) * (1.5f - u);
+    return u <= 1.f ? (4.f - 6.f * u * u + 3.f * u * u * u) * (1.f / 6.f) : (2.f - u) * (2.f - u) * (2.f - u) * (1.f / 6.f);
+}
+template <int ORDER>
+__device__ __forceinline__ float dkern(float s) {
+    const float u = fabsf(s), sg = s > 0.f ? 1.f : (s < 0.f ? -1.f : 0.f);
+    float kp;
+    if (ORDER == 3) kp = u <= 0.5f ? -2.f * u : -(1.5f - u);
+    else kp = u <= 1.f ? (-12.f * u + 9.f * u * u) * (1.f / 6.f) : -0.5f * (2.f - u) * (2.f - u);
+    return -kp * sg;
 }
 
 // Thread -> particle mapping.
@@ -105,33 +123,58 @@ __device__ __forceinline__ void locate(const Geom &g, const PIdx &pi, P3 d, int 
     axis_cell<ORDER>(qz, fz + d.z, c[2], f[2]);
 }
 
-// Flat mesh offsets of the 2x2x2 (CIC) or single (NGP) stencil, periodic.
+// Flat mesh offsets of the ORDER^3 stencil (NGP 1, CIC 2, TSC 3, PCS 4 points per axis), periodic.  The stencil
+// starts at id0 - (ORDER-1)/2 (nbody.py:376).
 template <int ORDER>
 struct Stencil {
-    int64_t xo[2], yo[2];
-    int zo[2];
+    static constexpr int NP = ORDER < 2 ? 2 : ORDER;
+    int64_t xo[NP], yo[NP];
+    int zo[NP];
     __device__ __forceinline__ Stencil(const Geom &g, const int (&c)[3]) {
-        // slab mode: x is not periodic on the ghost-extended mesh; clamp (only particles displaced beyond the
-        // ghost width are affected, see DESIGN.md "Multi-GPU")
-        int x0 = g.xslab ? min(max(c[0], 0), g.nx - ORDER) : wrapi(c[0], g.nx);
-        int y0 = wrapi(c[1], g.ny), z0 = wrapi(c[2], g.nz);
-        xo[0] = (int64_t)x0 * g.ny * g.nz;
-        yo[0] = (int64_t)y0 * g.nz;
-        zo[0] = z0;
-        if (ORDER == 2) {
-            int x1 = x0 + 1 == g.nx ? 0 : x0 + 1;
-            int y1 = y0 + 1 == g.ny ? 0 : y0 + 1;
-            int z1 = z0 + 1 == g.nz ? 0 : z0 + 1;
-            xo[1] = (int64_t)x1 * g.ny * g.nz;
-            yo[1] = (int64_t)y1 * g.nz;
-            zo[1] = z1;
+        if (ORDER <= 2) {
+            // slab mode: x is not periodic on the ghost-extended mesh; clamp (only particles displaced beyond the
+            // ghost width are affected, see DESIGN.md "Multi-GPU")
+            int x0 = g.xslab ? min(max(c[0], 0), g.nx - ORDER) : wrapi(c[0], g.nx);
+            int y0 = wrapi(c[1], g.ny), z0 = wrapi(c[2], g.nz);
+            xo[0] = (int64_t)x0 * g.ny * g.nz;
+            yo[0] = (int64_t)y0 * g.nz;
+            zo[0] = z0;
+            if (ORDER == 2) {
+                int x1 = x0 + 1 == g.nx ? 0 : x0 + 1;
+                int y1 = y0 + 1 == g.ny ? 0 : y0 + 1;
+                int z1 = z0 + 1 == g.nz ? 0 : z0 + 1;
+                xo[1] = (int64_t)x1 * g.ny * g.nz;
+                yo[1] = (int64_t)y1 * g.nz;
+                zo[1] = z1;
+            } else {
+                xo[1] = xo[0];
+                yo[1] = yo[0];
+                zo[1] = zo[0];
+            }
         } else {
-            xo[1] = xo[0];
-            yo[1] = yo[0];
-            zo[1] = zo[0];
+            constexpr int SH = -((ORDER - 1) / 2);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int x = g.xslab ? min(max(c[0] + SH + j, 0), g.nx - 1) : wrapi(c[0] + SH + j, g.nx);
+                xo[j] = (int64_t)x * g.ny * g.nz;
+                yo[j] = (int64_t)wrapi(c[1] + SH + j, g.ny) * g.nz;
+                zo[j] = wrapi(c[2] + SH + j, g.nz);
+            }
         }
     }
 };
+
+// per-axis weights (and d/dpos) of the ORDER >= 3 stencils from the offsets f = pos - id0
+template <int ORDER, bool GRAD>
+__device__ __forceinline__ void axis_weights(float f, float (&w)[ORDER], float (&dw)[ORDER]) {
+    constexpr int SH = -((ORDER - 1) / 2);
+#pragma unroll
+    for (int j = 0; j < ORDER; ++j) {
+        const float sj = (float)(SH + j) - f;
+        w[j] = kern<ORDER>(sj);
+        dw[j] = GRAD ? dkern<ORDER>(sj) : 0.f;
+    }
+}
 
 // Trilinear value and gradient of one mesh at (cell, frac).  d/dpos of K(c - x) = sign(c - x):
 // -1 for the lower corner (0 when the fraction is exactly 0, jax's sign(0) = 0), +1 for the upper.
@@ -141,6 +184,37 @@ __device__ __forceinline__ void interp(const float *__restrict__ m, const Stenci
     if (ORDER == 1) {
         val = m[s.xo[0] + s.yo[0] + s.zo[0]];
         gx = gy = gz = 0.f;
+        return;
+    }
+    if (ORDER >= 3) {
+        constexpr int NPG = ORDER < 3 ? 3 : ORDER;
+        float wx[NPG], wy[NPG], wz[NPG], dx[NPG], dy[NPG], dz[NPG];
+        axis_weights<NPG, GRAD>(f[0], wx, dx);
+        axis_weights<NPG, GRAD>(f[1], wy, dy);
+        axis_weights<NPG, GRAD>(f[2], wz, dz);
+        float v = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+        for (int a = 0; a < NPG; ++a)
+#pragma unroll
+            for (int b = 0; b < NPG; ++b) {
+                float r0 = 0.f, r1 = 0.f;  // sum over z of m*wz and m*dz
+#pragma unroll
+                for (int e = 0; e < NPG; ++e) {
+                    const float mv = m[s.xo[a] + s.yo[b] + s.zo[e]];
+                    r0 += mv * wz[e];
+                    if (GRAD) r1 += mv * dz[e];
+                }
+                v += wx[a] * wy[b] * r0;
+                if (GRAD) {
+                    ax += dx[a] * wy[b] * r0;
+                    ay += wx[a] * dy[b] * r0;
+                    az += wx[a] * wy[b] * r1;
+                }
+            }
+        val = v;
+        gx = ax;
+        gy = ay;
+        gz = az;
         return;
     }
     // z and z+1 are adjacent in memory: one 8-byte gather per (x, y) corner instead of two 4-byte ones (the

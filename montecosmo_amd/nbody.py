@@ -252,8 +252,8 @@ def rectangular_hat(kvec, order: int = 2):
 def _check_kernel(kernel_type, order):
     if kernel_type != "rectangular":
         raise NotImplementedError("only kernel_type='rectangular' is implemented on the HIP path")
-    if order not in (1, 2):
-        raise NotImplementedError("only orders 1 (NGP) and 2 (CIC) are implemented on the HIP path")
+    if order not in (1, 2, 3, 4):
+        raise ValueError("order must be 1 (NGP), 2 (CIC), 3 (TSC) or 4 (PCS)")
 
 
 def _weights_args(weights, n):

@@ -283,8 +283,8 @@ def test_errors_are_loud(nb):
     from montecosmo_amd._lib import McpmError
     with pytest.raises(McpmError):
         nb.Plan((16, 16, 15))          # odd nz
-    with pytest.raises(NotImplementedError):
-        nb.paint(np.zeros((4, 3), np.float32), (8, 8, 8), order=3)
+    with pytest.raises(ValueError):
+        nb.paint(np.zeros((4, 3), np.float32), (8, 8, 8), order=5)
     with pytest.raises(ValueError):
         nb.invlaplace_hat(nb.rfftk((8, 8, 8)), fd_order=3)
 
@@ -361,3 +361,55 @@ def test_nbody_bf_snapshots(nb, snapshots):
     assert tuple(p_g.shape) == p_o.shape == (3, n ** 3, 3) and tuple(v_g.shape) == v_o.shape
     assert rel_l2(to_np(p_g) - pos, p_o - pos) < 1e-5
     assert rel_l2(to_np(v_g), v_o) < 1e-5
+
+
+@pytest.mark.parametrize("order", [3, 4])
+def test_tsc_pcs_paint_read_and_vjps(nb, order):
+    """Higher-order assignment (TSC, PCS; nbody.py:243-244): paint, read, cell indices and both VJPs, absolute and
+    lattice positions."""
+    shape = (16, 12, 20)
+    rng = np.random.default_rng(40 + order)
+    N = 6000
+    pos = random_pos(20, N, 41, spread=1.5)
+    w = rng.standard_normal(N).astype(np.float32)
+    p64, w64 = pos.astype(np.float64), w.astype(np.float64)
+    assert np.array_equal(to_np(nb.cell_index(pos, shape, order)), o.cell_index(p64, shape, order))
+    assert rel_l2(to_np(nb.paint(pos, shape, w, order)), o.paint(p64, shape, w64, order)) < 2e-6
+    assert abs(float(nb.paint(pos, shape, 1., order).double().sum()) / N - 1) < 1e-6
+    mesh = rng.standard_normal(shape).astype(np.float32)
+    assert rel_l2(to_np(nb.read(pos, mesh, order)), o.read(p64, mesh.astype(np.float64), order)) < 2e-6
+    mb = rng.standard_normal(shape).astype(np.float32)
+    pb, wb = nb.paint_vjp(pos, shape, w, mb, order)
+    pb_o, wb_o = o.paint_vjp(p64, shape, w64, mb.astype(np.float64), order)
+    assert rel_l2(to_np(pb), pb_o) < 1e-5 and rel_l2(to_np(wb), wb_o) < 1e-5
+    ob = rng.standard_normal(N).astype(np.float32)
+    pb, meshb = nb.read_vjp(pos, mb, ob, order)
+    pb_o, meshb_o = o.read_vjp(p64, mb.astype(np.float64), ob.astype(np.float64), order)
+    assert rel_l2(to_np(pb), pb_o) < 1e-5 and rel_l2(to_np(meshb), meshb_o) < 1e-5
+    # lattice displacements
+    n = 16
+    disp = (rng.standard_normal((n ** 3, 3)) * 1.5).astype(np.float32)
+    lp = nb.LatticePos(disp, (n, n, n))
+    pos64 = o.regular_pos((n, n, n)) + disp.astype(np.float64)
+    assert rel_l2(to_np(nb.paint(lp, (n, n, n), order=order)), o.paint(pos64, (n, n, n), order=order)) < 2e-6
+    assert rel_l2(to_np(nb.pm_forces(lp, (n, n, n), order)), o.pm_forces(pos64, (n, n, n), order)) < 1e-5
+
+
+@pytest.mark.parametrize("order", [3, 4])
+def test_nbody_bf_tsc_pcs(nb, order):
+    from montecosmo_amd import bricks
+    n, n_steps = 16, 3
+    shape = (n, n, n)
+    spec = _ics(n, rms=1.0)
+    pos = bricks.regular_pos(shape)
+    cos_o, cos_g = obg.Planck18(), bricks.Planck18()
+    p_o, v_o = o.nbody_bf(cos_o, spec.astype(np.complex128), pos, 0.1, 1., n_steps, paint_order=order)
+    (lp, vel), ctx = nb.nbody_bf(cos_g, spec, pos, a0=0.1, a1=1., n_steps=n_steps, paint_order=order, lattice_out=True,
+                                 return_ctx=True)
+    assert rel_l2(to_np(lp.disp), p_o[0] - pos) < 1e-5 and rel_l2(to_np(vel), v_o[0]) < 1e-5
+    rng = np.random.default_rng(7)
+    xb, vb = rng.standard_normal((n ** 3, 3)).astype(np.float32), rng.standard_normal((n ** 3, 3)).astype(np.float32)
+    mb_o, _ = o.nbody_bf_vjp(cos_o, spec.astype(np.complex128), pos, xb.astype(np.float64), vb.astype(np.float64), 0.1, 1.,
+                             n_steps, paint_order=order)
+    mb_g, _ = nb.nbody_bf_vjp(ctx, xb, vb)
+    assert rel_l2(to_np(mb_g), mb_o) < 1e-4
