@@ -170,6 +170,11 @@ int mcpm_pm_forces_f32(mcpm_plan *plan, const float *pos, int64_t n, int pos_mod
 /* pm_forces with mesh = half-spectrum (not modified). */
 int mcpm_pm_forces_spec_f32(mcpm_plan *plan, const float *spec, const float *pos, int64_t n, int pos_mode,
                             int order, int lap_fd, int grad_fd, float kcut, float *forces);
+/* VJP of pm_forces (spectral kernels, no deconvolution / smoothing).  spec == NULL: painted case (mesh = shape
+   tuple), pos_bar [N][3] carries the read and the paint dependence.  spec != NULL: pos_bar from the read, and
+   spec_bar = cotangent of the half-spectrum (real-pair convention, irfftn multiplicity weights included). */
+int mcpm_pm_forces_vjp_f32(mcpm_plan *plan, const float *spec, const float *pos, int64_t n, int pos_mode, int order,
+                           const float *forces_bar, float *pos_bar, float *spec_bar);
 /* pm_forces2 (2LPT source, nbody.py:607-631). */
 int mcpm_pm_forces2_f32(mcpm_plan *plan, const float *spec, const float *pos, int64_t n, int pos_mode,
                         int order, int lap_fd, int grad_fd, float *forces);

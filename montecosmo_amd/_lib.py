@@ -52,6 +52,7 @@ SIGNATURES = {
     "mcpm_slab_zinv": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int]),
     "mcpm_pm_forces_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f32p]),
     "mcpm_pm_forces_spec_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f32p]),
+    "mcpm_pm_forces_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
     "mcpm_pm_forces2_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "mcpm_plan_force_meshes": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mcpm_drift_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_float, _f32p]),

@@ -245,6 +245,16 @@ static int delta2_to_force_meshes(mcpm_plan *p, int lap_fd, int grad_fd, float *
     return spec_to_force_meshes(p, p->spec1, lap_fd, grad_fd, 0.f, 0, fm);
 }
 
+// variable-size float scratch (pm_forces_vjp with arbitrary particle counts)
+static int ensure_pscratch_n(mcpm_plan *p, int64_t nfloats) {
+    if (p->vscratch && p->vscratch_n >= nfloats) return MCPM_OK;
+    if (p->vscratch) (void)hipFree(p->vscratch);
+    p->vscratch = nullptr;
+    if (hipMalloc((void **)&p->vscratch, sizeof(float) * nfloats) != hipSuccess) return mcpm_fail(p, MCPM_E_NOMEM, "particle scratch");
+    p->vscratch_n = nfloats;
+    return MCPM_OK;
+}
+
 static int ensure_pscratch(mcpm_plan *p) {
     if (!p->pscratch && hipMalloc((void **)&p->pscratch, sizeof(float) * 9 * p->Np) != hipSuccess)
         return mcpm_fail(p, MCPM_E_NOMEM, "adjoint particle scratch");
@@ -336,6 +346,40 @@ int mcpm_pm_forces_spec_f32(mcpm_plan *p, const float *spec, const float *pos, i
     MCPM_TRY(spec_to_force_meshes(p, spec, lap_fd, grad_fd, kcut, 0, p->fmesh));
     MCPM_TRY(mcpm_read_f32(p, pos, n, mode, p->fmesh, 3, order, forces));
     return MCPM_OK;
+}
+
+// VJP of pm_forces (fd_order = inf, no deconvolution / smoothing).  spec == NULL: the particles were painted
+// (mesh = shape tuple) and pos_bar carries both the read and the paint dependence; otherwise spec_bar (plain
+// half-spectrum, real-pair convention with the irfftn multiplicity weights) is written as well.
+int mcpm_pm_forces_vjp_f32(mcpm_plan *p, const float *spec, const float *pos, int64_t n, int mode, int order,
+                           const float *forces_bar, float *pos_bar, float *spec_bar) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, pos && forces_bar && pos_bar, MCPM_E_ARG, "mcpm_pm_forces_vjp_f32: null buffer");
+    MCPM_REQUIRE(p, spec == nullptr || spec_bar != nullptr, MCPM_E_ARG, "mcpm_pm_forces_vjp_f32: spec given without spec_bar");
+    const int64_t M = p->M;
+    float *fm = p->fmesh, *fb = p->fmesh + 3 * M, *tmp = p->fmesh + 6 * M;  // force meshes, their cotangents, scratch
+    // forward force meshes
+    if (spec) {
+        MCPM_TRY(spec_to_force_meshes(p, spec, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, fm));
+    } else {
+        MCPM_TRY(mcpm_paint_f32(p, pos, n, mode, nullptr, 1, 1.f, order, p->rho, 0));
+        MCPM_TRY(mcpm_force_meshes_f32(p, p->rho, fm));
+    }
+    // read: pos_bar = sum_c F_bar_c grad f_c ; mesh cotangents f_bar_c = paint(pos, F_bar_c)
+    MCPM_TRY(mcpm_read_vjp_pos_f32(p, pos, n, mode, fm, 3, order, forces_bar, pos_bar));
+    MCPM_TRY(mcpm_paint3_f32(p, pos, n, mode, forces_bar, order, fb, 0));
+    if (spec) {
+        if (spec_custom(p, spec, MCPM_FD_INF, MCPM_FD_INF)) return mcpm_fftpm_spec_meshes_vjp(p, fb, spec_bar, 3);
+        MCPM_TRY(mcpm_fft_r2c(p, fb, p->spec, 3));
+        return mcpm_kspace_force_vjp_f32(p, p->spec, spec_bar, 1.f / (float)M, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 1, 0, 0);
+    }
+    // painted: rho_bar = adjoint Poisson solve, then the paint's dependence on pos
+    MCPM_TRY(mcpm_force_meshes_vjp_f32(p, fb, p->rho));
+    MCPM_TRY(ensure_pscratch_n(p, 3 * n));
+    float *pb2 = p->vscratch;
+    MCPM_TRY(mcpm_paint_vjp_f32(p, pos, n, mode, nullptr, 1, 1.f, order, p->rho, pb2, nullptr));
+    (void)tmp;
+    return axpby(p, pos_bar, pb2, 3 * n, 1.f, 1.f, pos_bar);
 }
 
 int mcpm_pm_forces2_f32(mcpm_plan *p, const float *spec, const float *pos, int64_t n, int mode, int order, int lap_fd,

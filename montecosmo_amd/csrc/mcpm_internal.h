@@ -74,6 +74,8 @@ struct mcpm_plan {
     int *outlier_count;  // device counter (2 ints: live counter, copy of last)
     double *reduce;  // device accumulators for scalar cotangents (MCPM_NREDUCE doubles)
     float *pscratch; // 9*Np floats, allocated on first VJP (adjoint state + force cotangent)
+    float *vscratch;  // variable-size particle scratch (pm_forces_vjp)
+    int64_t vscratch_n;
     float *tw[3];    // twiddle tables exp(-2 pi i j / n) of the hand-written FFT, per axis (x, y, z)
 
     // optional profile: HIP events recorded on the plan's stream around every leaf stage

@@ -100,6 +100,8 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->outliers = p->outlier_count = nullptr;
     p->reduce = nullptr;
     p->pscratch = nullptr;
+    p->vscratch = nullptr;
+    p->vscratch_n = 0;
     p->tw[0] = p->tw[1] = p->tw[2] = nullptr;
     p->profiling = 0;
     std::call_once(g_rocfft_once, [] { rocfft_setup(); });
@@ -149,6 +151,7 @@ int mcpm_plan_destroy(mcpm_plan *p) {
     (void)hipFree(p->outlier_count);
     (void)hipFree(p->reduce);
     (void)hipFree(p->pscratch);
+    (void)hipFree(p->vscratch);
     for (int a = 0; a < 3; ++a) (void)hipFree(p->tw[a]);
     delete p;
     return MCPM_OK;

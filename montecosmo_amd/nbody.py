@@ -23,7 +23,7 @@ from .utils import safe_div, ch2rshape, r2chshape, scale_shape  # noqa: F401 (re
 
 __all__ = [
     "rfftk", "fftk", "invlaplace_hat", "gradient_hat", "gaussian_hat", "rectangular", "rectangular_hat",
-    "paint", "read", "paint_vjp", "read_vjp", "pm_forces", "pm_forces2", "lpt", "lpt_vjp",
+    "paint", "read", "paint_vjp", "read_vjp", "pm_forces", "pm_forces_vjp", "pm_forces2", "lpt", "lpt_vjp",
     "a2g", "a2g2", "a2f", "a2f2", "a2dg2dg", "g2a", "g2g2", "g2f", "g2f2", "g2dg2dg", "a2chi", "chi2a",
     "bullfrog_vf", "nbody_bf", "nbody_bf_vjp", "alpha_bf", "alpha_fpm", "LatticePos", "get_plan",
     "deconv_paint", "interlace", "nufft", "nufft_vjp",
@@ -443,6 +443,23 @@ def pm_forces(pos, mesh, read_order: int = 2, paint_deconv: bool = False, grad_f
     out = torch.empty((n, 3), dtype=torch.float32, device=p.device)
     plan.call("mcpm_pm_forces_spec_f32", _ptr(spec), _ptr(p), n, mode, read_order, _fd(lap_fd), _fd(grad_fd), kc, _ptr(out))
     return out
+
+
+def pm_forces_vjp(pos, mesh, forces_bar, read_order: int = 2):
+    """VJP of pm_forces (spectral kernels): -> (pos_bar (N,3), mesh_bar).  `mesh` a shape tuple (painted case,
+    mesh_bar is None and pos_bar includes the dependence through the painted density) or a half-spectrum (mesh_bar
+    in the real-pair convention)."""
+    if isinstance(mesh, tuple):
+        shape, spec = tuple(int(s) for s in mesh), None
+    else:
+        spec = _c64(mesh)
+        shape = ch2rshape(spec.shape)
+    plan, p, n, mode = _pos_args(pos, shape)
+    fb = _f32(forces_bar, (n, 3))
+    pos_bar = torch.empty((n, 3), dtype=torch.float32, device=p.device)
+    spec_bar = torch.empty(tuple(spec.shape), dtype=torch.complex64, device=p.device) if spec is not None else None
+    plan.call("mcpm_pm_forces_vjp_f32", _ptr(spec), _ptr(p), n, mode, int(read_order), _ptr(fb), _ptr(pos_bar), _ptr(spec_bar))
+    return pos_bar, spec_bar
 
 
 def pm_forces2(pos, mesh, read_order: int = 2, grad_fd=np.inf, lap_fd=np.inf):

@@ -413,3 +413,21 @@ def test_nbody_bf_tsc_pcs(nb, order):
                              n_steps, paint_order=order)
     mb_g, _ = nb.nbody_bf_vjp(ctx, xb, vb)
     assert rel_l2(to_np(mb_g), mb_o) < 1e-4
+
+
+@pytest.mark.parametrize("n", [16, 64])
+def test_pm_forces_vjp(nb, n):
+    """pm_forces_vjp, painted and spectrum cases (n = 64 runs the hand-written FFT), against the oracle's VJP."""
+    shape = (n, n, n)
+    rng = np.random.default_rng(50)
+    N = 20000
+    pos = rng.uniform(0, n, (N, 3)).astype(np.float32)
+    R = rng.standard_normal((N, 3)).astype(np.float32)
+    p64, R64 = pos.astype(np.float64), R.astype(np.float64)
+    pb, none = nb.pm_forces_vjp(pos, shape, R)
+    pb_o, _ = o.pm_forces_vjp(p64, shape, R64)
+    assert none is None and rel_l2(to_np(pb), pb_o) < 2e-5
+    spec = np.fft.rfftn(rng.standard_normal(shape)).astype(np.complex64)
+    pb, mb = nb.pm_forces_vjp(pos, spec, R)
+    pb_o, mb_o = o.pm_forces_vjp(p64, spec.astype(np.complex128), R64)
+    assert rel_l2(to_np(pb), pb_o) < 2e-5 and rel_l2(to_np(mb), mb_o) < 2e-5
