@@ -71,7 +71,7 @@ class Runner:
         self.vel_bar = torch.from_numpy(rng.standard_normal((N, 3), dtype=np.float32)).to(device)
         self.xb = torch.empty((N, 3), **f32)
         self.vb = torch.empty((N, 3), **f32)
-        self.sbar = torch.zeros((2 * K,), dtype=torch.float64, device=device)
+        self.sbar = torch.zeros((2 * K + 1,), dtype=torch.float64, device=device)
         self.init_state()
 
     def p(self, t):
@@ -103,7 +103,8 @@ class Runner:
             self.plan.call("mcpm_bullfrog_step_vjp_f32", self.p(self.states[i, 0]), self.p(self.states[i, 1]),
                            self.p(self.fmesh[i]), float(self.alphas[i]), float(self.betas[i]), float(tau), 2,
                            self.p(self.xb), self.p(self.vb), C.c_void_p(self.sbar.data_ptr() + 8 * i),
-                           C.c_void_p(self.sbar.data_ptr() + 8 * (K + i)))
+                           C.c_void_p(self.sbar.data_ptr() + 8 * (K + i)), 0.5 if i == K - 1 else 1.0,
+                           C.c_void_p(self.sbar.data_ptr() + 8 * 2 * K))
 
     def run(self, steps):
         self.forward(steps)
@@ -159,7 +160,7 @@ class SlabRunner:
         self.pos_bar = torch.from_numpy(rng.standard_normal((pm.Nl, 3), dtype=np.float32)).to(device)
         self.vel_bar = torch.from_numpy(rng.standard_normal((pm.Nl, 3), dtype=np.float32)).to(device)
         self.xb, self.vb = torch.empty((pm.Nl, 3), **f32), torch.empty((pm.Nl, 3), **f32)
-        self.sbar = torch.zeros((2 * K,), dtype=torch.float64, device=device)
+        self.sbar = torch.zeros((2 * K + 1,), dtype=torch.float64, device=device)
 
     def forward(self, steps):
         K = self.K
@@ -176,7 +177,8 @@ class SlabRunner:
             tau = self.dg / 2 if i == K - 1 else self.dg
             self.pm.step_vjp(self.states[i, 0], self.states[i, 1], self.f3s[i], self.alphas[i], self.betas[i], tau,
                              self.xb, self.vb, C.c_void_p(self.sbar.data_ptr() + 8 * i),
-                             C.c_void_p(self.sbar.data_ptr() + 8 * (K + i)))
+                             C.c_void_p(self.sbar.data_ptr() + 8 * (K + i)), 0.5 if i == K - 1 else 1.0,
+                             C.c_void_p(self.sbar.data_ptr() + 8 * 2 * K))
 
     def run(self, steps):
         self.forward(steps)

@@ -199,10 +199,12 @@ int mcpm_kick_drift_f32(mcpm_plan *plan, const float *pos_in, const float *vel_i
 int mcpm_bullfrog_step_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in, double alpha, double beta,
                            double tau, int paint_order, float *force_meshes, float *pos_out, float *vel_out);
 /* Adjoint of that step: pos_bar / vel_bar (cotangents of the step's outputs) are updated in place to the
-   cotangents of its inputs; alpha_bar / beta_bar are DEVICE double accumulators (may be NULL). */
+   cotangents of its inputs; alpha_bar / beta_bar are DEVICE double accumulators (may be NULL).  dg_bar (DEVICE,
+   may be NULL) accumulates the explicit dependence of the drift on the step size, <pos_bar_in, vel_out> * dtau_ddg
+   with dtau_ddg = d tau / d dg (1, or 0.5 on the last step). */
 int mcpm_bullfrog_step_vjp_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in, const float *force_meshes,
                                double alpha, double beta, double tau, int paint_order, float *pos_bar,
-                               float *vel_bar, double *alpha_bar, double *beta_bar);
+                               float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg, double *dg_bar);
 /* Optional chaining of consecutive adjoint steps: call this before the adjoint of step i with beta and tau of step
    i-1; the particle kernel then also writes step i-1's force cotangent beta'(v_bar + tau' x_bar), and the next
    mcpm_bullfrog_step_vjp_f32 call skips its own pass over the cotangents IF it is given the same pos_bar / vel_bar
@@ -213,7 +215,7 @@ int mcpm_plan_hint_next_adjoint(mcpm_plan *plan, double beta_next, double tau_ne
 int mcpm_step_adjoint_particles_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in,
                                     const float *force_meshes, const float *rho_bar, double alpha, double beta,
                                     double tau, int paint_order, float *pos_bar, float *vel_bar, double *alpha_bar,
-                                    double *beta_bar);
+                                    double *beta_bar, double dtau_ddg, double *dg_bar);
 int mcpm_lpt_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg,
                  int lap_fd, int grad_fd, float *dpos, float *vel);
 /* Lattice-point pieces of lpt (read_order = 1 at pos = regular_pos, nbody.py:984-985), exposed for the slab path:
@@ -239,7 +241,8 @@ int mcpm_nbody_bf_f32(mcpm_plan *plan, const float *init_mesh, int n_steps, cons
 int64_t mcpm_nbody_ckpt_floats(const mcpm_plan *plan, int n_steps, int lpt_order);
 /* Reverse sweep: cotangents of (pos_out, vel_out) -> init_mesh_bar (half-spectrum, real-pair convention
    dL = Re sum conj(bar) dz) and host scalar bars (may be NULL; forces a stream sync when given):
-   scalar_bars[0..n_steps) = alpha_bar, [n_steps..2 n_steps) = beta_bar, then {g_bar, g2_bar, dg2dg_bar}. */
+   scalar_bars[0..n_steps) = alpha_bar, [n_steps..2 n_steps) = beta_bar, then {g_bar, g2_bar, dg2dg_bar, dg_bar}
+   (2 n_steps + 4 doubles; dg_bar is the explicit dependence of the drifts on the step size). */
 int mcpm_nbody_bf_vjp_f32(mcpm_plan *plan, const float *init_mesh, int n_steps, const double *alpha,
                           const double *beta, double dg, const double *lpt_scalars, int lpt_order,
                           int paint_order, const float *ckpt, const float *pos_bar, const float *vel_bar,

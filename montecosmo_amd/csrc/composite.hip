@@ -73,23 +73,28 @@ __device__ __forceinline__ double wave_sum(double v) {
 #define MCPM_NSLOT 1024
 
 // sum the MCPM_NSLOT partial slots of the step adjoint into the two accumulators
-__global__ __launch_bounds__(MCPM_NSLOT) void reduce_slots_kernel(const double *__restrict__ slots, double *out0, double *out1) {
-    __shared__ double sh[2][MCPM_NSLOT / 64];
+__global__ __launch_bounds__(MCPM_NSLOT) void reduce_slots_kernel(const double *__restrict__ slots, double *out0, double *out1,
+                                                                  double *out2) {
+    __shared__ double sh[3][MCPM_NSLOT / 64];
     double a = wave_sum(slots[threadIdx.x]), b = wave_sum(slots[MCPM_NSLOT + threadIdx.x]);
+    double c = wave_sum(slots[2 * MCPM_NSLOT + threadIdx.x]);
     int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     if (l == 0) {
         sh[0][w] = a;
         sh[1][w] = b;
+        sh[2][w] = c;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double sa = 0., sb = 0.;
+        double sa = 0., sb = 0., sc = 0.;
         for (int i = 0; i < MCPM_NSLOT / 64; ++i) {
             sa += sh[0][i];
             sb += sh[1][i];
+            sc += sh[2][i];
         }
         if (out0) *out0 += sa;
         if (out1) *out1 += sb;
+        if (out2) *out2 += sc;
     }
 }
 
@@ -147,9 +152,9 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
                                                            const float *__restrict__ fm, const float *__restrict__ rho_bar,
                                                            int64_t M, float alpha, float beta, float tau,
                                                            double *slots, float *__restrict__ fb_next, float beta_next,
-                                                           float tau_next) {
+                                                           float tau_next, float dtau_ddg) {
     PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
-    double ra = 0., rb = 0.;
+    double ra = 0., rb = 0., rc = 0.;
     if (pi.valid) {
         const P3 d = load3(x, pi.i), vi = load3(v, pi.i);
         P3 xbi = load3(xb, pi.i), vbi = load3(vb, pi.i);
@@ -177,6 +182,11 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
         }
         ra = (double)(vt.x * vi.x + vt.y * vi.y + vt.z * vi.z);
         rb = (double)(vt.x * F[0] + vt.y * F[1] + vt.z * F[2]);
+        {   // explicit dependence of the drift x' += v_new tau on the step size: <x_bar_in, v_new> dtau/ddg
+            const P3 xin = load3(xb, pi.i);
+            const float vnx = alpha * vi.x + beta * F[0], vny = alpha * vi.y + beta * F[1], vnz = alpha * vi.z + beta * F[2];
+            rc = (double)(dtau_ddg * (xin.x * vnx + xin.y * vny + xin.z * vnz));
+        }
         const P3 vnew = {alpha * vt.x, alpha * vt.y, alpha * vt.z};
         store3(xb, pi.i, xbi);
         store3(vb, pi.i, vnew);
@@ -186,6 +196,33 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
     }
     const int slot = blockIdx.x % MCPM_NSLOT;
     block_add2(ra, rb, slots + slot, slots + MCPM_NSLOT + slot);
+    __syncthreads();
+    block_add2(rc, 0., slots + 2 * MCPM_NSLOT + slot, nullptr);
+}
+
+// *out += scale * sum_i a[i] b[i]  (a few thousand blocks: spread atomics are not needed)
+__global__ __launch_bounds__(256) void dot_scaled_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n,
+                                                         double scale, double *out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double r = i < n ? scale * (double)a[i] * (double)b[i] : 0.;
+    __shared__ double sh[4];
+    r = wave_sum(r);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0] + sh[1] + sh[2] + sh[3];
+        if (t != 0.) atomicAdd(out + 1 + (blockIdx.x & 255), t);
+    }
+}
+
+// folds the 256 spread partial sums behind *out into *out
+__global__ void fold256_kernel(double *out) {
+    double t = 0.;
+    for (int i = 0; i < 256; ++i) {
+        t += out[1 + i];
+        out[1 + i] = 0.;
+    }
+    out[0] += t;
 }
 
 __global__ void axpby_kernel(const float *__restrict__ x, const float *__restrict__ y, int64_t n, float a, float b,
@@ -463,7 +500,7 @@ int mcpm_bullfrog_step_f32(mcpm_plan *p, const float *pos_in, const float *vel_i
 
 int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes,
                                double alpha, double beta, double tau, int paint_order, float *pos_bar, float *vel_bar,
-                               double *alpha_bar, double *beta_bar) {
+                               double *alpha_bar, double *beta_bar, double dtau_ddg, double *dg_bar) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, pos_in && vel_in && force_meshes && pos_bar && vel_bar, MCPM_E_ARG, "mcpm_bullfrog_step_vjp_f32: null buffer");
     MCPM_REQUIRE(p, paint_order >= 1 && paint_order <= 4, MCPM_E_ORDER, "mcpm_bullfrog_step_vjp_f32: paint_order must be 1..4");
@@ -480,12 +517,13 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *v
     // adjoint of 3 C2R + k-space + R2C: rho_bar = C2R( (1/M) sum_c conj(m_c) R2C(f_bar_c) )
     MCPM_TRY(mcpm_force_meshes_vjp_f32(p, p->fmesh, p->rho));
     return mcpm_step_adjoint_particles_f32(p, pos_in, vel_in, force_meshes, p->rho, alpha, beta, tau, paint_order, pos_bar,
-                                           vel_bar, alpha_bar, beta_bar);
+                                           vel_bar, alpha_bar, beta_bar, dtau_ddg, dg_bar);
 }
 
 int mcpm_step_adjoint_particles_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes,
                                     const float *rho_bar, double alpha, double beta, double tau, int paint_order,
-                                    float *pos_bar, float *vel_bar, double *alpha_bar, double *beta_bar) {
+                                    float *pos_bar, float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg,
+                                    double *dg_bar) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, pos_in && vel_in && force_meshes && rho_bar && pos_bar && vel_bar, MCPM_E_ARG,
                  "mcpm_step_adjoint_particles_f32: null buffer");
@@ -506,19 +544,19 @@ int mcpm_step_adjoint_particles_f32(mcpm_plan *p, const float *pos_in, const flo
         p->fb_vb = vel_bar;
         p->hint_set = 0;
     }
-    double *slots = p->reduce + (MCPM_NREDUCE - 2 * MCPM_NSLOT);
-    MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 2 * MCPM_NSLOT, p->stream));
+    double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);
+    MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 3 * MCPM_NSLOT, p->stream));
 #define ADJ(OR)                                                                                                                   \
     step_adjoint_kernel<OR><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
-                                                           slots, fb_next, p->hint_beta, p->hint_tau)
+                                                           slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg)
     if (paint_order == 2) ADJ(2);
     else if (paint_order == 1) ADJ(1);
     else if (paint_order == 3) ADJ(3);
     else ADJ(4);
 #undef ADJ
     MCPM_LAUNCH_CHECK(p, "step_adjoint_kernel");
-    if (alpha_bar || beta_bar) {
-        reduce_slots_kernel<<<1, MCPM_NSLOT, 0, p->stream>>>(slots, alpha_bar, beta_bar);
+    if (alpha_bar || beta_bar || dg_bar) {
+        reduce_slots_kernel<<<1, MCPM_NSLOT, 0, p->stream>>>(slots, alpha_bar, beta_bar, dg_bar);
         MCPM_LAUNCH_CHECK(p, "reduce_slots_kernel");
     }
     return MCPM_OK;
@@ -578,7 +616,7 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, init_mesh && alpha && beta && lpt_scalars && ckpt && pos_bar && vel_bar && init_mesh_bar, MCPM_E_ARG,
                  "mcpm_nbody_bf_vjp_f32: null argument");
-    MCPM_REQUIRE(p, n_steps >= 1 && 2 * n_steps + 3 <= MCPM_NREDUCE - 2 * MCPM_NSLOT, MCPM_E_ARG, "mcpm_nbody_bf_vjp_f32: bad n_steps");
+    MCPM_REQUIRE(p, n_steps >= 1 && 2 * n_steps + 4 + 256 <= MCPM_NREDUCE - 3 * MCPM_NSLOT, MCPM_E_ARG, "mcpm_nbody_bf_vjp_f32: bad n_steps");
     MCPM_REQUIRE(p, paint_order >= 1 && paint_order <= 4, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: paint_order must be 1..4");
     MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: lpt_order must be 1 or 2");
     const int64_t N = p->Np, M = p->M;
@@ -589,21 +627,27 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     auto force_m = [&](int i) { return ckpt + (int64_t)n_steps * 6 * N + (int64_t)i * 3 * M; };
     MCPM_HIP(p, hipMemcpyAsync(xb, pos_bar, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, p->stream));
     MCPM_HIP(p, hipMemcpyAsync(vb, vel_bar, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, p->stream));
-    MCPM_HIP(p, hipMemsetAsync(p->reduce, 0, sizeof(double) * (2 * n_steps + 3), p->stream));
+    MCPM_HIP(p, hipMemsetAsync(p->reduce, 0, sizeof(double) * (2 * n_steps + 4 + 256), p->stream));
     p->fb_valid = 0;
     for (int i = n_steps - 1; i >= 0; --i) {
         if (i > 0) MCPM_TRY(mcpm_plan_hint_next_adjoint(p, beta[i - 1], dg));
         MCPM_TRY(mcpm_bullfrog_step_vjp_f32(p, state_x(i), state_v(i), force_m(i), alpha[i], beta[i],
                                             (i == n_steps - 1) ? dg / 2 : dg, paint_order, xb, vb, p->reduce + i,
-                                            p->reduce + n_steps + i));
+                                            p->reduce + n_steps + i, (i == n_steps - 1) ? 0.5 : 1.0, p->reduce + 2 * n_steps + 3));
     }
-    // initial half drift x'_0 = x_0 + v_0 dg/2
+    // initial half drift x'_0 = x_0 + v_0 dg/2 (its explicit dg dependence: <x_bar, v_0> / 2)
+    {
+        unsigned nbk = (unsigned)((3 * N + 255) / 256);
+        dot_scaled_kernel<<<nbk, 256, 0, p->stream>>>(xb, state_v(0), 3 * N, 0.5, p->reduce + 2 * n_steps + 3);
+        fold256_kernel<<<1, 1, 0, p->stream>>>(p->reduce + 2 * n_steps + 3);
+        MCPM_LAUNCH_CHECK(p, "dot_scaled_kernel");
+    }
     MCPM_TRY(axpby(p, vb, xb, 3 * N, 1.f, (float)(dg / 2), vb));
 
     // ---- adjoint of lpt (nbody.py:634-667) at the lattice, read_order = 1
     MCPM_TRY(lpt_vjp_device(p, init_mesh, lpt_order, lpt_scalars, xb, vb, init_mesh_bar, p->reduce + 2 * n_steps));
     if (scalar_bars) {
-        MCPM_HIP(p, hipMemcpyAsync(scalar_bars, p->reduce, sizeof(double) * (2 * n_steps + 3), hipMemcpyDeviceToHost, p->stream));
+        MCPM_HIP(p, hipMemcpyAsync(scalar_bars, p->reduce, sizeof(double) * (2 * n_steps + 4), hipMemcpyDeviceToHost, p->stream));
         MCPM_HIP(p, hipStreamSynchronize(p->stream));
         scalar_bars[2 * n_steps + 1] = -scalar_bars[2 * n_steps + 1];
         scalar_bars[2 * n_steps + 2] = -scalar_bars[2 * n_steps + 2];

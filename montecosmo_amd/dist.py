@@ -350,7 +350,7 @@ class SlabPM(HaloMixin):
         self.call("mcpm_kick_drift_f32", _p(x), _p(v), self.Nl, POS_LATTICE, _p(f3_out), paint_order, float(alpha),
                   float(beta), float(tau), _p(x_out), _p(v_out))
 
-    def step_vjp(self, x, v, f3, alpha, beta, tau, xb, vb, abar_ptr, bbar_ptr, paint_order=2):
+    def step_vjp(self, x, v, f3, alpha, beta, tau, xb, vb, abar_ptr, bbar_ptr, dtau_ddg=1.0, dgbar_ptr=None, paint_order=2):
         """Adjoint of `step`: xb, vb (cotangents of its outputs) are updated in place."""
         self.call("mcpm_kick_f32", _p(vb), _p(xb), self.Nl, float(beta), float(beta * tau), _p(self.Fb))
         self.call("mcpm_paint3_f32", _p(x), self.Nl, POS_LATTICE, _p(self.Fb), paint_order, _p(self.f3), 0)
@@ -358,7 +358,7 @@ class SlabPM(HaloMixin):
         self.force_meshes_vjp(self.f3, self.rho, adds)
         self.halo_fill(self.rho)
         self.call("mcpm_step_adjoint_particles_f32", _p(x), _p(v), _p(f3), _p(self.rho), float(alpha), float(beta),
-                  float(tau), paint_order, _p(xb), _p(vb), abar_ptr, bbar_ptr)
+                  float(tau), paint_order, _p(xb), _p(vb), abar_ptr, bbar_ptr, float(dtau_ddg), dgbar_ptr)
 
 
 class SlabCtx:
@@ -399,12 +399,15 @@ def nbody_bf_slab_vjp(ctx, disp_bar, vel_bar):
     dev = ctx.spec.device
     xb = nbody._f32(disp_bar, (pm.Nl, 3)).clone()
     vb = nbody._f32(vel_bar, (pm.Nl, 3)).clone()
-    sbar = torch.zeros(2 * K, dtype=torch.float64, device=dev)
+    sbar = torch.zeros(2 * K + 1, dtype=torch.float64, device=dev)
     for i in reversed(range(K)):
         tau = ctx.dg / 2 if i == K - 1 else ctx.dg
         pm.step_vjp(ctx.states[i, 0], ctx.states[i, 1], ctx.f3s[i], ctx.alphas[i], ctx.betas[i], tau, xb, vb,
-                    C.c_void_p(sbar.data_ptr() + 8 * i), C.c_void_p(sbar.data_ptr() + 8 * (K + i)), ctx.paint_order)
-    vb += xb * (ctx.dg / 2)                      # initial half drift x'_0 = x_0 + v_0 dg/2
+                    C.c_void_p(sbar.data_ptr() + 8 * i), C.c_void_p(sbar.data_ptr() + 8 * (K + i)),
+                    0.5 if i == K - 1 else 1.0, C.c_void_p(sbar.data_ptr() + 8 * 2 * K), ctx.paint_order)
+    sbar[2 * K] += 0.5 * (xb.double() * ctx.states[0, 1].double()).sum()    # initial half drift x'_0 = x_0 + v_0 dg/2
+    vb += xb * (ctx.dg / 2)
     sbar = pm.comm.all_reduce_sum(sbar).cpu().numpy()
     out, ls = pm.lpt_vjp(ctx.spec, ctx.lpt_order, ctx.lpt_s[0], ctx.lpt_s[1], ctx.lpt_s[2], xb, vb)
-    return out, {"alpha": sbar[:K].copy(), "beta": sbar[K:].copy(), "g": ls[0], "g2": ls[1], "dg2dg": ls[2]}
+    return out, {"alpha": sbar[:K].copy(), "beta": sbar[K:2 * K].copy(), "g": ls[0], "g2": ls[1], "dg2dg": ls[2],
+                 "dg": float(sbar[2 * K])}

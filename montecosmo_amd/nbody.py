@@ -25,7 +25,7 @@ __all__ = [
     "rfftk", "fftk", "invlaplace_hat", "gradient_hat", "gaussian_hat", "rectangular", "rectangular_hat",
     "paint", "read", "paint_vjp", "read_vjp", "pm_forces", "pm_forces_vjp", "pm_forces2", "lpt", "lpt_vjp",
     "a2g", "a2g2", "a2f", "a2f2", "a2dg2dg", "g2a", "g2g2", "g2f", "g2f2", "g2dg2dg", "a2chi", "chi2a",
-    "bullfrog_vf", "nbody_bf", "nbody_bf_vjp", "alpha_bf", "alpha_fpm", "LatticePos", "get_plan",
+    "bullfrog_vf", "nbody_bf", "nbody_bf_vjp", "cosmo_vjp", "alpha_bf", "alpha_fpm", "LatticePos", "get_plan",
     "deconv_paint", "interlace", "nufft", "nufft_vjp",
     "safe_div", "ch2rshape", "r2chshape", "scale_shape",
 ]
@@ -764,11 +764,37 @@ def nbody_bf_vjp(ctx, pos_bar, vel_bar):
     if xb.shape[0] != plan.N or vb.shape[0] != plan.N:
         raise ValueError("cotangent shape does not match the particle count")
     out = torch.empty(tuple(ctx.init_mesh.shape), dtype=torch.complex64, device=xb.device)
-    sb = np.zeros(2 * n + 3)
+    sb = np.zeros(2 * n + 4)
     plan.call("mcpm_nbody_bf_vjp_f32", _ptr(ctx.init_mesh), n, _dptr(ctx.alphas), _dptr(ctx.betas), float(ctx.dg),
               _dptr(ctx.lpt_s), ctx.lpt_order, ctx.paint_order, _ptr(ctx.ckpt), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
-    bars = {"alpha": sb[:n].copy(), "beta": sb[n:2 * n].copy(), "g": sb[2 * n], "g2": sb[2 * n + 1], "dg2dg": sb[2 * n + 2]}
+    bars = {"alpha": sb[:n].copy(), "beta": sb[n:2 * n].copy(), "g": sb[2 * n], "g2": sb[2 * n + 1], "dg2dg": sb[2 * n + 2],
+            "dg": sb[2 * n + 3]}
     return out, bars
+
+
+def cosmo_vjp(ctx, scalar_bars, params=("Omega_c",), rel_eps=1e-5):
+    """Chains the scalar cotangents of `nbody_bf_vjp` through the host float64 growth tables to cosmological
+    parameters: dL/dtheta = sum_i alpha_bar_i dalpha_i/dtheta + beta_bar_i dbeta_i/dtheta + dg_bar ddg/dtheta
+    + g_bar dg(a0)/dtheta + g2_bar dg2(a0)/dtheta + dg2dg_bar d(dg2dg)(a0)/dtheta, with the Jacobian of the
+    (128-point RK4) tables taken by central finite differences (nbody.py:679-808, :907-931 are host scalars).
+    `params` are attribute names of the cosmology object (e.g. 'Omega_c', 'Omega_b', 'w0')."""
+    import copy
+    out = {}
+    for name in params:
+        base = float(getattr(ctx.cosmo, name))
+        h = rel_eps * max(abs(base), 1e-2)
+        vals = []
+        for sgn in (+1, -1):
+            c = copy.copy(ctx.cosmo)
+            c._workspace = {}
+            setattr(c, name, base + sgn * h)
+            vals.append(_step_scalars(c, ctx.a0, ctx.a1, ctx.n_steps, ctx.integrator))
+        (dgp, ap, bp, lp), (dgm, am, bm, lm) = vals
+        d = lambda p_, m_: (np.asarray(p_) - np.asarray(m_)) / (2 * h)
+        out[name] = float(np.dot(scalar_bars["alpha"], d(ap, am)) + np.dot(scalar_bars["beta"], d(bp, bm))
+                          + scalar_bars["dg"] * d(dgp, dgm)
+                          + np.dot([scalar_bars["g"], scalar_bars["g2"], scalar_bars["dg2dg"]], d(lp, lm)))
+    return out
 
 
 def lpt_vjp(cosmo, init_mesh, pos, a, dpos_bar, vel_bar, lpt_order: int = 2):
