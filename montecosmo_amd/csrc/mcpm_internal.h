@@ -24,6 +24,7 @@ enum McpmStage {
     ST_STEPADJ,     // fused adjoint particle kernel
     ST_AXPY,        // drift / kick / cotangent axpy
     ST_LPT,         // lattice kernels of lpt and its adjoint, hessian combine
+    ST_PAINT3,      // three-component tiled paint (adjoint of the three-component read)
     ST_NSTAGES
 };
 

@@ -628,7 +628,7 @@ int mcpm_paint3_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const f
         for (int c = 0; c < 3; ++c) MCPM_TRY(mcpm_paint_f32(p, pos, n, mode, weights3 + c, 3, 0.f, order, meshes3 + c * p->M, accumulate));
         return MCPM_OK;
     }
-    StageTimer st_(p, ST_PAINT, 24.0 * n + (accumulate ? 24.0 : 12.0) * p->M);
+    StageTimer st_(p, ST_PAINT3, 24.0 * n + (accumulate ? 24.0 : 12.0) * p->M);
     (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int), p->stream);
     const unsigned nb = (unsigned)((g.nx / 16) * (g.ny / 16) * (g.nz / 16));
 #define CALL3(HH)                                                                                                             \

@@ -174,7 +174,7 @@ int mcpm_plan_last_outliers(mcpm_plan *p, int64_t *count) {
 }
 
 static const char *k_stage_names[ST_NSTAGES] = {"paint", "fft_r2c", "fft_c2r", "kspace", "read", "kick_drift",
-                                                 "step_adjoint", "axpy", "lpt_lattice"};
+                                                 "step_adjoint", "axpy", "lpt_lattice", "paint3"};
 
 const char *mcpm_stage_name(int stage) { return (stage >= 0 && stage < ST_NSTAGES) ? k_stage_names[stage] : ""; }
 

@@ -3,7 +3,7 @@ usage: python tools/make_traffic_json.py <fetch_dir> <write_dir> <mesh> <out.jso
 import collections, csv, glob, json, sys
 
 fetch_dir, write_dir, mesh, out_json, out_txt = sys.argv[1:6]
-stage_of = [("paint3_", "paint"), ("paint_tile_kernel", "paint"), ("paint_outlier_kernel", "paint"), ("paint_atomic_kernel", "paint"),
+stage_of = [("paint3_", "paint3"), ("paint_tile_kernel", "paint"), ("paint_outlier_kernel", "paint"), ("paint_atomic_kernel", "paint"),
             ("zfwd_kernel", "fft_r2c"), ("ycol_kernel<512, -1>", "fft_r2c"), ("ycol_kernel<256, -1>", "fft_r2c"),
             ("ycol_kernel<512, 1>", "fft_c2r"), ("ycol_kernel<256, 1>", "fft_c2r"), ("zinv_kernel", "fft_c2r"),
             ("xfused_kernel", "kspace"), ("kick_drift_kernel", "kick_drift"), ("step_adjoint_kernel", "step_adjoint"),
