@@ -336,44 +336,46 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xfused_kernel(FGeom g, c
         sx[m] = (special && x == N / 2) ? 0.f : kx * L[m];
     }
     TL tile{l};
+    // The y and z multipliers are (ky, kz) * L(kx): constant factors of ONE x-dependent spectrum, so they share one
+    // x transform -- two inverse (MODE 0) or forward (MODE 1) transforms instead of three.
     if (MODE == 0) {
         cf v[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) v[m] = ok ? in[o1[m]] : make_float2(0.f, 0.f);
         fft_line<N, -1>(v, lds, W, u, tile);
+        cf w[8];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            cf w[8];
+        for (int m = 0; m < 8; ++m) w[m] = make_float2(sx[m] * v[m].y, -sx[m] * v[m].x);  // (a + i b)(-i s_x)
+        fft_line<N, +1>(w, lds, W, u, tile);
+        if (ok) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) out[o3[m]] = w[m];
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) w[m] = make_float2(L[m] * v[m].y, -L[m] * v[m].x);  // (a + i b)(-i L)
+        fft_line<N, +1>(w, lds, W, u, tile);
+        if (ok) {
+            cf *oy = out + xl.SC, *oz = out + 2 * xl.SC;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                const float sc = c == 0 ? sx[m] : (c == 1 ? fy : fz) * L[m];
-                w[m] = make_float2(sc * v[m].y, -sc * v[m].x);  // (a + i b)(-i s)
-            }
-            fft_line<N, +1>(w, lds, W, u, tile);
-            if (ok) {
-                cf *oc = out + c * xl.SC;
-#pragma unroll
-                for (int m = 0; m < 8; ++m) oc[o3[m]] = w[m];
+                oy[o3[m]] = make_float2(fy * w[m].x, fy * w[m].y);
+                oz[o3[m]] = make_float2(fz * w[m].x, fz * w[m].y);
             }
         }
     } else {
+        cf a[8], b[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            a[m] = ok ? in[o3[m]] : make_float2(0.f, 0.f);
+            const cf iy2 = ok ? in[xl.SC + o3[m]] : make_float2(0.f, 0.f), iz2 = ok ? in[2 * xl.SC + o3[m]] : make_float2(0.f, 0.f);
+            b[m] = make_float2(fy * iy2.x + fz * iz2.x, fy * iy2.y + fz * iz2.y);
+        }
+        fft_line<N, -1>(a, lds, W, u, tile);
+        fft_line<N, -1>(b, lds, W, u, tile);
         cf acc[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) acc[m] = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            cf v[8];
-            const cf *ic = in + c * xl.SC;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = ok ? ic[o3[m]] : make_float2(0.f, 0.f);
-            fft_line<N, -1>(v, lds, W, u, tile);
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const float sc = c == 0 ? sx[m] : (c == 1 ? fy : fz) * L[m];
-                acc[m].x += -sc * v[m].y;  // (a + i b)(+i s)
-                acc[m].y += sc * v[m].x;
-            }
-        }
+        for (int m = 0; m < 8; ++m)  // (a + i b)(+i s): conj of the forward multipliers
+            acc[m] = make_float2(-sx[m] * a[m].y - L[m] * b[m].y, sx[m] * a[m].x + L[m] * b[m].x);
         fft_line<N, +1>(acc, lds, W, u, tile);
         if (ok) {
 #pragma unroll
