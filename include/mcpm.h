@@ -149,8 +149,11 @@ int mcpm_force_meshes_vjp_f32(mcpm_plan *plan, const float *fbar3, float *rho_ba
      ycol  : FFT along y (sign -1 forward / +1 inverse) of `batch` spectra; *_packed = transposed-order layout
              [c][dest rank][x_local][y_local][nzp] (what one all-to-all per spectrum exchanges), plain =
              [c][x_local][y][nzp]
-     xfused: mode 0: one spectrum [x][y_local][nzp] -> x FFT, k-space force multiply, inverse x FFT -> three
-             spectra [c][dest rank][x_local][y_local][nzp]; mode 1 is the adjoint (three in that layout -> one).
+     xfused: mode 0: one spectrum [x][y_local][nzp] -> x FFT -> {-i kx L X, -i L X} (L = -1/(M k^2)) -> inverse x FFT
+             -> TWO spectra A, G in [c][dest rank][x_local][y_local][nzp]; mode 1 is the adjoint (two -> one).
+     ycol2 : the y pass that carries the remaining force factors, so only two spectra cross the all-to-all:
+             expand = 1 (inverse): {A, G} -> three force spectra {IFFTy A, IFFTy(ky G), kz IFFTy G};
+             expand = 0 (forward, adjoint): three spectra {a, b, c} -> {FFTy a, ky FFTy b + kz FFTy c}.
              Modes 2..5 are the spectrum-side variants of lpt: the single spectrum is the caller's FULL plain
              half-spectrum [nx][ny][nz/2+1] (this rank touches its y rows only) and one x transform disappears:
              2: spectrum -> 3 force spectra, 3: spectrum -> 6 Hessian spectra (00 01 02 11 12 22),
@@ -159,6 +162,7 @@ int mcpm_force_meshes_vjp_f32(mcpm_plan *plan, const float *fbar3, float *rho_ba
 int64_t mcpm_slab_spec_elems(const mcpm_plan *plan);
 int mcpm_slab_zfwd(mcpm_plan *plan, const float *real, int64_t real_bstride, float *spec, int batch);
 int mcpm_slab_ycol(mcpm_plan *plan, const float *in, float *out, int batch, int sign, int in_packed, int out_packed);
+int mcpm_slab_ycol2(mcpm_plan *plan, const float *in, float *out, int expand, int in_packed, int out_packed);
 int mcpm_slab_xfused(mcpm_plan *plan, const float *in, float *out, int mode);
 int mcpm_slab_zinv(mcpm_plan *plan, const float *spec, float *real, int64_t real_bstride, int batch);
 

@@ -297,15 +297,91 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol_kernel(FGeom g, con
     }
 }
 
-// k-space multipliers (nbody.py:109-163 with fd_order = inf), wavevectors from indices
 #define MCPM_TWO_PI 6.283185307179586f
+
+// y pass that also applies the y / z force factors, so that only TWO spectra travel between the y and x passes:
+// the x pass produces A = IFFTx(-i kx L X) and G = IFFTx(-i L X), and the force spectra are A, ky G, kz G
+// (ky = 0 at its Nyquist on the kz = 0 / Nyquist planes, kz = 0 at its Nyquist: the Hermitian projection).
+//   EXPAND  (inverse): in = {A, G} -> out = {IFFTy A, IFFTy(ky G), kz IFFTy G}
+//   CONTRACT (forward, adjoint): in = {a, b, c} -> out = {FFTy a, ky FFTy b + kz FFTy c}
+template <int N, bool EXPAND>
+__global__ __launch_bounds__(ColShape<N>::THREADS) void ycol2_kernel(FGeom g, const cf *__restrict__ in, cf *__restrict__ out,
+                                                                     YLayout li, YLayout lo, const cf *__restrict__ W) {
+    constexpr int T = ColShape<N>::T, LINES = ColShape<N>::LINES;
+    typedef Tile<N, LINES, true> TL;
+    __shared__ cf lds[TL::FLOATS2];
+    const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
+    const int kzi = blockIdx.x * LINES + l;
+    const bool ok = kzi < g.nzh;
+    const cf *ib = in + (int64_t)blockIdx.y * li.PS + kzi;   // blockIdx.y = x plane; component c adds c * BS
+    cf *ob = out + (int64_t)blockIdx.y * lo.PS + kzi;
+    const bool special = (kzi == 0) || (kzi == g.nz / 2);
+    const float fz = (kzi == g.nz / 2) ? 0.f : MCPM_TWO_PI * (float)kzi / (float)g.nz;
+    int64_t oi[8], oo[8];
+    float fy[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int y = u + T * m, ybi = y >> li.lgYB, ybo = y >> lo.lgYB;
+        oi[m] = ybi * li.SB + (int64_t)(y & (li.YB - 1)) * g.nzp;
+        oo[m] = ybo * lo.SB + (int64_t)(y & (lo.YB - 1)) * g.nzp;
+        fy[m] = (special && y == N / 2) ? 0.f : MCPM_TWO_PI * (float)(y < N / 2 ? y : y - N) / (float)N;
+    }
+    TL tile{l};
+    if (EXPAND) {
+        cf a[8], gq[8], h[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            a[m] = ok ? ib[oi[m]] : make_float2(0.f, 0.f);
+            gq[m] = ok ? ib[li.BS + oi[m]] : make_float2(0.f, 0.f);
+            h[m] = make_float2(fy[m] * gq[m].x, fy[m] * gq[m].y);
+        }
+        fft_line<N, +1>(a, lds, W, u, tile);
+        if (ok) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) ob[oo[m]] = a[m];
+        }
+        fft_line<N, +1>(h, lds, W, u, tile);
+        if (ok) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) ob[lo.BS + oo[m]] = h[m];
+        }
+        fft_line<N, +1>(gq, lds, W, u, tile);
+        if (ok) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) ob[2 * lo.BS + oo[m]] = make_float2(fz * gq[m].x, fz * gq[m].y);
+        }
+    } else {
+        cf a[8], b[8], c[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            a[m] = ok ? ib[oi[m]] : make_float2(0.f, 0.f);
+            b[m] = ok ? ib[li.BS + oi[m]] : make_float2(0.f, 0.f);
+            c[m] = ok ? ib[2 * li.BS + oi[m]] : make_float2(0.f, 0.f);
+        }
+        fft_line<N, -1>(a, lds, W, u, tile);
+        if (ok) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) ob[oo[m]] = a[m];
+        }
+        fft_line<N, -1>(b, lds, W, u, tile);
+        fft_line<N, -1>(c, lds, W, u, tile);
+        if (ok) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                ob[lo.BS + oo[m]] = make_float2(fy[m] * b[m].x + fz * c[m].x, fy[m] * b[m].y + fz * c[m].y);
+        }
+    }
+}
+
+// k-space multipliers (nbody.py:109-163 with fd_order = inf), wavevectors from indices
 __device__ __forceinline__ float kfreq_i(int i, int n) {
     int s = (i < (n + 1) / 2) ? i : i - n;
     return MCPM_TWO_PI * (float)s / (float)n;
 }
 
-// MODE 0: in (1 spectrum) -> forward x FFT -> x (-(i k_c))(-1/k^2) scale -> inverse x FFT -> out (3 spectra)
-// MODE 1: in (3 spectra) -> forward x FFT -> sum_c conj(multiplier_c) -> inverse x FFT -> out (1 spectrum)
+// MODE 0: in (1 spectrum) -> forward x FFT -> {-i kx L X, -i L X} -> inverse x FFT -> out (2 spectra: A and G)
+// MODE 1: in (2 spectra a, b) -> forward x FFT -> i kx L FFTx(a) + i L FFTx(b) -> inverse x FFT -> out (1 spectrum)
+// (L = -scale/k^2; the y pass applies ky, kz: ycol2_kernel.)
 // The multiplier of component c at mode (kx, ky, kz) is s_c * (-i), s_c = k_c * (-scale/k^2), Hermitian-projected:
 // on the kz = 0 / Nyquist planes a component whose own index sits at Nyquist is dropped (kspace.hip header).
 template <int N, int MODE>
@@ -323,7 +399,6 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xfused_kernel(FGeom g, c
     float sx[8], L[8];
     const float ky = kfreq_i(iy, g.ny), kz = MCPM_TWO_PI * (float)kzi / (float)g.nz;
     const bool special = (kzi == 0) || (kzi == g.nz / 2);
-    const float fy = (special && iy == g.ny / 2) ? 0.f : ky, fz = (kzi == g.nz / 2) ? 0.f : kz;
     const float dkx = MCPM_TWO_PI / (float)N;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -354,21 +429,17 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xfused_kernel(FGeom g, c
 #pragma unroll
         for (int m = 0; m < 8; ++m) w[m] = make_float2(L[m] * v[m].y, -L[m] * v[m].x);  // (a + i b)(-i L)
         fft_line<N, +1>(w, lds, W, u, tile);
-        if (ok) {
-            cf *oy = out + xl.SC, *oz = out + 2 * xl.SC;
+        if (ok) {  // G: the y pass turns it into the y and z components (ycol2_kernel)
+            cf *og = out + xl.SC;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                oy[o3[m]] = make_float2(fy * w[m].x, fy * w[m].y);
-                oz[o3[m]] = make_float2(fz * w[m].x, fz * w[m].y);
-            }
+            for (int m = 0; m < 8; ++m) og[o3[m]] = w[m];
         }
     } else {
         cf a[8], b[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < 8; ++m) {  // b = ky FFTy(f_bar_y) + kz FFTy(f_bar_z), formed by the y pass (ycol2_kernel)
             a[m] = ok ? in[o3[m]] : make_float2(0.f, 0.f);
-            const cf iy2 = ok ? in[xl.SC + o3[m]] : make_float2(0.f, 0.f), iz2 = ok ? in[2 * xl.SC + o3[m]] : make_float2(0.f, 0.f);
-            b[m] = make_float2(fy * iy2.x + fz * iz2.x, fy * iy2.y + fz * iz2.y);
+            b[m] = ok ? in[xl.SC + o3[m]] : make_float2(0.f, 0.f);
         }
         fft_line<N, -1>(a, lds, W, u, tile);
         fft_line<N, -1>(b, lds, W, u, tile);
@@ -595,6 +666,24 @@ static int y_columns(mcpm_plan *p, const cf *in, cf *out, int batch, int sign, b
     return MCPM_OK;
 }
 
+// y pass with the y / z force factors: expand (2 -> 3 spectra, inverse) or contract (3 -> 2, forward)
+static int y_columns2(mcpm_plan *p, const cf *in, cf *out, bool expand, bool in_packed, bool out_packed) {
+    const FGeom g = fgeom(p);
+    const YLayout li = ylayout(p, in_packed), lo = ylayout(p, out_packed);
+    StageTimer st_(p, expand ? ST_C2R : ST_R2C, pass_bytes(p, 3));
+#define CALL(NN)                                                                                       \
+    {                                                                                                  \
+        constexpr int LINES = ColShape<NN>::LINES, TH = ColShape<NN>::THREADS;                         \
+        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)p->nxl);                          \
+        if (expand) ycol2_kernel<NN, true><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1]);  \
+        else ycol2_kernel<NN, false><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1]);        \
+    }
+    DISPATCH_N(g.ny, CALL)
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "ycol2_kernel");
+    return MCPM_OK;
+}
+
 // x pass over the y rows this rank holds after the transpose (all of them on one GPU)
 static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
     const FGeom g = fgeom(p);
@@ -671,10 +760,11 @@ int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3) {
     MCPM_TRY(ensure_twiddles(p));
     const int64_t ss = spec_elems(p);
     cf *s0 = (cf *)p->spec, *s123 = s0 + ss;
+    cf *s45 = s123 + 3 * ss;  // A, G between the x and y passes
     MCPM_TRY(z_forward(p, rho, p->M, s0, 1));
     MCPM_TRY(y_columns(p, s0, s0, 1, -1, false, false));
-    MCPM_TRY(x_fused(p, s0, s123, 0));
-    MCPM_TRY(y_columns(p, s123, s123, 3, +1, false, false));
+    MCPM_TRY(x_fused(p, s0, s45, 0));
+    MCPM_TRY(y_columns2(p, s45, s123, true, false, false));
     MCPM_TRY(z_inverse(p, s123, fm3, p->M, 3));
     return MCPM_OK;
 }
@@ -684,9 +774,10 @@ int mcpm_fftpm_force_meshes_vjp(mcpm_plan *p, const float *fbar3, float *rho_bar
     MCPM_TRY(ensure_twiddles(p));
     const int64_t ss = spec_elems(p);
     cf *s0 = (cf *)p->spec, *s123 = s0 + ss;
+    cf *s45 = s123 + 3 * ss;
     MCPM_TRY(z_forward(p, fbar3, p->M, s123, 3));
-    MCPM_TRY(y_columns(p, s123, s123, 3, -1, false, false));
-    MCPM_TRY(x_fused(p, s123, s0, 1));
+    MCPM_TRY(y_columns2(p, s123, s45, false, false, false));
+    MCPM_TRY(x_fused(p, s45, s0, 1));
     MCPM_TRY(y_columns(p, s0, s0, 1, +1, false, false));
     MCPM_TRY(z_inverse(p, s0, rho_bar, p->M, 1));
     return MCPM_OK;
@@ -720,6 +811,14 @@ int mcpm_slab_ycol(mcpm_plan *p, const float *in, float *out, int batch, int sig
     MCPM_REQUIRE(p, mcpm_fftpm_supported(p), MCPM_E_UNSUPPORTED, "slab FFT needs power-of-two axes in [64, 1024]");
     MCPM_TRY(ensure_twiddles(p));
     return y_columns(p, (const cf *)in, (cf *)out, batch, sign, in_packed != 0, out_packed != 0);
+}
+
+int mcpm_slab_ycol2(mcpm_plan *p, const float *in, float *out, int expand, int in_packed, int out_packed) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, in && out && in != out, MCPM_E_ARG, "mcpm_slab_ycol2: bad argument");
+    MCPM_REQUIRE(p, mcpm_fftpm_supported(p), MCPM_E_UNSUPPORTED, "slab FFT needs power-of-two axes in [64, 1024]");
+    MCPM_TRY(ensure_twiddles(p));
+    return y_columns2(p, (const cf *)in, (cf *)out, expand != 0, in_packed != 0, out_packed != 0);
 }
 
 int mcpm_slab_xfused(mcpm_plan *p, const float *in, float *out, int mode) {

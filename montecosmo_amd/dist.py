@@ -241,18 +241,20 @@ class SlabPM(HaloMixin):
         return C.c_void_p(buf.data_ptr() + 8 * c * self.ss)
 
     def force_meshes(self, rho_ext, f3_ext, fill_ghosts=True):
-        """Interior of rho_ext (ghosts already added) -> the three force meshes f3_ext (ghosts filled)."""
+        """Interior of rho_ext (ghosts already added) -> the three force meshes f3_ext (ghosts filled).
+        Only two spectra (A, G) cross the second all-to-all: the y pass applies the y / z force factors."""
         ss = self.ss
         self.call("mcpm_slab_zfwd", self._interior(rho_ext), self.Me, _p(self.s1a), 1)
         self.call("mcpm_slab_ycol", _p(self.s1a), _p(self.s1b), 1, -1, 0, 1)          # plain -> transposed order
         self.comm.all_to_all(self.s1a, self.s1b)                                     # x <-> y transpose
-        self.call("mcpm_slab_xfused", _p(self.s1a), _p(self.s3a), 0)
+        self.call("mcpm_slab_xfused", _p(self.s1a), _p(self.s3a), 0)                  # -> A, G
         a2a = [self.comm.all_to_all(self.s3b[c * ss:(c + 1) * ss], self.s3a[c * ss:(c + 1) * ss], async_op=True)
-               for c in range(3)]
+               for c in range(2)]
+        for h in a2a:
+            h.wait()
+        self.call("mcpm_slab_ycol2", _p(self.s3b), _p(self.s3a), 1, 1, 0)             # {A, G} -> 3 force spectra
         fills = []
         for c in range(3):
-            a2a[c].wait()
-            self.call("mcpm_slab_ycol", self._spec(self.s3b, c), self._spec(self.s3a, c), 1, +1, 1, 0)
             self.call("mcpm_slab_zinv", self._spec(self.s3a, c), self._interior(f3_ext, c), self.Me, 1)
             if fill_ghosts:
                 fills.append(self.halo_fill(f3_ext[c], async_op=True))
@@ -262,15 +264,13 @@ class SlabPM(HaloMixin):
     def force_meshes_vjp(self, fbar3_ext, rhobar_ext, ghost_adds=None):
         """fbar3_ext: three cotangent meshes (ghosts added, or `ghost_adds[c]` handles still in flight)."""
         ss = self.ss
-        a2a = []
         for c in range(3):
             if ghost_adds is not None:
                 ghost_adds[c].wait()
             self.call("mcpm_slab_zfwd", self._interior(fbar3_ext, c), self.Me, self._spec(self.s3a, c), 1)
-            self.call("mcpm_slab_ycol", self._spec(self.s3a, c), self._spec(self.s3b, c), 1, -1, 0, 1)
-            a2a.append(self.comm.all_to_all(self.s3a[c * ss:(c + 1) * ss], self.s3b[c * ss:(c + 1) * ss], async_op=True))
-        # s3a is both the z/y scratch of component c and the receive buffer of component c: the receive of c is
-        # ordered after the y pass that consumed it (same stream), and nothing touches it again before xfused
+        self.call("mcpm_slab_ycol2", _p(self.s3a), _p(self.s3b), 0, 0, 1)             # 3 spectra -> {a, b}, transposed order
+        a2a = [self.comm.all_to_all(self.s3a[c * ss:(c + 1) * ss], self.s3b[c * ss:(c + 1) * ss], async_op=True)
+               for c in range(2)]
         for h in a2a:
             h.wait()
         self.call("mcpm_slab_xfused", _p(self.s3a), _p(self.s1a), 1)
