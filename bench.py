@@ -111,6 +111,21 @@ class Runner:
         if not self.forward_only:
             self.backward(steps)
 
+    def force_cycle_ms(self, reps=10):
+        """pm_forces(pos, mesh_shape) on its own (paint -> Poisson -> 3-component read; nbody.py:583-604) on the
+        evolved particles of the last checkpoint: HIP events on the plan's stream, mean of `reps` calls."""
+        forces = self.xb                                   # (N, 3) scratch, overwritten by the next backward()
+        x = self.states[self.K, 0]
+        args = (self.p(x), self.N, 1, 2, 0, 0, 0, 0.0, self.p(forces))   # MCPM_POS_LATTICE, CIC, fd = inf, no kcut
+        self.plan.call("mcpm_pm_forces_f32", *args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            self.plan.call("mcpm_pm_forces_f32", *args)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
     def profile(self):
         """Per-stage HIP-event timings of one more pass over the same K steps (events on the plan's stream)."""
         from montecosmo_amd._lib import lib
@@ -283,6 +298,7 @@ def main():
 
     out = None
     prof = r.profile() if (slab or rank == 0) else None     # slabbed: collective, every rank takes part
+    pmf_ms = r.force_cycle_ms() if (rank == 0 and not slab) else None
     if rank == 0:
         M = float(n) ** 3          # whole mesh: stage times below are rank 0's, which holds 1/world of it when slabbed
         steps_per_s = (1 if slab else world) * K / dt
@@ -314,12 +330,18 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(stages[dom]["algorithmic_GBps"] / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic(dom, n) if world == 1 else None},
+            # "ms": the stages of the cycle inside a step, where the read also kicks and drifts (60 B/particle instead of
+            # the 36 the 100 B/cell figure counts); "pm_forces_*": the function pm_forces itself, which is what 100 B/cell describes
             "force_cycle": {"ms": round(cyc_ms, 4), "algorithmic_GBps": round(B_PER_CELL_CYCLE * Mloc / (cyc_ms * 1e-3) / 1e9, 1),
                             "frac_of_hbm_peak": round(B_PER_CELL_CYCLE * Mloc / (cyc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "fwd_adj_step": {"ms_events": round(step_ms, 4), "algorithmic_GBps": round(B_PER_CELL_STEP * Mloc / (step_ms * 1e-3) / 1e9, 1),
                              "frac_of_hbm_peak": round(B_PER_CELL_STEP * Mloc / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "stages": stages,
         }
+        if pmf_ms is not None:
+            out["force_cycle"].update({"pm_forces_ms": round(pmf_ms, 4),
+                                       "pm_forces_GBps": round(B_PER_CELL_CYCLE * M / (pmf_ms * 1e-3) / 1e9, 1),
+                                       "pm_forces_frac_of_hbm_peak": round(B_PER_CELL_CYCLE * M / (pmf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
         if slab:
             out["comm_and_host_ms_per_step"] = round(dt / K * 1e3 - step_ms, 3)   # wall minus rank-0 kernel stages
             out["deposits_beyond_ghost_rank0"] = r.pm.out_of_ghost()                # must be 0

@@ -564,6 +564,7 @@ static bool try_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int6
         switch (H) {
             case 1: launch_tile_variant<64, 1>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
             case 2: launch_tile_variant<64, 2>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 3: launch_tile_variant<64, 3>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
             case 4: launch_tile_variant<64, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
             default: launch_tile_variant<64, 6>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
         }
@@ -571,6 +572,7 @@ static bool try_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int6
         switch (H) {
             case 1: launch_tile_variant<16, 1>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
             case 2: launch_tile_variant<16, 2>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
+            case 3: launch_tile_variant<16, 3>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
             case 4: launch_tile_variant<16, 4>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
             default: launch_tile_variant<16, 6>(p, pos, w, wstride, wscalar, mesh, accumulate); break;
         }
@@ -643,6 +645,7 @@ int mcpm_paint3_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const f
     switch (H) {
         case 1: CALL3(1) break;
         case 2: CALL3(2) break;
+        case 3: CALL3(3) break;
         case 4: CALL3(4) break;
         default: CALL3(6) break;
     }

@@ -159,7 +159,7 @@ int mcpm_plan_destroy(mcpm_plan *p) {
 
 int mcpm_plan_set_halo(mcpm_plan *p, int halo) {
     if (!p) return MCPM_E_ARG;
-    MCPM_REQUIRE(p, halo == 1 || halo == 2 || halo == 4 || halo == 6, MCPM_E_ARG, "halo must be 1, 2, 4 or 6");
+    MCPM_REQUIRE(p, halo == 1 || halo == 2 || halo == 3 || halo == 4 || halo == 6, MCPM_E_ARG, "halo must be 1, 2, 3, 4 or 6");
     p->halo = halo;
     return MCPM_OK;
 }

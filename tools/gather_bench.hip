@@ -1,0 +1,128 @@
+// Micro-benchmark: cost of the CIC z-pair gathers (what bounds read_kernel / kick_drift_kernel at zero displacement?)
+//   hipcc -O3 --offload-arch=gfx950 tools/gather_bench.hip -o /tmp/gather_bench && /tmp/gather_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+
+// 12 "rows" (3 meshes x 4 (x,y) corners), z-pair per row.  n = 512: particle i -> cell (x, y, z)
+template <int VARIANT, int ROWS>
+__global__ __launch_bounds__(256) void k(const float *__restrict__ m, float *__restrict__ out, int n, int64_t M) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int z = (int)(i % n), y = (int)((i / n) % n), x = (int)(i / ((int64_t)n * n));
+    const int z1 = (z + 1) % n;
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int c = r >> 2, dx = (r >> 1) & 1, dy = r & 1;
+        const float *row = m + c * M + ((int64_t)((x + dx) % n) * n + (y + dy) % n) * n;
+        if (VARIANT == 0) {            // one b32 per row
+            acc += row[z];
+        } else if (VARIANT == 1) {     // two b32 per row
+            acc += row[z] + 0.5f * row[z1];
+        } else if (VARIANT == 2) {     // one b64 per row at 4-byte alignment (the shipped kernel)
+            const int zc = z < n - 1 ? z : n - 2;
+            F2 v = *(const F2 *)(row + zc);
+            acc += v.a + 0.5f * v.b;
+        } else if (VARIANT == 3) {     // one aligned b64 per row
+            float2 v = *(const float2 *)(row + (z & ~1));
+            acc += v.x + 0.5f * v.y;
+        } else if (VARIANT == 5 || VARIANT == 6 || VARIANT == 7 || VARIANT == 8) {
+            const float *base = m + c * M;                                      // uniform (SGPR) base
+            const uint32_t off = (uint32_t)(((x + dx) % n) * n + (y + dy) % n) * (uint32_t)n;   // 32-bit element offset
+            if (VARIANT == 5) {
+                acc += *(const float *)((const char *)base + (off + (uint32_t)z) * 4u) + 0.5f * *(const float *)((const char *)base + (off + (uint32_t)z1) * 4u);
+            } else if (VARIANT == 6) {
+                const int zc = z < n - 1 ? z : n - 2;
+                F2 v = *(const F2 *)((const char *)base + (off + (uint32_t)zc) * 4u);
+                acc += v.a + 0.5f * v.b;
+            } else {
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(M * 4), 0x00020000);
+                if (VARIANT == 7) {
+                    acc += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (off + z) * 4, 0, 0)) +
+                           0.5f * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (off + z1) * 4, 0, 0));
+                } else {
+                    const int zc = z < n - 1 ? z : n - 2;
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, (off + zc) * 4, 0, 0);
+                    acc += __uint_as_float(v.x) + 0.5f * __uint_as_float(v.y);   // (bit_cast of v[1] reads element 0 with this clang)
+                }
+            }
+        } else if (VARIANT == 4) {     // b32 + neighbour lane's value via DPP-like shuffle
+            const float a = row[z];
+            const float b = __shfl_down(a, 1);
+            acc += a + 0.5f * b;
+        }
+    }
+    out[i] = acc;
+}
+
+// interleaved force mesh [cell][W] (W = 3 or 4 floats): 8 corner gathers of 12 / 16 bytes per lane
+struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
+template <int W>
+__global__ __launch_bounds__(256) void kaos(const float *__restrict__ m, float *__restrict__ out, int n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int z = (int)(i % n), y = (int)((i / n) % n), x = (int)(i / ((int64_t)n * n));
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const char *mb = (const char *)m;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int dx = (r >> 2) & 1, dy = (r >> 1) & 1, dz = r & 1;
+        const uint32_t cell = (uint32_t)((((x + dx) % n) * n + (y + dy) % n) * n + (z + dz) % n);
+        if (W == 3) {
+            const F3 v = *(const F3 *)(mb + cell * 12u);
+            a0 += v.a; a1 += v.b; a2 += v.c;
+        } else {
+            const float4 v = *(const float4 *)(mb + (size_t)cell * 16u);
+            a0 += v.x; a1 += v.y; a2 += v.z;
+        }
+    }
+    out[i] = a0 + 2.f * a1 + 3.f * a2;
+}
+
+template <int W>
+static int runaos(const float *m, float *out, int n, const char *name) {
+    const int64_t N = (int64_t)n * n * n;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    kaos<W><<<(unsigned)(N / 256), 256>>>(m, out, n);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) kaos<W><<<(unsigned)(N / 256), 256>>>(m, out, n);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-28s corners=8  %.3f ms\n", name, ms / 5);
+    return 0;
+}
+
+template <int V, int ROWS>
+static int run(const float *m, float *out, int n, const char *name) {
+    const int64_t N = (int64_t)n * n * n;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    k<V, ROWS><<<(unsigned)(N / 256), 256>>>(m, out, n, N);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) k<V, ROWS><<<(unsigned)(N / 256), 256>>>(m, out, n, N);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-28s rows=%2d  %.3f ms\n", name, ROWS, ms / 5);
+    return 0;
+}
+
+int main() {
+    const int n = 512;
+    const int64_t N = (int64_t)n * n * n;
+    float *m, *out;
+    CK(hipMalloc(&m, 4 * N * 4 + 64)); CK(hipMalloc(&out, N * 4));
+    CK(hipMemset(m, 0, 4 * N * 4 + 64));
+    run<0, 4>(m, out, n, "b32"); run<0, 12>(m, out, n, "b32");
+    run<1, 4>(m, out, n, "2 x b32"); run<1, 12>(m, out, n, "2 x b32");
+    run<2, 4>(m, out, n, "b64 align4"); run<2, 12>(m, out, n, "b64 align4");
+    run<3, 4>(m, out, n, "b64 align8"); run<3, 12>(m, out, n, "b64 align8");
+    run<5, 12>(m, out, n, "2 x b32 saddr"); run<6, 12>(m, out, n, "b64 saddr");
+    run<7, 12>(m, out, n, "2 x b32 buffer"); run<8, 12>(m, out, n, "b64 buffer");
+    runaos<3>(m, out, n, "AoS3 dwordx3 saddr"); runaos<4>(m, out, n, "AoS4 dwordx4");
+    run<4, 4>(m, out, n, "b32 + shuffle"); run<4, 12>(m, out, n, "b32 + shuffle");
+    return 0;
+}
