@@ -305,8 +305,8 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol_kernel(FGeom g, con
 //   EXPAND  (inverse): in = {A, G} -> out = {IFFTy A, IFFTy(ky G), kz IFFTy G}
 //   CONTRACT (forward, adjoint): in = {a, b, c} -> out = {FFTy a, ky FFTy b + kz FFTy c}
 template <int N, bool EXPAND>
-__global__ __launch_bounds__(ColShape<N>::THREADS) void ycol2_kernel(FGeom g, const cf *__restrict__ in, cf *__restrict__ out,
-                                                                     YLayout li, YLayout lo, const cf *__restrict__ W) {
+__global__ __launch_bounds__(ColShape<N>::THREADS) void ycol2_kernel(
+    FGeom g, const cf *__restrict__ in, cf *__restrict__ out, YLayout li, YLayout lo, const cf *__restrict__ W) {
     constexpr int T = ColShape<N>::T, LINES = ColShape<N>::LINES;
     typedef Tile<N, LINES, true> TL;
     __shared__ cf lds[TL::FLOATS2];
@@ -317,60 +317,66 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol2_kernel(FGeom g, co
     cf *ob = out + (int64_t)blockIdx.y * lo.PS + kzi;
     const bool special = (kzi == 0) || (kzi == g.nz / 2);
     const float fz = (kzi == g.nz / 2) ? 0.f : MCPM_TWO_PI * (float)kzi / (float)g.nz;
-    int64_t oi[8], oo[8];
-    float fy[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int y = u + T * m, ybi = y >> li.lgYB, ybo = y >> lo.lgYB;
-        oi[m] = ybi * li.SB + (int64_t)(y & (li.YB - 1)) * g.nzp;
-        oo[m] = ybo * lo.SB + (int64_t)(y & (lo.YB - 1)) * g.nzp;
-        fy[m] = (special && y == N / 2) ? 0.f : MCPM_TWO_PI * (float)(y < N / 2 ? y : y - N) / (float)N;
-    }
+    // one transform at a time (load, FFT, store) keeps the kernel at two workgroups per CU; offsets are recomputed
+    // (a shift, a mask, a multiply) rather than held in registers
+#define ioff(m) ((uint32_t)((u + T * (m)) >> li.lgYB) * (uint32_t)li.SB + (uint32_t)((u + T * (m)) & (li.YB - 1)) * (uint32_t)g.nzp)
+#define ooff(m) ((uint32_t)((u + T * (m)) >> lo.lgYB) * (uint32_t)lo.SB + (uint32_t)((u + T * (m)) & (lo.YB - 1)) * (uint32_t)g.nzp)
+#define fy(m) ((special && (u + T * (m)) == N / 2) ? 0.f : MCPM_TWO_PI * (float)((u + T * (m)) < N / 2 ? (u + T * (m)) : (u + T * (m)) - N) / (float)N)
+    const cf zero = make_float2(0.f, 0.f);
     TL tile{l};
+    cf v[8];
     if (EXPAND) {
-        cf a[8], gq[8], h[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = ok ? ib[ioff(m)] : zero;
+        fft_line<N, +1>(v, lds, W, u, tile);
+        if (ok) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) ob[ooff(m)] = v[m];
+        }
+        cf gq[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            a[m] = ok ? ib[oi[m]] : make_float2(0.f, 0.f);
-            gq[m] = ok ? ib[li.BS + oi[m]] : make_float2(0.f, 0.f);
-            h[m] = make_float2(fy[m] * gq[m].x, fy[m] * gq[m].y);
+            gq[m] = ok ? ib[li.BS + ioff(m)] : zero;
+            const float f = fy(m);
+            v[m] = make_float2(f * gq[m].x, f * gq[m].y);
         }
-        fft_line<N, +1>(a, lds, W, u, tile);
+        fft_line<N, +1>(v, lds, W, u, tile);
         if (ok) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) ob[oo[m]] = a[m];
-        }
-        fft_line<N, +1>(h, lds, W, u, tile);
-        if (ok) {
-#pragma unroll
-            for (int m = 0; m < 8; ++m) ob[lo.BS + oo[m]] = h[m];
+            for (int m = 0; m < 8; ++m) ob[lo.BS + ooff(m)] = v[m];
         }
         fft_line<N, +1>(gq, lds, W, u, tile);
         if (ok) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) ob[2 * lo.BS + oo[m]] = make_float2(fz * gq[m].x, fz * gq[m].y);
+            for (int m = 0; m < 8; ++m) ob[2 * lo.BS + ooff(m)] = make_float2(fz * gq[m].x, fz * gq[m].y);
         }
     } else {
-        cf a[8], b[8], c[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            a[m] = ok ? ib[oi[m]] : make_float2(0.f, 0.f);
-            b[m] = ok ? ib[li.BS + oi[m]] : make_float2(0.f, 0.f);
-            c[m] = ok ? ib[2 * li.BS + oi[m]] : make_float2(0.f, 0.f);
-        }
-        fft_line<N, -1>(a, lds, W, u, tile);
+        for (int m = 0; m < 8; ++m) v[m] = ok ? ib[ioff(m)] : zero;
+        fft_line<N, -1>(v, lds, W, u, tile);
         if (ok) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) ob[oo[m]] = a[m];
+            for (int m = 0; m < 8; ++m) ob[ooff(m)] = v[m];
         }
-        fft_line<N, -1>(b, lds, W, u, tile);
+        cf c[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            v[m] = ok ? ib[li.BS + ioff(m)] : zero;
+            c[m] = ok ? ib[2 * li.BS + ioff(m)] : zero;
+        }
+        fft_line<N, -1>(v, lds, W, u, tile);
         fft_line<N, -1>(c, lds, W, u, tile);
         if (ok) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
-                ob[lo.BS + oo[m]] = make_float2(fy[m] * b[m].x + fz * c[m].x, fy[m] * b[m].y + fz * c[m].y);
+            for (int m = 0; m < 8; ++m) {
+                const float f = fy(m);
+                ob[lo.BS + ooff(m)] = make_float2(f * v[m].x + fz * c[m].x, f * v[m].y + fz * c[m].y);
+            }
         }
     }
+#undef ioff
+#undef ooff
+#undef fy
 }
 
 // k-space multipliers (nbody.py:109-163 with fd_order = inf), wavevectors from indices

@@ -6,12 +6,21 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+__constant__ float g_amp;   // amplitude (cells) of a smooth synthetic displacement field; 0 = regular lattice
+__device__ __forceinline__ void displaced(int n, int &x, int &y, int &z) {
+    if (g_amp == 0.f) return;
+    const float px = 0.049f * x, py = 0.037f * y, pz = 0.043f * z;
+    const int ox = (int)floorf(g_amp * __sinf(py + 2.f * pz + 0.5f * px)), oy = (int)floorf(g_amp * __sinf(pz + 2.f * px + 0.5f * py)),
+              oz = (int)floorf(g_amp * __sinf(px + 2.f * py + 0.5f * pz));
+    x = (x + ox + n) % n; y = (y + oy + n) % n; z = (z + oz + n) % n;
+}
 
 // 12 "rows" (3 meshes x 4 (x,y) corners), z-pair per row.  n = 512: particle i -> cell (x, y, z)
 template <int VARIANT, int ROWS>
 __global__ __launch_bounds__(256) void k(const float *__restrict__ m, float *__restrict__ out, int n, int64_t M) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int z = (int)(i % n), y = (int)((i / n) % n), x = (int)(i / ((int64_t)n * n));
+    int z = (int)(i % n), y = (int)((i / n) % n), x = (int)(i / ((int64_t)n * n));
+    displaced(n, x, y, z);
     const int z1 = (z + 1) % n;
     float acc = 0.f;
 #pragma unroll
@@ -64,7 +73,8 @@ struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
 template <int W>
 __global__ __launch_bounds__(256) void kaos(const float *__restrict__ m, float *__restrict__ out, int n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int z = (int)(i % n), y = (int)((i / n) % n), x = (int)(i / ((int64_t)n * n));
+    int z = (int)(i % n), y = (int)((i / n) % n), x = (int)(i / ((int64_t)n * n));
+    displaced(n, x, y, z);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     const char *mb = (const char *)m;
 #pragma unroll
@@ -116,13 +126,16 @@ int main() {
     float *m, *out;
     CK(hipMalloc(&m, 4 * N * 4 + 64)); CK(hipMalloc(&out, N * 4));
     CK(hipMemset(m, 0, 4 * N * 4 + 64));
-    run<0, 4>(m, out, n, "b32"); run<0, 12>(m, out, n, "b32");
-    run<1, 4>(m, out, n, "2 x b32"); run<1, 12>(m, out, n, "2 x b32");
-    run<2, 4>(m, out, n, "b64 align4"); run<2, 12>(m, out, n, "b64 align4");
-    run<3, 4>(m, out, n, "b64 align8"); run<3, 12>(m, out, n, "b64 align8");
-    run<5, 12>(m, out, n, "2 x b32 saddr"); run<6, 12>(m, out, n, "b64 saddr");
-    run<7, 12>(m, out, n, "2 x b32 buffer"); run<8, 12>(m, out, n, "b64 buffer");
-    runaos<3>(m, out, n, "AoS3 dwordx3 saddr"); runaos<4>(m, out, n, "AoS4 dwordx4");
-    run<4, 4>(m, out, n, "b32 + shuffle"); run<4, 12>(m, out, n, "b32 + shuffle");
+    for (float amp : {0.f, 1.f, 3.f, 6.f}) {
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_amp), &amp, sizeof(float)));
+        printf("--- smooth displacement amplitude %.0f cells\n", amp);
+        run<1, 12>(m, out, n, "2 x b32");
+        run<5, 12>(m, out, n, "2 x b32 saddr");
+        run<2, 12>(m, out, n, "b64 align4");
+        run<6, 12>(m, out, n, "b64 saddr");
+        run<8, 12>(m, out, n, "b64 buffer");
+        runaos<3>(m, out, n, "AoS3 dwordx3 saddr");
+        runaos<4>(m, out, n, "AoS4 (dwordx3 of 16 B cells)");
+    }
     return 0;
 }
