@@ -162,7 +162,13 @@ int mcpm_force_meshes_vjp_f32(mcpm_plan *plan, const float *fbar3, float *rho_ba
 int64_t mcpm_slab_spec_elems(const mcpm_plan *plan);
 int mcpm_slab_zfwd(mcpm_plan *plan, const float *real, int64_t real_bstride, float *spec, int batch);
 int mcpm_slab_ycol(mcpm_plan *plan, const float *in, float *out, int batch, int sign, int in_packed, int out_packed);
-int mcpm_slab_ycol2(mcpm_plan *plan, const float *in, float *out, int expand, int in_packed, int out_packed);
+/* parts: bit 0 = the spectrum-0 transform (A / a), bit 1 = the other two; 3 = all.  The halves travel in separate
+   all-to-alls, so a caller can run one half while the other is still in flight. */
+int mcpm_slab_ycol2(mcpm_plan *plan, const float *in, float *out, int expand, int in_packed, int out_packed, int parts);
+/* Restricts the following zfwd / zinv / ycol / ycol2 calls to the local planes [x0, x0 + count) (pointer arguments
+   still address plane 0).  Planes are independent in those passes, so a caller can transform the planes a halo
+   exchange does not touch while the exchange is in flight.  (0, nx_local) restores the default. */
+int mcpm_slab_set_window(mcpm_plan *plan, int x0, int count);
 int mcpm_slab_xfused(mcpm_plan *plan, const float *in, float *out, int mode);
 int mcpm_slab_zinv(mcpm_plan *plan, const float *spec, float *real, int64_t real_bstride, int batch);
 

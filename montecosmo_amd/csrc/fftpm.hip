@@ -173,6 +173,7 @@ struct ZBatch {
 struct YLayout {
     int64_t BS, PS, SB;
     int YB, NXL, lgYB;  // YB is a power of two
+    int X0, NXW;        // the pass covers local planes [X0, X0 + NXW)
 };
 // x-line addressing of the fused pass.  One-spectrum side: [x][yl][nzp] (NYL rows per x).  Three-spectra side:
 // c*SC + (x / XB)*SBx + ((x % XB)*NYL + yl)*nzp  (single GPU: XB = nx; slabs: [c][src/dest rank][xl][yl][nzp]).
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol_kernel(FGeom g, con
     const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
     const int kz = blockIdx.x * LINES + l;
     const bool ok = kz < g.nzh;
-    const int pc = blockIdx.y / li.NXL, pxl = blockIdx.y - pc * li.NXL;
+    const int pc = blockIdx.y / li.NXW, pxl = li.X0 + (blockIdx.y - pc * li.NXW);
     const cf *ib = in + pc * li.BS + pxl * li.PS + kz;
     cf *ob = out + pc * lo.BS + pxl * lo.PS + kz;
     cf v[8];
@@ -306,15 +307,16 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol_kernel(FGeom g, con
 //   CONTRACT (forward, adjoint): in = {a, b, c} -> out = {FFTy a, ky FFTy b + kz FFTy c}
 template <int N, bool EXPAND>
 __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol2_kernel(
-    FGeom g, const cf *__restrict__ in, cf *__restrict__ out, YLayout li, YLayout lo, const cf *__restrict__ W) {
+    FGeom g, const cf *__restrict__ in, cf *__restrict__ out, YLayout li, YLayout lo, const cf *__restrict__ W, int parts) {
     constexpr int T = ColShape<N>::T, LINES = ColShape<N>::LINES;
     typedef Tile<N, LINES, true> TL;
     __shared__ cf lds[TL::FLOATS2];
     const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
     const int kzi = blockIdx.x * LINES + l;
     const bool ok = kzi < g.nzh;
-    const cf *ib = in + (int64_t)blockIdx.y * li.PS + kzi;   // blockIdx.y = x plane; component c adds c * BS
-    cf *ob = out + (int64_t)blockIdx.y * lo.PS + kzi;
+    const int plane = li.X0 + blockIdx.y;                    // local x plane; component c adds c * BS
+    const cf *ib = in + (int64_t)plane * li.PS + kzi;
+    cf *ob = out + (int64_t)plane * lo.PS + kzi;
     const bool special = (kzi == 0) || (kzi == g.nz / 2);
     const float fz = (kzi == g.nz / 2) ? 0.f : MCPM_TWO_PI * (float)kzi / (float)g.nz;
     // one transform at a time (load, FFT, store) keeps the kernel at two workgroups per CU; offsets are recomputed
@@ -325,14 +327,18 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol2_kernel(
     const cf zero = make_float2(0.f, 0.f);
     TL tile{l};
     cf v[8];
+    // parts (uniform): bit 0 = the spectrum-0 transform, bit 1 = the other two (they travel in separate all-to-alls)
     if (EXPAND) {
+        if (parts & 1) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = ok ? ib[ioff(m)] : zero;
-        fft_line<N, +1>(v, lds, W, u, tile);
-        if (ok) {
+            for (int m = 0; m < 8; ++m) v[m] = ok ? ib[ioff(m)] : zero;
+            fft_line<N, +1>(v, lds, W, u, tile);
+            if (ok) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) ob[ooff(m)] = v[m];
+                for (int m = 0; m < 8; ++m) ob[ooff(m)] = v[m];
+            }
         }
+        if (!(parts & 2)) return;
         cf gq[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -351,13 +357,16 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol2_kernel(
             for (int m = 0; m < 8; ++m) ob[2 * lo.BS + ooff(m)] = make_float2(fz * gq[m].x, fz * gq[m].y);
         }
     } else {
+        if (parts & 1) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = ok ? ib[ioff(m)] : zero;
-        fft_line<N, -1>(v, lds, W, u, tile);
-        if (ok) {
+            for (int m = 0; m < 8; ++m) v[m] = ok ? ib[ioff(m)] : zero;
+            fft_line<N, -1>(v, lds, W, u, tile);
+            if (ok) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) ob[ooff(m)] = v[m];
+                for (int m = 0; m < 8; ++m) ob[ooff(m)] = v[m];
+            }
         }
+        if (!(parts & 2)) return;
         cf c[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -602,7 +611,7 @@ static FGeom fgeom(const mcpm_plan *p) { return FGeom{p->nx_global, p->g.ny, p->
 // one local spectrum: nxl planes x ny x nzp complex
 static int64_t spec_elems(const mcpm_plan *p) { return (int64_t)p->nxl * p->g.ny * (p->g.nz / 2 + 16); }
 static double pass_bytes(const mcpm_plan *p, int batch) {  // algorithmic share of one pass of a 3-pass transform
-    return (double)batch * (4.0 * p->nxl * p->g.ny * p->g.nz + 8.0 * p->nxl * p->g.ny * p->g.nzh) / 3.0;
+    return (double)batch * (4.0 * p->xwn * p->g.ny * p->g.nz + 8.0 * p->xwn * p->g.ny * p->g.nzh) / 3.0;
 }
 
 #define DISPATCH_N(n, CALL)                  \
@@ -616,7 +625,9 @@ static double pass_bytes(const mcpm_plan *p, int batch) {  // algorithmic share 
 
 static int z_forward(mcpm_plan *p, const float *real, int64_t real_bstride, cf *spec, int batch) {
     const FGeom g = fgeom(p);
-    const ZBatch zb{(int64_t)p->nxl * g.ny, real_bstride, spec_elems(p)};
+    const ZBatch zb{(int64_t)p->xwn * g.ny, real_bstride, spec_elems(p)};
+    real += (int64_t)p->xw0 * g.ny * g.nz;   // window of local planes (all of them unless mcpm_slab_set_window)
+    spec += (int64_t)p->xw0 * g.ny * g.nzp;
     const int64_t npairs = (int64_t)batch * zb.lines / 2;
     StageTimer st_(p, ST_R2C, pass_bytes(p, batch));
 #define CALL(NN)                                                                                                   \
@@ -632,7 +643,9 @@ static int z_forward(mcpm_plan *p, const float *real, int64_t real_bstride, cf *
 
 static int z_inverse(mcpm_plan *p, const cf *spec, float *real, int64_t real_bstride, int batch) {
     const FGeom g = fgeom(p);
-    const ZBatch zb{(int64_t)p->nxl * g.ny, real_bstride, spec_elems(p)};
+    const ZBatch zb{(int64_t)p->xwn * g.ny, real_bstride, spec_elems(p)};
+    real += (int64_t)p->xw0 * g.ny * g.nz;
+    spec += (int64_t)p->xw0 * g.ny * g.nzp;
     const int64_t npairs = (int64_t)batch * zb.lines / 2;
     StageTimer st_(p, ST_C2R, pass_bytes(p, batch));
 #define CALL(NN)                                                                                                   \
@@ -650,9 +663,9 @@ static int z_inverse(mcpm_plan *p, const cf *spec, float *real, int64_t real_bst
 static YLayout ylayout(const mcpm_plan *p, bool packed) {
     const int64_t nzp = p->g.nz / 2 + 16;
     auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
-    if (!packed) return YLayout{spec_elems(p), (int64_t)p->g.ny * nzp, 0, p->g.ny, p->nxl, lg(p->g.ny)};
+    if (!packed) return YLayout{spec_elems(p), (int64_t)p->g.ny * nzp, 0, p->g.ny, p->nxl, lg(p->g.ny), p->xw0, p->xwn};
     const int nyl = p->g.ny / p->nranks;
-    return YLayout{spec_elems(p), (int64_t)nyl * nzp, (int64_t)p->nxl * nyl * nzp, nyl, p->nxl, lg(nyl)};
+    return YLayout{spec_elems(p), (int64_t)nyl * nzp, (int64_t)p->nxl * nyl * nzp, nyl, p->nxl, lg(nyl), p->xw0, p->xwn};
 }
 
 static int y_columns(mcpm_plan *p, const cf *in, cf *out, int batch, int sign, bool in_packed, bool out_packed) {
@@ -662,7 +675,7 @@ static int y_columns(mcpm_plan *p, const cf *in, cf *out, int batch, int sign, b
 #define CALL(NN)                                                                                       \
     {                                                                                                  \
         constexpr int LINES = ColShape<NN>::LINES, TH = ColShape<NN>::THREADS;                         \
-        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)(batch * p->nxl));                \
+        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)(batch * p->xwn));                \
         if (sign < 0) ycol_kernel<NN, -1><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1]);  \
         else ycol_kernel<NN, +1><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1]);           \
     }
@@ -673,16 +686,16 @@ static int y_columns(mcpm_plan *p, const cf *in, cf *out, int batch, int sign, b
 }
 
 // y pass with the y / z force factors: expand (2 -> 3 spectra, inverse) or contract (3 -> 2, forward)
-static int y_columns2(mcpm_plan *p, const cf *in, cf *out, bool expand, bool in_packed, bool out_packed) {
+static int y_columns2(mcpm_plan *p, const cf *in, cf *out, bool expand, bool in_packed, bool out_packed, int parts = 3) {
     const FGeom g = fgeom(p);
     const YLayout li = ylayout(p, in_packed), lo = ylayout(p, out_packed);
-    StageTimer st_(p, expand ? ST_C2R : ST_R2C, pass_bytes(p, 3));
+    StageTimer st_(p, expand ? ST_C2R : ST_R2C, pass_bytes(p, parts == 3 ? 3 : (parts == 1 ? 1 : 2)));
 #define CALL(NN)                                                                                       \
     {                                                                                                  \
         constexpr int LINES = ColShape<NN>::LINES, TH = ColShape<NN>::THREADS;                         \
-        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)p->nxl);                          \
-        if (expand) ycol2_kernel<NN, true><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1]);  \
-        else ycol2_kernel<NN, false><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1]);        \
+        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)p->xwn);                          \
+        if (expand) ycol2_kernel<NN, true><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1], parts);  \
+        else ycol2_kernel<NN, false><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1], parts);        \
     }
     DISPATCH_N(g.ny, CALL)
 #undef CALL
@@ -819,12 +832,20 @@ int mcpm_slab_ycol(mcpm_plan *p, const float *in, float *out, int batch, int sig
     return y_columns(p, (const cf *)in, (cf *)out, batch, sign, in_packed != 0, out_packed != 0);
 }
 
-int mcpm_slab_ycol2(mcpm_plan *p, const float *in, float *out, int expand, int in_packed, int out_packed) {
+int mcpm_slab_set_window(mcpm_plan *p, int x0, int count) {
     if (!p) return MCPM_E_ARG;
-    MCPM_REQUIRE(p, in && out && in != out, MCPM_E_ARG, "mcpm_slab_ycol2: bad argument");
+    MCPM_REQUIRE(p, x0 >= 0 && count >= 1 && x0 + count <= p->nxl, MCPM_E_ARG, "mcpm_slab_set_window: window outside the local planes");
+    p->xw0 = x0;
+    p->xwn = count;
+    return MCPM_OK;
+}
+
+int mcpm_slab_ycol2(mcpm_plan *p, const float *in, float *out, int expand, int in_packed, int out_packed, int parts) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, in && out && in != out && parts >= 1 && parts <= 3, MCPM_E_ARG, "mcpm_slab_ycol2: bad argument");
     MCPM_REQUIRE(p, mcpm_fftpm_supported(p), MCPM_E_UNSUPPORTED, "slab FFT needs power-of-two axes in [64, 1024]");
     MCPM_TRY(ensure_twiddles(p));
-    return y_columns2(p, (const cf *)in, (cf *)out, expand != 0, in_packed != 0, out_packed != 0);
+    return y_columns2(p, (const cf *)in, (cf *)out, expand != 0, in_packed != 0, out_packed != 0, parts);
 }
 
 int mcpm_slab_xfused(mcpm_plan *p, const float *in, float *out, int mode) {

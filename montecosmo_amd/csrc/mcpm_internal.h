@@ -60,6 +60,7 @@ struct mcpm_plan {
     const void *fb_xb, *fb_vb;
     // x-slab decomposition (mcpm_plan_create_slab): this rank owns global planes [rank*nxl, (rank+1)*nxl)
     int nranks, rank, ghost, nx_global, nxl;
+    int xw0, xwn;  // window of local planes the slab z / y passes work on (mcpm_slab_set_window; default all nxl)
 
     // rocFFT plans keyed by batch
     std::map<int, rocfft_plan> r2c, c2r;

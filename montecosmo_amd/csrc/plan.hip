@@ -85,6 +85,8 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->ghost = ghost;
     p->nx_global = nx_global;
     p->nxl = slab ? px : nx;
+    p->xw0 = 0;
+    p->xwn = p->nxl;
     p->stream = (hipStream_t)stream;
     p->M = (int64_t)nx * ny * nz;
     p->Mh = (int64_t)nx * ny * p->g.nzh;

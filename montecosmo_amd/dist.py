@@ -240,43 +240,89 @@ class SlabPM(HaloMixin):
     def _spec(self, buf, c):
         return C.c_void_p(buf.data_ptr() + 8 * c * self.ss)
 
-    def force_meshes(self, rho_ext, f3_ext, fill_ghosts=True):
-        """Interior of rho_ext (ghosts already added) -> the three force meshes f3_ext (ghosts filled).
-        Only two spectra (A, G) cross the second all-to-all: the y pass applies the y / z force factors."""
+    def _windows(self, pending):
+        """Plane windows in issue order.  With a halo exchange pending (or about to start) the passes are split into
+        the G edge planes on each side, which the exchange touches, and the inner planes, which it does not."""
+        G, nxl = self.G, self.nxl
+        if not pending or nxl <= 2 * G:
+            return None, [(0, nxl)]
+        return (G, nxl - 2 * G), [(0, G), (nxl - G, G)]
+
+    def _win(self, w):
+        self.call("mcpm_slab_set_window", int(w[0]), int(w[1]))
+
+    def _zinv_fill(self, spec_buf, c, ext, fill):
+        """z C2R of spectrum c into the interior of ext; the edge planes go first so that their ghost fill (async) runs
+        under the inner planes' transform."""
+        inner, edges = self._windows(fill)
+        for w in edges:
+            self._win(w)
+            self.call("mcpm_slab_zinv", self._spec(spec_buf, c), self._interior(ext), self.Me, 1)
+        h = self.halo_fill(ext, async_op=True) if fill else None
+        if inner is not None:
+            self._win(inner)
+            self.call("mcpm_slab_zinv", self._spec(spec_buf, c), self._interior(ext), self.Me, 1)
+        self._win((0, self.nxl))
+        return h
+
+    def force_meshes(self, rho_ext, f3_ext, fill_ghosts=True, rho_add=None):
+        """Interior of rho_ext -> the three force meshes f3_ext (ghosts filled).  `rho_add`: handle of the ghost add of
+        rho_ext still in flight (None: ghosts already added); the inner planes' z / y passes run under it.
+        Only two spectra (A, G) cross the second all-to-all: the y pass applies the y / z force factors, and the
+        transfer of G runs under the y / z passes (and ghost fill) of the first component."""
         ss = self.ss
-        self.call("mcpm_slab_zfwd", self._interior(rho_ext), self.Me, _p(self.s1a), 1)
-        self.call("mcpm_slab_ycol", _p(self.s1a), _p(self.s1b), 1, -1, 0, 1)          # plain -> transposed order
+        inner, edges = self._windows(rho_add is not None)
+        for w in ([inner] if inner is not None else []) + edges:
+            if rho_add is not None and w is not inner:
+                rho_add.wait()
+                rho_add = None
+            self._win(w)
+            self.call("mcpm_slab_zfwd", self._interior(rho_ext), self.Me, _p(self.s1a), 1)
+            self.call("mcpm_slab_ycol", _p(self.s1a), _p(self.s1b), 1, -1, 0, 1)      # plain -> transposed order
+        self._win((0, self.nxl))
         self.comm.all_to_all(self.s1a, self.s1b)                                     # x <-> y transpose
         self.call("mcpm_slab_xfused", _p(self.s1a), _p(self.s3a), 0)                  # -> A, G
-        a2a = [self.comm.all_to_all(self.s3b[c * ss:(c + 1) * ss], self.s3a[c * ss:(c + 1) * ss], async_op=True)
-               for c in range(2)]
-        for h in a2a:
-            h.wait()
-        self.call("mcpm_slab_ycol2", _p(self.s3b), _p(self.s3a), 1, 1, 0)             # {A, G} -> 3 force spectra
-        fills = []
-        for c in range(3):
-            self.call("mcpm_slab_zinv", self._spec(self.s3a, c), self._interior(f3_ext, c), self.Me, 1)
-            if fill_ghosts:
-                fills.append(self.halo_fill(f3_ext[c], async_op=True))
+        hA = self.comm.all_to_all(self.s3b[:ss], self.s3a[:ss], async_op=True)
+        hG = self.comm.all_to_all(self.s3b[ss:2 * ss], self.s3a[ss:2 * ss], async_op=True)
+        hA.wait()
+        self.call("mcpm_slab_ycol2", _p(self.s3b), _p(self.s3a), 1, 1, 0, 1)          # A -> force spectrum 0 (s3a[0])
+        fills = [self._zinv_fill(self.s3a, 0, f3_ext[0], fill_ghosts)]
+        hG.wait()
+        self.call("mcpm_slab_ycol2", _p(self.s3b), _p(self.s3a), 1, 1, 0, 2)          # G -> force spectra 1, 2
+        for c in (1, 2):
+            fills.append(self._zinv_fill(self.s3a, c, f3_ext[c], fill_ghosts))
         for f in fills:
-            f.wait()
+            if f is not None:
+                f.wait()
 
-    def force_meshes_vjp(self, fbar3_ext, rhobar_ext, ghost_adds=None):
-        """fbar3_ext: three cotangent meshes (ghosts added, or `ghost_adds[c]` handles still in flight)."""
+    def force_meshes_vjp(self, fbar3_ext, rhobar_ext, ghost_adds=None, fill_ghosts=False):
+        """fbar3_ext: three cotangent meshes (ghosts added, or `ghost_adds[c]` handles still in flight).  Writes the
+        interior of rhobar_ext (and its ghosts if fill_ghosts)."""
         ss = self.ss
+        handles = []
         for c in range(3):
-            if ghost_adds is not None:
-                ghost_adds[c].wait()
-            self.call("mcpm_slab_zfwd", self._interior(fbar3_ext, c), self.Me, self._spec(self.s3a, c), 1)
-        self.call("mcpm_slab_ycol2", _p(self.s3a), _p(self.s3b), 0, 0, 1)             # 3 spectra -> {a, b}, transposed order
-        a2a = [self.comm.all_to_all(self.s3a[c * ss:(c + 1) * ss], self.s3b[c * ss:(c + 1) * ss], async_op=True)
-               for c in range(2)]
-        for h in a2a:
+            add = ghost_adds[c] if ghost_adds is not None else None
+            inner, edges = self._windows(add is not None)
+            for w in ([inner] if inner is not None else []) + edges:
+                if add is not None and w is not inner:
+                    add.wait()
+                    add = None
+                self._win(w)
+                self.call("mcpm_slab_zfwd", self._interior(fbar3_ext, c), self.Me, self._spec(self.s3a, c), 1)
+            self._win((0, self.nxl))
+            if c == 0:    # a = FFTy(f_bar_x) leaves while the other two components are still being transformed
+                self.call("mcpm_slab_ycol2", _p(self.s3a), _p(self.s3b), 0, 0, 1, 1)
+                handles.append(self.comm.all_to_all(self.s3a[:ss], self.s3b[:ss], async_op=True))
+        self.call("mcpm_slab_ycol2", _p(self.s3a), _p(self.s3b), 0, 0, 1, 2)          # b = ky FFTy(f_bar_y) + kz FFTy(f_bar_z)
+        handles.append(self.comm.all_to_all(self.s3a[ss:2 * ss], self.s3b[ss:2 * ss], async_op=True))
+        for h in handles:
             h.wait()
         self.call("mcpm_slab_xfused", _p(self.s3a), _p(self.s1a), 1)
         self.comm.all_to_all(self.s1b, self.s1a)
         self.call("mcpm_slab_ycol", _p(self.s1b), _p(self.s1a), 1, +1, 1, 0)
-        self.call("mcpm_slab_zinv", _p(self.s1a), self._interior(rhobar_ext), self.Me, 1)
+        h = self._zinv_fill(self.s1a, 0, rhobar_ext, fill_ghosts)
+        if h is not None:
+            h.wait()
 
     # ---- lpt on slabs (nbody.py:634-667 at the lattice, read_order = 1) -------------------------------------
     def spec_to_meshes(self, spec_full, out_ext, nc):
@@ -345,8 +391,7 @@ class SlabPM(HaloMixin):
     def step(self, x, v, alpha, beta, tau, f3_out, x_out, v_out, paint_order=2):
         """x, v: (Nl,3) local state; f3_out: (3, nxe, ny, nz) receives the ghost-filled force meshes."""
         self.call("mcpm_paint_f32", _p(x), self.Nl, POS_LATTICE, None, 1, 1.0, paint_order, _p(self.rho), 0)
-        self.halo_add(self.rho)
-        self.force_meshes(self.rho, f3_out)
+        self.force_meshes(self.rho, f3_out, rho_add=self.halo_add(self.rho, async_op=True))
         self.call("mcpm_kick_drift_f32", _p(x), _p(v), self.Nl, POS_LATTICE, _p(f3_out), paint_order, float(alpha),
                   float(beta), float(tau), _p(x_out), _p(v_out))
 
@@ -355,8 +400,7 @@ class SlabPM(HaloMixin):
         self.call("mcpm_kick_f32", _p(vb), _p(xb), self.Nl, float(beta), float(beta * tau), _p(self.Fb))
         self.call("mcpm_paint3_f32", _p(x), self.Nl, POS_LATTICE, _p(self.Fb), paint_order, _p(self.f3), 0)
         adds = [self.halo_add(self.f3[c], async_op=True) for c in range(3)]   # overlap with the z / y passes below
-        self.force_meshes_vjp(self.f3, self.rho, adds)
-        self.halo_fill(self.rho)
+        self.force_meshes_vjp(self.f3, self.rho, adds, fill_ghosts=True)
         self.call("mcpm_step_adjoint_particles_f32", _p(x), _p(v), _p(f3), _p(self.rho), float(alpha), float(beta),
                   float(tau), paint_order, _p(xb), _p(vb), abar_ptr, bbar_ptr, float(dtau_ddg), dgbar_ptr)
 
