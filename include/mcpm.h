@@ -259,6 +259,16 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *plan, const float *init_mesh, int n_steps, 
                           float *init_mesh_bar, double *scalar_bars);
 
 /* ---- host-side float64 growth tables (nbody.py:679-745) ------------------------------------- */
+/* chreshape (montecosmo/utils.py:924-1013): half-spectrum of a real (in_nx, in_ny, in_nz) mesh -> half-spectrum of a
+   real (out_nx, out_ny, out_nz) mesh, truncating / zero-padding the centred wavevectors with the reference's Nyquist-plane
+   aggregation (1/sqrt2 weights) and cell-count scale, so Hermitian symmetry and mean power are preserved.  Plain
+   complex64 layout (nx, ny, nz/2+1) on both sides, all sizes even; no plan: `stream` is a hipStream_t.  The VJP takes the
+   cotangent of the output (real-pair convention dL = Re sum conj(bar) dz) and writes the cotangent of the input. */
+int mcpm_chreshape_c64(void *stream, const float *in, int in_nx, int in_ny, int in_nz, float *out, int out_nx, int out_ny,
+                       int out_nz);
+int mcpm_chreshape_vjp_c64(void *stream, const float *out_bar, int out_nx, int out_ny, int out_nz, float *in_bar, int in_nx,
+                           int in_ny, int in_nz);
+
 /* RK4 on atab = logspace(log10_amin, 0, steps); writes seven host arrays of length `steps`. */
 int mcpm_growth_table(double Omega_m, double Omega_de, double Omega_k, double w0, double wa,
                       double log10_amin, int steps, double *a, double *g, double *f, double *h, double *g2,

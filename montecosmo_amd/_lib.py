@@ -45,6 +45,8 @@ SIGNATURES = {
     "mcpm_hessian_combine_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p]),
     "mcpm_force_meshes_f32": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "mcpm_force_meshes_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p]),
+    "mcpm_chreshape_c64": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int]),
+    "mcpm_chreshape_vjp_c64": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int]),
     "mcpm_slab_spec_elems": (C.c_int64, [C.c_void_p]),
     "mcpm_slab_zfwd": (C.c_int, [C.c_void_p, _f32p, C.c_int64, _f32p, C.c_int]),
     "mcpm_slab_ycol": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from ._lib import lib, check, POS_ABSOLUTE, POS_LATTICE
-from .utils import safe_div, ch2rshape, r2chshape, scale_shape  # noqa: F401 (re-exported like the reference)
+from .utils import safe_div, ch2rshape, r2chshape, scale_shape, chreshape, chreshape_vjp  # noqa: F401 (re-exported like the reference)
 
 __all__ = [
     "rfftk", "fftk", "invlaplace_hat", "gradient_hat", "gaussian_hat", "rectangular", "rectangular_hat",
@@ -392,36 +392,62 @@ def _nufft_shapes(final_shape, paint_shape):
     return final_shape, tuple(int(s) for s in paint_shape)
 
 
+def _scale_pos(pos, ratio, shape, final_shape):
+    """Positions in cell units of final_shape -> cell units of `shape` (nbody.py:568).  A LatticePos keeps its particle
+    lattice: displacements scale with the cell ratio."""
+    if all(r == 1.0 for r in ratio):
+        return pos
+    if isinstance(pos, LatticePos):
+        r = torch.as_tensor(np.asarray(ratio, dtype=np.float32), device=pos.disp.device)
+        return LatticePos(pos.disp * r, shape, pos.ptcl_shape)
+    p = torch.as_tensor(pos)
+    return p * torch.as_tensor(np.asarray(ratio), dtype=p.dtype, device=p.device)
+
+
 def nufft(pos, final_shape: tuple, paint_shape=None, weights=1., paint_order: int = 2, interlace_order: int = 2,
           kernel_type='rectangular', paint_deconv=True):
-    """Non-uniform FFT with interlacing and kernel deconvolution (nbody.py:532-577).  `pos` in cell units of
-    `final_shape`.  A `paint_shape` different from `final_shape` needs `chreshape`, not implemented."""
+    """Non-uniform FFT with oversampling, interlacing and kernel deconvolution (nbody.py:532-577).  `pos` in cell
+    units of `final_shape`; the particles are painted on `paint_shape` (tuple, or float = oversampling factor on
+    final_shape), deconvolved there and reshaped to the half-spectrum of final_shape with `chreshape`."""
     final_shape, paint_shape = _nufft_shapes(final_shape, paint_shape)
-    if final_shape != paint_shape:
-        raise NotImplementedError("nufft with paint_shape != final_shape needs chreshape (next row)")
-    mesh = interlace(pos, paint_shape, weights, paint_order, interlace_order, kernel_type=kernel_type)
+    ratio = tuple(p / f for p, f in zip(paint_shape, final_shape))
+    mesh = interlace(_scale_pos(pos, ratio, paint_shape, final_shape), paint_shape, weights, paint_order, interlace_order,
+                     kernel_type=kernel_type)
+    jac = float(np.prod(ratio))
+    if jac != 1.0:
+        mesh *= jac                       # jacobian of final units to paint units (nbody.py:570)
     if paint_deconv:
         mesh = deconv_paint(mesh, paint_order, kernel_type=kernel_type)
+    if final_shape != paint_shape:
+        mesh = chreshape(mesh, r2chshape(final_shape))
     return mesh
 
 
-def nufft_vjp(pos, final_shape: tuple, weights, mesh_bar, paint_order: int = 2, interlace_order: int = 2, paint_deconv=True):
-    """VJP of nufft (paint_shape = final_shape) w.r.t. (pos, weights); mesh_bar is the half-spectrum cotangent in
-    the real-pair convention.  Returns (pos_bar (N,3), weights_bar)."""
-    shape = tuple(int(s) for s in final_shape)
-    mb = _c64(mesh_bar, r2chshape(shape))
-    plan = get_plan(shape, pos.ptcl_shape if isinstance(pos, LatticePos) else None)
+def nufft_vjp(pos, final_shape: tuple, weights, mesh_bar, paint_order: int = 2, interlace_order: int = 2, paint_deconv=True,
+              paint_shape=None):
+    """VJP of nufft w.r.t. (pos, weights); mesh_bar is the cotangent of the returned half-spectrum (shape
+    r2chshape(final_shape)) in the real-pair convention.  Returns (pos_bar (N,3) in final_shape cell units, weights_bar)."""
+    final_shape, shape = _nufft_shapes(final_shape, paint_shape)
+    ratio = tuple(p / f for p, f in zip(shape, final_shape))
+    mb = _c64(mesh_bar, r2chshape(final_shape))
+    if shape != final_shape:
+        mb = chreshape_vjp(mb, r2chshape(shape))
+    jac = float(np.prod(ratio))
+    ppos = _scale_pos(pos, ratio, shape, final_shape)
+    plan = get_plan(shape, ppos.ptcl_shape if isinstance(ppos, LatticePos) else None)
     tmp = torch.empty_like(mb)
     real = torch.empty(shape, dtype=torch.float32, device=mb.device)
     pos_bar, w_bar = None, None
     for j in range(int(interlace_order)):
         s = j / interlace_order
         # adjoint of (x phase / deconv / interlace_order) then of rfftn: C2R(conj(mult) * bar / multiplicity)
-        plan.call("mcpm_kspace_phase_f32", _ptr(mb), _ptr(tmp), 1.0 / interlace_order, float(s), int(paint_order) if paint_deconv else 0, 1, 1, 0)
+        plan.call("mcpm_kspace_phase_f32", _ptr(mb), _ptr(tmp), jac / interlace_order, float(s), int(paint_order) if paint_deconv else 0, 1, 1, 0)
         plan.call("mcpm_fft_c2r", _ptr(tmp), _ptr(real), 1)
-        pb, wb = paint_vjp(_shift_pos(pos, s), shape, weights, real, paint_order)
+        pb, wb = paint_vjp(_shift_pos(ppos, s), shape, weights, real, paint_order)
         pos_bar = pb if pos_bar is None else pos_bar + pb
         w_bar = wb if w_bar is None else w_bar + wb
+    if jac != 1.0 or any(r != 1.0 for r in ratio):
+        pos_bar = pos_bar * torch.as_tensor(np.asarray(ratio, dtype=np.float32), device=pos_bar.device)
     return pos_bar, w_bar
 
 

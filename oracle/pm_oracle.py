@@ -269,25 +269,153 @@ def interlace(pos, shape, weights=1., paint_order=2, interlace_order=2):
     return mesh
 
 
+# --------------------------------------------------------------------------- spectrum reshape
+def hermitian_symmetric(arr):
+    """montecosmo/utils.py:968-978: conj of the index-reversed array, rolled by one along every axis
+    (element i -> conj(arr[-i mod n]))."""
+    arr = np.asarray(arr)
+    out = arr[(slice(None, None, -1),) * arr.ndim].conj()
+    for ax in range(arr.ndim):
+        out = np.roll(out, 1, axis=ax)
+    return out
+
+
+def _chreshape_naive(mesh, shape):
+    """montecosmo/utils.py:924-964: crop / zero-pad the centred wavevectors, scale by the real cell-count ratio."""
+    scale = np.divide(ch2rshape(shape), ch2rshape(mesh.shape)).prod()
+    for ax, s in enumerate(mesh.shape[:-1]):
+        mesh = np.roll(mesh, s // 2, ax)
+    slices = ()
+    for ax, (ms, s) in enumerate(zip(mesh.shape, shape)):
+        trunc = max(ms - s, 0)
+        if ax < len(shape) - 1:
+            trunc //= 2
+            slices += (slice(trunc, None if trunc == 0 else -trunc),)
+        else:
+            slices += (slice(0, None if trunc == 0 else -trunc),)
+    mesh = mesh[slices]
+    pad_width = ()
+    for ax, (ms, s) in enumerate(zip(mesh.shape, shape)):
+        pad = max(s - ms, 0)
+        if ax < len(shape) - 1:
+            pad //= 2
+            pad_width += ((pad, pad),)
+        else:
+            pad_width += ((0, pad),)
+    mesh = np.pad(mesh, pad_width=pad_width)
+    for ax, s in enumerate(mesh.shape[:-1]):
+        mesh = np.roll(mesh, -s // 2, ax)
+    return mesh * scale
+
+
+def chreshape(mesh, shape):
+    """montecosmo/utils.py:981-1013: reshape a half-spectrum to the half-spectrum shape `shape`, truncating or
+    padding so that Hermitian symmetry and the mean power are preserved (Nyquist planes aggregated / split with
+    1/sqrt(2) weights).  Axes are visited last-to-first for the truncations, first-to-last for the pads."""
+    mesh = np.array(mesh, dtype=np.complex128)
+    shape = tuple(int(v) for v in shape)
+    nd = len(shape)
+    for ax, (ms, s) in reversed(list(enumerate(zip(mesh.shape, shape)))):
+        if s < ms:
+            if ax < nd - 1:
+                neg_ids = (slice(None),) * ax + (-s // 2,)
+                pos_ids = (slice(None),) * ax + (s // 2,)
+                mesh[neg_ids] = (mesh[pos_ids] + mesh[neg_ids]) / 2 ** .5
+            else:
+                pos_ids = (slice(None),) * ax + (s - 1,)
+                nyq = mesh[pos_ids].copy()
+                mesh[pos_ids] = (nyq + hermitian_symmetric(nyq)) / 2 ** .5
+    in_shape = mesh.shape
+    out = _chreshape_naive(mesh, shape)
+    for ax, (ms, s) in enumerate(zip(in_shape, shape)):
+        if s > ms:
+            if ax < nd - 1:
+                neg_ids = (slice(None),) * ax + (-ms // 2,)
+                pos_ids = (slice(None),) * ax + (ms // 2,)
+                out[neg_ids] /= 2 ** .5
+                out[pos_ids] = out[neg_ids]
+            else:
+                pos_ids = (slice(None),) * ax + (ms - 1,)
+                out[pos_ids] /= 2 ** .5
+    return out
+
+
+def chreshape_vjp(out_bar, in_shape):
+    """VJP of chreshape (a real-linear map: it conjugates on the truncated last-axis Nyquist plane) under
+    dL = Re sum conj(bar) dz.  Built by transposing the forward statement step by step."""
+    ob = np.array(out_bar, dtype=np.complex128)
+    shape = ob.shape
+    in_shape = tuple(int(v) for v in in_shape)
+    nd = len(shape)
+    # transpose of the pad fix-ups, last applied first
+    for ax, (ms, s) in reversed(list(enumerate(zip(in_shape, shape)))):
+        if s > ms:
+            if ax < nd - 1:
+                neg_ids = (slice(None),) * ax + (-ms // 2,)
+                pos_ids = (slice(None),) * ax + (ms // 2,)
+                ob[neg_ids] = (ob[neg_ids] + ob[pos_ids]) / 2 ** .5   # out[neg] /= r2; out[pos] = out[neg]
+                ob[pos_ids] = 0.
+            else:
+                pos_ids = (slice(None),) * ax + (ms - 1,)
+                ob[pos_ids] /= 2 ** .5
+    # transpose of the naive crop/pad (a selection matrix times a scale) = the naive map the other way round,
+    # rescaled: crop <-> zero-pad
+    scale = np.divide(ch2rshape(shape), ch2rshape(in_shape)).prod()
+    back = _chreshape_naive(ob, in_shape) * scale / np.divide(ch2rshape(in_shape), ch2rshape(shape)).prod()
+    # transpose of the truncation aggregations, first axis first (they were applied last axis first)
+    for ax, (ms, s) in enumerate(zip(in_shape, shape)):
+        if s < ms:
+            if ax < nd - 1:
+                neg_ids = (slice(None),) * ax + (-s // 2,)
+                pos_ids = (slice(None),) * ax + (s // 2,)
+                t = back[neg_ids] / 2 ** .5       # new_neg = (pos + neg)/r2, pos kept
+                back[pos_ids] = back[pos_ids] + t
+                back[neg_ids] = t
+            else:
+                pos_ids = (slice(None),) * ax + (s - 1,)
+                t = back[pos_ids] / 2 ** .5       # new = (z + Hsym(z))/r2 ; adjoint of z -> Hsym(z) is w -> Hsym(w)
+                back[pos_ids] = t + hermitian_symmetric(t)
+    return back
+
+
 def nufft(pos, final_shape, paint_shape=None, weights=1., paint_order=2, interlace_order=2, paint_deconv=True):
-    """montecosmo/nbody.py:532-577 for paint_shape == final_shape (no chreshape)."""
-    assert paint_shape is None or tuple(paint_shape) == tuple(final_shape)
-    mesh = interlace(pos, final_shape, weights, paint_order, interlace_order)
+    """montecosmo/nbody.py:532-577 (rectangular kernels): `pos` in cell units of final_shape; the particles are
+    painted on paint_shape (tuple, or float oversampling factor), deconvolved there and reshaped to final_shape."""
+    final_shape = tuple(int(v) for v in final_shape)
+    if paint_shape is None:
+        paint_shape = final_shape
+    elif isinstance(paint_shape, float):
+        paint_shape = scale_shape(final_shape, paint_shape)
+    paint_shape = tuple(int(v) for v in paint_shape)
+    ratio = np.divide(paint_shape, final_shape)
+    mesh = interlace(np.asarray(pos) * ratio, paint_shape, weights, paint_order, interlace_order)
+    mesh = mesh * ratio.prod()
     if paint_deconv:
         mesh = deconv_paint(mesh, paint_order)
+    if final_shape != paint_shape:
+        mesh = chreshape(mesh, r2chshape(final_shape))
     return mesh
 
 
-def nufft_vjp(pos, final_shape, weights, mesh_bar, paint_order=2, interlace_order=2, paint_deconv=True):
+def nufft_vjp(pos, final_shape, weights, mesh_bar, paint_order=2, interlace_order=2, paint_deconv=True, paint_shape=None):
     """VJP of nufft w.r.t. (pos, weights); mesh_bar in the real-pair convention."""
-    shape = tuple(final_shape)
+    final_shape = tuple(int(v) for v in final_shape)
+    if paint_shape is None:
+        paint_shape = final_shape
+    elif isinstance(paint_shape, float):
+        paint_shape = scale_shape(final_shape, paint_shape)
+    shape = tuple(int(v) for v in paint_shape)
+    ratio = np.divide(shape, final_shape)
+    if shape != final_shape:
+        mesh_bar = chreshape_vjp(mesh_bar, r2chshape(shape))
+    mesh_bar = mesh_bar * ratio.prod()
     kvec = rfftk(shape)
     mult = 1.0 / rectangular_hat(kvec, paint_order) if paint_deconv else 1.0
     pos_bar, w_bar = 0., 0.
     for shift in np.arange(interlace_order) / interlace_order:
         sb = mesh_bar * np.conj(mult * np.exp(1j * shift * sum(kvec)) / interlace_order)
-        pb, wb = paint_vjp(pos + shift, shape, weights, rfftn_vjp(sb, shape), paint_order)
-        pos_bar, w_bar = pos_bar + pb, w_bar + wb
+        pb, wb = paint_vjp(np.asarray(pos) * ratio + shift, shape, weights, rfftn_vjp(sb, shape), paint_order)
+        pos_bar, w_bar = pos_bar + pb * ratio, w_bar + wb
     return pos_bar, w_bar
 
 

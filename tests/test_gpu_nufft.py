@@ -50,3 +50,50 @@ def test_nufft_vjp(nb):
     pb, wb = nb.nufft_vjp(pos, shape, w, mb, 2, 2, True)
     pb_o, wb_o = o.nufft_vjp(pos.astype(np.float64), shape, w.astype(np.float64), mb.astype(np.complex128), 2, 2, True)
     assert rel_l2(pb.cpu().numpy(), pb_o) < 1e-4 and rel_l2(wb.cpu().numpy(), wb_o) < 1e-4
+
+
+CHRESHAPES = [((16, 16, 16), (8, 8, 8)), ((8, 8, 8), (16, 16, 16)), ((16, 12, 8), (8, 20, 12)), ((12, 12, 12), (12, 12, 12)),
+              ((16, 16, 16), (16, 16, 8)), ((8, 16, 16), (16, 8, 16))]
+
+
+@pytest.mark.parametrize("ishape,oshape", CHRESHAPES)
+def test_chreshape_and_vjp(nb, ishape, oshape):
+    """utils.py:981-1013 on arbitrary complex input (the Nyquist aggregation conjugates, so Hermitian inputs alone
+    would not pin it), truncation, padding and mixed axes; then the VJP against the oracle's."""
+    from montecosmo_amd import utils
+    rng = np.random.default_rng(4)
+    ic, oc = o.r2chshape(ishape), o.r2chshape(oshape)
+    x = (rng.standard_normal(ic) + 1j * rng.standard_normal(ic))
+    got = utils.chreshape(x.astype(np.complex64), oc).cpu().numpy()
+    assert got.shape == tuple(oc)
+    assert rel_l2(got, o.chreshape(x, oc)) < 1e-6
+    w = (rng.standard_normal(oc) + 1j * rng.standard_normal(oc))
+    gb = utils.chreshape_vjp(w.astype(np.complex64), ic).cpu().numpy()
+    assert rel_l2(gb, o.chreshape_vjp(w, ic)) < 1e-6
+
+
+def test_nufft_oversampled_paint_shape(nb):
+    """nbody.py:559-577 with paint_shape != final_shape: scaled positions, jacobian, deconvolution on the paint mesh,
+    chreshape to the final half-spectrum; float and tuple forms, and the VJP."""
+    final = (16, 16, 16)
+    rng = np.random.default_rng(2)
+    N = 4000
+    pos = rng.uniform(0, 16, (N, 3)).astype(np.float32)
+    w = (1.0 + 0.3 * rng.standard_normal(N)).astype(np.float32)
+    p64, w64 = pos.astype(np.float64), w.astype(np.float64)
+    for ps in (1.5, (24, 24, 24), (12, 12, 12)):
+        got = nb.nufft(pos, final, ps, w, 2, 2, paint_deconv=True).cpu().numpy()
+        assert got.shape == (16, 16, 9)
+        assert rel_l2(got, o.nufft(p64, final, ps, w64, 2, 2, True)) < 1e-5
+    assert abs(got[0, 0, 0].real - w64.sum()) < 1e-3 * N               # the mean (total weight) survives the reshape
+    mb = (rng.standard_normal((16, 16, 9)) + 1j * rng.standard_normal((16, 16, 9))).astype(np.complex64)
+    pb, wb = nb.nufft_vjp(pos, final, w, mb, 2, 2, True, paint_shape=(24, 24, 24))
+    pb_o, wb_o = o.nufft_vjp(p64, final, w64, mb.astype(np.complex128), 2, 2, True, paint_shape=(24, 24, 24))
+    assert rel_l2(pb.cpu().numpy(), pb_o) < 1e-4 and rel_l2(wb.cpu().numpy(), wb_o) < 1e-4
+    # lattice-displacement positions (what nbody_bf returns with lattice_out=True) through the same path
+    disp = (0.8 * rng.standard_normal((16 ** 3, 3))).astype(np.float32)
+    lp = nb.LatticePos(disp, final)
+    w3 = (1.0 + 0.1 * rng.standard_normal(16 ** 3)).astype(np.float32)
+    got = nb.nufft(lp, final, (24, 24, 24), w3, 2, 2, paint_deconv=True).cpu().numpy()
+    ref = o.nufft(lp.to_absolute().cpu().numpy(), final, (24, 24, 24), w3.astype(np.float64), 2, 2, True)
+    assert rel_l2(got, ref) < 1e-5

@@ -190,3 +190,50 @@ def test_oracle_reproduces_golden_fixtures():
     for order in (1, 2):
         assert np.array_equal(o.cell_index(pr["pos"].astype(np.float64), shape, order), pr[f"cell_{order}"])
         assert np.allclose(o.paint(pr["pos"].astype(np.float64), shape, pr["weights"].astype(np.float64), order), pr[f"paint_{order}"])
+
+
+@pytest.mark.parametrize("ishape,oshape", [((8, 8, 8), (4, 4, 4)), ((4, 4, 4), (8, 8, 8)), ((8, 6, 4), (4, 10, 6)),
+                                           ((6, 6, 6), (6, 6, 6))])
+def test_chreshape_known_answers(rng, ishape, oshape):
+    """utils.py:981-1013: same shape is the identity; the mean and the Hermitian symmetry are preserved; padding then
+    truncating a real field's spectrum returns it; the hand-derived VJP is the transpose (dot test)."""
+    ic, oc = o.r2chshape(ishape), o.r2chshape(oshape)
+    f = rng.standard_normal(ishape)
+    X = np.fft.rfftn(f)
+    Y = o.chreshape(X, oc)
+    assert Y.shape == tuple(oc)
+    if ishape == oshape:
+        assert np.allclose(Y, X)
+    y = np.fft.irfftn(Y, s=oshape, axes=(0, 1, 2))
+    assert np.isclose(y.mean(), f.mean())                                   # mean preserved
+    assert np.allclose(np.fft.rfftn(y), Y, atol=1e-9 * np.abs(Y).max())     # Y is the spectrum of a real field
+    big = tuple(2 * s for s in ishape)
+    assert np.allclose(o.chreshape(o.chreshape(X, o.r2chshape(big)), ic), X)
+    # dot test on arbitrary (non-Hermitian) complex tensors, real-pair inner product
+    x = rng.standard_normal(ic) + 1j * rng.standard_normal(ic)
+    w = rng.standard_normal(oc) + 1j * rng.standard_normal(oc)
+    lhs = np.sum(np.conj(w) * o.chreshape(x, oc)).real
+    rhs = np.sum(np.conj(o.chreshape_vjp(w, ic)) * x).real
+    assert np.isclose(lhs, rhs, rtol=1e-10)
+
+
+def test_nufft_oversampled_mean_and_vjp(rng):
+    """nbody.py:559-577 with an oversampled paint mesh: the k = 0 mode is the total weight whatever the paint shape,
+    and the VJP matches finite differences."""
+    final, N = (8, 8, 8), 50
+    pos = rng.uniform(0, 8, (N, 3))
+    w = 1.0 + 0.2 * rng.standard_normal(N)
+    for ps in (None, 1.5, (12, 12, 12), (4, 4, 4)):
+        m = o.nufft(pos, final, ps, w, 2, 2, True)
+        assert m.shape == (8, 8, 5) and np.isclose(m[0, 0, 0].real, w.sum())
+    mb = rng.standard_normal((8, 8, 5)) + 1j * rng.standard_normal((8, 8, 5))
+    L = lambda p, ww: np.sum(np.conj(mb) * o.nufft(p, final, (12, 12, 12), ww, 2, 2, True)).real
+    pb, wb = o.nufft_vjp(pos, final, w, mb, 2, 2, True, paint_shape=(12, 12, 12))
+    eps = 1e-6
+    for (i, ax) in ((3, 0), (17, 2)):
+        dp = np.zeros_like(pos)
+        dp[i, ax] = eps
+        assert np.isclose((L(pos + dp, w) - L(pos - dp, w)) / (2 * eps), pb[i, ax], rtol=1e-5, atol=1e-7)
+    dw = np.zeros_like(w)
+    dw[5] = eps
+    assert np.isclose((L(pos, w + dw) - L(pos, w - dw)) / (2 * eps), wb[5], rtol=1e-6)
