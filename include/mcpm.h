@@ -259,6 +259,26 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *plan, const float *init_mesh, int n_steps, 
                           float *init_mesh_bar, double *scalar_bars);
 
 /* ---- host-side float64 growth tables (nbody.py:679-745) ------------------------------------- */
+/* Lagrangian bias expansion (montecosmo/bricks.py:327-443, png_type = None).
+   fields : lin_mesh (plain half-spectrum of the plan's mesh) -> fields7 = {delta, shear^2, 3 det(shear), laplacian(delta),
+            grad_x, grad_y, grad_z} as 7 real meshes M apart; wavevectors in h/Mpc, kphys[a] = mesh_shape[a] / box_size[a]
+            (bricks.py:352).  The VJP maps the 7 cotangent meshes to the cotangent of lin_mesh (real-pair convention).
+   weights: the raw reads of those fields at the particles (dr, s2r, s3r, lr: n floats each; gr: n x 3) -> weights (n) and
+            dvel (n x 3).  growth = a2g(a): one float per particle, or NULL and growth_scalar.  bias8 (host) =
+            {b1, b2, bs2, b3, bds2, bs3, bn2, bnpar}.  The VJP returns the cotangents of the raw reads, of growth (per
+            particle if growth_bar != NULL) and scalars_out (device, 10 doubles) = 8 bias cotangents, summed growth
+            cotangent, <d^2>.  The reads between the two halves are mcpm_read_f32; their adjoints mcpm_paint_f32. */
+int mcpm_bias_fields_f32(mcpm_plan *plan, const float *lin_mesh, float kphys_x, float kphys_y, float kphys_z, float *fields7);
+int mcpm_bias_fields_vjp_f32(mcpm_plan *plan, const float *lin_mesh, float kphys_x, float kphys_y, float kphys_z,
+                             const float *fields7_bar, float *lin_mesh_bar);
+int mcpm_bias_weights_f32(mcpm_plan *plan, int64_t n, const float *dr, const float *s2r, const float *s3r, const float *lr,
+                          const float *gr, const float *growth, float growth_scalar, const float *bias8, float *weights,
+                          float *dvel, double *sigma2_out);
+int mcpm_bias_weights_vjp_f32(mcpm_plan *plan, int64_t n, const float *dr, const float *s2r, const float *s3r, const float *lr,
+                              const float *gr, const float *growth, float growth_scalar, const float *bias8,
+                              const float *weights_bar, const float *dvel_bar, float *dr_bar, float *s2r_bar, float *s3r_bar,
+                              float *lr_bar, float *gr_bar, float *growth_bar, double *scalars_out);
+
 /* chreshape (montecosmo/utils.py:924-1013): half-spectrum of a real (in_nx, in_ny, in_nz) mesh -> half-spectrum of a
    real (out_nx, out_ny, out_nz) mesh, truncating / zero-padding the centred wavevectors with the reference's Nyquist-plane
    aggregation (1/sqrt2 weights) and cell-count scale, so Hermitian symmetry and mean power are preserved.  Plain

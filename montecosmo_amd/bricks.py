@@ -41,3 +41,81 @@ def regular_pos(mesh_shape, ptcl_shape=None):
     ptcl_shape = mesh_shape if ptcl_shape is None else ptcl_shape
     axes = [np.arange(p) * (m / p) for m, p in zip(mesh_shape, ptcl_shape)]
     return np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, 3)
+
+
+# ------------------------------------------------------------------------------------------------
+# Lagrangian bias expansion (bricks.py:327-443), png_type = None
+BIAS_KEYS = ("b1", "b2", "bs2", "b3", "bds2", "bs3", "bn2", "bnpar")
+
+
+class BiasCtx:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def lagrangian_bias(cosmo, pos, a, box_size, lin_mesh, bias, png=None, png_type=None, kpow=None, read_order: int = 2,
+                    return_ctx=False):
+    """Lagrangian bias expansion weights (bricks.py:327-443): returns (weights (N,), dvel (N,3), phi) like the
+    reference (phi = 0. without primordial non-Gaussianity, the only case built).  `a`: scalar or (N,1) scale
+    factor(s); `pos`: the Lagrangian positions in cell units ((N,3) array or LatticePos); `bias`: dict with the keys
+    BIAS_KEYS (missing keys = 0).  HIP: mcpm_bias_fields_f32 -> mcpm_read_f32 x5 -> mcpm_bias_weights_f32."""
+    import ctypes as C
+    import torch
+    from . import nbody
+    if png_type is not None:
+        raise NotImplementedError("primordial non-Gaussianity terms are not built")
+    spec = nbody._c64(lin_mesh)
+    shape = nbody.ch2rshape(spec.shape)
+    plan, p, n, mode = nbody._pos_args(pos, shape)
+    M = plan.M
+    dev = spec.device
+    kphys = [float(s) / float(b) for s, b in zip(shape, box_size)]
+    fields = torch.empty((7,) + tuple(shape), dtype=torch.float32, device=dev)
+    plan.call("mcpm_bias_fields_f32", nbody._ptr(spec), kphys[0], kphys[1], kphys[2], nbody._ptr(fields))
+    reads = torch.empty((4, n), dtype=torch.float32, device=dev)
+    for c in range(4):
+        plan.call("mcpm_read_f32", nbody._ptr(p), n, mode, nbody._ptr(fields[c]), 1, int(read_order), nbody._ptr(reads[c]))
+    gr = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    plan.call("mcpm_read_f32", nbody._ptr(p), n, mode, nbody._ptr(fields[4]), 3, int(read_order), nbody._ptr(gr))
+    g = np.asarray(nbody.a2g(cosmo, a), dtype=np.float64)
+    gp = nbody._f32(g.reshape(-1), (n,)) if g.size == n and n > 1 else None
+    gs = float(g.reshape(-1)[0]) if gp is None else 0.0
+    b8 = (C.c_float * 8)(*[float(bias.get(k, 0.0)) for k in BIAS_KEYS])
+    w = torch.empty(n, dtype=torch.float32, device=dev)
+    dvel = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    plan.call("mcpm_bias_weights_f32", n, nbody._ptr(reads[0]), nbody._ptr(reads[1]), nbody._ptr(reads[2]), nbody._ptr(reads[3]),
+              nbody._ptr(gr), nbody._ptr(gp), gs, b8, nbody._ptr(w), nbody._ptr(dvel), None)
+    if return_ctx:
+        ctx = BiasCtx(plan=plan, spec=spec, shape=shape, p=p, n=n, mode=mode, kphys=kphys, reads=reads, gr=gr, gp=gp, gs=gs,
+                      g_shape=g.shape, b8=b8, read_order=int(read_order))
+        return (w, dvel, 0.), ctx
+    return w, dvel, 0.
+
+
+def lagrangian_bias_vjp(ctx, weights_bar, dvel_bar):
+    """VJP of lagrangian_bias w.r.t. (lin_mesh, bias, growth factor(s) a2g(a)): returns (lin_mesh_bar [complex64,
+    real-pair convention], bias_bar dict, growths_bar [shape of a2g(a)]).  Positions are the fixed Lagrangian
+    lattice of the model (model.py:738), so no position cotangent is formed."""
+    import torch
+    from . import nbody
+    plan, n, dev = ctx.plan, ctx.n, ctx.spec.device
+    wb = nbody._f32(weights_bar, (n,))
+    vb = nbody._f32(dvel_bar, (n, 3))
+    rb = torch.empty((4, n), dtype=torch.float32, device=dev)
+    grb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    gbar = torch.empty(n, dtype=torch.float32, device=dev) if ctx.gp is not None else None
+    scal = torch.zeros(10, dtype=torch.float64, device=dev)
+    r = ctx.reads
+    plan.call("mcpm_bias_weights_vjp_f32", n, nbody._ptr(r[0]), nbody._ptr(r[1]), nbody._ptr(r[2]), nbody._ptr(r[3]), nbody._ptr(ctx.gr),
+              nbody._ptr(ctx.gp), ctx.gs, ctx.b8, nbody._ptr(wb), nbody._ptr(vb), nbody._ptr(rb[0]), nbody._ptr(rb[1]), nbody._ptr(rb[2]),
+              nbody._ptr(rb[3]), nbody._ptr(grb), nbody._ptr(gbar), nbody._ptr(scal))
+    fb = torch.empty((7,) + tuple(ctx.shape), dtype=torch.float32, device=dev)
+    for c in range(4):       # adjoint of a read w.r.t. its mesh = a weighted paint
+        plan.call("mcpm_paint_f32", nbody._ptr(ctx.p), n, ctx.mode, nbody._ptr(rb[c]), 1, 0.0, ctx.read_order, nbody._ptr(fb[c]), 0)
+    plan.call("mcpm_paint3_f32", nbody._ptr(ctx.p), n, ctx.mode, nbody._ptr(grb), ctx.read_order, nbody._ptr(fb[4]), 0)
+    out = torch.empty(tuple(ctx.spec.shape), dtype=torch.complex64, device=dev)
+    plan.call("mcpm_bias_fields_vjp_f32", nbody._ptr(ctx.spec), ctx.kphys[0], ctx.kphys[1], ctx.kphys[2], nbody._ptr(fb), nbody._ptr(out))
+    s = scal.cpu().numpy()
+    bias_bar = {k: float(s[i]) for i, k in enumerate(BIAS_KEYS)}
+    growths_bar = gbar.double().cpu().numpy().reshape(ctx.g_shape) if gbar is not None else np.asarray(s[8]).reshape(ctx.g_shape)
+    return out, bias_bar, growths_bar

@@ -1,0 +1,201 @@
+"""
+TEST INFRASTRUCTURE (see oracle/__init__.py) -- numpy float64 restatement of the operators either side of the PM path
+inside `FieldLevelModel.evolve` (montecosmo/model.py:740-810): the Lagrangian bias expansion weights, the
+cell <-> physical coordinate maps, line of sight / scale factor, and redshift-space distortions, with hand-derived
+VJPs.  Paths are relative to /root/reference.  Primordial non-Gaussianity (png_type != None), Alcock-Paczynski and the
+Eulerian bias branch are not restated.
+
+scipy.spatial.transform.Rotation (box_rot) is replaced by its 3x3 matrix R: `box_rot.apply(x)` = x @ R.T,
+`apply(x, inverse=True)` = x @ R (scipy's documented convention).
+"""
+import numpy as np
+
+from . import pm_oracle as o
+
+BIAS_KEYS = ("b1", "b2", "bs2", "b3", "bds2", "bs3", "bn2", "bnpar")
+
+
+def rotvec_matrix(rotvec):
+    """Rotation matrix of a rotation vector (Rodrigues), = scipy Rotation.from_rotvec(rotvec).as_matrix()."""
+    v = np.asarray(rotvec, dtype=float)
+    th = np.linalg.norm(v)
+    if th == 0:
+        return np.eye(3)
+    k = v / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+# --------------------------------------------------------------------------- bias
+def bias_fields(lin_mesh, box_size):
+    """The real-space fields lagrangian_bias reads (bricks.py:350-352, :372-399, :438-441):
+    delta, shear^2, 3 det(shear), laplacian(delta) (h/Mpc)^2, grad(delta) (h/Mpc).  Returns (fields dict, parts)."""
+    delta = np.fft.irfftn(lin_mesh)
+    shape = delta.shape
+    kvec = o.rfftk(shape, box_size)
+    k2 = sum(ki ** 2 for ki in kvec)
+    pot = lin_mesh * o.invlaplace_hat(kvec)
+    sh = {}
+    for i in range(2):
+        nabi = o.gradient_hat(kvec, i)
+        sh[(i, i)] = np.fft.irfftn(nabi ** 2 * pot - lin_mesh / 3)
+        for j in range(i + 1, 3):
+            sh[(i, j)] = np.fft.irfftn(nabi * o.gradient_hat(kvec, j) * pot)
+    sh[(2, 2)] = -(sh[(0, 0)] + sh[(1, 1)])
+    a, b, c = sh[(0, 0)], sh[(1, 1)], sh[(2, 2)]
+    d, e, f = sh[(0, 1)], sh[(0, 2)], sh[(1, 2)]
+    shear2 = a ** 2 + b ** 2 + c ** 2 + 2 * (d ** 2 + e ** 2 + f ** 2)
+    shear3 = 3 * (a * (b * c - f ** 2) - d * (d * c - e * f) + e * (d * f - b * e))
+    nab2 = np.fft.irfftn(-k2 * lin_mesh)
+    grad = [np.fft.irfftn(o.gradient_hat(kvec, i) * lin_mesh) for i in range(3)]
+    return dict(delta=delta, shear2=shear2, shear3=shear3, nab2=nab2, grad=grad), (a, b, c, d, e, f)
+
+
+def lagrangian_bias(growths, pos, box_size, lin_mesh, bias, read_order=2):
+    """bricks.py:327-443 with png_type=None.  `growths` = a2g(cosmo, a): scalar or (N,1).  Returns (weights (N,),
+    dvel (N,3))."""
+    fld, _ = bias_fields(lin_mesh, box_size)
+    g = np.asarray(growths, dtype=float)
+    gs = g.squeeze()
+    delta_pos = o.read(pos, fld["delta"], read_order) * gs
+    weights = 1. + bias["b1"] * delta_pos
+    delta2_pos = delta_pos ** 2
+    sigma2 = delta2_pos.mean()
+    delta2_pos = delta2_pos - sigma2
+    weights = weights + bias["b2"] * delta2_pos / 2
+    shear2_pos = o.read(pos, fld["shear2"], read_order) * gs ** 2
+    shear2_pos = shear2_pos - 2 / 3 * sigma2
+    weights = weights + bias["bs2"] * shear2_pos
+    delta3_pos = delta_pos ** 3 - 3 * sigma2 * delta_pos
+    weights = weights + bias["b3"] * delta3_pos / 6
+    weights = weights + bias["bds2"] * delta_pos * shear2_pos
+    shear3_pos = o.read(pos, fld["shear3"], read_order) * gs ** 3
+    weights = weights + bias["bs3"] * shear3_pos
+    weights = weights + bias["bn2"] * o.read(pos, fld["nab2"], read_order) * gs
+    nabpar = np.stack([o.read(pos, fld["grad"][i], read_order) for i in range(3)], axis=-1)
+    dvel = bias["bnpar"] * nabpar * (g if g.ndim else gs)
+    return weights, dvel
+
+
+def lagrangian_bias_vjp(growths, pos, box_size, lin_mesh, bias, w_bar, dvel_bar, read_order=2):
+    """VJP of lagrangian_bias w.r.t. (lin_mesh, bias dict, growths) -- positions are the fixed Lagrangian lattice.
+    Returns (lin_mesh_bar [real-pair convention], bias_bar dict, growths_bar [shape of growths])."""
+    fld, (a, b, c, d, e, f) = bias_fields(lin_mesh, box_size)
+    shape = fld["delta"].shape
+    N = len(pos)
+    g = np.asarray(growths, dtype=float)
+    gs = np.broadcast_to(g.squeeze(), (N,)).astype(float)
+    dr = o.read(pos, fld["delta"], read_order)
+    s2r = o.read(pos, fld["shear2"], read_order)
+    s3r = o.read(pos, fld["shear3"], read_order)
+    lr = o.read(pos, fld["nab2"], read_order)
+    gr = np.stack([o.read(pos, fld["grad"][i], read_order) for i in range(3)], axis=-1)
+    dl = dr * gs
+    sigma2 = (dl ** 2).mean()
+    s2 = s2r * gs ** 2 - 2 / 3 * sigma2
+    s3 = s3r * gs ** 3
+    ll = lr * gs
+    B = bias
+    wb = np.asarray(w_bar, dtype=float)
+    vb = np.asarray(dvel_bar, dtype=float)
+    bias_bar = dict(b1=(wb * dl).sum(), b2=(wb * (dl ** 2 - sigma2) / 2).sum(), bs2=(wb * s2).sum(),
+                    b3=(wb * (dl ** 3 - 3 * sigma2 * dl) / 6).sum(), bds2=(wb * dl * s2).sum(), bs3=(wb * s3).sum(),
+                    bn2=(wb * ll).sum(), bnpar=(vb * gr * gs[:, None]).sum())
+    dw_ds2 = B["bs2"] + B["bds2"] * dl
+    dw_dsig = -B["b2"] / 2 - B["b3"] * dl / 2 - 2 / 3 * dw_ds2
+    sig_bar = (wb * dw_dsig).sum()
+    d_bar = wb * (B["b1"] + B["b2"] * dl + B["b3"] * (dl ** 2 - sigma2) / 2 + B["bds2"] * s2) + sig_bar * 2 * dl / N
+    dr_bar = d_bar * gs
+    s2r_bar = wb * dw_ds2 * gs ** 2
+    s3r_bar = wb * B["bs3"] * gs ** 3
+    lr_bar = wb * B["bn2"] * gs
+    gr_bar = vb * B["bnpar"] * gs[:, None]
+    g_bar = d_bar * dr + wb * dw_ds2 * 2 * gs * s2r + wb * B["bs3"] * 3 * gs ** 2 * s3r + wb * B["bn2"] * lr \
+        + (vb * gr).sum(-1) * B["bnpar"]
+    growths_bar = g_bar.reshape(g.shape) if g.size == N else np.asarray(g_bar.sum()).reshape(g.shape)
+    # reads -> meshes
+    D_bar = o.read_vjp(pos, fld["delta"], dr_bar, read_order)[1]
+    S2_bar = o.read_vjp(pos, fld["shear2"], s2r_bar, read_order)[1]
+    S3_bar = o.read_vjp(pos, fld["shear3"], s3r_bar, read_order)[1]
+    L_bar = o.read_vjp(pos, fld["nab2"], lr_bar, read_order)[1]
+    G_bar = [o.read_vjp(pos, fld["grad"][i], gr_bar[:, i], read_order)[1] for i in range(3)]
+    # shear2, shear3 -> a, b (c = -a-b), d, e, f
+    cof = dict(a=b * c - f ** 2, b=a * c - e ** 2, c=a * b - d ** 2, d=2 * (e * f - d * c), e=2 * (d * f - b * e),
+               f=2 * (d * e - a * f))
+    a_bar = S2_bar * (2 * a - 2 * c) + 3 * S3_bar * (cof["a"] - cof["c"])
+    b_bar = S2_bar * (2 * b - 2 * c) + 3 * S3_bar * (cof["b"] - cof["c"])
+    d_bar_m = S2_bar * 4 * d + 3 * S3_bar * cof["d"]
+    e_bar_m = S2_bar * 4 * e + 3 * S3_bar * cof["e"]
+    f_bar_m = S2_bar * 4 * f + 3 * S3_bar * cof["f"]
+    # irfftn adjoints and the k-space multipliers (all real-linear in lin_mesh; multipliers m_s: y_s = irfftn(m_s X))
+    kvec = o.rfftk(shape, box_size)
+    k2 = sum(ki ** 2 for ki in kvec)
+    il = o.invlaplace_hat(kvec)
+    nab = [o.gradient_hat(kvec, i) for i in range(3)]
+    out = np.conj(1.0 + 0 * k2) * o.irfftn_vjp(D_bar)
+    out = out + np.conj(nab[0] ** 2 * il - 1 / 3) * o.irfftn_vjp(a_bar)
+    out = out + np.conj(nab[1] ** 2 * il - 1 / 3) * o.irfftn_vjp(b_bar)
+    out = out + np.conj(nab[0] * nab[1] * il) * o.irfftn_vjp(d_bar_m)
+    out = out + np.conj(nab[0] * nab[2] * il) * o.irfftn_vjp(e_bar_m)
+    out = out + np.conj(nab[1] * nab[2] * il) * o.irfftn_vjp(f_bar_m)
+    out = out + np.conj(-k2) * o.irfftn_vjp(L_bar)
+    for i in range(3):
+        out = out + np.conj(nab[i]) * o.irfftn_vjp(G_bar[i])
+    return out, bias_bar, growths_bar
+
+
+# --------------------------------------------------------------------------- geometry
+def cell2phys_pos(pos, box_center, R, box_size, mesh_shape):
+    """bricks.py:628-636"""
+    pos = pos * np.divide(box_size, mesh_shape)
+    pos = pos - np.asarray(box_size) / 2
+    pos = pos @ np.asarray(R).T
+    return pos + np.asarray(box_center)
+
+
+def phys2cell_pos(pos, box_center, R, box_size, mesh_shape):
+    """bricks.py:638-646"""
+    pos = pos - np.asarray(box_center)
+    pos = pos @ np.asarray(R)
+    pos = pos + np.asarray(box_size) / 2
+    return pos / np.divide(box_size, mesh_shape)
+
+
+def cell2phys_vel(vel, R, box_size, mesh_shape):
+    """bricks.py:648-654"""
+    return (vel * np.divide(box_size, mesh_shape)) @ np.asarray(R).T
+
+
+def phys2cell_vel(vel, R, box_size, mesh_shape):
+    """bricks.py:656-662"""
+    return (vel @ np.asarray(R)) / np.divide(box_size, mesh_shape)
+
+
+def los_scalefactor_pos(pos, box_center, R, box_size, mesh_shape, cosmo, a_obs=None, curved_sky=True):
+    """bricks.py:750-768: line of sight(s) and scale factor(s) of particles given in cell units."""
+    p = cell2phys_pos(pos, box_center, R, box_size, mesh_shape)
+    if curved_sky:
+        rpos = np.linalg.norm(p, axis=-1, keepdims=True)
+        los = o.safe_div(p, rpos)
+    else:
+        los = o.safe_div(np.asarray(box_center, dtype=float), np.linalg.norm(box_center))
+        rpos = np.abs((p * los).sum(-1, keepdims=True))
+    a = o.chi2a(cosmo, rpos) if a_obs is None else a_obs
+    return los, a
+
+
+def rsd(cosmo, vel, los, a, R, box_size, mesh_shape, dvel=0.):
+    """bricks.py:791-803: displacement (Mpc/h) along the line of sight; vel is dq/dg in cell units."""
+    v = cell2phys_vel(vel, R, box_size, mesh_shape)
+    v = v * (o.a2g(cosmo, a) * o.a2f(cosmo, a))
+    v = v + dvel
+    return (v * los).sum(-1, keepdims=True) * los
+
+
+def observe_pos(cosmo, pos, vel, box_center, R, box_size, evol_shape, paint_shape, a_obs=None, curved_sky=True, dvel=0.):
+    """model.py:780-784, :797: evolved particles (cell units of evol_shape) -> redshift-space positions in cell units of
+    paint_shape (no Alcock-Paczynski)."""
+    los, a = los_scalefactor_pos(pos, box_center, R, box_size, evol_shape, cosmo, a_obs, curved_sky)
+    p = cell2phys_pos(pos, box_center, R, box_size, evol_shape)
+    p = p + rsd(cosmo, vel, los, a, R, box_size, evol_shape, dvel)
+    return phys2cell_pos(p, box_center, R, box_size, paint_shape)

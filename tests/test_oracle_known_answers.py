@@ -237,3 +237,44 @@ def test_nufft_oversampled_mean_and_vjp(rng):
     dw = np.zeros_like(w)
     dw[5] = eps
     assert np.isclose((L(pos, w + dw) - L(pos, w - dw)) / (2 * eps), wb[5], rtol=1e-6)
+
+
+def test_lagrangian_bias_known_answers_and_vjp(rng):
+    """bricks.py:327-443 (png_type None).  b1-only weights are 1 + b1 g delta_L(q); the shear is traceless so a pure
+    plane wave has shear^2 = 2/3 delta^2 and det(shear) = 2/27 delta^3 (eigenvalues 2/3, -1/3, -1/3 of delta);
+    the renormalised operators have zero mean; VJP = central finite differences."""
+    from oracle import bias_oracle as bo
+    shape, box = (8, 8, 8), (80., 80., 80.)
+    pos = np.stack(np.meshgrid(*[np.arange(s, dtype=float) for s in shape], indexing="ij"), -1).reshape(-1, 3)
+    x = pos[:, 0].reshape(shape)
+    wave = 0.1 * np.cos(2 * np.pi * x / 8)
+    X = np.fft.rfftn(wave)
+    zero = {k: 0. for k in bo.BIAS_KEYS}
+    w, dv = bo.lagrangian_bias(0.7, pos, box, X, dict(zero, b1=2.0), 1)
+    assert np.allclose(w, 1 + 2.0 * 0.7 * wave.ravel()) and np.allclose(dv, 0)
+    fld, _ = bo.bias_fields(X, box)
+    assert np.allclose(fld["shear2"], 2 / 3 * wave ** 2) and np.allclose(fld["shear3"], 3 * 2 / 27 * wave ** 3)
+    kx = 2 * np.pi / 80.                                                  # physical wavenumber of the wave, h/Mpc
+    assert np.allclose(fld["nab2"], -kx ** 2 * wave)
+    assert np.allclose(fld["grad"][0], -0.1 * kx * np.sin(2 * np.pi * x / 8)) and np.allclose(fld["grad"][1], 0)
+    X = np.fft.rfftn(0.3 * rng.standard_normal(shape))
+    w, _ = bo.lagrangian_bias(0.7, pos, box, X, dict(zero, b2=1.0), 1)
+    assert abs(w.mean() - 1) < 1e-12                                      # (delta^2 - <delta^2>) has zero mean
+    bias = dict(b1=1.1, b2=0.3, bs2=-0.2, b3=0.15, bds2=0.25, bs3=-0.1, bn2=2.0, bnpar=1.5)
+    N = len(pos)
+    g = 0.5 + 0.4 * rng.uniform(size=(N, 1))
+    p = pos + rng.uniform(0, 1, pos.shape)
+    wb, vb = rng.standard_normal(N), rng.standard_normal((N, 3))
+
+    def L(X_, bias_, g_):
+        w_, dv_ = bo.lagrangian_bias(g_, p, box, X_, bias_, 2)
+        return (wb * w_).sum() + (vb * dv_).sum()
+    mb, bb, gb = bo.lagrangian_bias_vjp(g, p, box, X, bias, wb, vb, 2)
+    eps = 1e-6
+    dX = np.fft.rfftn(rng.standard_normal(shape))
+    assert np.isclose((L(X + eps * dX, bias, g) - L(X - eps * dX, bias, g)) / (2 * eps), np.sum(np.conj(mb) * dX).real, rtol=1e-5)
+    for k in bias:
+        assert np.isclose((L(X, dict(bias, **{k: bias[k] + eps}), g) - L(X, dict(bias, **{k: bias[k] - eps}), g)) / (2 * eps), bb[k],
+                          rtol=1e-5, atol=1e-7)
+    dg = rng.standard_normal(g.shape)
+    assert np.isclose((L(X, bias, g + eps * dg) - L(X, bias, g - eps * dg)) / (2 * eps), (gb * dg).sum(), rtol=1e-5)
