@@ -279,6 +279,21 @@ int mcpm_bias_weights_vjp_f32(mcpm_plan *plan, int64_t n, const float *dr, const
                               const float *weights_bar, const float *dvel_bar, float *dr_bar, float *s2r_bar, float *s3r_bar,
                               float *lr_bar, float *gr_bar, float *growth_bar, double *scalars_out);
 
+/* Evolved particles -> redshift-space positions on the paint mesh (montecosmo/model.py:780-797 without Alcock-Paczynski;
+   bricks.py:628-662 cell <-> physical maps, :750-768 line of sight and scale factor, :791-803 rsd), one fused pass.
+   The plan's mesh is the evolution mesh.  geom (host, 19 floats) = box_rot matrix R[9] (row major, apply(x) = R x),
+   box_size[3], box_center[3], paint_shape[3], g(a_obs) f(a_obs).  flags: bit 0 = curved sky, bit 1 = light cone; on the
+   light cone `tables` (DEVICE float64) = chi ascending [nchi], a(chi) [nchi], a [ngrow], g [ngrow], f [ngrow].
+   pos_mode MCPM_POS_LATTICE: pos = displacements from the plan's particle lattice, out = displacements from that lattice
+   scaled to the paint mesh; MCPM_POS_ABSOLUTE: absolute cell coordinates in and out.  dvel (Mpc/h, may be NULL) is the
+   bias velocity term.  The VJP returns the cotangents of pos, vel, dvel and of the scalar g f (device double; 0 on the
+   light cone, where the cosmology dependence of the tables is not propagated). */
+int mcpm_observe_pos_f32(mcpm_plan *plan, const float *pos, const float *vel, const float *dvel, int64_t n, int pos_mode,
+                         const float *geom, int flags, const double *tables, int nchi, int ngrow, float *out);
+int mcpm_observe_pos_vjp_f32(mcpm_plan *plan, const float *pos, const float *vel, const float *dvel, int64_t n, int pos_mode,
+                             const float *geom, int flags, const double *tables, int nchi, int ngrow, const float *out_bar,
+                             float *pos_bar, float *vel_bar, float *dvel_bar, double *gf_bar);
+
 /* chreshape (montecosmo/utils.py:924-1013): half-spectrum of a real (in_nx, in_ny, in_nz) mesh -> half-spectrum of a
    real (out_nx, out_ny, out_nz) mesh, truncating / zero-padding the centred wavevectors with the reference's Nyquist-plane
    aggregation (1/sqrt2 weights) and cell-count scale, so Hermitian symmetry and mean power are preserved.  Plain

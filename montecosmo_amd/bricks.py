@@ -119,3 +119,96 @@ def lagrangian_bias_vjp(ctx, weights_bar, dvel_bar):
     bias_bar = {k: float(s[i]) for i, k in enumerate(BIAS_KEYS)}
     growths_bar = gbar.double().cpu().numpy().reshape(ctx.g_shape) if gbar is not None else np.asarray(s[8]).reshape(ctx.g_shape)
     return out, bias_bar, growths_bar
+
+
+# ------------------------------------------------------------------------------------------------
+# Cell <-> physical coordinates, line of sight, redshift-space distortions (bricks.py:628-662, :750-803)
+def rot_matrix(box_rot):
+    """3x3 matrix of `box_rot`: a scipy Rotation (as the reference passes), a rotation vector (3,) or a matrix."""
+    if hasattr(box_rot, "as_matrix"):
+        return np.asarray(box_rot.as_matrix(), dtype=np.float64)
+    r = np.asarray(box_rot, dtype=np.float64)
+    if r.shape == (3, 3):
+        return r
+    th = np.linalg.norm(r)
+    if th == 0:
+        return np.eye(3)
+    k = r / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def cell2phys_pos(pos, box_center, box_rot, box_size, mesh_shape):
+    """Cell positions to physical positions (bricks.py:628-636); host numpy (set-up sized arrays)."""
+    pos = np.asarray(pos, dtype=np.float64) * np.divide(box_size, mesh_shape) - np.asarray(box_size) / 2
+    return pos @ rot_matrix(box_rot).T + np.asarray(box_center)
+
+
+def phys2cell_pos(pos, box_center, box_rot, box_size, mesh_shape):
+    """bricks.py:638-646"""
+    pos = (np.asarray(pos, dtype=np.float64) - np.asarray(box_center)) @ rot_matrix(box_rot) + np.asarray(box_size) / 2
+    return pos / np.divide(box_size, mesh_shape)
+
+
+def cell2phys_vel(vel, box_rot, box_size, mesh_shape):
+    """bricks.py:648-654"""
+    return (np.asarray(vel, dtype=np.float64) * np.divide(box_size, mesh_shape)) @ rot_matrix(box_rot).T
+
+
+def phys2cell_vel(vel, box_rot, box_size, mesh_shape):
+    """bricks.py:656-662"""
+    return (np.asarray(vel, dtype=np.float64) @ rot_matrix(box_rot)) / np.divide(box_size, mesh_shape)
+
+
+class ObsCtx:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def observe_pos(cosmo, pos, vel, box_center, box_rot, box_size, evol_shape, paint_shape, a_obs=None, curved_sky=True,
+                dvel=None, return_ctx=False):
+    """Evolved particles (cell units of evol_shape) -> redshift-space positions in cell units of paint_shape: the chain
+    los_scalefactor_pos -> cell2phys_pos -> + rsd(vel, los, a, dvel) -> phys2cell_pos of model.py:780-797 (no
+    Alcock-Paczynski), fused in one HIP pass (mcpm_observe_pos_f32).  a_obs=None is the light cone (a = chi2a(|x|)).
+    A LatticePos comes back as a LatticePos on the paint mesh (same particle lattice), an array as an (N,3) tensor."""
+    import ctypes as C
+    import torch
+    from . import nbody
+    evol_shape = tuple(int(s) for s in evol_shape)
+    paint_shape = tuple(int(s) for s in paint_shape)
+    plan, p, n, mode = nbody._pos_args(pos, evol_shape)
+    v = nbody._f32(vel, (n, 3))
+    dv = nbody._f32(dvel, (n, 3)) if dvel is not None else None
+    R = rot_matrix(box_rot)
+    lightcone = a_obs is None
+    gf = 0.0 if lightcone else float(nbody.a2g(cosmo, a_obs) * nbody.a2f(cosmo, a_obs))
+    geom = (C.c_float * 19)(*[float(x) for x in list(R.reshape(-1)) + list(box_size) + list(box_center) + list(paint_shape) + [gf]])
+    flags = (1 if curved_sky else 0) | (2 if lightcone else 0)
+    tables, nchi, ngrow = None, 0, 0
+    if lightcone:
+        d, gtab = nbody._dist_cache(cosmo), nbody._growth_cache(cosmo)
+        nchi, ngrow = len(d["chi"]), len(gtab["a"])
+        tables = torch.from_numpy(np.concatenate([d["chi"][::-1], d["a"][::-1], gtab["a"], gtab["g"], gtab["f"]])).to(p.device)
+    out = torch.empty((n, 3), dtype=torch.float32, device=p.device)
+    plan.call("mcpm_observe_pos_f32", nbody._ptr(p), nbody._ptr(v), nbody._ptr(dv), n, mode, geom, flags, nbody._ptr(tables), nchi,
+              ngrow, nbody._ptr(out))
+    res = nbody.LatticePos(out, paint_shape, pos.ptcl_shape) if isinstance(pos, nbody.LatticePos) else out
+    if return_ctx:
+        return res, ObsCtx(plan=plan, p=p, v=v, dv=dv, n=n, mode=mode, geom=geom, flags=flags, tables=tables, nchi=nchi, ngrow=ngrow)
+    return res
+
+
+def observe_pos_vjp(ctx, out_bar):
+    """VJP of observe_pos: cotangent of the returned positions (N,3) -> (pos_bar, vel_bar, dvel_bar or None, gf_bar) where
+    gf_bar is the cotangent of the scalar a2g(a_obs) a2f(a_obs) (0.0 on the light cone)."""
+    import torch
+    from . import nbody
+    n, dev = ctx.n, ctx.p.device
+    ob = nbody._f32(out_bar, (n, 3))
+    pb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    vb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    db = torch.empty((n, 3), dtype=torch.float32, device=dev) if ctx.dv is not None else None
+    gfb = torch.zeros(1, dtype=torch.float64, device=dev)
+    ctx.plan.call("mcpm_observe_pos_vjp_f32", nbody._ptr(ctx.p), nbody._ptr(ctx.v), nbody._ptr(ctx.dv), n, ctx.mode, ctx.geom, ctx.flags,
+                  nbody._ptr(ctx.tables), ctx.nchi, ctx.ngrow, nbody._ptr(ob), nbody._ptr(pb), nbody._ptr(vb), nbody._ptr(db), nbody._ptr(gfb))
+    return pb, vb, db, float(gfb.item())

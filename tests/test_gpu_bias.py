@@ -53,3 +53,51 @@ def test_lagrangian_bias_forward_and_vjp(gpu, shape, box, read_order, per_partic
     for k in bo.BIAS_KEYS:
         assert abs(bb[k] - bb_o[k]) < 2e-4 * scale, (k, bb[k], bb_o[k])
     assert rel_l2(np.asarray(gb, dtype=np.float64).reshape(-1), np.asarray(gb_o).reshape(-1)) < 2e-4
+
+
+@pytest.mark.parametrize("curved,lightcone,lattice", [(True, True, True), (True, False, False), (False, True, False),
+                                                      (False, False, True)])
+def test_observe_pos_forward_and_vjp(gpu, curved, lightcone, lattice):
+    """model.py:780-797 (los/scale factor, cell2phys, rsd with the bias velocity term, phys2cell on another mesh) fused
+    in mcpm_observe_pos_f32, against the float64 oracle chain; the VJP against central differences of that chain."""
+    from montecosmo_amd import bricks, nbody
+    rng = np.random.default_rng(21)
+    cosmo = bricks.Planck18()
+    evol, paint = (16, 16, 16), (24, 20, 16)
+    box, center, rotvec = (640., 640., 640.), (100., -50., 1500.), (0.2, -0.1, 0.3)
+    R = bo.rotvec_matrix(rotvec)
+    N = 16 ** 3
+    disp = (1.5 * rng.standard_normal((N, 3))).astype(np.float32)
+    vel = (3.0 * rng.standard_normal((N, 3))).astype(np.float32)
+    dvel = (0.5 * rng.standard_normal((N, 3))).astype(np.float32)
+    a_obs = None if lightcone else 0.7
+    lp = nbody.LatticePos(disp, evol)
+    x64 = lp.to_absolute().cpu().numpy()
+    pos_in = lp if lattice else x64.astype(np.float32)
+    if not lattice:
+        x64 = pos_in.astype(np.float64)
+    got, ctx = bricks.observe_pos(cosmo, pos_in, vel, center, rotvec, box, evol, paint, a_obs=a_obs, curved_sky=curved, dvel=dvel,
+                                  return_ctx=True)
+    got_abs = got.to_absolute().cpu().numpy() if lattice else got.cpu().numpy().astype(np.float64)
+    f = lambda x, v, dv: bo.observe_pos(cosmo, x, v, center, R, box, evol, paint, a_obs, curved, dv)
+    ref = f(x64, vel.astype(np.float64), dvel.astype(np.float64))
+    assert np.abs(got_abs - ref).max() < 2e-4 and rel_l2(got_abs - x64 * np.divide(paint, evol), ref - x64 * np.divide(paint, evol)) < 2e-5
+    ob = rng.standard_normal((N, 3))
+    pb, vb, db, gfb = bricks.observe_pos_vjp(ctx, ob.astype(np.float32))
+    eps = 1e-4
+    for name, bar, idx in (("pos", pb, 0), ("vel", vb, 1), ("dvel", db, 2)):
+        d = rng.standard_normal((N, 3))
+        args_p = [x64, vel.astype(np.float64), dvel.astype(np.float64)]
+        args_m = [a.copy() for a in args_p]
+        args_p[idx] = args_p[idx] + eps * d
+        args_m[idx] = args_m[idx] - eps * d
+        fd = ((f(*args_p) - f(*args_m)) * ob).sum() / (2 * eps)
+        an = float((bar.double().cpu().numpy() * d).sum())
+        assert abs(fd - an) < 2e-3 * max(abs(fd), np.linalg.norm(ob) * np.linalg.norm(d) * 1e-2), (name, fd, an)
+    if not lightcone:    # scalar growth product: d/d(gf) by scaling the velocities
+        gf = float(o.a2g(cosmo, 0.7) * o.a2f(cosmo, 0.7))
+        v64 = vel.astype(np.float64)
+        fd = ((f(x64, v64 * (1 + eps), dvel.astype(np.float64)) - f(x64, v64 * (1 - eps), dvel.astype(np.float64))) * ob).sum() / (2 * eps * gf)
+        assert abs(fd - gfb) < 2e-3 * abs(fd)
+    else:
+        assert gfb == 0.0
