@@ -279,6 +279,20 @@ int mcpm_bias_weights_vjp_f32(mcpm_plan *plan, int64_t n, const float *dr, const
                               const float *weights_bar, const float *dvel_bar, float *dr_bar, float *s2r_bar, float *s3r_bar,
                               float *lr_bar, float *gr_bar, float *growth_bar, double *scalars_out);
 
+/* white2lin / lin2white multiplier (montecosmo/bricks.py:83-100, :149-161): out = in * sqrt(amp * P(|k|)), |k| in h/Mpc
+   (kphys = mesh_shape / box_size), P linearly interpolated from the DEVICE float64 table (ks ascending, pows) and zero
+   outside it (jnp.interp left = right = 0); amp = sigma8^2 for a table normalised to sigma8 = 1.  Real multiplier: the same
+   call is its own adjoint. */
+int mcpm_power_mult_f32(mcpm_plan *plan, const float *in, float kphys_x, float kphys_y, float kphys_z, double amp,
+                        const double *ks, const double *pows, int ntab, float *out);
+/* Light-cone LPT (montecosmo/nbody.py:652-666 with a of shape (N,1)): per-particle growth (gtab (n,3) = a2g, a2g2, a2dg2dg at
+   a_i) applied to the first / second order forces at the particles: dpos = g F1 - g2 F2, vel = F1 - dg2dg F2 (F2 NULL for
+   lpt_order 1).  F2 and F1 are what mcpm_lpt_f32 returns as (dpos, vel) for (g, g2, dg2dg) = (0, -1, 0).  The VJP works in
+   place: (xb, vb) cotangents of (dpos, vel) become those of (F2, F1), ready for mcpm_lpt_vjp_f32 with the same scalars. */
+int mcpm_lpt_combine_f32(mcpm_plan *plan, const float *F1, const float *F2, const float *gtab, int64_t n, float *dpos, float *vel);
+int mcpm_lpt_combine_vjp_f32(mcpm_plan *plan, const float *F1, const float *F2, const float *gtab, int64_t n, float *xb, float *vb,
+                             float *gtab_bar);
+
 /* Evolved particles -> redshift-space positions on the paint mesh (montecosmo/model.py:780-797 without Alcock-Paczynski;
    bricks.py:628-662 cell <-> physical maps, :750-768 line of sight and scale factor, :791-803 rsd), one fused pass.
    The plan's mesh is the evolution mesh.  geom (host, 19 floats) = box_rot matrix R[9] (row major, apply(x) = R x),

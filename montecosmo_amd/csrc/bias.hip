@@ -250,6 +250,69 @@ __global__ __launch_bounds__(256) void bias_vjp_particles_kernel(const float *__
     block_add<1>(v, slots);
 }
 
+// jnp.interp(x, xp, fp, left=0, right=0) on float64 device tables
+__device__ __forceinline__ double interp_zero(double x, const double *xp, const double *fp, int n) {
+    if (x < xp[0] || x > xp[n - 1]) return 0.;
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xp[mid] <= x) lo = mid; else hi = mid;
+    }
+    return fp[lo] + (fp[hi] - fp[lo]) / (xp[hi] - xp[lo]) * (x - xp[lo]);
+}
+
+// out = in * sqrt(amp * P(|k|)), P linearly interpolated from (ks, pows), zero outside the table (bricks.py:83-100, :149-154)
+__global__ __launch_bounds__(256) void power_mult_kernel(Geom g, float kx, float ky, float kz, double amp,
+                                                         const double *__restrict__ ks, const double *__restrict__ pows, int nt,
+                                                         const float2 *__restrict__ in, float2 *__restrict__ out, int64_t Mh) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= Mh) return;
+    const BMode m = bdecode(g, kx, ky, kz, idx);
+    const double k = sqrt((double)m.k[0] * m.k[0] + (double)m.k[1] * m.k[1] + (double)m.k[2] * m.k[2]);
+    const float t = (float)sqrt(amp * interp_zero(k, ks, pows, nt));
+    const float2 v = in[idx];
+    out[idx] = make_float2(t * v.x, t * v.y);
+}
+
+// light-cone LPT (nbody.py:652-666 with a of shape (N,1)): dpos = g F1 - g2 F2, vel = F1 - c F2, per-particle (g, g2, c)
+__global__ __launch_bounds__(256) void lpt_combine_kernel(const float *__restrict__ F1, const float *__restrict__ F2,
+                                                          const float *__restrict__ gt, int64_t n, float *__restrict__ dpos,
+                                                          float *__restrict__ vel) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = gt[3 * i], g2 = gt[3 * i + 1], c = gt[3 * i + 2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float f1 = F1[3 * i + a], f2 = F2 ? F2[3 * i + a] : 0.f;
+        dpos[3 * i + a] = g * f1 - g2 * f2;
+        vel[3 * i + a] = f1 - c * f2;
+    }
+}
+
+// in place: (xb, vb) = cotangents of (dpos, vel) -> cotangents of (F2, F1) [so that they feed mcpm_lpt_vjp_f32 called
+// with (g, g2, c) = (0, -1, 0)]; gtb = per-particle cotangents of (g, g2, c)
+__global__ __launch_bounds__(256) void lpt_combine_vjp_kernel(const float *__restrict__ F1, const float *__restrict__ F2,
+                                                              const float *__restrict__ gt, int64_t n, float *xb, float *vb,
+                                                              float *__restrict__ gtb) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = gt[3 * i], g2 = gt[3 * i + 1], c = gt[3 * i + 2];
+    float gb = 0.f, g2b = 0.f, cb = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = xb[3 * i + a], v = vb[3 * i + a];
+        const float f1 = F1[3 * i + a], f2 = F2 ? F2[3 * i + a] : 0.f;
+        gb += x * f1;
+        g2b -= x * f2;
+        cb -= v * f2;
+        xb[3 * i + a] = -g2 * x - c * v;   // F2_bar
+        vb[3 * i + a] = g * x + v;         // F1_bar
+    }
+    gtb[3 * i] = gb;
+    gtb[3 * i + 1] = g2b;
+    gtb[3 * i + 2] = cb;
+}
+
 int fields_group(mcpm_plan *p, const float *lin_mesh, float kx, float ky, float kz, int group, float *spec, float *real) {
     const unsigned nb = (unsigned)((p->Mh + 255) / 256);
     const float scale = 1.f / (float)p->M;
@@ -355,6 +418,43 @@ int mcpm_bias_weights_vjp_f32(mcpm_plan *p, int64_t n, const float *dr, const fl
                                                          weights_bar, dvel_bar, n, drb, s2rb, s3rb, lrb, grb, growth_bar, slots);
     fold_kernel<<<1, NSLOT, 0, p->stream>>>(slots, 1, 1.0, scalars_out + 8);   // summed growth cotangent
     MCPM_LAUNCH_CHECK(p, "bias_vjp_particles_kernel");
+    return MCPM_OK;
+}
+
+// white2lin / lin2white multiplier (bricks.py:149-161): out = in * sqrt(amp * P(|k|)) on the plan's half-spectrum, |k| in h/Mpc
+// (kphys = mesh_shape / box_size), P from the DEVICE float64 table (ks ascending, pows), zero outside it; amp = sigma8^2
+// for a table normalised to sigma8 = 1.  The multiplier is real, so the same call is its own adjoint.
+int mcpm_power_mult_f32(mcpm_plan *p, const float *in, float kpx, float kpy, float kpz, double amp, const double *ks,
+                        const double *pows, int ntab, float *out) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, in && out && ks && pows && ntab >= 2, MCPM_E_ARG, "mcpm_power_mult_f32: bad argument");
+    StageTimer st_(p, ST_KSPACE, 16.0 * p->Mh);
+    power_mult_kernel<<<(unsigned)((p->Mh + 255) / 256), 256, 0, p->stream>>>(p->g, kpx, kpy, kpz, amp, ks, pows, ntab,
+                                                                             (const float2 *)in, (float2 *)out, p->Mh);
+    MCPM_LAUNCH_CHECK(p, "power_mult_kernel");
+    return MCPM_OK;
+}
+
+// Light-cone LPT combination: F1, F2 (n,3) first / second order forces at the particles (F2 may be NULL), gtab (n,3) =
+// per-particle (a2g, a2g2, a2dg2dg)(a_i) -> dpos = g F1 - g2 F2, vel = F1 - dg2dg F2 (nbody.py:652-666).
+int mcpm_lpt_combine_f32(mcpm_plan *p, const float *F1, const float *F2, const float *gtab, int64_t n, float *dpos, float *vel) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, F1 && gtab && dpos && vel && n > 0, MCPM_E_ARG, "mcpm_lpt_combine_f32: bad argument");
+    StageTimer st_(p, ST_LPT, 60.0 * n);
+    lpt_combine_kernel<<<(unsigned)((n + 255) / 256), 256, 0, p->stream>>>(F1, F2, gtab, n, dpos, vel);
+    MCPM_LAUNCH_CHECK(p, "lpt_combine_kernel");
+    return MCPM_OK;
+}
+
+// VJP, in place: on entry (xb, vb) = cotangents of (dpos, vel); on exit xb = cotangent of F2, vb = cotangent of F1 (feed
+// them to mcpm_lpt_vjp_f32 with (g, g2, dg2dg) = (0, -1, 0)); gtab_bar (n,3) = per-particle growth cotangents.
+int mcpm_lpt_combine_vjp_f32(mcpm_plan *p, const float *F1, const float *F2, const float *gtab, int64_t n, float *xb, float *vb,
+                             float *gtab_bar) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, F1 && gtab && xb && vb && gtab_bar && n > 0, MCPM_E_ARG, "mcpm_lpt_combine_vjp_f32: bad argument");
+    StageTimer st_(p, ST_LPT, 96.0 * n);
+    lpt_combine_vjp_kernel<<<(unsigned)((n + 255) / 256), 256, 0, p->stream>>>(F1, F2, gtab, n, xb, vb, gtab_bar);
+    MCPM_LAUNCH_CHECK(p, "lpt_combine_vjp_kernel");
     return MCPM_OK;
 }
 

@@ -498,23 +498,34 @@ def pm_forces2(pos, mesh, read_order: int = 2, grad_fd=np.inf, lap_fd=np.inf):
     return out
 
 
+def _growth_tab3(cosmo, a, n):
+    """(n,3) float32 device table of (a2g, a2g2, a2dg2dg) at the per-particle scale factors a (N,1)."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    if a.size != n:
+        raise ValueError(f"a must be a scalar or have one entry per particle ({n}), got {a.size}")
+    return _f32(np.stack([a2g(cosmo, a), a2g2(cosmo, a), a2dg2dg(cosmo, a)], axis=-1))
+
+
 def lpt(cosmo, init_mesh, pos, a, lpt_order: int = 2, read_order: int = 2, grad_fd=np.inf, lap_fd=np.inf):
     """First or second order LPT displacement and growth-time velocity at scale factor(s) `a`
-    (nbody.py:634-667).  `a` may be a scalar or an (N,1) array (light-cone)."""
+    (nbody.py:634-667).  `a` may be a scalar or an (N,1) array (light-cone: per-particle growth applied by
+    mcpm_lpt_combine_f32)."""
     init_mesh = torch.as_tensor(init_mesh)
     if not init_mesh.is_complex():
         init_mesh = rfftn(init_mesh)
     force1 = pm_forces(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
-
-    def scal(x):
-        return float(x) if np.ndim(x) == 0 else _f32(np.asarray(x, dtype=np.float64))
-
-    dpos = scal(a2g(cosmo, a)) * force1
-    vel = force1
-    if lpt_order == 2:
-        force2 = pm_forces2(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
-        dpos = dpos - scal(a2g2(cosmo, a)) * force2
-        vel = vel - scal(a2dg2dg(cosmo, a)) * force2
+    force2 = pm_forces2(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd) if lpt_order == 2 else None
+    n = force1.shape[0]
+    if np.ndim(a) == 0 or np.size(a) == 1:
+        dpos, vel = float(a2g(cosmo, a)) * force1, force1
+        if force2 is not None:
+            dpos = dpos - float(a2g2(cosmo, a)) * force2
+            vel = vel - float(a2dg2dg(cosmo, a)) * force2
+        return dpos, vel
+    gt = _growth_tab3(cosmo, a, n)
+    dpos, vel = torch.empty_like(force1), torch.empty_like(force1)
+    plan = get_plan(ch2rshape(init_mesh.shape), pos.ptcl_shape if isinstance(pos, LatticePos) else None)
+    plan.call("mcpm_lpt_combine_f32", _ptr(force1), _ptr(force2), _ptr(gt), n, _ptr(dpos), _ptr(vel))
     return dpos, vel
 
 
@@ -824,18 +835,33 @@ def cosmo_vjp(ctx, scalar_bars, params=("Omega_c",), rel_eps=1e-5):
 
 
 def lpt_vjp(cosmo, init_mesh, pos, a, dpos_bar, vel_bar, lpt_order: int = 2):
-    """VJP of `lpt(..., read_order=1)` on the regular lattice w.r.t. init_mesh (half-spectrum) for scalar `a`.
-    Returns (init_mesh_bar, {'g','g2','dg2dg'} scalar cotangents)."""
+    """VJP of `lpt(..., read_order=1)` on the regular lattice w.r.t. init_mesh (half-spectrum).  Scalar `a`: returns
+    (init_mesh_bar, {'g','g2','dg2dg'} scalar cotangents).  `a` of shape (N,1) (light cone): the growth cotangents are
+    per-particle arrays (N,)."""
     spec = _c64(init_mesh)
     mesh_shape = ch2rshape(spec.shape)
     ptcl_shape = pos.ptcl_shape if isinstance(pos, LatticePos) else _infer_lattice(pos, mesh_shape)
     plan = get_plan(mesh_shape, ptcl_shape)
     xb, vb = _f32(dpos_bar, (plan.N, 3)), _f32(vel_bar, (plan.N, 3))
-    sc = np.array([float(a2g(cosmo, a)), float(a2g2(cosmo, a)), float(a2dg2dg(cosmo, a))])
     out = torch.empty(tuple(spec.shape), dtype=torch.complex64, device=spec.device)
     sb = np.zeros(3)
+    if np.ndim(a) == 0 or np.size(a) == 1:
+        sc = np.array([float(a2g(cosmo, a)), float(a2g2(cosmo, a)), float(a2dg2dg(cosmo, a))])
+        plan.call("mcpm_lpt_vjp_f32", _ptr(spec), int(lpt_order), _dptr(sc), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
+        return out, {"g": sb[0], "g2": sb[1], "dg2dg": sb[2]}
+    # light cone: (F2, F1) = mcpm_lpt_f32 with (g, g2, dg2dg) = (0, -1, 0); the per-particle combination is adjointed by
+    # mcpm_lpt_combine_vjp_f32, the rest by the scalar LPT adjoint with the same three scalars
+    gt = _growth_tab3(cosmo, a, plan.N)
+    F2 = torch.empty((plan.N, 3), dtype=torch.float32, device=spec.device)
+    F1 = torch.empty((plan.N, 3), dtype=torch.float32, device=spec.device)
+    plan.call("mcpm_lpt_f32", _ptr(spec), int(lpt_order), 0.0, -1.0, 0.0, 0, 0, _ptr(F2), _ptr(F1))
+    xb, vb = xb.clone(), vb.clone()
+    gtb = torch.empty((plan.N, 3), dtype=torch.float32, device=spec.device)
+    plan.call("mcpm_lpt_combine_vjp_f32", _ptr(F1), _ptr(F2) if lpt_order == 2 else None, _ptr(gt), plan.N, _ptr(xb), _ptr(vb), _ptr(gtb))
+    sc = np.array([0.0, -1.0, 0.0])
     plan.call("mcpm_lpt_vjp_f32", _ptr(spec), int(lpt_order), _dptr(sc), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
-    return out, {"g": sb[0], "g2": sb[1], "dg2dg": sb[2]}
+    g = gtb.double().cpu().numpy()
+    return out, {"g": g[:, 0], "g2": g[:, 1], "dg2dg": g[:, 2]}
 
 
 def _infer_lattice(pos, mesh_shape):

@@ -557,16 +557,18 @@ def lpt(cosmo, init_mesh, pos, a, lpt_order=2, read_order=2, grad_fd=np.inf, lap
 
 def lpt_vjp(cosmo, init_mesh, pos, a, dpos_bar, vel_bar, lpt_order=2, read_order=2, grad_fd=np.inf, lap_fd=np.inf):
     """VJP of lpt w.r.t. init_mesh (complex half-spectrum), pos, and the three growth scalars.
-    Returns (init_mesh_bar, pos_bar, {'g':..., 'g2':..., 'dg2dg':...}); scalar `a` only."""
+    Returns (init_mesh_bar, pos_bar, {'g':..., 'g2':..., 'dg2dg':...}); the growth cotangents are scalars for a scalar
+    `a` and per-particle arrays (N,) for `a` of shape (N,1) (light cone)."""
     g, g2, c = a2g(cosmo, a), a2g2(cosmo, a), a2dg2dg(cosmo, a)
+    red = (lambda x: float(np.sum(x))) if np.ndim(a) == 0 else (lambda x: np.sum(x, axis=-1))
     force1 = pm_forces(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
     f1_bar = g * dpos_bar + vel_bar
-    sbar = {'g': float(np.sum(dpos_bar * force1)), 'g2': 0., 'dg2dg': 0.}
+    sbar = {'g': red(dpos_bar * force1), 'g2': 0., 'dg2dg': 0.}
     pos_bar, mesh_bar = pm_forces_vjp(pos, init_mesh, f1_bar, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
     if lpt_order == 2:
         force2 = pm_forces2(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
-        sbar['g2'] = -float(np.sum(dpos_bar * force2))
-        sbar['dg2dg'] = -float(np.sum(vel_bar * force2))
+        sbar['g2'] = -red(dpos_bar * force2)
+        sbar['dg2dg'] = -red(vel_bar * force2)
         f2_bar = -g2 * dpos_bar - c * vel_bar
         pb, mb = pm_forces2_vjp(pos, init_mesh, f2_bar, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
         pos_bar = pos_bar + pb

@@ -348,6 +348,28 @@ def test_lpt_vjp_standalone(nb):
         assert np.isclose(sb_g[k], sb_o[k], rtol=1e-4, atol=1e-4 * abs(sb_o["g"])), k
 
 
+@pytest.mark.parametrize("lpt_order", [1, 2])
+def test_lpt_light_cone(nb, lpt_order):
+    """nbody.py:634-667 with `a` of shape (N,1): per-particle growth (mcpm_lpt_combine_f32) and its VJP."""
+    from montecosmo_amd import bricks, synth
+    n = 16
+    shape = (n, n, n)
+    spec = synth.init_mesh(n, seed=8, rms_disp=1.0)
+    pos = bricks.regular_pos(shape)
+    rng = np.random.default_rng(4)
+    a = 0.3 + 0.6 * rng.uniform(size=(n ** 3, 1))
+    dp, v = nb.lpt(bricks.Planck18(), spec, nb.LatticePos.regular(shape), a, lpt_order=lpt_order, read_order=1)
+    dp_o, v_o = o.lpt(obg.Planck18(), spec.astype(np.complex128), pos, a, lpt_order=lpt_order, read_order=1)
+    assert rel_l2(to_np(dp), dp_o) < 1e-5 and rel_l2(to_np(v), v_o) < 1e-5
+    xb, vb = rng.standard_normal((n ** 3, 3)), rng.standard_normal((n ** 3, 3))
+    mb_o, _, sb_o = o.lpt_vjp(obg.Planck18(), spec.astype(np.complex128), pos, a, xb, vb, lpt_order=lpt_order, read_order=1)
+    mb_g, sb_g = nb.lpt_vjp(bricks.Planck18(), spec, pos, a, xb.astype(np.float32), vb.astype(np.float32), lpt_order=lpt_order)
+    assert rel_l2(to_np(mb_g), mb_o) < 1e-5
+    assert rel_l2(sb_g["g"], sb_o["g"]) < 1e-5
+    if lpt_order == 2:
+        assert rel_l2(sb_g["g2"], sb_o["g2"]) < 1e-5 and rel_l2(sb_g["dg2dg"], sb_o["dg2dg"]) < 1e-5
+
+
 @pytest.mark.parametrize("snapshots", [3, [0.3, 0.55, 1.0]])
 def test_nbody_bf_snapshots(nb, snapshots):
     """SaveAt(ts=...) (nbody.py:990-997): linear interpolation of the Euler solution between steps."""
