@@ -1,0 +1,154 @@
+"""`FieldLevelModel.evolve` (montecosmo/model.py:686-838) on the HIP path, with its hand-written reverse sweep.
+
+Built branch: bias_type 'lagrangian', evolution 'lpt' (scalar a_obs or light cone) or 'nbody' (scalar a_obs, as the
+reference asserts), png_type None, ap_auto None, kernel_type 'rectangular', tabulated linear power (`lin_kpow`,
+bricks.py:75-77).  Everything else of the model (priors, likelihood, samplers, registers) stays in the reference.
+
+    fwd = FieldLevelForward(final_shape=(64, 64, 64), cell_length=20., box_center=(0, 0, 2000.), evolution='nbody',
+                            a_obs=0.7, lin_kpow=(ks, pows))
+    gxy_mesh, ctx = fwd.evolve(cosmology, bias, white_mesh, return_ctx=True)       # gxy_mesh = 1 + delta_obs
+    grads = fwd.evolve_vjp(ctx, gxy_mesh_bar)      # {'white_mesh': ..., 'bias': {...}, 'sigma8': ..., 'growth': ...}
+
+Chain (every arrow is a HIP kernel sequence of libmcpm.so, each with its VJP):
+white_mesh -white2lin-> init_mesh -chreshape-> evol mesh -lagrangian_bias-> (weights, dvel); -lpt | nbody_bf-> (pos, vel)
+-observe_pos (los, rsd)-> pos on init_shape -nufft(weights, paint_shape)-> spectrum -chreshape-> -irfftn-> gxy_mesh.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import nbody, bricks
+from .utils import scale_shape, r2chshape, chreshape, chreshape_vjp
+
+
+class EvolveCtx:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class FieldLevelForward:
+    def __init__(self, final_shape=(64, 64, 64), cell_length=20., box_center=(0., 0., 0.), box_rotvec=(0., 0., 0.),
+                 evolution='lpt', nbody_a_start=0., nbody_n_steps=10, lpt_order=2, paint_order=2, paint_deconv=True,
+                 init_oversamp=3 / 2, evol_oversamp=7 / 4, ptcl_oversamp=7 / 4, paint_oversamp=7 / 4, interlace_order=2,
+                 a_obs=None, curved_sky=True, lin_kpow=None):
+        if evolution not in ('lpt', 'nbody'):
+            raise NotImplementedError("evolution must be 'lpt' or 'nbody' (the Kaiser model is not built)")
+        if lin_kpow is None:
+            raise NotImplementedError("a tabulated linear power spectrum lin_kpow = (ks, pows) normalised to sigma8 = 1 is "
+                                      "required (the Eisenstein-Hu emulation of jax_cosmo is not built)")
+        self.final_shape = tuple(int(s) for s in final_shape)
+        self.cell_length = float(cell_length)
+        self.box_center = np.asarray(box_center, dtype=np.float64)
+        self.box_rotvec = np.asarray(box_rotvec, dtype=np.float64)
+        self.box_size = np.multiply(self.final_shape, self.cell_length)            # model.py:568-573
+        self.init_shape = scale_shape(self.final_shape, init_oversamp)
+        self.evol_shape = scale_shape(self.final_shape, evol_oversamp)
+        self.ptcl_shape = scale_shape(self.final_shape, ptcl_oversamp)
+        self.paint_shape = scale_shape(self.final_shape, paint_oversamp)
+        self.evolution, self.nbody_a_start, self.nbody_n_steps = evolution, float(nbody_a_start), int(nbody_n_steps)
+        self.lpt_order, self.paint_order, self.paint_deconv = int(lpt_order), int(paint_order), bool(paint_deconv)
+        self.interlace_order, self.a_obs, self.curved_sky = int(interlace_order), a_obs, bool(curved_sky)
+        if evolution == 'nbody' and a_obs is None:
+            raise NotImplementedError("N-body light-cone not implemented (model.py:770)")
+        ks, pows = lin_kpow
+        self.lin_kpow = (np.asarray(ks, dtype=np.float64), np.asarray(pows, dtype=np.float64))
+        self._dev_kpow = None
+        self._r0 = None
+
+    def config(self):
+        """The attributes the oracle composition needs (tests)."""
+        keys = ("init_shape", "evol_shape", "ptcl_shape", "paint_shape", "box_size", "box_center", "box_rotvec", "a_obs",
+                "curved_sky", "evolution", "nbody_a_start", "nbody_n_steps", "lpt_order", "paint_order", "paint_deconv",
+                "interlace_order", "lin_kpow")
+        return {k: getattr(self, k) for k in keys}
+
+    # ---- pieces ------------------------------------------------------------------------------------------
+    def _kphys(self, shape):
+        return [float(s) / float(b) for s, b in zip(shape, self.box_size)]
+
+    def _power_mult(self, spec, sigma8):
+        """white2lin (bricks.py:149-154): spec * sqrt(sigma8^2 P(|k|)); real multiplier, self-adjoint."""
+        if self._dev_kpow is None:
+            self._dev_kpow = torch.from_numpy(np.concatenate(self.lin_kpow)).to(spec.device)
+        nt = len(self.lin_kpow[0])
+        plan = nbody.get_plan(self.init_shape)
+        out = torch.empty_like(spec)
+        kp = self._kphys(self.init_shape)
+        plan.call("mcpm_power_mult_f32", nbody._ptr(spec), kp[0], kp[1], kp[2], float(sigma8) ** 2, nbody._ptr(self._dev_kpow),
+                  nbody.C.c_void_p(self._dev_kpow.data_ptr() + 8 * nt), nt, nbody._ptr(out))
+        return out
+
+    def _scale_factors(self, cosmo):
+        """Scale factor(s) of the Lagrangian lattice (model.py:741-742): a_obs, or chi2a(|x|) per particle."""
+        if self.a_obs is not None:
+            return self.a_obs
+        if self._r0 is None:      # the lattice is fixed: its physical distances are computed once (host float64)
+            pos = bricks.regular_pos(self.evol_shape, self.ptcl_shape)
+            p = bricks.cell2phys_pos(pos, self.box_center, self.box_rotvec, self.box_size, self.evol_shape)
+            if self.curved_sky:
+                self._r0 = np.linalg.norm(p, axis=-1, keepdims=True)
+            else:
+                los = nbody.safe_div(self.box_center, np.linalg.norm(self.box_center))
+                self._r0 = np.abs((p * los).sum(-1, keepdims=True))
+        return nbody.chi2a(cosmo, self._r0)
+
+    # ---- forward -----------------------------------------------------------------------------------------
+    def evolve(self, cosmo, bias, white_mesh, return_ctx=False):
+        """cosmo: duck-typed cosmology (Omega_m, Omega_de, Omega_k, w0, wa, sigma8, _workspace); bias: dict of the
+        Lagrangian bias parameters; white_mesh: complex half-spectrum of shape r2chshape(init_shape) (what
+        samp2base_mesh returns).  Returns gxy_mesh (paint_shape, float32 device tensor) = 1 + delta_obs."""
+        white = nbody._c64(white_mesh, r2chshape(self.init_shape))
+        init_k = self._power_mult(white, cosmo.sigma8)
+        evol_k = chreshape(init_k, r2chshape(self.evol_shape))
+        pos0 = nbody.LatticePos.regular(self.evol_shape, self.ptcl_shape)
+        a = self._scale_factors(cosmo)
+        (w, dvel, _), bctx = bricks.lagrangian_bias(cosmo, pos0, a, self.box_size, evol_k, bias, read_order=1, return_ctx=True)
+        cosmo._workspace = {}                                                        # model.py:762, :769
+        if self.evolution == 'lpt':
+            dpos, vel = nbody.lpt(cosmo, evol_k, pos0, a, lpt_order=self.lpt_order, read_order=1)
+            pos, nctx = pos0 + dpos, None
+        else:
+            (pos, vel), nctx = nbody.nbody_bf(cosmo, evol_k, pos0, a0=self.nbody_a_start, a1=a, n_steps=self.nbody_n_steps,
+                                              paint_order=self.paint_order, lpt_order=self.lpt_order, return_ctx=True,
+                                              lattice_out=True)
+            vel = vel.reshape(-1, 3)
+        pos_c, octx = bricks.observe_pos(cosmo, pos, vel, self.box_center, self.box_rotvec, self.box_size, self.evol_shape,
+                                         self.init_shape, a_obs=self.a_obs, curved_sky=self.curved_sky, dvel=dvel, return_ctx=True)
+        gxy_k = nbody.nufft(pos_c, self.init_shape, self.paint_shape, weights=w, paint_order=self.paint_order,
+                            interlace_order=self.interlace_order, paint_deconv=self.paint_deconv)
+        jac = float(np.divide(self.init_shape, self.ptcl_shape).prod())
+        gxy_k = chreshape(gxy_k * jac, r2chshape(self.paint_shape))
+        gxy = nbody.irfftn(gxy_k)
+        if return_ctx:
+            return gxy, EvolveCtx(cosmo=cosmo, white=white, evol_k=evol_k, pos0=pos0, a=a, bctx=bctx, nctx=nctx, octx=octx,
+                                  pos_c=pos_c, w=w, jac=jac)
+        return gxy
+
+    # ---- reverse sweep -----------------------------------------------------------------------------------
+    def evolve_vjp(self, ctx, gxy_bar):
+        """Cotangent of gxy_mesh (real, paint_shape) -> {'white_mesh': complex64 cotangent (real-pair convention),
+        'bias': dict, 'sigma8': float, 'growth': cotangents of the growth scalars (see nbody.lpt_vjp / nbody_bf_vjp),
+        'bias_growth': cotangent(s) of a2g(a) through the bias weights, 'gf': cotangent of a2g(a_obs) a2f(a_obs) through rsd}."""
+        cosmo = ctx.cosmo
+        gb = nbody._f32(gxy_bar, self.paint_shape)
+        # irfftn adjoint: X_bar = (w / M) rfftn(y_bar)
+        Mp = float(np.prod(self.paint_shape))
+        kb = nbody.rfftn(gb) / Mp
+        kb[..., 1:self.paint_shape[-1] // 2] *= 2.0
+        kb = chreshape_vjp(kb, r2chshape(self.init_shape)) * ctx.jac
+        pb, wb = nbody.nufft_vjp(ctx.pos_c, self.init_shape, ctx.w, kb, self.paint_order, self.interlace_order, self.paint_deconv,
+                                 paint_shape=self.paint_shape)
+        xb, vb, dvb, gfb = bricks.observe_pos_vjp(ctx.octx, pb)
+        mesh_b, bias_bar, bg_bar = bricks.lagrangian_bias_vjp(ctx.bctx, wb, dvb)
+        if self.evolution == 'lpt':
+            mb, growth = nbody.lpt_vjp(cosmo, ctx.evol_k, ctx.pos0, ctx.a, xb, vb, lpt_order=self.lpt_order)
+        else:
+            mb, growth = nbody.nbody_bf_vjp(ctx.nctx, xb, vb)
+        mesh_b = mesh_b + mb
+        init_b = chreshape_vjp(mesh_b, r2chshape(self.init_shape))
+        white_b = self._power_mult(init_b, cosmo.sigma8)
+        # d/d sigma8: init_mesh is linear in sigma8
+        init_k = self._power_mult(ctx.white, cosmo.sigma8)
+        s8b = float((init_b.conj() * init_k).real.sum().item()) / float(cosmo.sigma8)
+        return {"white_mesh": white_b, "bias": bias_bar, "sigma8": s8b, "growth": growth, "bias_growth": bg_bar, "gf": gfb}

@@ -199,3 +199,42 @@ def observe_pos(cosmo, pos, vel, box_center, R, box_size, evol_shape, paint_shap
     p = cell2phys_pos(pos, box_center, R, box_size, evol_shape)
     p = p + rsd(cosmo, vel, los, a, R, box_size, evol_shape, dvel)
     return phys2cell_pos(p, box_center, R, box_size, paint_shape)
+
+
+# --------------------------------------------------------------------------- evolve (model.py:686-838)
+def white2lin(sigma8, white_mesh, init_shape, box_size, kpow):
+    """bricks.py:83-100, :149-154 with a tabulated power spectrum normalised to sigma8 = 1."""
+    ks, pows = kpow
+    kvec = o.rfftk(init_shape, box_size)
+    kmesh = sum(ki ** 2 for ki in kvec) ** .5
+    pmesh = np.interp(kmesh.reshape(-1), ks, np.asarray(pows) * sigma8 ** 2, left=0., right=0.).reshape(kmesh.shape)
+    return white_mesh * pmesh ** .5
+
+
+def evolve(cfg, cosmo, bias, white_mesh):
+    """FieldLevelModel.evolve (model.py:686-838) for bias_type 'lagrangian', evolution 'lpt' or 'nbody', png_type None,
+    ap_auto None.  cfg: dict with the model's attributes (shapes, box, a_obs, curved_sky, orders...).  Returns the real
+    galaxy mesh 1 + delta_obs of shape paint_shape, and the intermediates a test may want."""
+    R = rotvec_matrix(cfg["box_rotvec"])
+    box, ctr = cfg["box_size"], cfg["box_center"]
+    init_mesh = white2lin(cosmo.sigma8, white_mesh, cfg["init_shape"], box, cfg["lin_kpow"])
+    init_mesh = o.chreshape(init_mesh, o.r2chshape(cfg["evol_shape"]))
+    pos = o.regular_pos(cfg["evol_shape"], cfg["ptcl_shape"])
+    _, a = los_scalefactor_pos(pos, ctr, R, box, cfg["evol_shape"], cosmo, cfg["a_obs"], cfg["curved_sky"])
+    w, dvel = lagrangian_bias(o.a2g(cosmo, a), pos, box, init_mesh, bias, read_order=1)
+    if cfg["evolution"] == "lpt":
+        cosmo._workspace = {}
+        dpos, vel = o.lpt(cosmo, init_mesh, pos, a, lpt_order=cfg["lpt_order"], read_order=1)
+        pos = pos + dpos
+    else:
+        cosmo._workspace = {}
+        assert np.ndim(a) == 0
+        p, v = o.nbody_bf(cosmo, init_mesh, pos, a0=cfg["nbody_a_start"], a1=a, n_steps=cfg["nbody_n_steps"],
+                          paint_order=cfg["paint_order"], lpt_order=cfg["lpt_order"])
+        pos, vel = p[-1], v[-1]
+    pos_c = observe_pos(cosmo, pos, vel, ctr, R, box, cfg["evol_shape"], cfg["init_shape"], cfg["a_obs"], cfg["curved_sky"], dvel)
+    gxy = o.nufft(pos_c, cfg["init_shape"], tuple(cfg["paint_shape"]), weights=w, paint_order=cfg["paint_order"],
+                  interlace_order=cfg["interlace_order"], paint_deconv=cfg["paint_deconv"])
+    gxy = gxy * np.divide(cfg["init_shape"], cfg["ptcl_shape"]).prod()
+    gxy = o.chreshape(gxy, o.r2chshape(cfg["paint_shape"]))
+    return np.fft.irfftn(gxy, s=tuple(cfg["paint_shape"]), axes=(0, 1, 2)), dict(init_mesh=init_mesh, weights=w, pos=pos_c)

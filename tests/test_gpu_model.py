@@ -1,0 +1,63 @@
+"""FieldLevelModel.evolve on the HIP path (montecosmo_amd/model.py) against the float64 oracle composition
+(oracle/bias_oracle.py::evolve), forward and reverse sweep.  model.py:686-838, lagrangian bias, lpt / nbody."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pm_oracle as o, bias_oracle as bo, background as obg  # noqa: E402  (checker only)
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+BIAS = dict(b1=0.8, b2=0.2, bs2=-0.15, b3=0.1, bds2=0.1, bs3=-0.05, bn2=20.0, bnpar=5.0)
+
+
+def _kpow():
+    ks = np.logspace(-3, 1, 128)
+    return ks, 3.0e4 * (ks / 0.02) / (1 + (ks / 0.02) ** 2.6)
+
+
+@pytest.mark.parametrize("evolution,a_obs,curved", [("lpt", None, True), ("lpt", 0.6, False), ("nbody", 0.7, True)])
+def test_evolve_forward_and_vjp(gpu, evolution, a_obs, curved):
+    from montecosmo_amd import bricks, model
+    rng = np.random.default_rng(31)
+    fwd = model.FieldLevelForward(final_shape=(8, 8, 8), cell_length=40., box_center=(60., -40., 1400.), box_rotvec=(0.1, 0.2, -0.1),
+                                  evolution=evolution, nbody_n_steps=3, lpt_order=2, init_oversamp=1.5, evol_oversamp=2.,
+                                  ptcl_oversamp=2., paint_oversamp=2., a_obs=a_obs, curved_sky=curved, lin_kpow=_kpow(),
+                                  nbody_a_start=0.1)
+    cfg = fwd.config()
+    assert cfg["init_shape"] == (12, 12, 12) and cfg["evol_shape"] == (16, 16, 16)
+    cosmo, cosmo_o = bricks.Planck18(), obg.Planck18()
+    cosmo_o.sigma8 = cosmo.sigma8
+    white = np.fft.rfftn(rng.standard_normal((12, 12, 12))) * (12 ** 3 / np.prod(cfg["box_size"])) ** .5   # bricks.py:138-146
+    gxy, ctx = fwd.evolve(cosmo, BIAS, white.astype(np.complex64), return_ctx=True)
+    ref, aux = bo.evolve(cfg, cosmo_o, BIAS, white)
+    d_lin = np.fft.irfftn(aux["init_mesh"], s=(16, 16, 16), axes=(0, 1, 2))
+    assert 0.05 < d_lin.std() < 1.0                                   # a clustered but perturbative field
+    assert gxy.shape == (16, 16, 16)
+    assert rel_l2(gxy.cpu().numpy(), ref) < 2e-4
+    assert abs(float(gxy.mean()) - 1.0) < 0.1                         # 1 + delta_obs
+    gb = rng.standard_normal((16, 16, 16))
+    grads = fwd.evolve_vjp(ctx, gb.astype(np.float32))
+    L = lambda wh, bias_, s8: float((gb * bo.evolve(cfg, _with_s8(cosmo_o, s8), bias_, wh)[0]).sum())
+    eps = 1e-5
+    dW = np.fft.rfftn(rng.standard_normal((12, 12, 12))) * np.abs(white).mean() / 40.
+    fd = (L(white + eps * dW, BIAS, cosmo.sigma8) - L(white - eps * dW, BIAS, cosmo.sigma8)) / (2 * eps)
+    an = float(np.sum(np.conj(grads["white_mesh"].cpu().numpy().astype(np.complex128)) * dW).real)
+    assert abs(fd - an) < 3e-3 * abs(fd), ("white_mesh", fd, an)
+    for k in ("b1", "bs2", "bnpar"):
+        h = 1e-4 * max(1.0, abs(BIAS[k]))
+        fdk = (L(white, dict(BIAS, **{k: BIAS[k] + h}), cosmo.sigma8) - L(white, dict(BIAS, **{k: BIAS[k] - h}), cosmo.sigma8)) / (2 * h)
+        assert abs(fdk - grads["bias"][k]) < 3e-3 * max(abs(fdk), 1e-3 * abs(fd)), (k, fdk, grads["bias"][k])
+    h = 1e-4
+    fds = (L(white, BIAS, cosmo.sigma8 + h) - L(white, BIAS, cosmo.sigma8 - h)) / (2 * h)
+    assert abs(fds - grads["sigma8"]) < 3e-3 * abs(fds), ("sigma8", fds, grads["sigma8"])
+
+
+def _with_s8(c, s8):
+    c.sigma8 = s8
+    return c
