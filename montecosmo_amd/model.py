@@ -57,7 +57,7 @@ class FieldLevelForward:
         self._r0 = None
 
     def config(self):
-        """The attributes the oracle composition needs (tests)."""
+        """The model attributes as a dict (what the parity tests hand to their float64 checker)."""
         keys = ("init_shape", "evol_shape", "ptcl_shape", "paint_shape", "box_size", "box_center", "box_rotvec", "a_obs",
                 "curved_sky", "evolution", "nbody_a_start", "nbody_n_steps", "lpt_order", "paint_order", "paint_deconv",
                 "interlace_order", "lin_kpow")
