@@ -285,6 +285,10 @@ int mcpm_bias_weights_vjp_f32(mcpm_plan *plan, int64_t n, const float *dr, const
    call is its own adjoint. */
 int mcpm_power_mult_f32(mcpm_plan *plan, const float *in, float kphys_x, float kphys_y, float kphys_z, double amp,
                         const double *ks, const double *pows, int ntab, float *out);
+/* out[i] = scale * np.interp(x[i], xp, fp) (clamped ends; the growth / distance look-ups of montecosmo/nbody.py:748-804,
+   :862-884 for per-particle scale factors on the light cone).  Tables float64 on the DEVICE, xp ascending. */
+int mcpm_interp_f32(mcpm_plan *plan, const float *x, int64_t n, const double *xp, const double *fp, int ntab, float scale,
+                    float *out);
 /* Light-cone LPT (montecosmo/nbody.py:652-666 with a of shape (N,1)): per-particle growth (gtab (n,3) = a2g, a2g2, a2dg2dg at
    a_i) applied to the first / second order forces at the particles: dpos = g F1 - g2 F2, vel = F1 - dg2dg F2 (F2 NULL for
    lpt_order 1).  F2 and F1 are what mcpm_lpt_f32 returns as (dpos, vel) for (g, g2, dg2dg) = (0, -1, 0).  The VJP works in

@@ -77,9 +77,16 @@ def lagrangian_bias(cosmo, pos, a, box_size, lin_mesh, bias, png=None, png_type=
         plan.call("mcpm_read_f32", nbody._ptr(p), n, mode, nbody._ptr(fields[c]), 1, int(read_order), nbody._ptr(reads[c]))
     gr = torch.empty((n, 3), dtype=torch.float32, device=dev)
     plan.call("mcpm_read_f32", nbody._ptr(p), n, mode, nbody._ptr(fields[4]), 3, int(read_order), nbody._ptr(gr))
-    g = np.asarray(nbody.a2g(cosmo, a), dtype=np.float64)
-    gp = nbody._f32(g.reshape(-1), (n,)) if g.size == n and n > 1 else None
-    gs = float(g.reshape(-1)[0]) if gp is None else 0.0
+    if isinstance(a, torch.Tensor) and a.is_cuda:      # per-particle scale factors on the device (light cone)
+        gp, g_shape = nbody.growth_dev(cosmo, a, "g"), tuple(a.shape)
+        if gp.numel() != n:
+            raise ValueError("a must have one entry per particle")
+        gs = 0.0
+    else:
+        g = np.asarray(nbody.a2g(cosmo, a), dtype=np.float64)
+        g_shape = g.shape
+        gp = nbody._f32(g.reshape(-1), (n,)) if g.size == n and n > 1 else None
+        gs = float(g.reshape(-1)[0]) if gp is None else 0.0
     b8 = (C.c_float * 8)(*[float(bias.get(k, 0.0)) for k in BIAS_KEYS])
     w = torch.empty(n, dtype=torch.float32, device=dev)
     dvel = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -87,7 +94,7 @@ def lagrangian_bias(cosmo, pos, a, box_size, lin_mesh, bias, png=None, png_type=
               nbody._ptr(gr), nbody._ptr(gp), gs, b8, nbody._ptr(w), nbody._ptr(dvel), None)
     if return_ctx:
         ctx = BiasCtx(plan=plan, spec=spec, shape=shape, p=p, n=n, mode=mode, kphys=kphys, reads=reads, gr=gr, gp=gp, gs=gs,
-                      g_shape=g.shape, b8=b8, read_order=int(read_order))
+                      g_shape=g_shape, b8=b8, read_order=int(read_order))
         return (w, dvel, 0.), ctx
     return w, dvel, 0.
 
@@ -117,7 +124,8 @@ def lagrangian_bias_vjp(ctx, weights_bar, dvel_bar):
     plan.call("mcpm_bias_fields_vjp_f32", nbody._ptr(ctx.spec), ctx.kphys[0], ctx.kphys[1], ctx.kphys[2], nbody._ptr(fb), nbody._ptr(out))
     s = scal.cpu().numpy()
     bias_bar = {k: float(s[i]) for i, k in enumerate(BIAS_KEYS)}
-    growths_bar = gbar.double().cpu().numpy().reshape(ctx.g_shape) if gbar is not None else np.asarray(s[8]).reshape(ctx.g_shape)
+    # per-particle growth cotangents stay on the device; a scalar one comes back as a float64 array of the shape of a2g(a)
+    growths_bar = gbar.reshape(ctx.g_shape) if gbar is not None else np.asarray(s[8]).reshape(ctx.g_shape)
     return out, bias_bar, growths_bar
 
 

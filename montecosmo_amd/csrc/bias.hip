@@ -274,6 +274,26 @@ __global__ __launch_bounds__(256) void power_mult_kernel(Geom g, float kx, float
     out[idx] = make_float2(t * v.x, t * v.y);
 }
 
+// np.interp / jnp.interp with clamped ends (what the growth and distance look-ups use, nbody.py:748-804, :862-884)
+__global__ __launch_bounds__(256) void interp_kernel(const float *__restrict__ x, int64_t n, const double *__restrict__ xp,
+                                                     const double *__restrict__ fp, int nt, float scale, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double v = (double)x[i];
+    double r;
+    if (v <= xp[0]) r = fp[0];
+    else if (v >= xp[nt - 1]) r = fp[nt - 1];
+    else {
+        int lo = 0, hi = nt - 1;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (xp[mid] <= v) lo = mid; else hi = mid;
+        }
+        r = fp[lo] + (fp[hi] - fp[lo]) / (xp[hi] - xp[lo]) * (v - xp[lo]);
+    }
+    out[i] = scale * (float)r;
+}
+
 // light-cone LPT (nbody.py:652-666 with a of shape (N,1)): dpos = g F1 - g2 F2, vel = F1 - c F2, per-particle (g, g2, c)
 __global__ __launch_bounds__(256) void lpt_combine_kernel(const float *__restrict__ F1, const float *__restrict__ F2,
                                                           const float *__restrict__ gt, int64_t n, float *__restrict__ dpos,
@@ -455,6 +475,15 @@ int mcpm_lpt_combine_vjp_f32(mcpm_plan *p, const float *F1, const float *F2, con
     StageTimer st_(p, ST_LPT, 96.0 * n);
     lpt_combine_vjp_kernel<<<(unsigned)((n + 255) / 256), 256, 0, p->stream>>>(F1, F2, gtab, n, xb, vb, gtab_bar);
     MCPM_LAUNCH_CHECK(p, "lpt_combine_vjp_kernel");
+    return MCPM_OK;
+}
+
+// out[i] = scale * interp(x[i]; xp, fp) with clamped ends (np.interp); xp ascending, tables float64 on the DEVICE.
+int mcpm_interp_f32(mcpm_plan *p, const float *x, int64_t n, const double *xp, const double *fp, int ntab, float scale, float *out) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, x && xp && fp && out && n > 0 && ntab >= 2, MCPM_E_ARG, "mcpm_interp_f32: bad argument");
+    interp_kernel<<<(unsigned)((n + 255) / 256), 256, 0, p->stream>>>(x, n, xp, fp, ntab, scale, out);
+    MCPM_LAUNCH_CHECK(p, "interp_kernel");
     return MCPM_OK;
 }
 

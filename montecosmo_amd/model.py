@@ -80,18 +80,22 @@ class FieldLevelForward:
         return out
 
     def _scale_factors(self, cosmo):
-        """Scale factor(s) of the Lagrangian lattice (model.py:741-742): a_obs, or chi2a(|x|) per particle."""
+        """Scale factor(s) of the Lagrangian lattice (model.py:741-742): a_obs, or chi2a(|x|) per particle as a device
+        tensor (N,1).  The lattice is fixed, so its physical distances are computed once (host float64) and kept on
+        the device; the cosmology-dependent look-up runs there (mcpm_interp_f32)."""
         if self.a_obs is not None:
             return self.a_obs
-        if self._r0 is None:      # the lattice is fixed: its physical distances are computed once (host float64)
+        if self._r0 is None:
             pos = bricks.regular_pos(self.evol_shape, self.ptcl_shape)
             p = bricks.cell2phys_pos(pos, self.box_center, self.box_rotvec, self.box_size, self.evol_shape)
             if self.curved_sky:
-                self._r0 = np.linalg.norm(p, axis=-1, keepdims=True)
+                r0 = np.linalg.norm(p, axis=-1)
             else:
                 los = nbody.safe_div(self.box_center, np.linalg.norm(self.box_center))
-                self._r0 = np.abs((p * los).sum(-1, keepdims=True))
-        return nbody.chi2a(cosmo, self._r0)
+                r0 = np.abs((p * los).sum(-1))
+            self._r0 = nbody._f32(r0)
+        d = nbody._dist_cache(cosmo)
+        return nbody.interp_dev(self._r0, d["chi"][::-1], d["a"][::-1]).reshape(-1, 1)
 
     # ---- forward -----------------------------------------------------------------------------------------
     def evolve(self, cosmo, bias, white_mesh, return_ctx=False):

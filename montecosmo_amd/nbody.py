@@ -498,8 +498,41 @@ def pm_forces2(pos, mesh, read_order: int = 2, grad_fd=np.inf, lap_fd=np.inf):
     return out
 
 
+def interp_dev(x, xp, fp, scale=1.0):
+    """np.interp(x, xp, fp) * scale for a float32 device tensor x (mcpm_interp_f32); xp, fp host float64 tables."""
+    x = _f32(x).reshape(-1)
+    tab = torch.from_numpy(np.concatenate([np.asarray(xp, dtype=np.float64), np.asarray(fp, dtype=np.float64)])).to(x.device)
+    out = torch.empty_like(x)
+    nt = len(xp)
+    get_plan((8, 8, 8)).call("mcpm_interp_f32", _ptr(x), x.numel(), _ptr(tab), C.c_void_p(tab.data_ptr() + 8 * nt), nt, float(scale), _ptr(out))
+    return out
+
+
+def growth_dev(cosmo, a, which):
+    """Growth quantity `which` in {'g', 'g2', 'dg2dg', 'f'} at per-particle scale factors `a` given as a device tensor
+    (same tables and linear interpolation as the host functions a2g, a2g2, a2dg2dg, a2f)."""
+    c = _growth_cache(cosmo)
+    if which == "g":
+        return interp_dev(a, c["a"], c["g"])
+    if which == "g2":
+        return interp_dev(a, c["a"], c["g2"], -3 / 7)
+    if which == "f":
+        return interp_dev(a, c["a"], c["f"])
+    if which == "f2":
+        return interp_dev(a, c["a"], c["f2"])
+    if which == "dg2dg":      # a2dg2dg = safe_div(g2 f2, g f) of the four separately interpolated values (nbody.py:775-777)
+        num = growth_dev(cosmo, a, "g2") * growth_dev(cosmo, a, "f2")
+        den = growth_dev(cosmo, a, "g") * growth_dev(cosmo, a, "f")
+        return torch.where(den != 0, num / torch.where(den != 0, den, torch.ones_like(den)), torch.zeros_like(den))
+    raise ValueError(which)
+
+
 def _growth_tab3(cosmo, a, n):
     """(n,3) float32 device table of (a2g, a2g2, a2dg2dg) at the per-particle scale factors a (N,1)."""
+    if isinstance(a, torch.Tensor) and a.is_cuda:
+        if a.numel() != n:
+            raise ValueError(f"a must have one entry per particle ({n}), got {a.numel()}")
+        return torch.stack([growth_dev(cosmo, a, "g"), growth_dev(cosmo, a, "g2"), growth_dev(cosmo, a, "dg2dg")], dim=-1).contiguous()
     a = np.asarray(a, dtype=np.float64).reshape(-1)
     if a.size != n:
         raise ValueError(f"a must be a scalar or have one entry per particle ({n}), got {a.size}")
@@ -516,7 +549,7 @@ def lpt(cosmo, init_mesh, pos, a, lpt_order: int = 2, read_order: int = 2, grad_
     force1 = pm_forces(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
     force2 = pm_forces2(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd) if lpt_order == 2 else None
     n = force1.shape[0]
-    if np.ndim(a) == 0 or np.size(a) == 1:
+    if not isinstance(a, torch.Tensor) and (np.ndim(a) == 0 or np.size(a) == 1):
         dpos, vel = float(a2g(cosmo, a)) * force1, force1
         if force2 is not None:
             dpos = dpos - float(a2g2(cosmo, a)) * force2
@@ -837,7 +870,7 @@ def cosmo_vjp(ctx, scalar_bars, params=("Omega_c",), rel_eps=1e-5):
 def lpt_vjp(cosmo, init_mesh, pos, a, dpos_bar, vel_bar, lpt_order: int = 2):
     """VJP of `lpt(..., read_order=1)` on the regular lattice w.r.t. init_mesh (half-spectrum).  Scalar `a`: returns
     (init_mesh_bar, {'g','g2','dg2dg'} scalar cotangents).  `a` of shape (N,1) (light cone): the growth cotangents are
-    per-particle arrays (N,)."""
+    per-particle float32 device tensors (N,)."""
     spec = _c64(init_mesh)
     mesh_shape = ch2rshape(spec.shape)
     ptcl_shape = pos.ptcl_shape if isinstance(pos, LatticePos) else _infer_lattice(pos, mesh_shape)
@@ -845,7 +878,7 @@ def lpt_vjp(cosmo, init_mesh, pos, a, dpos_bar, vel_bar, lpt_order: int = 2):
     xb, vb = _f32(dpos_bar, (plan.N, 3)), _f32(vel_bar, (plan.N, 3))
     out = torch.empty(tuple(spec.shape), dtype=torch.complex64, device=spec.device)
     sb = np.zeros(3)
-    if np.ndim(a) == 0 or np.size(a) == 1:
+    if not isinstance(a, torch.Tensor) and (np.ndim(a) == 0 or np.size(a) == 1):
         sc = np.array([float(a2g(cosmo, a)), float(a2g2(cosmo, a)), float(a2dg2dg(cosmo, a))])
         plan.call("mcpm_lpt_vjp_f32", _ptr(spec), int(lpt_order), _dptr(sc), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
         return out, {"g": sb[0], "g2": sb[1], "dg2dg": sb[2]}
@@ -860,8 +893,7 @@ def lpt_vjp(cosmo, init_mesh, pos, a, dpos_bar, vel_bar, lpt_order: int = 2):
     plan.call("mcpm_lpt_combine_vjp_f32", _ptr(F1), _ptr(F2) if lpt_order == 2 else None, _ptr(gt), plan.N, _ptr(xb), _ptr(vb), _ptr(gtb))
     sc = np.array([0.0, -1.0, 0.0])
     plan.call("mcpm_lpt_vjp_f32", _ptr(spec), int(lpt_order), _dptr(sc), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
-    g = gtb.double().cpu().numpy()
-    return out, {"g": g[:, 0], "g2": g[:, 1], "dg2dg": g[:, 2]}
+    return out, {"g": gtb[:, 0], "g2": gtb[:, 1], "dg2dg": gtb[:, 2]}      # per-particle cotangents stay on the device
 
 
 def _infer_lattice(pos, mesh_shape):

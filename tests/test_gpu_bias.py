@@ -52,6 +52,7 @@ def test_lagrangian_bias_forward_and_vjp(gpu, shape, box, read_order, per_partic
     scale = max(abs(v) for v in bb_o.values())
     for k in bo.BIAS_KEYS:
         assert abs(bb[k] - bb_o[k]) < 2e-4 * scale, (k, bb[k], bb_o[k])
+    gb = gb.cpu().numpy() if hasattr(gb, "cpu") else gb
     assert rel_l2(np.asarray(gb, dtype=np.float64).reshape(-1), np.asarray(gb_o).reshape(-1)) < 2e-4
 
 
