@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void lattice_dot_kernel(Geom g, const float *_
 // Adjoint of one fused step (see file header).  Inputs: x'_i, v_i (checkpoint), cotangents xb, vb of
 // (x'_{i+1}, v_{i+1}) (updated in place to those of (x'_i, v_i)), the step's three force meshes and
 // rho_bar = cotangent of the painted density.
-template <int ORDER>
+template <int ORDER, bool IL>
 __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *__restrict__ x, const float *__restrict__ v,
                                                            float *__restrict__ xb, float *__restrict__ vb,
                                                            const float *__restrict__ fm, const float *__restrict__ rho_bar,
@@ -164,14 +164,13 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
         Stencil<ORDER> s(g, c);
         const P3 vt = {vbi.x + tau * xbi.x, vbi.y + tau * xbi.y, vbi.z + tau * xbi.z};
         const float Fb[3] = {beta * vt.x, beta * vt.y, beta * vt.z};
-        float F[3];
+        float F[3], G[3][3];
+        interp3<ORDER, true, IL>(fm, M, s, f, F, G);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            float gx, gy, gz;
-            interp<ORDER, true>(fm + k * M, s, f, F[k], gx, gy, gz);
-            xbi.x += Fb[k] * gx;
-            xbi.y += Fb[k] * gy;
-            xbi.z += Fb[k] * gz;
+            xbi.x += Fb[k] * G[k][0];
+            xbi.y += Fb[k] * G[k][1];
+            xbi.z += Fb[k] * G[k][2];
         }
         {
             float val, gx, gy, gz;
@@ -341,6 +340,12 @@ static int lpt_vjp_device(mcpm_plan *p, const float *init_mesh, int lpt_order, c
     return MCPM_OK;
 }
 
+static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes, int layout,
+                                  const float *rho_bar, double alpha, double beta, double tau, int paint_order, float *pos_bar,
+                                  float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg, double *dg_bar);
+// force-mesh layout of the steppers' checkpoints: 1 = interleaved [cell][3] (hand-written Poisson solve), 0 = three meshes
+static inline int step_layout(const mcpm_plan *p) { return mcpm_fftpm_supported(p) ? 1 : 0; }
+
 extern "C" {
 
 int mcpm_force_meshes_f32(mcpm_plan *p, const float *rho, float *fm3) {
@@ -367,6 +372,10 @@ int mcpm_pm_forces_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, int 
     MCPM_REQUIRE(p, forces != nullptr, MCPM_E_ARG, "mcpm_pm_forces_f32: null output");
     MCPM_TRY(mcpm_paint_f32(p, pos, n, mode, nullptr, 1, 1.f, order, p->rho, 0));
     if (!paint_deconv && lap_fd == MCPM_FD_INF && grad_fd == MCPM_FD_INF && kcut <= 0.f) {
+        if (step_layout(p)) {   // interleaved force mesh: one 12-byte gather per stencil corner
+            MCPM_TRY(mcpm_fftpm_force_meshes(p, p->rho, p->fmesh, 1));
+            return mcpm_read3_il(p, pos, n, mode, p->fmesh, order, forces);
+        }
         MCPM_TRY(mcpm_force_meshes_f32(p, p->rho, p->fmesh));
     } else {
         MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
@@ -492,9 +501,13 @@ int mcpm_bullfrog_step_f32(mcpm_plan *p, const float *pos_in, const float *vel_i
     MCPM_REQUIRE(p, pos_in && vel_in && pos_out && vel_out, MCPM_E_ARG, "mcpm_bullfrog_step_f32: null buffer");
     float *fm = force_meshes ? force_meshes : p->fmesh;
     MCPM_TRY(mcpm_paint_f32(p, pos_in, p->Np, MCPM_POS_LATTICE, nullptr, 1, 1.f, paint_order, p->rho, 0));
-    MCPM_TRY(mcpm_force_meshes_f32(p, p->rho, fm));
-    MCPM_TRY(mcpm_kick_drift_f32(p, pos_in, vel_in, p->Np, MCPM_POS_LATTICE, fm, paint_order, (float)alpha, (float)beta,
-                                 (float)tau, pos_out, vel_out));
+    // On plans served by the hand-written Poisson solve the step's force meshes are interleaved [cell][3] (one 12-byte
+    // gather per stencil corner in the particle kernels); the checkpoint handed back to the caller is opaque either way.
+    const int il = step_layout(p);
+    if (il) MCPM_TRY(mcpm_fftpm_force_meshes(p, p->rho, fm, 1));
+    else MCPM_TRY(mcpm_force_meshes_f32(p, p->rho, fm));
+    MCPM_TRY(mcpm_kick_drift_layout(p, pos_in, vel_in, p->Np, MCPM_POS_LATTICE, fm, il, paint_order, (float)alpha, (float)beta,
+                                    (float)tau, pos_out, vel_out));
     return MCPM_OK;
 }
 
@@ -516,14 +529,25 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *v
     MCPM_TRY(mcpm_paint3_f32(p, pos_in, N, MCPM_POS_LATTICE, Fb, paint_order, p->fmesh, 0));
     // adjoint of 3 C2R + k-space + R2C: rho_bar = C2R( (1/M) sum_c conj(m_c) R2C(f_bar_c) )
     MCPM_TRY(mcpm_force_meshes_vjp_f32(p, p->fmesh, p->rho));
-    return mcpm_step_adjoint_particles_f32(p, pos_in, vel_in, force_meshes, p->rho, alpha, beta, tau, paint_order, pos_bar,
-                                           vel_bar, alpha_bar, beta_bar, dtau_ddg, dg_bar);
+    return step_adjoint_particles(p, pos_in, vel_in, force_meshes, step_layout(p), p->rho, alpha, beta, tau, paint_order, pos_bar,
+                                  vel_bar, alpha_bar, beta_bar, dtau_ddg, dg_bar);
 }
 
 int mcpm_step_adjoint_particles_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes,
                                     const float *rho_bar, double alpha, double beta, double tau, int paint_order,
                                     float *pos_bar, float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg,
                                     double *dg_bar) {
+    return step_adjoint_particles(p, pos_in, vel_in, force_meshes, 0, rho_bar, alpha, beta, tau, paint_order, pos_bar, vel_bar,
+                                  alpha_bar, beta_bar, dtau_ddg, dg_bar);
+}
+
+}  // extern "C"
+
+// layout 0: three force meshes M apart (public entry point); 1: interleaved [cell][3] (what the steppers checkpoint on
+// plans served by the hand-written Poisson solve)
+static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes, int layout,
+                                  const float *rho_bar, double alpha, double beta, double tau, int paint_order, float *pos_bar,
+                                  float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg, double *dg_bar) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, pos_in && vel_in && force_meshes && rho_bar && pos_bar && vel_bar, MCPM_E_ARG,
                  "mcpm_step_adjoint_particles_f32: null buffer");
@@ -547,7 +571,9 @@ int mcpm_step_adjoint_particles_f32(mcpm_plan *p, const float *pos_in, const flo
     double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);
     MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 3 * MCPM_NSLOT, p->stream));
 #define ADJ(OR)                                                                                                                   \
-    step_adjoint_kernel<OR><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
+    if (layout) step_adjoint_kernel<OR, true><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
+                                                           slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg);  \
+    else step_adjoint_kernel<OR, false><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
                                                            slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg)
     if (paint_order == 2) ADJ(2);
     else if (paint_order == 1) ADJ(1);
@@ -561,6 +587,8 @@ int mcpm_step_adjoint_particles_f32(mcpm_plan *p, const float *pos_in, const flo
     }
     return MCPM_OK;
 }
+
+extern "C" {
 
 int mcpm_lpt_vjp_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, const double *lpt_scalars, const float *dpos_bar,
                      const float *vel_bar, float *init_mesh_bar, double *scalar_bars) {

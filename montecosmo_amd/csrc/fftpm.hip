@@ -260,6 +260,56 @@ __global__ __launch_bounds__(256) void zinv_kernel(FGeom g, const cf *__restrict
     }
 }
 
+// z C2R of the three force spectra of one line pair, written interleaved [x][y][z][3] (one 12-byte store per cell):
+// the layout the step kernels gather from (particles_dev.h interp3)
+template <int N>
+__global__ __launch_bounds__(256) void zinv3_il_kernel(FGeom g, const cf *__restrict__ spec, float *__restrict__ real,
+                                                      const cf *__restrict__ W, int64_t npairs, int64_t spec_cstride) {
+    constexpr int T = FftShape<N>::T, PAIRS = 256 / T;
+    typedef Tile<N, PAIRS, false> TL;
+    __shared__ cf lds[TL::FLOATS2];
+    const int pl = threadIdx.x / T, u = threadIdx.x - pl * T;
+    const int64_t pair = (int64_t)blockIdx.x * PAIRS + pl;
+    const bool ok = pair < npairs;
+    const int64_t line = 2 * pair;
+    TL tile{pl};
+    cf r[3][8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const cf *ia = spec + c * spec_cstride + line * g.nzp, *ib = ia + g.nzp;
+        __syncthreads();  // the previous component's last exchange has been read by every thread
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int k = u + T * m;
+            cf A = ok ? ia[k] : make_float2(0.f, 0.f), B = ok ? ib[k] : make_float2(0.f, 0.f);
+            if (k == 0) {
+                lds[tile(0)] = make_float2(A.x, B.x);
+            } else {
+                lds[tile(k)] = make_float2(A.x - B.y, A.y + B.x);
+                lds[tile(N - k)] = make_float2(A.x + B.y, B.x - A.y);
+            }
+        }
+        if (u == 0) {
+            cf A = ok ? ia[N / 2] : make_float2(0.f, 0.f), B = ok ? ib[N / 2] : make_float2(0.f, 0.f);
+            lds[tile(N / 2)] = make_float2(A.x, B.x);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) r[c][m] = lds[tile(u + T * m)];
+        fft_line<N, +1>(r[c], lds, W, u, tile);
+    }
+    if (!ok) return;
+    struct __attribute__((packed, aligned(4))) F3 {
+        float a, b, c;
+    };
+    F3 *a = reinterpret_cast<F3 *>(real) + line * N, *b = a + N;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        a[u + T * m] = F3{r[0][m].x, r[1][m].x, r[2][m].x};
+        b[u + T * m] = F3{r[0][m].y, r[1][m].y, r[2][m].y};
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // column passes (y or x): 16 adjacent kz columns per workgroup
 template <int N>
@@ -659,6 +709,23 @@ static int z_inverse(mcpm_plan *p, const cf *spec, float *real, int64_t real_bst
     return MCPM_OK;
 }
 
+static int z_inverse3_il(mcpm_plan *p, const cf *spec3, float *real_il) {
+    const FGeom g = fgeom(p);
+    const int64_t npairs = (int64_t)p->xwn * g.ny / 2;
+    real_il += (int64_t)p->xw0 * g.ny * g.nz * 3;
+    spec3 += (int64_t)p->xw0 * g.ny * g.nzp;
+    StageTimer st_(p, ST_C2R, pass_bytes(p, 3));
+#define CALL(NN)                                                                                                   \
+    {                                                                                                              \
+        constexpr int PAIRS = 256 / (NN / 8);                                                                      \
+        zinv3_il_kernel<NN><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, spec3, real_il, (const cf *)p->tw[2], npairs, spec_elems(p)); \
+    }
+    DISPATCH_N(g.nz, CALL)
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "zinv3_il_kernel");
+    return MCPM_OK;
+}
+
 // packed = all-to-all layout [c][dest rank][xl][y_local][nzp]; every spectrum is spec_elems() complex
 static YLayout ylayout(const mcpm_plan *p, bool packed) {
     const int64_t nzp = p->g.nz / 2 + 16;
@@ -775,7 +842,7 @@ int mcpm_fftpm_spec_meshes_vjp(mcpm_plan *p, const float *meshes_bar, float *spe
 }
 
 // rho (real mesh) -> three force meshes irfftn(-(i k_c)(-1/k^2) rfftn(rho)); single-GPU plans
-int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3) {
+int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3, int interleaved) {
     MCPM_TRY(ensure_twiddles(p));
     const int64_t ss = spec_elems(p);
     cf *s0 = (cf *)p->spec, *s123 = s0 + ss;
@@ -784,6 +851,7 @@ int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3) {
     MCPM_TRY(y_columns(p, s0, s0, 1, -1, false, false));
     MCPM_TRY(x_fused(p, s0, s45, 0));
     MCPM_TRY(y_columns2(p, s45, s123, true, false, false));
+    if (interleaved) return z_inverse3_il(p, s123, fm3);   // [cell][3] for the step kernels
     MCPM_TRY(z_inverse(p, s123, fm3, p->M, 3));
     return MCPM_OK;
 }

@@ -124,7 +124,10 @@ int mcpm_fail(mcpm_plan *plan, int code, const std::string &msg);
 
 // hand-written FFT Poisson solve (fftpm.hip); power-of-two axes only
 bool mcpm_fftpm_supported(const mcpm_plan *p);
-int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3);
+int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3, int interleaved = 0);
+int mcpm_kick_drift_layout(mcpm_plan *p, const float *pos_in, const float *vel_in, int64_t n, int mode, const float *meshes3,
+                                      int layout, int order, float alpha, float beta, float dt, float *pos_out, float *vel_out);
+int mcpm_read3_il(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *fm_il, int order, float *out);
 int mcpm_fftpm_force_meshes_vjp(mcpm_plan *p, const float *fbar3, float *rho_bar);
 // plain half-spectrum -> nc = 3 force meshes or nc = 6 Hessian meshes (00 01 02 11 12 22), and the adjoints
 // (spec_bar overwritten for nc = 3, accumulated into for nc = 6)

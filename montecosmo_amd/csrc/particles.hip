@@ -401,6 +401,22 @@ __global__ __launch_bounds__(256) void read_kernel(Geom g, const float *__restri
     for (int k = 0; k < NCOMP; ++k) out[pi.i * NCOMP + k] = v[k];
 }
 
+// three components from one interleaved [cell][3] mesh
+template <int MODE, int ORDER>
+__global__ __launch_bounds__(256) void read3_il_kernel(Geom g, const float *__restrict__ pos, int64_t n,
+                                                       const float *__restrict__ fm, float *__restrict__ out) {
+    PIdx pi = particle_index<MODE>(g, n);
+    if (!pi.valid) return;
+    P3 d = load3(pos, pi.i);
+    int c[3];
+    float f[3];
+    locate<MODE, ORDER>(g, pi, d, c, f);
+    Stencil<ORDER> s(g, c);
+    float F[3], G[3][3];
+    interp3<ORDER, false, true>(fm, 0, s, f, F, G);
+    store3(out, pi.i, P3{F[0], F[1], F[2]});
+}
+
 // VJP of read w.r.t. pos (also the pos-VJP of paint with NCOMP = 1 and out_bar = weights).
 // If val_out != nullptr also writes the read values (the weights-VJP of paint).
 template <int MODE, int ORDER, int NCOMP>
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(256) void axpy_kernel(const float *__restrict__ x, 
     if (i < n) out[i] = a * x[i] + b * y[i];
 }
 
-template <int MODE, int ORDER>
+template <int MODE, int ORDER, bool IL>
 __global__ __launch_bounds__(256) void kick_drift_kernel(Geom g, const float *__restrict__ pos_in,
                                                          const float *__restrict__ vel_in, int64_t n,
                                                          const float *__restrict__ meshes, int64_t M, float alpha,
@@ -452,9 +468,8 @@ __global__ __launch_bounds__(256) void kick_drift_kernel(Geom g, const float *__
     float f[3];
     locate<MODE, ORDER>(g, pi, d, c, f);
     Stencil<ORDER> s(g, c);
-    float F[3], gx, gy, gz;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) interp<ORDER, false>(meshes + k * M, s, f, F[k], gx, gy, gz);
+    float F[3], G[3][3];
+    interp3<ORDER, false, IL>(meshes, M, s, f, F, G);
     P3 v1 = {alpha * v.x + beta * F[0], alpha * v.y + beta * F[1], alpha * v.z + beta * F[2]};
     P3 d1 = {d.x + v1.x * dt, d.y + v1.y * dt, d.z + v1.z * dt};
     store3(vel_out, pi.i, v1);
@@ -739,18 +754,41 @@ int mcpm_kick_f32(mcpm_plan *p, const float *vel_in, const float *forces, int64_
 int mcpm_kick_drift_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, int64_t n, int mode,
                         const float *meshes3, int order, float alpha, float beta, float dt, float *pos_out,
                         float *vel_out) {
+    return mcpm_kick_drift_layout(p, pos_in, vel_in, n, mode, meshes3, 0, order, alpha, beta, dt, pos_out, vel_out);
+}
+
+}  // extern "C"
+
+// three-component read of an interleaved [cell][3] force mesh (internal: pm_forces)
+int mcpm_read3_il(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *fm_il, int order, float *out) {
+    MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_read3_il"));
+    MCPM_REQUIRE(p, fm_il && out, MCPM_E_ARG, "mcpm_read3_il: null buffer");
+    StageTimer st_(p, ST_READ, 24.0 * n + 12.0 * p->M);
+    if (n == 0) return MCPM_OK;
+    dim3 grid, block;
+    if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
+#define CALL(MO, OR) read3_il_kernel<MO, OR><<<grid, block, 0, p->stream>>>(p->g, pos, n, fm_il, out)
+    DISPATCH_MODE_ORDER(mode, order, CALL);
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "read3_il_kernel");
+    return MCPM_OK;
+}
+
+// layout 0: three meshes M apart; 1: interleaved [cell][3] (internal: the fused Poisson solve's output for the steppers)
+int mcpm_kick_drift_layout(mcpm_plan *p, const float *pos_in, const float *vel_in, int64_t n, int mode, const float *meshes3,
+                           int layout, int order, float alpha, float beta, float dt, float *pos_out, float *vel_out) {
     MCPM_TRY(check_particles(p, pos_in, n, mode, order, "mcpm_kick_drift_f32"));
     MCPM_REQUIRE(p, vel_in && meshes3 && pos_out && vel_out, MCPM_E_ARG, "mcpm_kick_drift_f32: null buffer");
     StageTimer st_(p, ST_KICKDRIFT, 48.0 * n + 12.0 * p->M);
     if (n == 0) return MCPM_OK;
     dim3 grid, block;
     if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
-#define CALL(MO, OR) \
-    kick_drift_kernel<MO, OR><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, n, meshes3, p->M, alpha, beta, dt, pos_out, vel_out)
+#define CALL(MO, OR)                                                                                                             \
+    if (layout) kick_drift_kernel<MO, OR, true><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, n, meshes3, p->M, alpha, beta, dt, pos_out, vel_out); \
+    else kick_drift_kernel<MO, OR, false><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, n, meshes3, p->M, alpha, beta, dt, pos_out, vel_out)
     DISPATCH_MODE_ORDER(mode, order, CALL);
 #undef CALL
     MCPM_LAUNCH_CHECK(p, "kick_drift_kernel");
     return MCPM_OK;
 }
 
-}  // extern "C"

@@ -176,6 +176,29 @@ __device__ __forceinline__ void axis_weights(float f, float (&w)[ORDER], float (
     }
 }
 
+// Trilinear combination of the 8 corner values v[xyz] (and its gradient w.r.t. the position).  d/dpos of
+// K(c - x) = sign(c - x): -1 for the lower corner (0 when the fraction is exactly 0, jax's sign(0) = 0), +1 for the upper.
+template <bool GRAD>
+__device__ __forceinline__ void cic_combine(float v000, float v001, float v010, float v011, float v100, float v101, float v110,
+                                            float v111, const float (&f)[3], float &val, float &gx, float &gy, float &gz) {
+    float ax = 1.f - f[0], bx = f[0], ay = 1.f - f[1], by = f[1], az = 1.f - f[2], bz = f[2];
+    // collapse z, then y, then x
+    float v00 = az * v000 + bz * v001, v01 = az * v010 + bz * v011;
+    float v10 = az * v100 + bz * v101, v11 = az * v110 + bz * v111;
+    float v0 = ay * v00 + by * v01, v1 = ay * v10 + by * v11;
+    val = ax * v0 + bx * v1;
+    if (GRAD) {
+        float lx = f[0] > 0.f ? 1.f : 0.f, ly = f[1] > 0.f ? 1.f : 0.f, lz = f[2] > 0.f ? 1.f : 0.f;
+        gx = v1 - lx * v0;
+        float d0 = v01 - ly * v00, d1 = v11 - ly * v10;
+        gy = ax * d0 + bx * d1;
+        float e00 = v001 - lz * v000, e01 = v011 - lz * v010, e10 = v101 - lz * v100, e11 = v111 - lz * v110;
+        gz = ax * (ay * e00 + by * e01) + bx * (ay * e10 + by * e11);
+    } else {
+        gx = gy = gz = 0.f;
+    }
+}
+
 // Trilinear value and gradient of one mesh at (cell, frac).  d/dpos of K(c - x) = sign(c - x):
 // -1 for the lower corner (0 when the fraction is exactly 0, jax's sign(0) = 0), +1 for the upper.
 template <int ORDER, bool GRAD>
@@ -237,20 +260,75 @@ __device__ __forceinline__ void interp(const float *__restrict__ m, const Stenci
         v101 = m[s.xo[1] + s.yo[0] + s.zo[1]];
         v111 = m[s.xo[1] + s.yo[1] + s.zo[1]];
     }
-    float ax = 1.f - f[0], bx = f[0], ay = 1.f - f[1], by = f[1], az = 1.f - f[2], bz = f[2];
-    // collapse z, then y, then x
-    float v00 = az * v000 + bz * v001, v01 = az * v010 + bz * v011;
-    float v10 = az * v100 + bz * v101, v11 = az * v110 + bz * v111;
-    float v0 = ay * v00 + by * v01, v1 = ay * v10 + by * v11;
-    val = ax * v0 + bx * v1;
-    if (GRAD) {
-        float lx = f[0] > 0.f ? 1.f : 0.f, ly = f[1] > 0.f ? 1.f : 0.f, lz = f[2] > 0.f ? 1.f : 0.f;
-        gx = v1 - lx * v0;
-        float d0 = v01 - ly * v00, d1 = v11 - ly * v10;
-        gy = ax * d0 + bx * d1;
-        float e00 = v001 - lz * v000, e01 = v011 - lz * v010, e10 = v101 - lz * v100, e11 = v111 - lz * v110;
-        gz = ax * (ay * e00 + by * e01) + bx * (ay * e10 + by * e11);
-    } else {
-        gx = gy = gz = 0.f;
+    cic_combine<GRAD>(v000, v001, v010, v011, v100, v101, v110, v111, f, val, gx, gy, gz);
+}
+
+// Three force components at once.  IL = false: three meshes M apart (m + c*M); IL = true: one interleaved mesh
+// [cell][3] (what the fused Poisson solve writes for the step kernels): a CIC corner is then ONE 12-byte gather for
+// the three components, 8 gathers per particle instead of 12 z-pair gathers -- the gathers are bound by address
+// processing per instruction, not by bytes (tools/gather_bench.hip).
+template <int ORDER, bool GRAD, bool IL>
+__device__ __forceinline__ void interp3(const float *__restrict__ m, int64_t M, const Stencil<ORDER> &s, const float (&f)[3],
+                                        float (&F)[3], float (&G)[3][3]) {
+    if (!IL) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) interp<ORDER, GRAD>(m + c * M, s, f, F[c], G[c][0], G[c][1], G[c][2]);
+        return;
     }
+    struct __attribute__((packed, aligned(4))) F3 {
+        float a, b, c;
+    };
+    if (ORDER == 2) {
+        F3 v[8];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    v[a * 4 + b * 2 + e] = *reinterpret_cast<const F3 *>(m + 3 * (int64_t)(s.xo[a] + s.yo[b] + s.zo[e]));
+        cic_combine<GRAD>(v[0].a, v[1].a, v[2].a, v[3].a, v[4].a, v[5].a, v[6].a, v[7].a, f, F[0], G[0][0], G[0][1], G[0][2]);
+        cic_combine<GRAD>(v[0].b, v[1].b, v[2].b, v[3].b, v[4].b, v[5].b, v[6].b, v[7].b, f, F[1], G[1][0], G[1][1], G[1][2]);
+        cic_combine<GRAD>(v[0].c, v[1].c, v[2].c, v[3].c, v[4].c, v[5].c, v[6].c, v[7].c, f, F[2], G[2][0], G[2][1], G[2][2]);
+        return;
+    }
+    if (ORDER == 1) {
+        const F3 v = *reinterpret_cast<const F3 *>(m + 3 * (int64_t)(s.xo[0] + s.yo[0] + s.zo[0]));
+        F[0] = v.a; F[1] = v.b; F[2] = v.c;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) G[c][0] = G[c][1] = G[c][2] = 0.f;
+        return;
+    }
+    constexpr int NPG = ORDER < 3 ? 3 : ORDER;
+    float wx[NPG], wy[NPG], wz[NPG], dx[NPG], dy[NPG], dz[NPG];
+    axis_weights<NPG, GRAD>(f[0], wx, dx);
+    axis_weights<NPG, GRAD>(f[1], wy, dy);
+    axis_weights<NPG, GRAD>(f[2], wz, dz);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) F[c] = G[c][0] = G[c][1] = G[c][2] = 0.f;
+#pragma unroll
+    for (int a = 0; a < NPG; ++a)
+#pragma unroll
+        for (int b = 0; b < NPG; ++b) {
+            float r0[3] = {0.f, 0.f, 0.f}, r1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < NPG; ++e) {
+                const F3 mv = *reinterpret_cast<const F3 *>(m + 3 * (int64_t)(s.xo[a] + s.yo[b] + s.zo[e]));
+                const float t[3] = {mv.a, mv.b, mv.c};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    r0[c] += t[c] * wz[e];
+                    if (GRAD) r1[c] += t[c] * dz[e];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                F[c] += wx[a] * wy[b] * r0[c];
+                if (GRAD) {
+                    G[c][0] += dx[a] * wy[b] * r0[c];
+                    G[c][1] += wx[a] * dy[b] * r0[c];
+                    G[c][2] += wx[a] * wy[b] * r1[c];
+                }
+            }
+        }
 }
