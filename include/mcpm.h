@@ -259,6 +259,14 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *plan, const float *init_mesh, int n_steps, 
                           float *init_mesh_bar, double *scalar_bars);
 
 /* ---- host-side float64 growth tables (nbody.py:679-745) ------------------------------------- */
+/* rg2cgh / cgh2rg with norm = "backward" (montecosmo/utils.py:785-921): a real Gaussian tensor (nx, ny, nz), all sizes
+   even, <-> the complex Hermitian tensor (nx, ny, nz/2+1; plain complex64) distributed as rfftn of a real Gaussian tensor
+   (signed permutation with sqrt(M/2) / sqrt(M) weights).  The VJP of rg2cgh takes the cotangent of the complex tensor
+   (real-pair convention) to that of the real one.  No plan: `stream` is a hipStream_t. */
+int mcpm_rg2cgh_f32(void *stream, const float *real, int nx, int ny, int nz, float *spec);
+int mcpm_rg2cgh_vjp_f32(void *stream, const float *spec_bar, int nx, int ny, int nz, float *real_bar);
+int mcpm_cgh2rg_f32(void *stream, const float *spec, int nx, int ny, int nz, float *real);
+
 /* Lagrangian bias expansion (montecosmo/bricks.py:327-443, png_type = None).
    fields : lin_mesh (plain half-spectrum of the plan's mesh) -> fields7 = {delta, shear^2, 3 det(shear), laplacian(delta),
             grad_x, grad_y, grad_z} as 7 real meshes M apart; wavevectors in h/Mpc, kphys[a] = mesh_shape[a] / box_size[a]

@@ -92,6 +92,103 @@ __global__ __launch_bounds__(256) void chreshape_kernel(RS r, const float2 *__re
     }
 }
 
+// ---- rg2cgh / cgh2rg (montecosmo/utils.py:785-921, norm = "backward") ----------------------------------------------
+// A real Gaussian tensor (nx, ny, nz) is permuted and reweighted into a complex Hermitian one (nx, ny, nz/2+1) that is
+// distributed as rfftn of a real Gaussian tensor.  Source of the real / imaginary part of output mode (i, j, k):
+//   0 < k < hz          : re x[i, j, k]                 im  x[i, j, hz + k]
+//   k in {0, hz}, 0<j<hy: re x[i, j, k]                 im  x[i, hy + j, k]
+//                 j > hy: re x[-i, ny - j, k]           im -x[-i, hy + ny - j, k]        (-i = (nx - i) mod nx)
+//     j in {0, hy}, 0<i<hx: re x[i, j, k]               im  x[hx + i, j, k]
+//                   i > hx: re x[nx - i, j, k]          im -x[hx + nx - i, j, k]
+//                   i in {0, hx}: re sqrt2 x[i, j, k]   im 0
+// all times sqrt(M / 2).
+struct CghSrc {
+    int64_t re, im;   // flat indices into the real tensor (im < 0: none)
+    float wre, wim;
+};
+__device__ __forceinline__ CghSrc cgh_source(int nx, int ny, int nz, int i, int j, int k) {
+    const int hx = nx / 2, hy = ny / 2, hz = nz / 2;
+    auto at = [&](int a, int b, int c) { return ((int64_t)a * ny + b) * nz + c; };
+    CghSrc r;
+    r.wre = 1.f;
+    r.wim = 1.f;
+    if (k > 0 && k < hz) {
+        r.re = at(i, j, k);
+        r.im = at(i, j, hz + k);
+    } else if (j != 0 && j != hy) {
+        if (j < hy) {
+            r.re = at(i, j, k);
+            r.im = at(i, hy + j, k);
+        } else {
+            const int mi = i ? nx - i : 0;
+            r.re = at(mi, ny - j, k);
+            r.im = at(mi, hy + ny - j, k);
+            r.wim = -1.f;
+        }
+    } else if (i != 0 && i != hx) {
+        if (i < hx) {
+            r.re = at(i, j, k);
+            r.im = at(hx + i, j, k);
+        } else {
+            r.re = at(nx - i, j, k);
+            r.im = at(hx + nx - i, j, k);
+            r.wim = -1.f;
+        }
+    } else {
+        r.re = at(i, j, k);
+        r.im = -1;
+        r.wre = 1.41421356237309505f;
+        r.wim = 0.f;
+    }
+    return r;
+}
+
+// MODE 0: out = rg2cgh(in real).  MODE 1 (VJP): in = cotangent of the complex output, out = cotangent of the real
+// tensor (zeroed by the caller, scattered with atomics: face modes share their source with their Hermitian mirror)
+template <int MODE>
+__global__ __launch_bounds__(256) void rg2cgh_kernel(int nx, int ny, int nz, float scale, const float *__restrict__ in,
+                                                     float *__restrict__ out) {
+    const int nzc = nz / 2 + 1;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, n = (int64_t)nx * ny * nzc;
+    if (idx >= n) return;
+    const int k = (int)(idx % nzc);
+    const int64_t t = idx / nzc;
+    const int j = (int)(t % ny), i = (int)(t / ny);
+    const CghSrc s = cgh_source(nx, ny, nz, i, j, k);
+    if (MODE == 0) {
+        out[2 * idx] = scale * s.wre * in[s.re];
+        out[2 * idx + 1] = s.im >= 0 ? scale * s.wim * in[s.im] : 0.f;
+    } else {
+        atomicAdd(out + s.re, scale * s.wre * in[2 * idx]);
+        if (s.im >= 0) atomicAdd(out + s.im, scale * s.wim * in[2 * idx + 1]);
+    }
+}
+
+// out = cgh2rg(in complex): every real element takes the value of ONE stored mode (the mirrored one on the faces and
+// edges, as the reference's last assignment does); utils.py:839-889
+__global__ __launch_bounds__(256) void cgh2rg_kernel(int nx, int ny, int nz, float scale, const float *__restrict__ in,
+                                                     float *__restrict__ out) {
+    const int hx = nx / 2, hy = ny / 2, hz = nz / 2, nzc = hz + 1;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, n = (int64_t)nx * ny * nz;
+    if (idx >= n) return;
+    const int z = (int)(idx % nz);
+    const int64_t t = idx / nz;
+    const int y = (int)(t % ny), x = (int)(t / ny);
+    auto at = [&](int a, int b, int c) { return 2 * (((int64_t)a * ny + b) * nzc + c); };
+    float v;
+    if (z != 0 && z != hz) {
+        v = z < hz ? in[at(x, y, z)] : in[at(x, y, z - hz) + 1];
+    } else if (y != 0 && y != hy) {
+        const int mx_ = x ? nx - x : 0;
+        v = y < hy ? in[at(mx_, ny - y, z)] : -in[at(mx_, ny + hy - y, z) + 1];
+    } else if (x != 0 && x != hx) {
+        v = x < hx ? in[at(nx - x, y, z)] : -in[at(nx + hx - x, y, z) + 1];
+    } else {
+        v = in[at(x, y, z)] * 0.70710678118654752f;
+    }
+    out[idx] = scale * v;
+}
+
 int check(const void *a, const void *b, int mx, int my, int mz, int sx, int sy, int sz) {
     if (!a || !b) return MCPM_E_ARG;
     const int d[6] = {mx, my, mz, sx, sy, sz};
@@ -122,6 +219,31 @@ int mcpm_chreshape_vjp_c64(void *stream, const float *out_bar, int out_nx, int o
     const int64_t n = (int64_t)r.sx * r.sy * r.szc, ni = (int64_t)r.mx * r.my * r.mzc;
     if (hipMemsetAsync(in_bar, 0, sizeof(float2) * ni, (hipStream_t)stream) != hipSuccess) return MCPM_E_HIP;
     chreshape_kernel<true><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(r, (const float2 *)out_bar, (float2 *)in_bar);
+    return hipGetLastError() == hipSuccess ? MCPM_OK : MCPM_E_HIP;
+}
+
+int mcpm_rg2cgh_f32(void *stream, const float *real, int nx, int ny, int nz, float *spec) {
+    if (int rc = check(real, spec, nx, ny, nz, nx, ny, nz)) return rc;
+    const int64_t n = (int64_t)nx * ny * (nz / 2 + 1);
+    const float scale = (float)sqrt(0.5 * (double)nx * ny * nz);
+    rg2cgh_kernel<0><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(nx, ny, nz, scale, real, spec);
+    return hipGetLastError() == hipSuccess ? MCPM_OK : MCPM_E_HIP;
+}
+
+int mcpm_rg2cgh_vjp_f32(void *stream, const float *spec_bar, int nx, int ny, int nz, float *real_bar) {
+    if (int rc = check(spec_bar, real_bar, nx, ny, nz, nx, ny, nz)) return rc;
+    const int64_t n = (int64_t)nx * ny * (nz / 2 + 1);
+    const float scale = (float)sqrt(0.5 * (double)nx * ny * nz);
+    if (hipMemsetAsync(real_bar, 0, sizeof(float) * (size_t)nx * ny * nz, (hipStream_t)stream) != hipSuccess) return MCPM_E_HIP;
+    rg2cgh_kernel<1><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(nx, ny, nz, scale, spec_bar, real_bar);
+    return hipGetLastError() == hipSuccess ? MCPM_OK : MCPM_E_HIP;
+}
+
+int mcpm_cgh2rg_f32(void *stream, const float *spec, int nx, int ny, int nz, float *real) {
+    if (int rc = check(spec, real, nx, ny, nz, nx, ny, nz)) return rc;
+    const int64_t n = (int64_t)nx * ny * nz;
+    const float scale = (float)sqrt(2.0 / ((double)nx * ny * nz));
+    cgh2rg_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(nx, ny, nz, scale, spec, real);
     return hipGetLastError() == hipSuccess ? MCPM_OK : MCPM_E_HIP;
 }
 

@@ -56,3 +56,50 @@ def chreshape_vjp(out_bar, in_shape):
     check(lib.mcpm_chreshape_vjp_c64(C.c_void_p(torch.cuda.current_stream(ob.device).cuda_stream), nbody._ptr(ob), *oshape,
                                      nbody._ptr(ib), *ishape), None, "mcpm_chreshape_vjp_c64")
     return ib
+
+
+def _stream_of(t):
+    import ctypes as C
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def rg2cgh(mesh, norm="backward"):
+    """Permute and reweight a real Gaussian tensor (3D, even sizes) into a complex Gaussian Hermitian tensor
+    distributed as rfftn of a real Gaussian tensor (utils.py:892-906).  HIP kernel mcpm_rg2cgh_f32."""
+    import torch
+    from . import nbody
+    from ._lib import lib, check
+    if norm != "backward":
+        raise NotImplementedError('only norm="backward" (the model\'s) is built')
+    x = nbody._f32(mesh)
+    out = torch.empty(r2chshape(x.shape), dtype=torch.complex64, device=x.device)
+    check(lib.mcpm_rg2cgh_f32(_stream_of(x), nbody._ptr(x), *x.shape, nbody._ptr(out)), None, "mcpm_rg2cgh_f32")
+    return out
+
+
+def rg2cgh_vjp(meshk_bar):
+    """VJP of rg2cgh: cotangent of the complex tensor (real-pair convention) -> cotangent of the real tensor."""
+    import torch
+    from . import nbody
+    from ._lib import lib, check
+    kb = nbody._c64(meshk_bar)
+    shape = ch2rshape(kb.shape)
+    out = torch.empty(shape, dtype=torch.float32, device=kb.device)
+    check(lib.mcpm_rg2cgh_vjp_f32(_stream_of(kb), nbody._ptr(kb), *shape, nbody._ptr(out)), None, "mcpm_rg2cgh_vjp_f32")
+    return out
+
+
+def cgh2rg(meshk, norm="backward"):
+    """Permute and reweight a complex Gaussian Hermitian tensor into a real Gaussian tensor (utils.py:909-921): the
+    inverse of rg2cgh.  HIP kernel mcpm_cgh2rg_f32."""
+    import torch
+    from . import nbody
+    from ._lib import lib, check
+    if norm != "backward":
+        raise NotImplementedError('only norm="backward" (the model\'s) is built')
+    k = nbody._c64(meshk)
+    shape = ch2rshape(k.shape)
+    out = torch.empty(shape, dtype=torch.float32, device=k.device)
+    check(lib.mcpm_cgh2rg_f32(_stream_of(k), nbody._ptr(k), *shape, nbody._ptr(out)), None, "mcpm_cgh2rg_f32")
+    return out

@@ -269,6 +269,101 @@ def interlace(pos, shape, weights=1., paint_order=2, interlace_order=2):
     return mesh
 
 
+# --------------------------------------------------------------------------- real Gaussian <-> complex Hermitian
+def _rg2cgh(mesh, part="real", norm="backward"):
+    """montecosmo/utils.py:785-836, statement by statement (numpy slices instead of .at[].set)."""
+    shape = np.array(mesh.shape)
+    assert np.all(shape % 2 == 0), "dimension lengths must be even."
+    hx, hy, hz = shape // 2
+    meshk = np.zeros(r2chshape(tuple(int(v) for v in shape)))
+    if part == "imag":
+        slix, sliy, sliz = slice(hx + 1, None), slice(hy + 1, None), slice(hz + 1, None)
+    else:
+        assert part == "real"
+        slix, sliy, sliz = slice(1, hx), slice(1, hy), slice(1, hz)
+    meshk[:, :, 1:-1] = mesh[:, :, sliz]
+    for k in [0, hz]:
+        meshk[:, 1:hy, k] = mesh[:, sliy, k]
+        meshk[1:, hy + 1:, k] = mesh[1:, sliy, k][::-1, ::-1]
+        meshk[0, hy + 1:, k] = mesh[0, sliy, k][::-1]
+        if part == "imag" and norm != "amp":
+            meshk[:, hy + 1:, k] *= -1.
+        for j in [0, hy]:
+            meshk[1:hx, j, k] = mesh[slix, j, k]
+            meshk[hx + 1:, j, k] = mesh[slix, j, k][::-1]
+            if part == "imag" and norm != "amp":
+                meshk[hx + 1:, j, k] *= -1.
+            for i in [0, hx]:
+                if part == "real":
+                    meshk[i, j, k] = mesh[i, j, k]
+                    if norm != "amp":
+                        meshk[i, j, k] *= 2 ** .5
+    shape = shape.astype(float)
+    if norm == "backward":
+        meshk /= (2 / shape.prod()) ** .5
+    elif norm == "ortho":
+        meshk /= 2 ** .5
+    elif norm == "forward":
+        meshk /= (2 * shape.prod()) ** .5
+    else:
+        assert norm == "amp"
+    return meshk
+
+
+def rg2cgh(mesh, norm="backward"):
+    """montecosmo/utils.py:892-906: permute and reweight a real Gaussian tensor into a complex Gaussian Hermitian one,
+    distributed as rfftn of a real Gaussian tensor."""
+    real = _rg2cgh(mesh, "real", norm)
+    if norm == "amp":
+        return real
+    return real + 1j * _rg2cgh(mesh, "imag", norm)
+
+
+def _cgh2rg(meshk, part="real", norm="backward"):
+    """montecosmo/utils.py:839-889."""
+    shape = np.array(ch2rshape(meshk.shape))
+    assert np.all(shape % 2 == 0)
+    hx, hy, hz = shape // 2
+    mesh = np.zeros(tuple(int(v) for v in shape))
+    if part == "imag":
+        slix, sliy, sliz = slice(hx + 1, None), slice(hy + 1, None), slice(hz + 1, None)
+    else:
+        slix, sliy, sliz = slice(1, hx), slice(1, hy), slice(1, hz)
+    mesh[:, :, sliz] = meshk[:, :, 1:-1]
+    for k in [0, hz]:
+        mesh[:, sliy, k] = meshk[:, 1:hy, k]
+        mesh[1:, sliy, k] = meshk[1:, hy + 1:, k][::-1, ::-1]
+        mesh[0, sliy, k] = meshk[0, hy + 1:, k][::-1]
+        if part == "imag" and norm != "amp":
+            mesh[:, sliy, k] *= -1.
+        for j in [0, hy]:
+            mesh[slix, j, k] = meshk[1:hx, j, k]
+            mesh[slix, j, k] = meshk[hx + 1:, j, k][::-1]
+            if part == "imag" and norm != "amp":
+                mesh[slix, j, k] *= -1.
+            for i in [0, hx]:
+                if part == "real":
+                    mesh[i, j, k] = meshk[i, j, k]
+                    if norm != "amp":
+                        mesh[i, j, k] /= 2 ** .5
+    shape = shape.astype(float)
+    if norm == "backward":
+        mesh *= (2 / shape.prod()) ** .5
+    elif norm == "ortho":
+        mesh *= 2 ** .5
+    elif norm == "forward":
+        mesh *= (2 * shape.prod()) ** .5
+    return mesh
+
+
+def cgh2rg(meshk, norm="backward"):
+    """montecosmo/utils.py:909-921."""
+    meshk = np.asarray(meshk)
+    real = _cgh2rg(meshk.real, "real", norm)
+    imag = _cgh2rg(meshk.real if norm == "amp" else meshk.imag, "imag", norm)
+    return real + imag
+
+
 # --------------------------------------------------------------------------- spectrum reshape
 def hermitian_symmetric(arr):
     """montecosmo/utils.py:968-978: conj of the index-reversed array, rolled by one along every axis

@@ -278,3 +278,17 @@ def test_lagrangian_bias_known_answers_and_vjp(rng):
                           rtol=1e-5, atol=1e-7)
     dg = rng.standard_normal(g.shape)
     assert np.isclose((L(X, bias, g + eps * dg) - L(X, bias, g - eps * dg)) / (2 * eps), (gb * dg).sum(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(4, 4, 4), (8, 6, 4), (6, 8, 10)])
+def test_rg2cgh_known_answers(rng, shape):
+    """utils.py:785-921: rg2cgh(x) is the spectrum of a real field (Hermitian), cgh2rg inverts it, and the map is an
+    isometry onto rfftn-normalised spectra (sum y^2 = sum x^2 for y = irfftn(rg2cgh(x))), so rg2cgh(N(0,I)) has the
+    law of rfftn(N(0,I))."""
+    x = rng.standard_normal(shape)
+    X = o.rg2cgh(x)
+    y = np.fft.irfftn(X, s=shape, axes=(0, 1, 2))
+    assert np.allclose(np.fft.rfftn(y), X)
+    assert np.allclose(o.cgh2rg(X), x)
+    assert np.isclose((y ** 2).sum() * np.prod(shape), (x ** 2).sum() * np.prod(shape))
+    assert np.isclose((y ** 2).sum(), (x ** 2).sum())
