@@ -220,3 +220,45 @@ def observe_pos_vjp(ctx, out_bar):
     ctx.plan.call("mcpm_observe_pos_vjp_f32", nbody._ptr(ctx.p), nbody._ptr(ctx.v), nbody._ptr(ctx.dv), n, ctx.mode, ctx.geom, ctx.flags,
                   nbody._ptr(ctx.tables), ctx.nchi, ctx.ngrow, nbody._ptr(ob), nbody._ptr(pb), nbody._ptr(vb), nbody._ptr(db), nbody._ptr(gfb))
     return pb, vb, db, float(gfb.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# Sample mesh -> base mesh (bricks.py:290-320)
+def samp2base_mesh(init: dict, precond, transfer, inv=False, temp=1.) -> dict:
+    """Transform the sample mesh into the base mesh, i.e. the initial wavevector coefficients (bricks.py:290-320):
+    'real': rfftn(mesh) * transfer; 'fourier' / 'kaiser': rg2cgh(mesh) * transfer; and the inverse.  `transfer` is the
+    model's (fiducial, fixed) real k-space array; the permutation runs in mcpm_rg2cgh_f32 / mcpm_cgh2rg_f32."""
+    import torch
+    from . import nbody, utils
+    assert len(init) <= 1, "init dict should only have one or zero key"
+    for in_name, mesh in init.items():
+        out_name = in_name + '_' if inv else in_name[:-1]
+        tr = torch.as_tensor(np.asarray(transfer, dtype=np.float32) * temp ** .5, device=nbody._device())
+        if not inv:
+            mesh = nbody.rfftn(mesh) if precond == 'real' else utils.rg2cgh(mesh)
+            mesh = mesh * tr
+        else:
+            mesh = nbody._c64(mesh)
+            mesh = torch.where(tr != 0, mesh / torch.where(tr != 0, tr, torch.ones_like(tr)), torch.zeros_like(mesh))
+            mesh = nbody.irfftn(mesh) if precond == 'real' else utils.cgh2rg(mesh)
+        return {out_name: mesh}
+    return {}
+
+
+def samp2base_mesh_vjp(base_bar, precond, transfer, temp=1.):
+    """VJP of samp2base_mesh (forward direction): cotangent of the base mesh (complex, real-pair convention) -> cotangent
+    of the real sample mesh."""
+    import torch
+    from . import nbody, utils
+    tr = torch.as_tensor(np.asarray(transfer, dtype=np.float32) * temp ** .5, device=nbody._device())
+    kb = nbody._c64(base_bar) * tr
+    if precond == 'real':        # adjoint of rfftn under the real-pair convention: unnormalised C2R of the cotangent
+        kb = kb.clone()
+        shape = utils.ch2rshape(kb.shape)
+        plan = nbody.get_plan(shape)
+        # irfftn's multiplicity weights must not be applied: halve the doubly counted modes first
+        kb[..., 1:shape[-1] // 2] *= 0.5
+        out = torch.empty(shape, dtype=torch.float32, device=kb.device)
+        plan.call("mcpm_fft_c2r", nbody._ptr(kb), nbody._ptr(out), 1)
+        return out
+    return utils.rg2cgh_vjp(kb)

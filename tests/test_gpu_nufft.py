@@ -116,3 +116,23 @@ def test_rg2cgh_cgh2rg(nb, shape):
     d = rng.standard_normal(shape)
     lhs = np.sum(np.conj(Z) * o.rg2cgh(d)).real
     assert abs(lhs - np.sum(xb * d)) < 1e-4 * abs(lhs)
+
+
+@pytest.mark.parametrize("precond", ["real", "fourier", "kaiser"])
+def test_samp2base_mesh(nb, precond):
+    """bricks.py:290-320: sample mesh <-> base mesh under the three preconditionings, and the VJP by a dot test."""
+    from montecosmo_amd import bricks
+    rng = np.random.default_rng(10)
+    shape = (8, 12, 6)
+    x = rng.standard_normal(shape)
+    tr = np.abs(rng.standard_normal(o.r2chshape(shape))) + 0.1
+    ref = (np.fft.rfftn(x) if precond == "real" else o.rg2cgh(x)) * tr
+    got = bricks.samp2base_mesh({"white_mesh_": x.astype(np.float32)}, precond, tr)
+    assert list(got) == ["white_mesh"] and rel_l2(got["white_mesh"].cpu().numpy(), ref) < 1e-5
+    back = bricks.samp2base_mesh({"white_mesh": ref.astype(np.complex64)}, precond, tr, inv=True)
+    assert list(back) == ["white_mesh_"] and rel_l2(back["white_mesh_"].cpu().numpy(), x) < 1e-5
+    Z = rng.standard_normal(ref.shape) + 1j * rng.standard_normal(ref.shape)
+    xb = bricks.samp2base_mesh_vjp(Z.astype(np.complex64), precond, tr).cpu().numpy()
+    d = rng.standard_normal(shape)
+    lhs = np.sum(np.conj(Z) * ((np.fft.rfftn(d) if precond == "real" else o.rg2cgh(d)) * tr)).real
+    assert abs(lhs - np.sum(xb * d)) < 1e-4 * abs(lhs)
