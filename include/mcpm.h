@@ -71,6 +71,9 @@ const char *mcpm_version(void);
 int mcpm_plan_last_outliers(mcpm_plan *plan, int64_t *count);
 /* Tuning knob: halo radius (cells) of the LDS-tiled paint; displacements beyond it take the outlier path. */
 int mcpm_plan_set_halo(mcpm_plan *plan, int halo);
+/* Tuning knob: order in which the tiled paints hand tiles to the 8 XCDs: 0 = one contiguous run of tiles per XCD
+   (default), 1 = compact bricks of tiles (slower at 512^3; see particles.hip). */
+int mcpm_plan_set_tile_order(mcpm_plan *plan, int order);
 
 /* Optional per-stage profile: HIP events on the plan's stream around every leaf stage (paint, FFTs, k-space,
    read, fused particle kernels).  mcpm_plan_profile_read synchronises, fills up to nmax entries of

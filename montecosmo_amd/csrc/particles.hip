@@ -75,6 +75,37 @@ __global__ __launch_bounds__(256) void paint_atomic_kernel(Geom g, const float *
 // tiled paint (lattice displacements, lattice == mesh, CIC)
 // THREADS x U particle loads are issued before any is consumed: the pull loop is otherwise bound by load
 // latency (one 12-byte load in flight per thread moves < 1 TB/s chip-wide).
+// Tile of this workgroup.  Blocks b, b+8, ... run on the same XCD (and share its 4 MB L2), in dispatch order b/8.
+// order 0 (default): each XCD works through one contiguous run of tiles (z fastest: a pencil of tiles whose flushes and
+// particle reads are contiguous in memory).  order 1: compact bricks of tiles (2x4x4 ...) per XCD, meant to keep the halo
+// particles neighbouring tiles re-read in that L2 -- measured SLOWER at 512^3 (density paint 1.34 vs 1.15 ms, three-component
+// 3.10 vs 2.98 ms, tools/time_paint_halo.py): memory contiguity of the pencil wins over L2 reuse.  Kept as a knob.
+__device__ __forceinline__ void tile_of_block(int order, int ntx, int nty, int ntz, int per, int &tx, int &ty, int &tz) {
+    const int nb = gridDim.x, b = blockIdx.x;
+    if (order == 1 && nb % 8 == 0 && ntx % 8 == 0) {
+        const int sx = ntx / 8;
+        const int bxk = (sx % 2 == 0) ? 2 : 1;
+        int byk = 4, bzk = per / (bxk * 4);          // 32: 2x4x4 or 1x4x8;  128: 2x4x16 -> prefer 2x8x8 below
+        if (per >= 128) { byk = 8; bzk = per / (bxk * 8); }
+        if (bzk >= 1 && nty % byk == 0 && ntz % bzk == 0) {
+            const int xcd = b % 8, v = b / 8, pb = bxk * byk * bzk;
+            const int brick = v / pb, w = v % pb;
+            const int nbz = ntz / bzk, nby = nty / byk;
+            const int kz = brick % nbz, r = brick / nbz, ky = r % nby, kx = r / nby;
+            const int wz = w % bzk, r2 = w / bzk, wy = r2 % byk, wx = r2 / byk;
+            tx = xcd * sx + kx * bxk + wx;
+            ty = ky * byk + wy;
+            tz = kz * bzk + wz;
+            return;
+        }
+    }
+    const int t = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;   // contiguous run of tiles per XCD
+    tz = t % ntz;
+    const int tt = t / ntz;
+    ty = tt % nty;
+    tx = tt / nty;
+}
+
 template <int BX, int BY, int BZ, int H, bool WEIGHTED, int THREADS, int U>
 __global__ __launch_bounds__(THREADS) void paint_tile_kernel(Geom g, const float *__restrict__ disp,
                                                              const float *__restrict__ w, int64_t wstride, float wscalar,
@@ -86,12 +117,8 @@ __global__ __launch_bounds__(THREADS) void paint_tile_kernel(Geom g, const float
     // (tools/lds_atomic_bench.hip), and the sums become insensitive to arrival order at fp32 output precision.
     __shared__ double tile[NT];
 
-    // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
-    // run of tiles so that neighbouring tiles, which re-read each other's halo particles, share L2.
-    const int nb = gridDim.x, b = blockIdx.x;
-    const int t = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
-    const int ntz = g.nz / BZ, nty = g.ny / BY;
-    const int tz = t % ntz, tt = t / ntz, ty = tt % nty, tx = tt / nty;
+    int tx, ty, tz;
+    tile_of_block(g.tile_order, g.nx / BX, g.ny / BY, g.nz / BZ, 32 * ((160 * 1024) / (int)(sizeof(double) * NT) < 2048 / THREADS ? (160 * 1024) / (int)(sizeof(double) * NT) : 2048 / THREADS), tx, ty, tz);
     const int x0 = tx * BX, y0 = ty * BY, z0 = tz * BZ;
 
     double2 *tile2 = reinterpret_cast<double2 *>(tile);
@@ -202,10 +229,8 @@ __global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const floa
                                                               int *__restrict__ ocount) {
     constexpr int W = B + 2 * H + 1, NW = W * W * W, NT = B * B * B;
     __shared__ double tile[3 * NT];
-    const int nb = gridDim.x, b = blockIdx.x;
-    const int t = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
-    const int ntz = g.nz / B, nty = g.ny / B;
-    const int tz = t % ntz, tt = t / ntz, ty = tt % nty, tx = tt / nty;
+    int tx, ty, tz;
+    tile_of_block(g.tile_order, g.nx / B, g.ny / B, g.nz / B, 32, tx, ty, tz);   // 96 KB of LDS: one workgroup per CU, 32 per XCD
     const int x0 = tx * B, y0 = ty * B, z0 = tz * B;
     double2 *tile2 = reinterpret_cast<double2 *>(tile);
     for (int i = threadIdx.x; i < 3 * NT / 2; i += THREADS) tile2[i] = make_double2(0., 0.);

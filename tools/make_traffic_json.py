@@ -6,7 +6,7 @@ fetch_dir, write_dir, mesh, out_json, out_txt = sys.argv[1:6]
 stage_of = [("paint3_", "paint3"), ("paint_tile_kernel", "paint"), ("paint_outlier_kernel", "paint"), ("paint_atomic_kernel", "paint"),
             ("zfwd_kernel", "fft_r2c"), ("ycol2_kernel<512, false>", "fft_r2c"), ("ycol2_kernel<256, false>", "fft_r2c"),
             ("ycol2_kernel<512, true>", "fft_c2r"), ("ycol2_kernel<256, true>", "fft_c2r"), ("ycol_kernel<512, -1>", "fft_r2c"), ("ycol_kernel<256, -1>", "fft_r2c"),
-            ("ycol_kernel<512, 1>", "fft_c2r"), ("ycol_kernel<256, 1>", "fft_c2r"), ("zinv_kernel", "fft_c2r"),
+            ("ycol_kernel<512, 1>", "fft_c2r"), ("ycol_kernel<256, 1>", "fft_c2r"), ("zinv_kernel", "fft_c2r"), ("zinv3_il_kernel", "fft_c2r"),
             ("xfused_kernel", "kspace"), ("kick_drift_kernel", "kick_drift"), ("step_adjoint_kernel", "step_adjoint"),
             ("axpby_kernel", "axpy"), ("axpy_kernel", "axpy")]
 outlier_kernels = ("paint_outlier_kernel", "paint3_outlier_kernel")
