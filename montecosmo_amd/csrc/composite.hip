@@ -125,7 +125,7 @@ __device__ __forceinline__ void block_add2(double a, double b, double *out0, dou
 // out0 += sum_i a[i].F(q_i), out1 += sum_i b[i].F(q_i)  (growth-scalar cotangents of lpt)
 __global__ __launch_bounds__(256) void lattice_dot_kernel(Geom g, const float *__restrict__ meshes, int64_t M,
                                                           const float *__restrict__ a, const float *__restrict__ b,
-                                                          double *out0, double *out1) {
+                                                          double *slots) {
     PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
     double ra = 0., rb = 0.;
     if (pi.valid) {
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void lattice_dot_kernel(Geom g, const float *_
             rb = (double)(x.x * F0 + x.y * F1 + x.z * F2);
         }
     }
-    block_add2(ra, rb, out0, out1);
+    const int slot = blockIdx.x % MCPM_NSLOT;   // spread: one address would serialise the blocks' atomics
+    block_add2(ra, rb, a ? slots + slot : nullptr, b ? slots + MCPM_NSLOT + slot : nullptr);
 }
 
 // Adjoint of one fused step (see file header).  Inputs: x'_i, v_i (checkpoint), cotangents xb, vb of
@@ -237,6 +238,19 @@ static inline void lattice_launch(const Geom &g, dim3 &grid, dim3 &block) {
     grid = dim3((unsigned)((int64_t)g.px * g.py * cpr));
 }
 
+// out0 += sum_i a[i].F(q_i), out1 += sum_i b[i].F(q_i) through MCPM_NSLOT spread partial sums
+static int lattice_dot(mcpm_plan *p, const float *meshes3, const float *a, const float *b, double *out0, double *out1) {
+    dim3 grid, block;
+    lattice_launch(p->g, grid, block);
+    double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);
+    MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 3 * MCPM_NSLOT, p->stream));
+    lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, meshes3, p->M, a, b, slots);
+    MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
+    reduce_slots_kernel<<<1, MCPM_NSLOT, 0, p->stream>>>(slots, a ? out0 : nullptr, b ? out1 : nullptr, nullptr);
+    MCPM_LAUNCH_CHECK(p, "reduce_slots_kernel");
+    return MCPM_OK;
+}
+
 static int axpby(mcpm_plan *p, const float *x, const float *y, int64_t n, float a, float b, float *out) {
     StageTimer st_(p, ST_AXPY, 12.0 * n);
     unsigned nb = (unsigned)((n + 255) / 256);
@@ -307,8 +321,7 @@ static int lpt_vjp_device(mcpm_plan *p, const float *init_mesh, int lpt_order, c
     lattice_launch(p->g, grid, block);
     const float g = (float)lpt_scalars[0], g2 = (float)lpt_scalars[1], c2 = (float)lpt_scalars[2];
     MCPM_TRY(spec_to_force_meshes(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, p->fmesh));
-    lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, p->fmesh, M, xb, nullptr, sb + 0, nullptr);
-    MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
+    MCPM_TRY(lattice_dot(p, p->fmesh, xb, nullptr, sb + 0, nullptr));
     if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(p->fmesh, 0, sizeof(float) * 3 * M, p->stream));
     lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, g, 1.f, p->fmesh, M);
     MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
@@ -323,8 +336,7 @@ static int lpt_vjp_device(mcpm_plan *p, const float *init_mesh, int lpt_order, c
         float *h = p->fmesh, *f2 = p->fmesh + 6 * M;
         MCPM_TRY(spec_to_delta2_real(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF));        // h in fmesh[0:6], delta2 in rho
         MCPM_TRY(delta2_to_force_meshes(p, MCPM_FD_INF, MCPM_FD_INF, f2));            // F2 meshes
-        lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, f2, M, xb, vb, sb + 1, sb + 2);  // negated on the host
-        MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
+        MCPM_TRY(lattice_dot(p, f2, xb, vb, sb + 1, sb + 2));  // negated on the host
         if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(f2, 0, sizeof(float) * 3 * M, p->stream));
         lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, -g2, -c2, f2, M);
         MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
@@ -464,12 +476,8 @@ int mcpm_lattice_scatter_f32(mcpm_plan *p, const float *xb, const float *vb, flo
 int mcpm_lattice_dot_f32(mcpm_plan *p, const float *meshes3, const float *a, const float *b, double *out2) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, meshes3 && out2 && (a || b), MCPM_E_ARG, "mcpm_lattice_dot_f32: null buffer");
-    dim3 grid, block;
-    lattice_launch(p->g, grid, block);
     StageTimer st_(p, ST_LPT, 12.0 * p->M + 24.0 * p->Np);
-    lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, meshes3, p->M, a, b, a ? out2 : nullptr, b ? out2 + 1 : nullptr);
-    MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
-    return MCPM_OK;
+    return lattice_dot(p, meshes3, a, b, out2, out2 + 1);
 }
 
 int mcpm_lpt_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg, int lap_fd,
