@@ -275,7 +275,10 @@ int mcpm_cgh2rg_f32(void *stream, const float *spec, int nx, int ny, int nz, flo
             grad_x, grad_y, grad_z} as 7 real meshes M apart; wavevectors in h/Mpc, kphys[a] = mesh_shape[a] / box_size[a]
             (bricks.py:352).  The VJP maps the 7 cotangent meshes to the cotangent of lin_mesh (real-pair convention).
    weights: the raw reads of those fields at the particles (dr, s2r, s3r, lr: n floats each; gr: n x 3) -> weights (n) and
-            dvel (n x 3).  growth = a2g(a): one float per particle, or NULL and growth_scalar.  bias8 (host) =
+            dvel (n x 3).  gr_cstride = 0: gr (and gr_bar) are particle-major (n x 3); > 0: component-major, component c at
+            gr + c * gr_cstride (the three gradient meshes themselves when the particles are the mesh's own lattice and the
+            read is NGP: then no read / paint pass is needed at all).  growth = a2g(a): one float per particle, or NULL
+            and growth_scalar.  bias8 (host) =
             {b1, b2, bs2, b3, bds2, bs3, bn2, bnpar}.  The VJP returns the cotangents of the raw reads, of growth (per
             particle if growth_bar != NULL) and scalars_out (device, 10 doubles) = 8 bias cotangents, summed growth
             cotangent, <d^2>.  The reads between the two halves are mcpm_read_f32; their adjoints mcpm_paint_f32. */
@@ -283,10 +286,10 @@ int mcpm_bias_fields_f32(mcpm_plan *plan, const float *lin_mesh, float kphys_x, 
 int mcpm_bias_fields_vjp_f32(mcpm_plan *plan, const float *lin_mesh, float kphys_x, float kphys_y, float kphys_z,
                              const float *fields7_bar, float *lin_mesh_bar);
 int mcpm_bias_weights_f32(mcpm_plan *plan, int64_t n, const float *dr, const float *s2r, const float *s3r, const float *lr,
-                          const float *gr, const float *growth, float growth_scalar, const float *bias8, float *weights,
-                          float *dvel, double *sigma2_out);
+                          const float *gr, int64_t gr_cstride, const float *growth, float growth_scalar, const float *bias8,
+                          float *weights, float *dvel, double *sigma2_out);
 int mcpm_bias_weights_vjp_f32(mcpm_plan *plan, int64_t n, const float *dr, const float *s2r, const float *s3r, const float *lr,
-                              const float *gr, const float *growth, float growth_scalar, const float *bias8,
+                              const float *gr, int64_t gr_cstride, const float *growth, float growth_scalar, const float *bias8,
                               const float *weights_bar, const float *dvel_bar, float *dr_bar, float *s2r_bar, float *s3r_bar,
                               float *lr_bar, float *gr_bar, float *growth_bar, double *scalars_out);
 

@@ -48,9 +48,9 @@ SIGNATURES = {
     "mcpm_force_meshes_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "mcpm_bias_fields_f32": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_float, C.c_float, _f32p]),
     "mcpm_bias_fields_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_float, C.c_float, _f32p, _f32p]),
-    "mcpm_bias_weights_f32": (C.c_int, [C.c_void_p, C.c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float,
+    "mcpm_bias_weights_f32": (C.c_int, [C.c_void_p, C.c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int64, _f32p, C.c_float,
                                         C.POINTER(C.c_float), _f32p, _f32p, C.c_void_p]),
-    "mcpm_bias_weights_vjp_f32": (C.c_int, [C.c_void_p, C.c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float,
+    "mcpm_bias_weights_vjp_f32": (C.c_int, [C.c_void_p, C.c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int64, _f32p, C.c_float,
                                             C.POINTER(C.c_float), _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
     "mcpm_power_mult_f32": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_float, C.c_float, C.c_double, C.c_void_p, C.c_void_p, C.c_int, _f32p]),
     "mcpm_interp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_float, _f32p]),

@@ -72,11 +72,17 @@ def lagrangian_bias(cosmo, pos, a, box_size, lin_mesh, bias, png=None, png_type=
     kphys = [float(s) / float(b) for s, b in zip(shape, box_size)]
     fields = torch.empty((7,) + tuple(shape), dtype=torch.float32, device=dev)
     plan.call("mcpm_bias_fields_f32", nbody._ptr(spec), kphys[0], kphys[1], kphys[2], nbody._ptr(fields))
-    reads = torch.empty((4, n), dtype=torch.float32, device=dev)
-    for c in range(4):
-        plan.call("mcpm_read_f32", nbody._ptr(p), n, mode, nbody._ptr(fields[c]), 1, int(read_order), nbody._ptr(reads[c]))
-    gr = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    plan.call("mcpm_read_f32", nbody._ptr(p), n, mode, nbody._ptr(fields[4]), 3, int(read_order), nbody._ptr(gr))
+    # NGP read at the mesh's own lattice points is the identity: the fields themselves are the reads (no pass at all)
+    ident = (int(read_order) == 1 and isinstance(pos, nbody.LatticePos) and pos.is_regular and tuple(pos.ptcl_shape) == tuple(shape))
+    if ident:
+        reads, gr, gcs = fields[:4].reshape(4, n), fields[4:7], M
+    else:
+        gcs = 0
+        reads = torch.empty((4, n), dtype=torch.float32, device=dev)
+        for c in range(4):
+            plan.call("mcpm_read_f32", nbody._ptr(p), n, mode, nbody._ptr(fields[c]), 1, int(read_order), nbody._ptr(reads[c]))
+        gr = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        plan.call("mcpm_read_f32", nbody._ptr(p), n, mode, nbody._ptr(fields[4]), 3, int(read_order), nbody._ptr(gr))
     if isinstance(a, torch.Tensor) and a.is_cuda:      # per-particle scale factors on the device (light cone)
         gp, g_shape = nbody.growth_dev(cosmo, a, "g"), tuple(a.shape)
         if gp.numel() != n:
@@ -91,10 +97,10 @@ def lagrangian_bias(cosmo, pos, a, box_size, lin_mesh, bias, png=None, png_type=
     w = torch.empty(n, dtype=torch.float32, device=dev)
     dvel = torch.empty((n, 3), dtype=torch.float32, device=dev)
     plan.call("mcpm_bias_weights_f32", n, nbody._ptr(reads[0]), nbody._ptr(reads[1]), nbody._ptr(reads[2]), nbody._ptr(reads[3]),
-              nbody._ptr(gr), nbody._ptr(gp), gs, b8, nbody._ptr(w), nbody._ptr(dvel), None)
+              nbody._ptr(gr), gcs, nbody._ptr(gp), gs, b8, nbody._ptr(w), nbody._ptr(dvel), None)
     if return_ctx:
         ctx = BiasCtx(plan=plan, spec=spec, shape=shape, p=p, n=n, mode=mode, kphys=kphys, reads=reads, gr=gr, gp=gp, gs=gs,
-                      g_shape=g_shape, b8=b8, read_order=int(read_order))
+                      g_shape=g_shape, b8=b8, read_order=int(read_order), gcs=gcs)
         return (w, dvel, 0.), ctx
     return w, dvel, 0.
 
@@ -108,18 +114,22 @@ def lagrangian_bias_vjp(ctx, weights_bar, dvel_bar):
     plan, n, dev = ctx.plan, ctx.n, ctx.spec.device
     wb = nbody._f32(weights_bar, (n,))
     vb = nbody._f32(dvel_bar, (n, 3))
-    rb = torch.empty((4, n), dtype=torch.float32, device=dev)
-    grb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    fb = torch.empty((7,) + tuple(ctx.shape), dtype=torch.float32, device=dev)
+    if ctx.gcs:      # identity reads: the read cotangents ARE the mesh cotangents
+        rb, grb = fb[:4].reshape(4, n), fb[4:7]
+    else:
+        rb = torch.empty((4, n), dtype=torch.float32, device=dev)
+        grb = torch.empty((n, 3), dtype=torch.float32, device=dev)
     gbar = torch.empty(n, dtype=torch.float32, device=dev) if ctx.gp is not None else None
     scal = torch.zeros(10, dtype=torch.float64, device=dev)
     r = ctx.reads
     plan.call("mcpm_bias_weights_vjp_f32", n, nbody._ptr(r[0]), nbody._ptr(r[1]), nbody._ptr(r[2]), nbody._ptr(r[3]), nbody._ptr(ctx.gr),
-              nbody._ptr(ctx.gp), ctx.gs, ctx.b8, nbody._ptr(wb), nbody._ptr(vb), nbody._ptr(rb[0]), nbody._ptr(rb[1]), nbody._ptr(rb[2]),
-              nbody._ptr(rb[3]), nbody._ptr(grb), nbody._ptr(gbar), nbody._ptr(scal))
-    fb = torch.empty((7,) + tuple(ctx.shape), dtype=torch.float32, device=dev)
-    for c in range(4):       # adjoint of a read w.r.t. its mesh = a weighted paint
-        plan.call("mcpm_paint_f32", nbody._ptr(ctx.p), n, ctx.mode, nbody._ptr(rb[c]), 1, 0.0, ctx.read_order, nbody._ptr(fb[c]), 0)
-    plan.call("mcpm_paint3_f32", nbody._ptr(ctx.p), n, ctx.mode, nbody._ptr(grb), ctx.read_order, nbody._ptr(fb[4]), 0)
+              ctx.gcs, nbody._ptr(ctx.gp), ctx.gs, ctx.b8, nbody._ptr(wb), nbody._ptr(vb), nbody._ptr(rb[0]), nbody._ptr(rb[1]),
+              nbody._ptr(rb[2]), nbody._ptr(rb[3]), nbody._ptr(grb), nbody._ptr(gbar), nbody._ptr(scal))
+    if not ctx.gcs:
+        for c in range(4):       # adjoint of a read w.r.t. its mesh = a weighted paint
+            plan.call("mcpm_paint_f32", nbody._ptr(ctx.p), n, ctx.mode, nbody._ptr(rb[c]), 1, 0.0, ctx.read_order, nbody._ptr(fb[c]), 0)
+        plan.call("mcpm_paint3_f32", nbody._ptr(ctx.p), n, ctx.mode, nbody._ptr(grb), ctx.read_order, nbody._ptr(fb[4]), 0)
     out = torch.empty(tuple(ctx.spec.shape), dtype=torch.complex64, device=dev)
     plan.call("mcpm_bias_fields_vjp_f32", nbody._ptr(ctx.spec), ctx.kphys[0], ctx.kphys[1], ctx.kphys[2], nbody._ptr(fb), nbody._ptr(out))
     s = scal.cpu().numpy()

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void bias_moment_kernel(const float *__restric
 
 __global__ __launch_bounds__(256) void bias_weights_kernel(const float *__restrict__ dr, const float *__restrict__ s2r,
                                                            const float *__restrict__ s3r, const float *__restrict__ lr,
-                                                           const float *__restrict__ gr, const float *__restrict__ gp, float gs,
+                                                           const float *__restrict__ gr, int64_t ges, int64_t gcs,
+                                                           const float *__restrict__ gp, float gs,
                                                            Bias8 B, const double *__restrict__ sigma2p, int64_t n,
                                                            float *__restrict__ w, float *__restrict__ dvel) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -182,15 +183,16 @@ __global__ __launch_bounds__(256) void bias_weights_kernel(const float *__restri
     wt += B.bn2 * l;
     w[i] = wt;
     const float c = B.bnpar * g;
-    dvel[3 * i] = c * gr[3 * i];
-    dvel[3 * i + 1] = c * gr[3 * i + 1];
-    dvel[3 * i + 2] = c * gr[3 * i + 2];
+    dvel[3 * i] = c * gr[ges * i];                 // gr[i][c] at gr + i * ges + c * gcs (particle-major or mesh-major)
+    dvel[3 * i + 1] = c * gr[ges * i + gcs];
+    dvel[3 * i + 2] = c * gr[ges * i + 2 * gcs];
 }
 
 // pass 1 of the VJP: the 8 bias cotangents and sigma2_bar (slots rows 0..8)
 __global__ __launch_bounds__(256) void bias_vjp_reduce_kernel(const float *__restrict__ dr, const float *__restrict__ s2r,
                                                               const float *__restrict__ s3r, const float *__restrict__ lr,
-                                                              const float *__restrict__ gr, const float *__restrict__ gp, float gs,
+                                                              const float *__restrict__ gr, int64_t ges, int64_t gcs,
+                                                              const float *__restrict__ gp, float gs,
                                                               Bias8 B, const double *__restrict__ sigma2p,
                                                               const float *__restrict__ wb, const float *__restrict__ vb,
                                                               int64_t n, double *slots) {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void bias_vjp_reduce_kernel(const float *__res
         v[4] = (double)(w * d * s2);
         v[5] = (double)(w * s3);
         v[6] = (double)(w * l);
-        v[7] = (double)(g * (vb[3 * i] * gr[3 * i] + vb[3 * i + 1] * gr[3 * i + 1] + vb[3 * i + 2] * gr[3 * i + 2]));
+        v[7] = (double)(g * (vb[3 * i] * gr[ges * i] + vb[3 * i + 1] * gr[ges * i + gcs] + vb[3 * i + 2] * gr[ges * i + 2 * gcs]));
         const float dw_ds2 = B.bs2 + B.bds2 * d;
         v[8] = (double)(w * (-0.5f * B.b2 - 0.5f * B.b3 * d - (2.f / 3.f) * dw_ds2));
     }
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(256) void bias_vjp_reduce_kernel(const float *__res
 // pass 2: per-particle cotangents of the raw reads and of g (g_bar per particle, or block-summed into slots row 0)
 __global__ __launch_bounds__(256) void bias_vjp_particles_kernel(const float *__restrict__ dr, const float *__restrict__ s2r,
                                                                  const float *__restrict__ s3r, const float *__restrict__ lr,
-                                                                 const float *__restrict__ gr, const float *__restrict__ gp, float gs,
+                                                                 const float *__restrict__ gr, int64_t ges, int64_t gcs,
+                                                                 const float *__restrict__ gp, float gs,
                                                                  Bias8 B, const double *__restrict__ sigma2p,
                                                                  const double *__restrict__ sigbarp, const float *__restrict__ wb,
                                                                  const float *__restrict__ vb, int64_t n,
@@ -239,11 +242,11 @@ __global__ __launch_bounds__(256) void bias_vjp_particles_kernel(const float *__
         lrb[i] = w * B.bn2 * g;
         const float c = B.bnpar * g;
         const float v0 = vb[3 * i], v1 = vb[3 * i + 1], v2 = vb[3 * i + 2];
-        grb[3 * i] = c * v0;
-        grb[3 * i + 1] = c * v1;
-        grb[3 * i + 2] = c * v2;
+        grb[ges * i] = c * v0;
+        grb[ges * i + gcs] = c * v1;
+        grb[ges * i + 2 * gcs] = c * v2;
         const float gb = dbar * draw + w * dw_ds2 * 2.f * g * s2raw + w * B.bs3 * 3.f * g * g * s3raw + w * B.bn2 * lraw +
-                         B.bnpar * (v0 * gr[3 * i] + v1 * gr[3 * i + 1] + v2 * gr[3 * i + 2]);
+                         B.bnpar * (v0 * gr[ges * i] + v1 * gr[ges * i + gcs] + v2 * gr[ges * i + 2 * gcs]);
         if (gbar) gbar[i] = gb;
         v[0] = (double)gb;
     }
@@ -395,8 +398,9 @@ int mcpm_bias_fields_vjp_f32(mcpm_plan *p, const float *lin_mesh, float kpx, flo
 // growth: one value per particle, or NULL and growth_scalar.  bias8 = {b1, b2, bs2, b3, bds2, bs3, bn2, bnpar} (host).
 // sigma2_out (device double, may be NULL) receives <d^2>.
 int mcpm_bias_weights_f32(mcpm_plan *p, int64_t n, const float *dr, const float *s2r, const float *s3r, const float *lr,
-                          const float *gr, const float *growth, float growth_scalar, const float *bias8, float *weights,
-                          float *dvel, double *sigma2_out) {
+                          const float *gr, int64_t gr_cstride, const float *growth, float growth_scalar, const float *bias8,
+                          float *weights, float *dvel, double *sigma2_out) {
+    const int64_t ges = gr_cstride ? 1 : 3, gcs = gr_cstride ? gr_cstride : 1;
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, n > 0 && dr && s2r && s3r && lr && gr && bias8 && weights && dvel, MCPM_E_ARG, "mcpm_bias_weights_f32: bad argument");
     const Bias8 B{bias8[0], bias8[1], bias8[2], bias8[3], bias8[4], bias8[5], bias8[6], bias8[7]};
@@ -406,7 +410,7 @@ int mcpm_bias_weights_f32(mcpm_plan *p, int64_t n, const float *dr, const float 
     MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * NSLOT, p->stream));
     bias_moment_kernel<<<nb, 256, 0, p->stream>>>(dr, growth, growth_scalar, n, slots);
     fold_kernel<<<1, NSLOT, 0, p->stream>>>(slots, 1, 1.0 / (double)n, sig);
-    bias_weights_kernel<<<nb, 256, 0, p->stream>>>(dr, s2r, s3r, lr, gr, growth, growth_scalar, B, sig, n, weights, dvel);
+    bias_weights_kernel<<<nb, 256, 0, p->stream>>>(dr, s2r, s3r, lr, gr, ges, gcs, growth, growth_scalar, B, sig, n, weights, dvel);
     MCPM_LAUNCH_CHECK(p, "bias_weights_kernel");
     if (sigma2_out) MCPM_HIP(p, hipMemcpyAsync(sigma2_out, sig, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
     return MCPM_OK;
@@ -416,9 +420,10 @@ int mcpm_bias_weights_f32(mcpm_plan *p, int64_t n, const float *dr, const float 
 // (per particle into growth_bar if not NULL) and the scalars: scalars_out (device, 10 doubles) = 8 bias cotangents,
 // the summed growth cotangent, <d^2>.
 int mcpm_bias_weights_vjp_f32(mcpm_plan *p, int64_t n, const float *dr, const float *s2r, const float *s3r, const float *lr,
-                              const float *gr, const float *growth, float growth_scalar, const float *bias8,
+                              const float *gr, int64_t gr_cstride, const float *growth, float growth_scalar, const float *bias8,
                               const float *weights_bar, const float *dvel_bar, float *drb, float *s2rb, float *s3rb, float *lrb,
                               float *grb, float *growth_bar, double *scalars_out) {
+    const int64_t ges = gr_cstride ? 1 : 3, gcs = gr_cstride ? gr_cstride : 1;
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, n > 0 && dr && s2r && s3r && lr && gr && bias8 && weights_bar && dvel_bar && drb && s2rb && s3rb && lrb && grb && scalars_out,
                  MCPM_E_ARG, "mcpm_bias_weights_vjp_f32: bad argument");
@@ -430,11 +435,11 @@ int mcpm_bias_weights_vjp_f32(mcpm_plan *p, int64_t n, const float *dr, const fl
     bias_moment_kernel<<<nb, 256, 0, p->stream>>>(dr, growth, growth_scalar, n, slots);
     fold_kernel<<<1, NSLOT, 0, p->stream>>>(slots, 1, 1.0 / (double)n, scalars_out + 9);
     MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * NSLOT, p->stream));
-    bias_vjp_reduce_kernel<<<nb, 256, 0, p->stream>>>(dr, s2r, s3r, lr, gr, growth, growth_scalar, B, scalars_out + 9, weights_bar,
+    bias_vjp_reduce_kernel<<<nb, 256, 0, p->stream>>>(dr, s2r, s3r, lr, gr, ges, gcs, growth, growth_scalar, B, scalars_out + 9, weights_bar,
                                                       dvel_bar, n, slots);
     fold_kernel<<<1, NSLOT, 0, p->stream>>>(slots, 9, 1.0, scalars_out);   // [8] = sigma2_bar for now
     MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * NSLOT, p->stream));
-    bias_vjp_particles_kernel<<<nb, 256, 0, p->stream>>>(dr, s2r, s3r, lr, gr, growth, growth_scalar, B, scalars_out + 9, scalars_out + 8,
+    bias_vjp_particles_kernel<<<nb, 256, 0, p->stream>>>(dr, s2r, s3r, lr, gr, ges, gcs, growth, growth_scalar, B, scalars_out + 9, scalars_out + 8,
                                                          weights_bar, dvel_bar, n, drb, s2rb, s3rb, lrb, grb, growth_bar, slots);
     fold_kernel<<<1, NSLOT, 0, p->stream>>>(slots, 1, 1.0, scalars_out + 8);   // summed growth cotangent
     MCPM_LAUNCH_CHECK(p, "bias_vjp_particles_kernel");

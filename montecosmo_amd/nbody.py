@@ -127,7 +127,8 @@ class LatticePos:
     indices exact and fractions at full fp32 precision on large meshes (absolute fp32 coordinates lose
     ~3e-5 cells at n = 512).  `to_absolute()` gives the reference's (N,3) array."""
 
-    def __init__(self, disp, mesh_shape, ptcl_shape=None):
+    def __init__(self, disp, mesh_shape, ptcl_shape=None, is_regular=False):
+        self.is_regular = bool(is_regular)        # zero displacements: the particles ARE the lattice (set by `regular`)
         self.mesh_shape = tuple(int(s) for s in mesh_shape)
         self.ptcl_shape = self.mesh_shape if ptcl_shape is None else tuple(int(s) for s in ptcl_shape)
         n = int(np.prod(self.ptcl_shape))
@@ -136,7 +137,8 @@ class LatticePos:
     @classmethod
     def regular(cls, mesh_shape, ptcl_shape=None):
         ptcl = mesh_shape if ptcl_shape is None else ptcl_shape
-        return cls(torch.zeros((int(np.prod(ptcl)), 3), dtype=torch.float32, device=_device()), mesh_shape, ptcl_shape)
+        return cls(torch.zeros((int(np.prod(ptcl)), 3), dtype=torch.float32, device=_device()), mesh_shape, ptcl_shape,
+                   is_regular=True)
 
     def lattice(self, dtype=torch.float64):
         axes = [torch.arange(p, device=self.disp.device, dtype=dtype) * (m / p)

@@ -38,8 +38,11 @@ def test_lagrangian_bias_forward_and_vjp(gpu, shape, box, read_order, per_partic
     N = len(pos)
     a = (0.3 + 0.6 * rng.uniform(size=(N, 1))) if per_particle else 0.6
     g = o.a2g(cosmo, a)
-    (w, dvel, phi), ctx = bricks.lagrangian_bias(cosmo, pos.astype(np.float32), a, box, X.astype(np.complex64), BIAS,
+    # read_order 1 at the mesh's own lattice: the identity-read path (LatticePos.regular), as model.py:738-744 calls it
+    pos_in = nbody.LatticePos.regular(shape) if read_order == 1 else pos.astype(np.float32)
+    (w, dvel, phi), ctx = bricks.lagrangian_bias(cosmo, pos_in, a, box, X.astype(np.complex64), BIAS,
                                                   read_order=read_order, return_ctx=True)
+    assert bool(ctx.gcs) == (read_order == 1)
     p64 = pos.astype(np.float32).astype(np.float64)
     w_o, dv_o = bo.lagrangian_bias(g, p64, box, X, BIAS, read_order)
     assert phi == 0.
