@@ -630,6 +630,36 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xspec_kernel(FGeom g, co
     }
 }
 
+// Plain x transform between the caller's half-spectrum layout [x][ny][nz/2+1] and the internal padded one (single-GPU
+// plans): the third pass of a generic R2C (DIR = -1: padded -> forward x FFT -> plain) or the first of a generic C2R
+// (DIR = +1: plain -> inverse x FFT -> padded).  mcpm_fft_r2c / mcpm_fft_c2r on power-of-two meshes.
+template <int N, int DIR>
+__global__ __launch_bounds__(ColShape<N>::THREADS) void xplain_kernel(FGeom g, const cf *__restrict__ in, cf *__restrict__ out,
+                                                                      const cf *__restrict__ W) {
+    constexpr int T = ColShape<N>::T, LINES = ColShape<N>::LINES;
+    typedef Tile<N, LINES, true> TL;
+    __shared__ cf lds[TL::FLOATS2];
+    const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
+    const int kzi = blockIdx.x * LINES + l, iy = blockIdx.y;
+    const bool ok = kzi < g.nzh;
+    cf v[8];
+    TL tile{l};
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int x = u + T * m;
+        const uint32_t op = ((uint32_t)x * g.ny + iy) * g.nzh + kzi, oq = ((uint32_t)x * g.ny + iy) * g.nzp + kzi;
+        v[m] = ok ? in[DIR > 0 ? op : oq] : make_float2(0.f, 0.f);
+    }
+    fft_line<N, DIR>(v, lds, W, u, tile);
+    if (!ok) return;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int x = u + T * m;
+        const uint32_t op = ((uint32_t)x * g.ny + iy) * g.nzh + kzi, oq = ((uint32_t)x * g.ny + iy) * g.nzp + kzi;
+        out[DIR > 0 ? oq : op] = v[m];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 static bool pow2_ok(int n) { return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024; }
@@ -871,6 +901,56 @@ int mcpm_fftpm_force_meshes_vjp(mcpm_plan *p, const float *fbar3, float *rho_bar
 }
 
 // ---- pass-level entry points for the slab-decomposed solve (the all-to-all between them is the host's) ----------
+static int x_plain(mcpm_plan *p, const cf *in, cf *out, int dir) {
+    const FGeom g = fgeom(p);
+    StageTimer st_(p, dir < 0 ? ST_R2C : ST_C2R, pass_bytes(p, 1));
+#define CALL(NN)                                                                                              \
+    {                                                                                                         \
+        constexpr int LINES = ColShape<NN>::LINES, TH = ColShape<NN>::THREADS;                                \
+        dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)g.ny);                                   \
+        if (dir < 0) xplain_kernel<NN, -1><<<grid, TH, 0, p->stream>>>(g, in, out, (const cf *)p->tw[0]);     \
+        else xplain_kernel<NN, +1><<<grid, TH, 0, p->stream>>>(g, in, out, (const cf *)p->tw[0]);             \
+    }
+    DISPATCH_N(g.nx, CALL)
+#undef CALL
+    MCPM_LAUNCH_CHECK(p, "xplain_kernel");
+    return MCPM_OK;
+}
+
+// Generic unnormalised R2C / C2R of `batch` meshes (M floats apart) <-> plain half-spectra (Mh complex apart) with the
+// hand-written passes; one padded spectrum of scratch (allocated on first use), so each mesh is three kernels.
+// Like numpy's irfftn, the C2R ignores the imaginary parts of the kz = 0 and Nyquist modes after the x / y transforms.
+static int fft_scratch(mcpm_plan *p, cf **s) {
+    if (!p->fft_pad && hipMalloc((void **)&p->fft_pad, sizeof(cf) * spec_elems(p)) != hipSuccess)
+        return mcpm_fail(p, MCPM_E_NOMEM, "padded spectrum scratch");
+    *s = (cf *)p->fft_pad;
+    return MCPM_OK;
+}
+
+int mcpm_fftpm_r2c(mcpm_plan *p, const float *real, float *spec, int batch) {
+    MCPM_TRY(ensure_twiddles(p));
+    cf *s;
+    MCPM_TRY(fft_scratch(p, &s));
+    for (int b = 0; b < batch; ++b) {
+        MCPM_TRY(z_forward(p, real + (int64_t)b * p->M, p->M, s, 1));
+        MCPM_TRY(y_columns(p, s, s, 1, -1, false, false));
+        MCPM_TRY(x_plain(p, s, (cf *)spec + (int64_t)b * p->Mh, -1));
+    }
+    return MCPM_OK;
+}
+
+int mcpm_fftpm_c2r(mcpm_plan *p, const float *spec, float *real, int batch) {
+    MCPM_TRY(ensure_twiddles(p));
+    cf *s;
+    MCPM_TRY(fft_scratch(p, &s));
+    for (int b = 0; b < batch; ++b) {
+        MCPM_TRY(x_plain(p, (const cf *)spec + (int64_t)b * p->Mh, s, +1));
+        MCPM_TRY(y_columns(p, s, s, 1, +1, false, false));
+        MCPM_TRY(z_inverse(p, s, real + (int64_t)b * p->M, p->M, 1));
+    }
+    return MCPM_OK;
+}
+
 extern "C" {
 
 int64_t mcpm_slab_spec_elems(const mcpm_plan *p) { return p ? spec_elems(p) : 0; }

@@ -73,6 +73,7 @@ struct mcpm_plan {
     float *spec;     // 6 half-spectra (complex64) scratch
     float *fmesh;    // 9 real meshes scratch (force meshes / hessians)
     float *spec1;    // 1 half-spectrum scratch
+    float *fft_pad;  // 1 padded spectrum: scratch of the generic hand-written R2C / C2R (allocated on first use)
     int *outliers;   // outlier particle list of the tiled paint (Np ints)
     int *outlier_count;  // device counter (2 ints: live counter, copy of last)
     double *reduce;  // device accumulators for scalar cotangents (MCPM_NREDUCE doubles)
@@ -130,6 +131,8 @@ int mcpm_kick_drift_layout(mcpm_plan *p, const float *pos_in, const float *vel_i
                                       int layout, int order, float alpha, float beta, float dt, float *pos_out, float *vel_out);
 int mcpm_read3_il(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *fm_il, int order, float *out);
 int mcpm_fftpm_force_meshes_vjp(mcpm_plan *p, const float *fbar3, float *rho_bar);
+int mcpm_fftpm_r2c(mcpm_plan *p, const float *real, float *spec, int batch);
+int mcpm_fftpm_c2r(mcpm_plan *p, const float *spec, float *real, int batch);
 // plain half-spectrum -> nc = 3 force meshes or nc = 6 Hessian meshes (00 01 02 11 12 22), and the adjoints
 // (spec_bar overwritten for nc = 3, accumulated into for nc = 6)
 int mcpm_fftpm_spec_meshes(mcpm_plan *p, const float *spec, float *meshes, int nc);

@@ -98,7 +98,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->hint_set = 0;
     p->fb_valid = 0;
     if (const char *e = getenv("MCPM_PAINT3_VARIANT")) p->paint3_variant = atoi(e);
-    p->rho = p->spec = p->fmesh = p->spec1 = nullptr;
+    p->rho = p->spec = p->fmesh = p->spec1 = p->fft_pad = nullptr;
     p->outliers = p->outlier_count = nullptr;
     p->reduce = nullptr;
     p->pscratch = nullptr;
@@ -149,6 +149,7 @@ int mcpm_plan_destroy(mcpm_plan *p) {
     (void)hipFree(p->spec);
     (void)hipFree(p->fmesh);
     (void)hipFree(p->spec1);
+    (void)hipFree(p->fft_pad);
     (void)hipFree(p->outliers);
     (void)hipFree(p->outlier_count);
     (void)hipFree(p->reduce);
@@ -242,6 +243,7 @@ int mcpm_plan_force_meshes(mcpm_plan *p, float **meshes3) {
 int mcpm_fft_r2c(mcpm_plan *p, const float *real, float *spec, int batch) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, real && spec && batch >= 1, MCPM_E_ARG, "mcpm_fft_r2c: null buffer or batch < 1");
+    if (!p->g.xslab && mcpm_fftpm_supported(p) && !getenv("MCPM_FORCE_ROCFFT")) return mcpm_fftpm_r2c(p, real, spec, batch);
     MCPM_TRY(make_fft(p, true, batch));
     StageTimer st_(p, ST_R2C, (double)batch * (4.0 * p->M + 8.0 * p->Mh));
     void *in[1] = {(void *)real};
@@ -254,6 +256,7 @@ int mcpm_fft_r2c(mcpm_plan *p, const float *real, float *spec, int batch) {
 int mcpm_fft_c2r(mcpm_plan *p, float *spec, float *real, int batch) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, real && spec && batch >= 1, MCPM_E_ARG, "mcpm_fft_c2r: null buffer or batch < 1");
+    if (!p->g.xslab && mcpm_fftpm_supported(p) && !getenv("MCPM_FORCE_ROCFFT")) return mcpm_fftpm_c2r(p, spec, real, batch);
     MCPM_TRY(make_fft(p, false, batch));
     StageTimer st_(p, ST_C2R, (double)batch * (4.0 * p->M + 8.0 * p->Mh));
     void *in[1] = {(void *)spec};

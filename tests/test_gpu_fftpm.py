@@ -10,7 +10,8 @@ from oracle import pm_oracle as o  # noqa: E402  (checker only)
 
 
 def rel_l2(a, b):
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    dt = np.complex128 if (np.iscomplexobj(a) or np.iscomplexobj(b)) else np.float64
+    a, b = np.asarray(a, dt), np.asarray(b, dt)
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
@@ -69,3 +70,18 @@ def test_force_meshes_vjp_is_the_adjoint(nb, shape):
     lhs = np.sum(fm.astype(np.float64) * fbar)
     rhs = np.sum(rho.astype(np.float64) * got)
     assert abs(lhs - rhs) < 1e-5 * np.sqrt(np.sum(fm.astype(np.float64) ** 2) * np.sum(fbar.astype(np.float64) ** 2))
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (128, 64, 256), (48, 40, 24)])
+def test_generic_rfftn_irfftn_numpy_semantics(gpu, shape):
+    """nbody.rfftn / irfftn (hand-written passes on power-of-two meshes, rocFFT otherwise) against numpy, including a
+    NON-Hermitian half-spectrum: numpy's irfftn (ifft over x, y, then c2r over z) silently projects it, and so must we
+    (the interlacing phases of nufft violate Hermitian symmetry on the Nyquist planes, nbody.py:525)."""
+    from montecosmo_amd import nbody
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(shape).astype(np.float32)
+    X = nbody.rfftn(x).cpu().numpy()
+    assert rel_l2(X, np.fft.rfftn(x.astype(np.float64))) < 2e-6
+    Z = (rng.standard_normal(X.shape) + 1j * rng.standard_normal(X.shape)).astype(np.complex64)
+    y = nbody.irfftn(Z).cpu().numpy()
+    assert rel_l2(y, np.fft.irfftn(Z.astype(np.complex128), s=shape, axes=(0, 1, 2))) < 2e-6
