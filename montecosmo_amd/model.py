@@ -156,3 +156,45 @@ class FieldLevelForward:
         init_k = self._power_mult(ctx.white, cosmo.sigma8)
         s8b = float((init_b.conj() * init_k).real.sum().item()) / float(cosmo.sigma8)
         return {"white_mesh": white_b, "bias": bias_bar, "sigma8": s8b, "growth": growth, "bias_growth": bg_bar, "gf": gfb}
+
+    def cosmo_vjp(self, ctx, grads, params=("Omega_m",), rel_eps=1e-5):
+        """Chains the growth cotangents of `evolve_vjp` to cosmological parameters (fixed a_obs): every place the
+        cosmology enters evolve besides sigma8 is a host float64 scalar looked up in the 128-point growth tables -- the
+        BullFrog coefficients and the 2LPT start (nbody.cosmo_vjp), a2g(a_obs) in the bias weights, a2g a2f in the
+        RSD -- so dL/dtheta = sum_s s_bar ds/dtheta with the table Jacobian taken by central finite differences.
+        `params`: attribute names of the cosmology object; 'Omega_m' varies Omega_c at fixed Omega_b."""
+        import copy
+        if self.a_obs is None:
+            raise NotImplementedError("light cone: the cosmology dependence of the distance / growth look-ups is not propagated")
+        cosmo, a = ctx.cosmo, self.a_obs
+
+        def scalars(c):
+            c._workspace = {}
+            out = [float(nbody.a2g(c, a)), float(nbody.a2g(c, a) * nbody.a2f(c, a))]
+            if self.evolution == 'lpt':
+                out += [float(nbody.a2g(c, a)), float(nbody.a2g2(c, a)), float(nbody.a2dg2dg(c, a))]
+            else:
+                dg, al, be, ls = nbody._step_scalars(c, self.nbody_a_start, a, self.nbody_n_steps, "bullfrog")
+                out += [dg] + list(al) + list(be) + list(ls)
+            return np.array(out)
+
+        g = grads["growth"]
+        bars = [float(np.asarray(grads["bias_growth"]).sum()), float(grads["gf"])]
+        if self.evolution == 'lpt':
+            bars += [float(g["g"]), float(g["g2"]), float(g["dg2dg"])]
+        else:
+            bars += [float(g["dg"])] + list(g["alpha"]) + list(g["beta"]) + [float(g["g"]), float(g["g2"]), float(g["dg2dg"])]
+        bars = np.array(bars)
+        out = {}
+        for name in params:
+            attr = "Omega_c" if name == "Omega_m" else name
+            base = float(getattr(cosmo, attr))
+            h = rel_eps * max(abs(base), 1e-2)
+            vals = []
+            for sgn in (+1, -1):
+                c = copy.copy(cosmo)
+                setattr(c, attr, base + sgn * h)
+                vals.append(scalars(c))
+            out[name] = float(np.dot(bars, (vals[0] - vals[1]) / (2 * h)))
+        cosmo._workspace = {}
+        return out

@@ -58,6 +58,18 @@ def test_evolve_forward_and_vjp(gpu, evolution, a_obs, curved):
     assert abs(fds - grads["sigma8"]) < 3e-3 * abs(fds), ("sigma8", fds, grads["sigma8"])
 
 
+    if a_obs is not None:      # cosmology through the growth tables (finite-difference Jacobian of host scalars)
+        got = fwd.cosmo_vjp(ctx, grads, params=("Omega_m",))["Omega_m"]
+
+        def L_om(dom):
+            c = obg.Planck18(Omega_c=cosmo.Omega_c + dom)
+            c.sigma8 = cosmo.sigma8
+            return float((gb * bo.evolve(cfg, c, BIAS, white)[0]).sum())
+        h = 1e-4
+        fdo = (L_om(h) - L_om(-h)) / (2 * h)
+        assert abs(fdo - got) < 1e-2 * abs(fdo), ("Omega_m", fdo, got)
+
+
 def _with_s8(c, s8):
     c.sigma8 = s8
     return c
