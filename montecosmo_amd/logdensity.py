@@ -1,0 +1,172 @@
+"""Log density of the field-level model and its gradient, assembled around `FieldLevelForward` (the piece
+`samplers.py` consumes as `logdensity_fn(position)`; montecosmo/model.py:362-363, :640-679, :840-908).
+
+Built branch (everything else stays in the reference): latents with an unbounded Normal prior -- in sample space
+`name_ ~ Normal((loc - loc_fid) / scale_fid, scale / scale_fid)` (model.py:1117-1119) with the affine
+reparametrisation `base = name_ * scale_fid + loc_fid` (bricks.py:270-276); initial conditions `white_mesh_ ~ N(0, 1)`
+per cell with the 'fourier' (rg2cgh) or 'real' (rfftn) preconditioning at unit scale (model.py:1131-1132, :1146);
+`evolve`; the 'quad_gauss' likelihood (model.py:893-908) without mask, with unit selection, one radial bin and phi = 0:
+    count = ngbar cell^3 * irfftn(chreshape(rfftn(gxy_mesh), final_shape));  delta = count / selec - 1
+    obs ~ QuadGaussian(count, (|s_e + s_ed delta| + 1e-9) sqrt(selec), s_e2 sqrt(selec)),  selec = ngbar cell^3.
+Truncated-normal latents (bounded priors) are not built: give such parameters in `fixed`, or unbounded in `latents`.
+
+The gradient is hand-derived end to end: elementwise likelihood / prior terms here (device tensors), the mesh and
+particle operators through their `*_vjp` twins -- no autodiff framework.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import nbody, bricks
+from .utils import r2chshape, chreshape, chreshape_vjp, rg2cgh, rg2cgh_vjp
+
+LOG2PI = math.log(2 * math.pi)
+
+
+def quad_gaussian_log_prob_and_grad(value, loc, b, a):
+    """QuadGaussian.log_prob (utils.py:497-510) per element and its derivatives w.r.t. (loc, scale1 = b, scale2 = a);
+    `a` is a python float (one value for the whole mesh), the rest device tensors."""
+    if abs(a) < 1e-8:
+        z = (value - loc) / b
+        lp = -0.5 * LOG2PI - torch.log(b) - 0.5 * z * z
+        return lp, z / b, (z * z - 1.0) / b, torch.zeros_like(lp)
+    r = value - loc + a
+    D = b * b + 4.0 * a * r
+    ok = D > 0
+    Ds = torch.where(ok, D, torch.ones_like(D))
+    sq = torch.sqrt(Ds)
+    ep, em = (-b + sq) / (2.0 * a), (-b - sq) / (2.0 * a)
+    lpp, lpm = -0.5 * ep * ep, -0.5 * em * em
+    m = torch.maximum(lpp, lpm)
+    sp, sm = torch.exp(lpp - m), torch.exp(lpm - m)
+    lse = m + torch.log(sp + sm)
+    wp, wm = sp / (sp + sm), sm / (sp + sm)
+    lp = torch.where(ok, -0.5 * LOG2PI - 0.5 * torch.log(Ds) + lse, torch.full_like(D, -float("inf")))
+    # d lp = -dD / (2 D) - wp ep d(ep) - wm em d(em);  dD = 2 b db + 4 a dr + 4 r da,  dr = -dloc + da,
+    # d(sq) = dD / (2 sq);  d(ep) = (-db + d sq) / (2a) - ep da / a;  d(em) = (-db - d sq) / (2a) - em da / a
+    t = (wp * ep - wm * em) / (2.0 * a)            # coefficient of d(sq) in -(wp ep d ep + wm em d em), sign included below
+    s = (wp * ep + wm * em) / (2.0 * a)            # coefficient of db
+    dD_dloc, dD_db, dD_da = -4.0 * a, 2.0 * b, 4.0 * a + 4.0 * r
+    g_loc = -dD_dloc / (2 * Ds) - t * dD_dloc / (2 * sq)
+    g_b = -dD_db / (2 * Ds) - t * dD_db / (2 * sq) + s
+    g_a = -dD_da / (2 * Ds) - t * dD_da / (2 * sq) + (wp * ep * ep + wm * em * em) / a
+    z = torch.zeros_like(D)
+    return lp, torch.where(ok, g_loc, z), torch.where(ok, g_b, z), torch.where(ok, g_a, z)
+
+
+class FieldLevelLogDensity:
+    """log p(sample params, observed counts) and its gradient.
+
+    fwd      : FieldLevelForward (shapes, box, evolution, a_obs ...)
+    count_obs: observed count mesh, real, fwd.final_shape
+    latents  : name -> dict(loc, scale, loc_fid, scale_fid) for every SAMPLED scalar base parameter (unbounded Normal)
+    fixed    : name -> value for the base parameters that are not sampled; between them `latents` and `fixed` must
+               provide Omega_m, sigma8, the eight bias parameters, ngbars, s_e, s_ed, s_e2
+    make_cosmo(base) -> cosmology object (default: Planck18 with Omega_c = Omega_m - Omega_b and sigma8)
+    """
+
+    COSMO = ("Omega_m", "sigma8")
+    STOCH = ("s_e", "s_ed", "s_e2")
+
+    def __init__(self, fwd, count_obs, latents, fixed, precond="fourier", make_cosmo=None):
+        if precond not in ("fourier", "real"):
+            raise NotImplementedError("the 'kaiser' preconditioning (a fiducial-model transfer) is not built")
+        self.fwd, self.precond = fwd, precond
+        self.latents = {k: {kk: float(vv) for kk, vv in v.items()} for k, v in latents.items()}
+        self.fixed = dict(fixed)
+        need = set(self.COSMO) | set(bricks.BIAS_KEYS) | {"ngbars"} | set(self.STOCH)
+        missing = need - set(self.latents) - set(self.fixed)
+        if missing:
+            raise ValueError(f"parameters neither sampled nor fixed: {sorted(missing)}")
+        if "ngbars" in self.latents:
+            raise NotImplementedError("ngbars is kept fixed")
+        self.final_shape = tuple(fwd.final_shape)
+        self.count_obs = nbody._f32(count_obs, self.final_shape)
+        self.transfer = float(np.divide(fwd.init_shape, fwd.box_size).prod() ** .5)       # model.py:1146, scale = 1
+        self.make_cosmo = make_cosmo or self._planck
+
+    @staticmethod
+    def _planck(base):
+        c = bricks.Planck18()
+        c.Omega_c = float(base["Omega_m"]) - c.Omega_b
+        c.sigma8 = float(base["sigma8"])
+        return c
+
+    def names(self):
+        """Sample-space parameter names: scalars (in a fixed order) then 'white_mesh_'."""
+        return [k + "_" for k in self.latents] + ["white_mesh_"]
+
+    def base_params(self, sample):
+        base = dict(self.fixed)
+        for name, c in self.latents.items():
+            base[name] = float(sample[name + "_"]) * c["scale_fid"] + c["loc_fid"]
+        return base
+
+    def __call__(self, sample):
+        return self.logdensity_and_grad(sample)[0]
+
+    def logdensity_and_grad(self, sample, need_grad=True):
+        """sample: dict with the scalars `name_` (floats) and 'white_mesh_' (real tensor, fwd.init_shape).
+        Returns (log density, dict of gradients with the same keys)."""
+        fwd = self.fwd
+        base = self.base_params(sample)
+        lp, grad = 0.0, {}
+        for name, c in self.latents.items():
+            x = float(sample[name + "_"])
+            mu, sd = (c["loc"] - c["loc_fid"]) / c["scale_fid"], c["scale"] / c["scale_fid"]
+            lp += -0.5 * LOG2PI - math.log(sd) - 0.5 * ((x - mu) / sd) ** 2
+            grad[name + "_"] = -(x - mu) / sd ** 2
+        w = nbody._f32(sample["white_mesh_"], fwd.init_shape)
+        lp += float(-0.5 * LOG2PI * w.numel() - 0.5 * (w.double() ** 2).sum())
+        white = (rg2cgh(w) if self.precond == "fourier" else nbody.rfftn(w)) * self.transfer
+        cosmo = self.make_cosmo(base)
+        bias = {k: base[k] for k in bricks.BIAS_KEYS}
+        gxy, ctx = fwd.evolve(cosmo, bias, white, return_ctx=True)
+        # likelihood (model.py:852-855, :893-908)
+        rcount = float(base["ngbars"]) * fwd.cell_length ** 3
+        selec = rcount
+        gk = chreshape(nbody.rfftn(gxy), r2chshape(self.final_shape)) if tuple(gxy.shape) != self.final_shape else None
+        cm = (nbody.irfftn(gk) if gk is not None else gxy) * rcount
+        delta = cm / selec - 1.0
+        lin = base["s_e"] + base["s_ed"] * delta
+        b = (lin.abs() + 1e-9) * selec ** .5
+        a = float(base["s_e2"]) * selec ** .5
+        lpe, g_loc, g_b, g_a = quad_gaussian_log_prob_and_grad(self.count_obs, cm, b, a)
+        lp += float(lpe.double().sum())
+        if not need_grad:
+            return lp, None
+        sgn = torch.sign(lin) * selec ** .5
+        cm_bar = g_loc + g_b * sgn * (base["s_ed"] / selec)
+        stoch_bar = {"s_e": float((g_b * sgn).double().sum()), "s_ed": float((g_b * sgn * delta).double().sum()),
+                     "s_e2": float(g_a.double().sum()) * selec ** .5}
+        gxy_bar = cm_bar * rcount
+        if gk is not None:      # adjoints of irfftn, chreshape, rfftn (real-pair convention)
+            Mf = float(np.prod(self.final_shape))
+            kb = nbody.rfftn(gxy_bar) / Mf
+            kb[..., 1:self.final_shape[-1] // 2] *= 2.0
+            kb = chreshape_vjp(kb, r2chshape(tuple(gxy.shape)))
+            kb[..., 1:gxy.shape[-1] // 2] *= 0.5
+            plan = nbody.get_plan(tuple(gxy.shape))
+            gxy_bar = torch.empty(tuple(gxy.shape), dtype=torch.float32, device=kb.device)
+            plan.call("mcpm_fft_c2r", nbody._ptr(kb), nbody._ptr(gxy_bar), 1)
+        g = fwd.evolve_vjp(ctx, gxy_bar)
+        wb = g["white_mesh"] * self.transfer
+        if self.precond == "fourier":
+            wbar = rg2cgh_vjp(wb)
+        else:
+            wb = wb.clone()
+            wb[..., 1:fwd.init_shape[-1] // 2] *= 0.5
+            wbar = torch.empty(fwd.init_shape, dtype=torch.float32, device=wb.device)
+            nbody.get_plan(fwd.init_shape).call("mcpm_fft_c2r", nbody._ptr(wb), nbody._ptr(wbar), 1)
+        grad["white_mesh_"] = wbar - w
+        base_bar = dict(g["bias"])
+        base_bar.update(stoch_bar)
+        base_bar["sigma8"] = g["sigma8"]
+        if "Omega_m" in self.latents:
+            base_bar["Omega_m"] = fwd.cosmo_vjp(ctx, g, params=("Omega_m",))["Omega_m"]
+        for name, c in self.latents.items():
+            grad[name + "_"] += base_bar[name] * c["scale_fid"]
+        return lp, grad

@@ -238,3 +238,54 @@ def evolve(cfg, cosmo, bias, white_mesh):
     gxy = gxy * np.divide(cfg["init_shape"], cfg["ptcl_shape"]).prod()
     gxy = o.chreshape(gxy, o.r2chshape(cfg["paint_shape"]))
     return np.fft.irfftn(gxy, s=tuple(cfg["paint_shape"]), axes=(0, 1, 2)), dict(init_mesh=init_mesh, weights=w, pos=pos_c)
+
+
+# --------------------------------------------------------------------------- log density (model.py:640-679, :840-908)
+def quad_gaussian_log_prob(value, loc, scale1, scale2):
+    """montecosmo/utils.py:497-510 (QuadGaussian.log_prob)."""
+    a, b = np.broadcast_to(scale2, np.shape(value)).astype(float), np.broadcast_to(scale1, np.shape(value)).astype(float)
+    r = value - loc + a
+    D = b ** 2 + 4.0 * a * r
+    D_safe = np.where(D > 0, D, 1.0)
+    sq = np.sqrt(D_safe)
+    a_safe = np.where(np.abs(a) < 1e-12, 1.0, a)
+    ep = (-b + sq) / (2.0 * a_safe)
+    em = (-b - sq) / (2.0 * a_safe)
+    m = np.maximum(-0.5 * ep ** 2, -0.5 * em ** 2)
+    lse = m + np.log(np.exp(-0.5 * ep ** 2 - m) + np.exp(-0.5 * em ** 2 - m))
+    lp_quad = -0.5 * np.log(2 * np.pi) - 0.5 * np.log(D_safe) + lse
+    lp_quad = np.where(D > 0, lp_quad, -np.inf)
+    lp_gauss = -0.5 * np.log(2 * np.pi) - np.log(b) - 0.5 * ((value - loc) / b) ** 2
+    return np.where(np.abs(a) < 1e-8, lp_gauss, lp_quad)
+
+
+def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo):
+    """log p(sample params, count_obs) of the field-level model for unbounded Normal latents (model.py:1105-1125 prior in
+    sample space; bricks.py:255-287 affine reparametrisation; model.py:1127-1148 'fourier' / 'real' preconditioning with
+    unit scale; model.py:686-838 evolve; model.py:840-908 'quad_gauss' likelihood with no mask, unit selection, one radial
+    bin and phi = 0).  `latents`: name -> dict(loc, scale, loc_fid, scale_fid); `fixed`: name -> value of the base
+    parameters that are not sampled; `sample`: name_ -> value (scalars) and 'white_mesh_' (real, init_shape)."""
+    lp = 0.0
+    base = dict(fixed)
+    for name, conf in latents.items():
+        x = sample[name + "_"]
+        mu, sd = (conf["loc"] - conf["loc_fid"]) / conf["scale_fid"], conf["scale"] / conf["scale_fid"]
+        lp += -0.5 * np.log(2 * np.pi) - np.log(sd) - 0.5 * ((x - mu) / sd) ** 2
+        base[name] = x * conf["scale_fid"] + conf["loc_fid"]
+    w = np.asarray(sample["white_mesh_"], dtype=float)
+    lp += np.sum(-0.5 * np.log(2 * np.pi) - 0.5 * w ** 2)
+    transfer = np.divide(cfg["init_shape"], cfg["box_size"]).prod() ** .5
+    white = (o.rg2cgh(w) if cfg["precond"] != "real" else np.fft.rfftn(w)) * transfer
+    cosmo = make_cosmo(base)
+    bias = {k: base[k] for k in BIAS_KEYS}
+    gxy, _ = evolve(cfg, cosmo, bias, white)
+    final = tuple(cfg["final_shape"])
+    cm = np.fft.irfftn(o.chreshape(np.fft.rfftn(gxy), o.r2chshape(final)), s=final, axes=(0, 1, 2))
+    rcount = base["ngbars"] * cfg["cell_length"] ** 3
+    cm = cm * rcount
+    selec = rcount
+    delta = cm / selec - 1
+    scale1 = (np.abs(base["s_e"] + base["s_ed"] * delta) + 1e-9) * selec ** .5
+    scale2 = base["s_e2"] * selec ** .5
+    lp += np.sum(quad_gaussian_log_prob(count_obs, cm, scale1, scale2))
+    return float(lp)
