@@ -1,0 +1,228 @@
+"""Host sampler loop for the field-level log density (the role of montecosmo/samplers.py:17-269, which drives blackjax
+NUTS): a from-scratch multinomial No-U-Turn sampler (Hoffman & Gelman 2014; Betancourt 2017) with dual-averaging
+step-size adaptation, operating on one flat tensor (device or host) and a callable returning (log density, gradient).
+Third-party algorithm: what is montecosmo's is the call contract `logdensity_fn(position) -> scalar`, kept here as
+`logdensity_and_grad(q) -> (float, tensor)`.  The mass matrix is the identity: the model's sample space is already
+standardised (`scale_fid`, white noise of unit variance)."""
+from __future__ import annotations
+
+import math
+import time
+
+import torch
+
+
+class DualAveraging:
+    """Nesterov dual averaging of log(step size) towards a target acceptance statistic (Hoffman & Gelman 2014, alg. 5)."""
+
+    def __init__(self, eps0, target=0.8, gamma=0.05, t0=10.0, kappa=0.75):
+        self.mu = math.log(10.0 * eps0)
+        self.target, self.gamma, self.t0, self.kappa = target, gamma, t0, kappa
+        self.hbar, self.log_eps_bar, self.t = 0.0, 0.0, 0
+        self.eps = eps0
+
+    def update(self, accept_stat):
+        self.t += 1
+        eta = 1.0 / (self.t + self.t0)
+        self.hbar = (1 - eta) * self.hbar + eta * (self.target - accept_stat)
+        log_eps = self.mu - math.sqrt(self.t) / self.gamma * self.hbar
+        w = self.t ** (-self.kappa)
+        self.log_eps_bar = w * log_eps + (1 - w) * self.log_eps_bar
+        self.eps = math.exp(log_eps)
+        return self.eps
+
+    def final(self):
+        return math.exp(self.log_eps_bar)
+
+
+class _State:
+    __slots__ = ("q", "p", "lp", "g")
+
+    def __init__(self, q, p, lp, g):
+        self.q, self.p, self.lp, self.g = q, p, lp, g
+
+
+def _leapfrog(fn, s, eps):
+    p = s.p + (0.5 * eps) * s.g
+    q = s.q + eps * p
+    lp, g = fn(q)
+    p = p + (0.5 * eps) * g
+    return _State(q, p, lp, g)
+
+
+def _energy(s):
+    return -s.lp + 0.5 * float(torch.dot(s.p, s.p))
+
+
+def _logaddexp(a, b):
+    if a == -math.inf:
+        return b
+    if b == -math.inf:
+        return a
+    m = max(a, b)
+    return m + math.log(math.exp(a - m) + math.exp(b - m))
+
+
+def _build_tree(fn, edge, direction, depth, eps, H0, rng, max_delta=1000.0):
+    """Recursively doubles from `edge` in `direction`.  Returns (new edge, proposal, log_w, rho, n_leapfrog,
+    sum_accept, diverging, turning) where log_w = log sum exp(-H) over the subtree and rho its summed momentum."""
+    if depth == 0:
+        s = _leapfrog(fn, edge, direction * eps)
+        H = _energy(s)
+        if not math.isfinite(H):
+            H = math.inf
+        diverging = (H - H0) > max_delta
+        acc = min(1.0, math.exp(min(0.0, H0 - H))) if math.isfinite(H) else 0.0
+        return s, s, (-H if math.isfinite(H) else -math.inf), s.p.clone(), 1, acc, diverging, False, s
+    e1, prop1, lw1, rho1, n1, a1, div1, turn1, first1 = _build_tree(fn, edge, direction, depth - 1, eps, H0, rng, max_delta)
+    if div1 or turn1:
+        return e1, prop1, lw1, rho1, n1, a1, div1, turn1, first1
+    e2, prop2, lw2, rho2, n2, a2, div2, turn2, _ = _build_tree(fn, e1, direction, depth - 1, eps, H0, rng, max_delta)
+    lw = _logaddexp(lw1, lw2)
+    prop = prop1
+    if not (div2 or turn2) and lw2 > -math.inf:
+        if math.log(max(rng.random(), 1e-300)) < lw2 - lw:      # multinomial sampling within the subtree
+            prop = prop2
+    rho = rho1 + rho2
+    # generalised no-U-turn criterion between the two ends of this subtree (identity metric: p_sharp = p)
+    p_first, p_last = first1.p, e2.p
+    if direction < 0:
+        p_first, p_last = p_last, p_first
+    turning = turn2 or (float(torch.dot(rho, p_first)) <= 0.0) or (float(torch.dot(rho, p_last)) <= 0.0)
+    return e2, prop, lw, rho, n1 + n2, a1 + a2, div2, turning, first1
+
+
+def nuts_step(fn, q, lp, g, eps, rng, max_tree_depth=10):
+    """One NUTS transition.  Returns (q, lp, g, info)."""
+    p0 = torch.randn(q.shape, dtype=q.dtype, device=q.device, generator=rng.torch_gen(q.device))
+    start = _State(q, p0, lp, g)
+    H0 = _energy(start)
+    left = right = start
+    sample = start
+    log_w = -H0
+    rho = p0.clone()
+    n_leap, sum_acc, depth, diverging = 0, 0.0, 0, False
+    while depth < max_tree_depth:
+        direction = 1 if rng.random() < 0.5 else -1
+        edge = right if direction > 0 else left
+        new_edge, prop, lw_sub, rho_sub, n, acc, div, turn, _ = _build_tree(fn, edge, direction, depth, eps, H0, rng)
+        n_leap += n
+        sum_acc += acc
+        if div:
+            diverging = True
+            break
+        if turn:
+            break
+        if lw_sub > -math.inf and math.log(max(rng.random(), 1e-300)) < lw_sub - log_w:   # biased progressive sampling
+            sample = prop
+        log_w = _logaddexp(log_w, lw_sub)
+        rho = rho + rho_sub
+        if direction > 0:
+            right = new_edge
+        else:
+            left = new_edge
+        depth += 1
+        if float(torch.dot(rho, left.p)) <= 0.0 or float(torch.dot(rho, right.p)) <= 0.0:
+            break
+    info = {"n_leapfrog": n_leap, "accept_stat": sum_acc / max(n_leap, 1), "depth": depth, "diverging": diverging,
+            "energy": H0}
+    return sample.q, sample.lp, sample.g, info
+
+
+class _Rng:
+    def __init__(self, seed):
+        import random
+        self._r = random.Random(seed)
+        self._seed = seed
+        self._gens = {}
+
+    def random(self):
+        return self._r.random()
+
+    def torch_gen(self, device):
+        key = str(device)
+        if key not in self._gens:
+            g = torch.Generator(device=device)
+            g.manual_seed(self._seed + 12345)
+            self._gens[key] = g
+        return self._gens[key]
+
+
+def find_reasonable_step_size(fn, q, lp, g, rng, eps=1.0):
+    """Heuristic of Hoffman & Gelman 2014, alg. 4: double / halve until the one-step acceptance crosses 1/2."""
+    p = torch.randn(q.shape, dtype=q.dtype, device=q.device, generator=rng.torch_gen(q.device))
+    s0 = _State(q, p, lp, g)
+    H0 = _energy(s0)
+    s1 = _leapfrog(fn, s0, eps)
+    dH = H0 - _energy(s1)
+    direction = 1.0 if (math.isfinite(dH) and dH > math.log(0.5)) else -1.0
+    for _ in range(50):
+        eps *= 2.0 ** direction
+        s1 = _leapfrog(fn, s0, eps)
+        dH = H0 - _energy(s1)
+        ok = math.isfinite(dH) and dH > math.log(0.5)
+        if (direction > 0 and not ok) or (direction < 0 and ok):
+            break
+    return eps
+
+
+def nuts_sample(logdensity_and_grad, q0, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0,
+                step_size=None, callback=None, keep=None):
+    """Runs warm-up (step-size adaptation by dual averaging) then sampling.  `logdensity_and_grad(q) -> (float, tensor)`.
+    `keep(q)` maps a state to what is stored per draw (default: the state itself; pass a reducer for 10^7-dimensional
+    states).  Returns dict(samples=[...], step_size, infos=[...], seconds)."""
+    rng = _Rng(seed)
+    q = q0.clone()
+    lp, g = logdensity_and_grad(q)
+    eps = step_size if step_size is not None else find_reasonable_step_size(logdensity_and_grad, q, lp, g, rng)
+    da = DualAveraging(eps, target=target_accept)
+    infos, samples = [], []
+    t0 = time.perf_counter()
+    for it in range(n_warmup + n_samples):
+        warm = it < n_warmup
+        q, lp, g, info = nuts_step(logdensity_and_grad, q, lp, g, eps, rng, max_tree_depth)
+        if warm:
+            eps = da.update(info["accept_stat"])
+            if it == n_warmup - 1:
+                eps = da.final()
+        else:
+            samples.append(keep(q) if keep is not None else q.clone())
+        info.update(step_size=eps, warmup=warm, logdensity=lp)
+        infos.append(info)
+        if callback is not None:
+            callback(it, info)
+    return {"samples": samples, "step_size": eps, "infos": infos, "seconds": time.perf_counter() - t0}
+
+
+# ---- packing the model's parameter dict into one flat vector -----------------------------------------------------
+class FlatLogDensity:
+    """Adapts `FieldLevelLogDensity` (dict of scalars + 'white_mesh_') to the flat-vector contract of `nuts_sample`:
+    q = [scalars in ld.names() order ..., white_mesh_.ravel()] as one float32 device tensor."""
+
+    def __init__(self, ld):
+        self.ld = ld
+        self.scalars = [n for n in ld.names() if n != "white_mesh_"]
+        self.shape = tuple(ld.fwd.init_shape)
+        self.n_eval = 0
+
+    def pack(self, sample):
+        from . import nbody
+        w = nbody._f32(sample["white_mesh_"], self.shape).reshape(-1)
+        s = torch.tensor([float(sample[n]) for n in self.scalars], dtype=torch.float32, device=w.device)
+        return torch.cat([s, w])
+
+    def unpack(self, q):
+        ns = len(self.scalars)
+        vals = q[:ns].tolist()
+        out = {n: v for n, v in zip(self.scalars, vals)}
+        out["white_mesh_"] = q[ns:].reshape(self.shape)
+        return out
+
+    def __call__(self, q):
+        self.n_eval += 1
+        lp, grad = self.ld.logdensity_and_grad(self.unpack(q))
+        if not math.isfinite(lp):
+            return -math.inf, torch.zeros_like(q)
+        g = torch.cat([torch.tensor([grad[n] for n in self.scalars], dtype=torch.float32, device=q.device),
+                       grad["white_mesh_"].reshape(-1)])
+        return lp, g

@@ -1,0 +1,42 @@
+"""The host NUTS loop (montecosmo_amd/samplers.py) on targets with known answers (CPU tensors)."""
+import math
+import numpy as np
+import torch
+
+from montecosmo_amd import samplers
+
+
+def test_dual_averaging_converges_to_target():
+    da = samplers.DualAveraging(1.0, target=0.8)
+    eps = 1.0
+    for _ in range(400):                      # acceptance falls with the step size: a = exp(-eps)
+        eps = da.update(math.exp(-eps))
+    assert abs(math.exp(-da.final()) - 0.8) < 0.03
+
+
+def test_nuts_recovers_gaussian_moments():
+    torch.manual_seed(0)
+    d = 40
+    sd = torch.linspace(0.5, 2.0, d, dtype=torch.float64)
+    mu = torch.linspace(-1.0, 1.0, d, dtype=torch.float64)
+
+    def fn(q):
+        z = (q - mu) / sd
+        return float(-0.5 * (z * z).sum()), -(z / sd)
+
+    out = samplers.nuts_sample(fn, torch.zeros(d, dtype=torch.float64), n_warmup=300, n_samples=1500, seed=3)
+    x = torch.stack(out["samples"]).numpy()
+    acc = np.mean([i["accept_stat"] for i in out["infos"][300:]])
+    assert 0.6 < acc < 0.95 and not any(i["diverging"] for i in out["infos"][300:])
+    se = sd.numpy() / np.sqrt(150)            # generous effective-sample-size allowance
+    assert np.all(np.abs(x.mean(0) - mu.numpy()) < 5 * se)
+    assert np.all(np.abs(x.std(0) / sd.numpy() - 1) < 0.2)
+    assert all(i["n_leapfrog"] <= 2 ** 10 for i in out["infos"])
+
+
+def test_nuts_is_reproducible_and_respects_depth():
+    fn = lambda q: (float(-0.5 * (q * q).sum()), -q)
+    a = samplers.nuts_sample(fn, torch.ones(5, dtype=torch.float64), n_warmup=20, n_samples=20, seed=1, max_tree_depth=3)
+    b = samplers.nuts_sample(fn, torch.ones(5, dtype=torch.float64), n_warmup=20, n_samples=20, seed=1, max_tree_depth=3)
+    assert all(torch.equal(x, y) for x, y in zip(a["samples"], b["samples"]))
+    assert all(i["n_leapfrog"] <= 2 ** 3 - 1 + 2 ** 3 for i in a["infos"])
