@@ -1,14 +1,15 @@
 """Log density of the field-level model and its gradient, assembled around `FieldLevelForward` (the piece
 `samplers.py` consumes as `logdensity_fn(position)`; montecosmo/model.py:362-363, :640-679, :840-908).
 
-Built branch (everything else stays in the reference): latents with an unbounded Normal prior -- in sample space
+Built branch (everything else stays in the reference): latents with a Normal prior -- in sample space
 `name_ ~ Normal((loc - loc_fid) / scale_fid, scale / scale_fid)` (model.py:1117-1119) with the affine
 reparametrisation `base = name_ * scale_fid + loc_fid` (bricks.py:270-276); initial conditions `white_mesh_ ~ N(0, 1)`
 per cell with the 'fourier' (rg2cgh) or 'real' (rfftn) preconditioning at unit scale (model.py:1131-1132, :1146);
 `evolve`; the 'quad_gauss' likelihood (model.py:893-908) without mask, with unit selection, one radial bin and phi = 0:
     count = ngbar cell^3 * irfftn(chreshape(rfftn(gxy_mesh), final_shape));  delta = count / selec - 1
     obs ~ QuadGaussian(count, (|s_e + s_ed delta| + 1e-9) sqrt(selec), s_e2 sqrt(selec)),  selec = ngbar cell^3.
-Truncated-normal latents (bounded priors) are not built: give such parameters in `fixed`, or unbounded in `latents`.
+Bounded latents (`low` / `high` in their config) use the reference's detruncated truncated-normal parametrisation
+(utils.py:189-226, :267-311) within |x| < 12 sigma.
 
 The gradient is hand-derived end to end: elementwise likelihood / prior terms here (device tensors), the mesh and
 particle operators through their `*_vjp` twins -- no autodiff framework.
@@ -57,6 +58,37 @@ def quad_gaussian_log_prob_and_grad(value, loc, b, a):
     return lp, torch.where(ok, g_loc, z), torch.where(ok, g_b, z), torch.where(ok, g_a, z)
 
 
+def std2trunc_and_derivs(x, loc, scale, low, high):
+    """std2trunc (utils.py:189-226, |x| < 12) with its first two derivatives, host float64:
+    y = Phi^-1(c_l + (c_h - c_l) Phi(x)) (and the mirrored form for x >= 0); dy/dx = phi(x) (c_h - c_l) / phi(y)."""
+    from scipy.special import ndtr, ndtri
+    if abs(x) >= 12:
+        raise NotImplementedError("the 12-sigma tail approximations of std2trunc are not built")
+    lo, hi = (low - loc) / scale, (high - loc) / scale
+    phi = lambda t: math.exp(-0.5 * t * t) / math.sqrt(2 * math.pi)
+    if x < 0:
+        cl, ch = ndtr(lo), ndtr(hi)
+        y = float(ndtri(cl + (ch - cl) * ndtr(x)))
+        w = ch - cl
+    else:
+        cnl, cnh = ndtr(-lo), ndtr(-hi)
+        y = -float(ndtri(cnh - (cnh - cnl) * ndtr(-x)))
+        w = cnl - cnh
+    d1 = phi(x) * w / phi(y)                    # dy/dx
+    d2 = d1 * (-x + y * d1)                     # d2y/dx2 = d1 (dlog phi(x)/dx - dlog phi(y)/dy dy/dx)
+    return loc + scale * y, scale * d1, scale * d2
+
+
+def detrunc_truncnorm_log_prob_and_grad(x, c):
+    """DetruncTruncNorm.log_prob (utils.py:296-311) and d/dx, plus the base value and d base / dx."""
+    from scipy.special import ndtr
+    y, d1, d2 = std2trunc_and_derivs(x, c["loc_fid"], c["scale_fid"], c["low"], c["high"])
+    z = (y - c["loc"]) / c["scale"]
+    logZ = math.log(ndtr((c["high"] - c["loc"]) / c["scale"]) - ndtr((c["low"] - c["loc"]) / c["scale"]))
+    lp = -0.5 * LOG2PI - math.log(c["scale"]) - 0.5 * z * z - logZ + math.log(abs(d1))
+    return lp, -z / c["scale"] * d1 + d2 / d1, y, d1
+
+
 class FieldLevelLogDensity:
     """log p(sample params, observed counts) and its gradient.
 
@@ -75,7 +107,7 @@ class FieldLevelLogDensity:
         if precond not in ("fourier", "real"):
             raise NotImplementedError("the 'kaiser' preconditioning (a fiducial-model transfer) is not built")
         self.fwd, self.precond = fwd, precond
-        self.latents = {k: {kk: float(vv) for kk, vv in v.items()} for k, v in latents.items()}
+        self.latents = {k: dict({"low": -math.inf, "high": math.inf}, **{kk: float(vv) for kk, vv in v.items()}) for k, v in latents.items()}
         self.fixed = dict(fixed)
         need = set(self.COSMO) | set(bricks.BIAS_KEYS) | {"ngbars"} | set(self.STOCH)
         missing = need - set(self.latents) - set(self.fixed)
@@ -99,10 +131,16 @@ class FieldLevelLogDensity:
         """Sample-space parameter names: scalars (in a fixed order) then 'white_mesh_'."""
         return [k + "_" for k in self.latents] + ["white_mesh_"]
 
+    @staticmethod
+    def _bounded(c):
+        return c["low"] != -math.inf or c["high"] != math.inf
+
     def base_params(self, sample):
         base = dict(self.fixed)
         for name, c in self.latents.items():
-            base[name] = float(sample[name + "_"]) * c["scale_fid"] + c["loc_fid"]
+            x = float(sample[name + "_"])
+            base[name] = std2trunc_and_derivs(x, c["loc_fid"], c["scale_fid"], c["low"], c["high"])[0] if self._bounded(c) \
+                else x * c["scale_fid"] + c["loc_fid"]
         return base
 
     def __call__(self, sample):
@@ -113,12 +151,17 @@ class FieldLevelLogDensity:
         Returns (log density, dict of gradients with the same keys)."""
         fwd = self.fwd
         base = self.base_params(sample)
-        lp, grad = 0.0, {}
+        lp, grad, dbase = 0.0, {}, {}
         for name, c in self.latents.items():
             x = float(sample[name + "_"])
-            mu, sd = (c["loc"] - c["loc_fid"]) / c["scale_fid"], c["scale"] / c["scale_fid"]
-            lp += -0.5 * LOG2PI - math.log(sd) - 0.5 * ((x - mu) / sd) ** 2
-            grad[name + "_"] = -(x - mu) / sd ** 2
+            if self._bounded(c):      # truncated-normal latent (model.py:1120-1121, bricks.py:271-273)
+                l, gl, _, d1 = detrunc_truncnorm_log_prob_and_grad(x, c)
+                lp += l
+                grad[name + "_"], dbase[name] = gl, d1
+            else:
+                mu, sd = (c["loc"] - c["loc_fid"]) / c["scale_fid"], c["scale"] / c["scale_fid"]
+                lp += -0.5 * LOG2PI - math.log(sd) - 0.5 * ((x - mu) / sd) ** 2
+                grad[name + "_"], dbase[name] = -(x - mu) / sd ** 2, c["scale_fid"]
         w = nbody._f32(sample["white_mesh_"], fwd.init_shape)
         lp += float(-0.5 * LOG2PI * w.numel() - 0.5 * (w.double() ** 2).sum())
         white = (rg2cgh(w) if self.precond == "fourier" else nbody.rfftn(w)) * self.transfer
@@ -167,6 +210,6 @@ class FieldLevelLogDensity:
         base_bar["sigma8"] = g["sigma8"]
         if "Omega_m" in self.latents:
             base_bar["Omega_m"] = fwd.cosmo_vjp(ctx, g, params=("Omega_m",))["Omega_m"]
-        for name, c in self.latents.items():
-            grad[name + "_"] += base_bar[name] * c["scale_fid"]
+        for name in self.latents:
+            grad[name + "_"] += base_bar[name] * dbase[name]
         return lp, grad

@@ -259,8 +259,34 @@ def quad_gaussian_log_prob(value, loc, scale1, scale2):
     return np.where(np.abs(a) < 1e-8, lp_gauss, lp_quad)
 
 
+def std2trunc(x, loc=0., scale=1., low=-np.inf, high=np.inf):
+    """montecosmo/utils.py:189-226: transport a standard normal variable to a truncated normal one; |x| < 12 (the
+    12-sigma tail approximations lowtail / hightail are not restated: they raise)."""
+    from scipy.stats import norm
+    lo, hi = (low - loc) / scale, (high - loc) / scale
+    if abs(x) >= 12:
+        raise NotImplementedError("12-sigma tails")
+    if x < 0:
+        cl, ch = norm.cdf(lo), norm.cdf(hi)
+        y = norm.ppf(cl + (ch - cl) * norm.cdf(x))
+    else:
+        cnl, cnh = norm.cdf(-lo), norm.cdf(-hi)
+        y = -norm.ppf(cnh - (cnh - cnl) * norm.cdf(-x))
+    return loc + scale * y
+
+
+def detrunc_truncnorm_log_prob(x, loc, scale, low, high, loc_fid, scale_fid, h=1e-6):
+    """montecosmo/utils.py:296-311 (DetruncTruncNorm.log_prob): TruncatedNormal(loc, scale, low, high).log_prob(
+    std2trunc(x; fid)) + log |d std2trunc / dx| (the reference differentiates with jax.grad; central difference here)."""
+    from scipy.stats import truncnorm
+    y = std2trunc(x, loc_fid, scale_fid, low, high)
+    jac = (std2trunc(x + h, loc_fid, scale_fid, low, high) - std2trunc(x - h, loc_fid, scale_fid, low, high)) / (2 * h)
+    a_, b_ = (low - loc) / scale, (high - loc) / scale
+    return truncnorm.logpdf(y, a_, b_, loc=loc, scale=scale) + np.log(abs(jac))
+
+
 def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo):
-    """log p(sample params, count_obs) of the field-level model for unbounded Normal latents (model.py:1105-1125 prior in
+    """log p(sample params, count_obs) of the field-level model for Normal or truncated-Normal latents (model.py:1105-1125 prior in
     sample space; bricks.py:255-287 affine reparametrisation; model.py:1127-1148 'fourier' / 'real' preconditioning with
     unit scale; model.py:686-838 evolve; model.py:840-908 'quad_gauss' likelihood with no mask, unit selection, one radial
     bin and phi = 0).  `latents`: name -> dict(loc, scale, loc_fid, scale_fid); `fixed`: name -> value of the base
@@ -269,9 +295,14 @@ def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo):
     base = dict(fixed)
     for name, conf in latents.items():
         x = sample[name + "_"]
-        mu, sd = (conf["loc"] - conf["loc_fid"]) / conf["scale_fid"], conf["scale"] / conf["scale_fid"]
-        lp += -0.5 * np.log(2 * np.pi) - np.log(sd) - 0.5 * ((x - mu) / sd) ** 2
-        base[name] = x * conf["scale_fid"] + conf["loc_fid"]
+        low, high = conf.get("low", -np.inf), conf.get("high", np.inf)
+        if low == -np.inf and high == np.inf:
+            mu, sd = (conf["loc"] - conf["loc_fid"]) / conf["scale_fid"], conf["scale"] / conf["scale_fid"]
+            lp += -0.5 * np.log(2 * np.pi) - np.log(sd) - 0.5 * ((x - mu) / sd) ** 2
+            base[name] = x * conf["scale_fid"] + conf["loc_fid"]
+        else:      # model.py:1120-1121, bricks.py:271-273
+            lp += detrunc_truncnorm_log_prob(x, conf["loc"], conf["scale"], low, high, conf["loc_fid"], conf["scale_fid"])
+            base[name] = std2trunc(x, conf["loc_fid"], conf["scale_fid"], low, high)
     w = np.asarray(sample["white_mesh_"], dtype=float)
     lp += np.sum(-0.5 * np.log(2 * np.pi) - 0.5 * w ** 2)
     transfer = np.divide(cfg["init_shape"], cfg["box_size"]).prod() ** .5

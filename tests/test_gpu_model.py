@@ -85,8 +85,8 @@ def test_log_density_and_gradient(gpu, evolution, s_e2):
                                   evolution=evolution, nbody_n_steps=3, lpt_order=2, init_oversamp=1.5, evol_oversamp=2.,
                                   ptcl_oversamp=2., paint_oversamp=2., a_obs=0.65, curved_sky=True, lin_kpow=_kpow(), nbody_a_start=0.1)
     cfg = dict(fwd.config(), final_shape=(8, 8, 8), cell_length=40., precond="fourier")
-    lat = {"Omega_m": dict(loc=0.3111, scale=0.1, loc_fid=0.3111, scale_fid=1e-2),
-           "sigma8": dict(loc=0.8102, scale=0.1, loc_fid=0.8102, scale_fid=1e-2),
+    lat = {"Omega_m": dict(loc=0.3111, scale=0.1, loc_fid=0.3111, scale_fid=1e-2, low=0.05, high=1.),   # model.py:76-83
+           "sigma8": dict(loc=0.8102, scale=0.1, loc_fid=0.8102, scale_fid=1e-2, low=0., high=np.inf),   # model.py:100-111
            "b1": dict(loc=1., scale=1e2, loc_fid=1., scale_fid=1e-2), "b2": dict(loc=0., scale=1e2, loc_fid=0., scale_fid=3e-2),
            "bs2": dict(loc=0., scale=1e2, loc_fid=0., scale_fid=1e-1), "bn2": dict(loc=0., scale=1e3, loc_fid=0., scale_fid=1.),
            "s_ed": dict(loc=0., scale=1e1, loc_fid=0., scale_fid=1e-2)}
@@ -95,7 +95,8 @@ def test_log_density_and_gradient(gpu, evolution, s_e2):
     sample = {k + "_": float(rng.normal(0, 1.0)) for k in lat}
     sample["white_mesh_"] = rng.standard_normal((12, 12, 12))
     truth = dict(sample, **{"b1_": 20.0})
-    base_t = dict(fixed, **{k: truth[k + "_"] * c["scale_fid"] + c["loc_fid"] for k, c in lat.items()})
+    base_t = dict(fixed, **{k: (bo.std2trunc(truth[k + "_"], c["loc_fid"], c["scale_fid"], c["low"], c["high"]) if "low" in c
+                                else truth[k + "_"] * c["scale_fid"] + c["loc_fid"]) for k, c in lat.items()})
     white_t = o.rg2cgh(truth["white_mesh_"]) * np.divide(cfg["init_shape"], cfg["box_size"]).prod() ** .5
     gxy_t, _ = bo.evolve(cfg, make_cosmo(base_t), {k: base_t[k] for k in bo.BIAS_KEYS}, white_t)
     rc = fixed["ngbars"] * 40. ** 3
