@@ -687,9 +687,9 @@ static int ensure_twiddles(mcpm_plan *p) {
     return MCPM_OK;
 }
 
-static FGeom fgeom(const mcpm_plan *p) { return FGeom{p->nx_global, p->g.ny, p->g.nz, p->g.nzh, p->g.nz / 2 + 16}; }
+static FGeom fgeom(const mcpm_plan *p) { return FGeom{p->nx_global, p->g.ny, p->g.nz, p->g.nzh, p->g.nz / 2 + MCPM_NZPAD}; }
 // one local spectrum: nxl planes x ny x nzp complex
-static int64_t spec_elems(const mcpm_plan *p) { return (int64_t)p->nxl * p->g.ny * (p->g.nz / 2 + 16); }
+static int64_t spec_elems(const mcpm_plan *p) { return (int64_t)p->nxl * p->g.ny * (p->g.nz / 2 + MCPM_NZPAD); }
 static double pass_bytes(const mcpm_plan *p, int batch) {  // algorithmic share of one pass of a 3-pass transform
     return (double)batch * (4.0 * p->xwn * p->g.ny * p->g.nz + 8.0 * p->xwn * p->g.ny * p->g.nzh) / 3.0;
 }
@@ -758,7 +758,7 @@ static int z_inverse3_il(mcpm_plan *p, const cf *spec3, float *real_il) {
 
 // packed = all-to-all layout [c][dest rank][xl][y_local][nzp]; every spectrum is spec_elems() complex
 static YLayout ylayout(const mcpm_plan *p, bool packed) {
-    const int64_t nzp = p->g.nz / 2 + 16;
+    const int64_t nzp = p->g.nz / 2 + MCPM_NZPAD;
     auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     if (!packed) return YLayout{spec_elems(p), (int64_t)p->g.ny * nzp, 0, p->g.ny, p->nxl, lg(p->g.ny), p->xw0, p->xwn};
     const int nyl = p->g.ny / p->nranks;

@@ -12,6 +12,9 @@
 #include "../../include/mcpm.h"
 
 #define MCPM_NREDUCE 4096
+#ifndef MCPM_NZPAD
+#define MCPM_NZPAD 16  // complex elements added to the nz/2 pitch of the internal spectra
+#endif
 
 // Stages of the path, for the optional per-stage HIP-event profile (mcpm_plan_profile*).
 enum McpmStage {

@@ -113,7 +113,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     };
     alloc((void **)&p->rho, sizeof(float) * p->M);
     {   // 6 plain half-spectra (rocFFT path) or 1 + 6 spectra in the padded layout of the hand-written FFT
-        const size_t plain = (size_t)p->Mh * 6, padded = (size_t)nx * ny * (nz / 2 + 16) * 7;
+        const size_t plain = (size_t)p->Mh * 6, padded = (size_t)nx * ny * (nz / 2 + MCPM_NZPAD) * 7;
         alloc((void **)&p->spec, sizeof(float) * 2 * (plain > padded ? plain : padded));
     }
     alloc((void **)&p->fmesh, sizeof(float) * p->M * 9);
