@@ -226,3 +226,92 @@ class FlatLogDensity:
         g = torch.cat([torch.tensor([grad[n] for n in self.scalars], dtype=torch.float32, device=q.device),
                        grad["white_mesh_"].reshape(-1)])
         return lp, g
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# MCLMC: microcanonical Langevin Monte Carlo (Robnik, De Luca, Silverstein & Seljak 2023), the sampler the reference's
+# production drivers run through blackjax (montecosmo/samplers.py:273-398: isokinetic McLachlan integrator, step size
+# tuned to an energy-error variance per dimension of 5e-4, L initialised at sqrt(d)).  From scratch, identity metric.
+_MCLACHLAN = 0.1931833275037836
+
+
+def _mclmc_B(u, g, eps, d):
+    """Isokinetic velocity update for the gradient g of the LOG density (force direction e = g / |g|).  Returns the new
+    unit velocity and the kinetic energy change (d - 1) log(cosh delta + e.u sinh delta)."""
+    gn = float(torch.linalg.vector_norm(g))
+    if gn == 0.0:
+        return u, 0.0
+    e = g / gn
+    delta = eps * gn / (d - 1)
+    ue = float(torch.dot(u, e))
+    if delta > 30.0:       # sinh / cosh overflow: the update saturates at u -> e
+        return e.clone(), (d - 1) * (delta + math.log(0.5 * (1.0 + ue) + 1e-300))
+    sh, ch = math.sinh(delta), math.cosh(delta)
+    un = (u + e * (sh + ue * (ch - 1.0))) / (ch + ue * sh)
+    return un / torch.linalg.vector_norm(un), (d - 1) * math.log(ch + ue * sh)
+
+
+def mclmc_step(fn, q, lp, g, u, eps, L, rng):
+    """One MCLMC transition (McLachlan minimal-norm splitting + partial velocity refreshment).
+    Returns (q, lp, g, u, energy_change)."""
+    d = q.numel()
+    lam = _MCLACHLAN
+    u, k1 = _mclmc_B(u, g, lam * eps, d)
+    q = q + (0.5 * eps) * u
+    lp1, g1 = fn(q)
+    u, k2 = _mclmc_B(u, g1, (1 - 2 * lam) * eps, d)
+    q = q + (0.5 * eps) * u
+    lp2, g2 = fn(q)
+    u, k3 = _mclmc_B(u, g2, lam * eps, d)
+    dE = (k1 + k2 + k3) - (lp2 - lp)           # kinetic + potential (V = -log p) change
+    nu = math.sqrt((math.exp(2.0 * eps / L) - 1.0) / d)
+    z = torch.randn(q.shape, dtype=q.dtype, device=q.device, generator=rng.torch_gen(q.device))
+    u = u + nu * z
+    u = u / torch.linalg.vector_norm(u)
+    return q, lp2, g2, u, dE
+
+
+def mclmc_sample(logdensity_and_grad, q0, n_warmup=200, n_samples=200, desired_energy_var=5e-4, L=None, step_size=None,
+                 seed=0, callback=None, keep=None):
+    """Warm-up: the step size is driven to an energy-error variance per dimension of `desired_energy_var`
+    (E[dE^2] / d = C eps^6 for this second-order splitting: C is a down-weighted running average, eps = C^(-1/6)), L stays at its initial value (default sqrt(d), samplers.py:285-287) unless given.  Then
+    `n_samples` transitions are recorded.  Two gradient evaluations per transition."""
+    rng = _Rng(seed)
+    q = q0.clone()
+    d = q.numel()
+    lp, g = logdensity_and_grad(q)
+    L = float(L) if L is not None else math.sqrt(d)
+    eps = float(step_size) if step_size is not None else math.sqrt(d) / 1e4 * 10.0
+    u = torch.randn(q.shape, dtype=q.dtype, device=q.device, generator=rng.torch_gen(q.device))
+    u = u / torch.linalg.vector_norm(u)
+    infos, samples = [], []
+    # step-size predictor (the scheme of blackjax's mclmc adaptation): the energy-error variance per dimension scales as
+    # xi = C eps^6; C is tracked as a weighted running average (outliers down-weighted in log space) and
+    # eps = C^(-1/6) puts xi at the target
+    neff, sigma_xi = 150.0, 1.5
+    gamma = (neff - 1.0) / (neff + 1.0)
+    c_avg, w_sum = 0.0, 0.0
+    t0 = time.perf_counter()
+    for it in range(n_warmup + n_samples):
+        warm = it < n_warmup
+        qn, lpn, gn, un, dE = mclmc_step(logdensity_and_grad, q, lp, g, u, eps, L, rng)
+        bad = not (math.isfinite(dE) and math.isfinite(lpn))
+        if bad:                  # reject a blown-up step, shrink the step
+            eps *= 0.5
+            dE = float("nan")
+        else:
+            q, lp, g, u = qn, lpn, gn, un
+        if warm and not bad:
+            xi = dE * dE / (d * desired_energy_var) + 1e-8
+            w = math.exp(-0.5 * (math.log(xi) / (6.0 * sigma_xi)) ** 2)
+            c_avg = gamma * c_avg + w * xi / eps ** 6
+            w_sum = gamma * w_sum + w
+            eps = (c_avg / w_sum) ** (-1.0 / 6.0)
+        if not warm:
+            samples.append(keep(q) if keep is not None else q.clone())
+        info = {"energy_change": dE, "mse_per_dim": dE * dE / d if not bad else float("nan"), "step_size": eps, "L": L,
+                "warmup": warm, "logdensity": lp, "n_evals": 2}
+        infos.append(info)
+        if callback is not None:
+            callback(it, info)
+    return {"samples": samples, "step_size": eps, "L": L, "infos": infos, "seconds": time.perf_counter() - t0}

@@ -40,3 +40,19 @@ def test_nuts_is_reproducible_and_respects_depth():
     b = samplers.nuts_sample(fn, torch.ones(5, dtype=torch.float64), n_warmup=20, n_samples=20, seed=1, max_tree_depth=3)
     assert all(torch.equal(x, y) for x, y in zip(a["samples"], b["samples"]))
     assert all(i["n_leapfrog"] <= 2 ** 3 - 1 + 2 ** 3 for i in a["infos"])
+
+
+def test_mclmc_recovers_gaussian_moments():
+    d = 100
+    sd = torch.linspace(0.5, 2.0, d, dtype=torch.float64)
+
+    def fn(q):
+        z = q / sd
+        return float(-0.5 * (z * z).sum()), -(z / sd)
+
+    out = samplers.mclmc_sample(fn, torch.ones(d, dtype=torch.float64), n_warmup=2000, n_samples=20000, seed=5, L=10.0)
+    x = torch.stack(out["samples"]).numpy()
+    mse = np.nanmean([i["mse_per_dim"] for i in out["infos"][2000:]])
+    assert 5e-5 < mse < 5e-3                              # the step size was tuned to the energy-error target
+    assert np.all(np.abs(x.std(0) / sd.numpy() - 1) < 0.25)
+    assert np.all(np.abs(x.mean(0)) < 0.5 * sd.numpy())

@@ -1,6 +1,6 @@
 """End-to-end field-level NUTS on one MI355X (BASELINE config 5 in miniature or at size): synthetic truth -> observed
 counts -> `FieldLevelLogDensity` -> `samplers.nuts_sample`.
-usage: python tools/run_nuts_field.py [final_n=146] [n_warmup=200] [n_samples=200] [max_depth=6] [evolution=nbody]"""
+usage: python tools/run_nuts_field.py [final_n=146] [n_warmup=200] [n_samples=200] [max_depth=6] [evolution=nbody] [out.json] [nuts|mclmc]"""
 import json, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -54,13 +54,24 @@ def cb(it, info):
 
 ns = len(flat.scalars)
 t_run = time.perf_counter()
-res = samplers.nuts_sample(flat, q0, n_warmup=n_warm, n_samples=n_samp, max_tree_depth=depth, seed=1, callback=cb,
-                           keep=lambda q: q[:ns].tolist() + [float(q[ns:].std())])
+sampler = sys.argv[7] if len(sys.argv) > 7 else "nuts"
+if sampler == "mclmc":       # montecosmo/samplers.py:273-398 (the production drivers' sampler); 2 gradients per transition
+    def cb(it, info):
+        if it % 50 == 0 or it == n_warm + n_samp - 1:
+            print(f"iter {it:4d} {'warm' if info['warmup'] else 'samp'} lp {info['logdensity']:.1f} eps {info['step_size']:.4f} "
+                  f"mse/dim {info['mse_per_dim']:.2e} [{time.perf_counter() - t_run:.0f} s]", flush=True)
+    res = samplers.mclmc_sample(flat, q0, n_warmup=n_warm, n_samples=n_samp, seed=1, callback=cb,
+                                keep=lambda q: q[:ns].tolist() + [float(q[ns:].std())])
+    for i in res["infos"]:
+        i.update(n_leapfrog=2, accept_stat=float("nan"), diverging=False)
+else:
+    res = samplers.nuts_sample(flat, q0, n_warmup=n_warm, n_samples=n_samp, max_tree_depth=depth, seed=1, callback=cb,
+                               keep=lambda q: q[:ns].tolist() + [float(q[ns:].std())])
 torch.cuda.synchronize()
 wall = time.perf_counter() - t_run
 infos = res["infos"]
 draws = np.array(res["samples"])
-summary = {"final_shape": fwd.final_shape, "evol_shape": fwd.evol_shape, "evolution": evolution, "dimension": int(q0.numel()),
+summary = {"sampler": sampler, "final_shape": fwd.final_shape, "evol_shape": fwd.evol_shape, "evolution": evolution, "dimension": int(q0.numel()),
            "n_warmup": n_warm, "n_samples": n_samp, "max_tree_depth": depth, "wall_s": round(wall, 1),
            "gradient_evals": flat.n_eval, "ms_per_gradient": round(1e3 * wall / max(flat.n_eval - 1, 1), 2),
            "mean_leapfrogs": float(np.mean([i["n_leapfrog"] for i in infos])), "step_size": res["step_size"],
