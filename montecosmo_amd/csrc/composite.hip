@@ -526,9 +526,9 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *v
     MCPM_REQUIRE(p, pos_in && vel_in && force_meshes && pos_bar && vel_bar, MCPM_E_ARG, "mcpm_bullfrog_step_vjp_f32: null buffer");
     MCPM_REQUIRE(p, paint_order >= 1 && paint_order <= 4, MCPM_E_ORDER, "mcpm_bullfrog_step_vjp_f32: paint_order must be 1..4");
     MCPM_TRY(ensure_pscratch(p));
-    const int64_t N = p->Np, M = p->M;
+    const int64_t N = p->Np;
     float *Fb = p->pscratch + 6 * N;
-    const float a = (float)alpha, b = (float)beta, t = (float)tau;
+    const float b = (float)beta, t = (float)tau;
     // force cotangent F_bar = beta (v_bar + tau x_bar), scattered onto three meshes (adjoint of read); already written
     // by the previous call's particle kernel when the caller chained the steps (mcpm_plan_hint_next_adjoint)
     if (!(p->fb_valid && p->fb_beta == b && p->fb_tau == t && p->fb_xb == pos_bar && p->fb_vb == vel_bar))
