@@ -21,14 +21,15 @@ def _kpow():
     return ks, 3.0e4 * (ks / 0.02) / (1 + (ks / 0.02) ** 2.6)
 
 
-@pytest.mark.parametrize("evolution,a_obs,curved", [("lpt", None, True), ("lpt", 0.6, False), ("nbody", 0.7, True)])
-def test_evolve_forward_and_vjp(gpu, evolution, a_obs, curved):
+@pytest.mark.parametrize("evolution,a_obs,curved,ptcl", [("lpt", None, True, 2.), ("lpt", 0.6, False, 2.), ("nbody", 0.7, True, 2.),
+                                                          ("nbody", 0.7, False, 1.5), ("lpt", None, True, 1.5)])
+def test_evolve_forward_and_vjp(gpu, evolution, a_obs, curved, ptcl):
     from montecosmo_amd import bricks, model
     rng = np.random.default_rng(31)
     fwd = model.FieldLevelForward(final_shape=(8, 8, 8), cell_length=40., box_center=(60., -40., 1400.), box_rotvec=(0.1, 0.2, -0.1),
                                   evolution=evolution, nbody_n_steps=3, lpt_order=2, init_oversamp=1.5, evol_oversamp=2.,
-                                  ptcl_oversamp=2., paint_oversamp=2., a_obs=a_obs, curved_sky=curved, lin_kpow=_kpow(),
-                                  nbody_a_start=0.1)
+                                  ptcl_oversamp=ptcl, paint_oversamp=2., a_obs=a_obs, curved_sky=curved, lin_kpow=_kpow(),
+                                  nbody_a_start=0.1)      # ptcl 1.5: particle lattice (12^3) coarser than the meshes (16^3)
     cfg = fwd.config()
     assert cfg["init_shape"] == (12, 12, 12) and cfg["evol_shape"] == (16, 16, 16)
     cosmo, cosmo_o = bricks.Planck18(), obg.Planck18()
