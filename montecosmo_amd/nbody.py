@@ -755,8 +755,6 @@ def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 
     `integrator='fastpm'` selects the alpha_fpm coefficient (nbody.py:921-931).
     `return_ctx=True` also returns the context for `nbody_bf_vjp` (checkpoints are then kept).
     """
-    if paint_deconv or grad_fd != np.inf or lap_fd != np.inf:
-        raise NotImplementedError("nbody_bf runs the model's configuration: paint_deconv=False, spectral kernels")
     if fn is not None:
         raise NotImplementedError("only the default save function (the state itself) is implemented")
     n_steps = int(n_steps)
@@ -771,6 +769,21 @@ def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 
     plan = get_plan(mesh_shape, ptcl_shape)
     dg, alphas, betas, lpt_s = _step_scalars(cosmo, a0, a1, n_steps, integrator)
     N = plan.N
+    if paint_deconv or grad_fd != np.inf or lap_fd != np.inf:
+        # The options the model never selects on this branch (model.py:771-773): forward only, one pm_forces call per step
+        # (paint -> rocFFT / hand-written R2C -> FD or deconvolved k-space kernel -> 3 C2R -> read) instead of the fused loop.
+        if return_ctx or not (snapshots is None or (isinstance(snapshots, int) and snapshots <= 1)):
+            raise NotImplementedError("paint_deconv / finite-difference kernels: forward final state only (no VJP, no snapshots)")
+        lp0 = LatticePos.regular(mesh_shape, ptcl_shape)
+        dpos, v = lpt(cosmo, spec, lp0, a0, lpt_order=lpt_order, read_order=1, grad_fd=grad_fd, lap_fd=lap_fd)
+        x = dpos + v * (dg / 2)
+        for i in range(n_steps):
+            F = pm_forces(LatticePos(x, mesh_shape, ptcl_shape), mesh_shape, paint_order, paint_deconv=paint_deconv, grad_fd=grad_fd,
+                          lap_fd=lap_fd)
+            v = float(alphas[i]) * v + float(betas[i]) * F
+            x = x + v * (dg / 2 if i == n_steps - 1 else dg)
+        lp = LatticePos(x, mesh_shape, ptcl_shape)
+        return (lp, v) if lattice_out else (lp.to_absolute()[None], v[None])
     x = torch.empty((N, 3), dtype=torch.float32, device=spec.device)
     v = torch.empty((N, 3), dtype=torch.float32, device=spec.device)
     ckpt = None

@@ -370,6 +370,20 @@ def test_lpt_light_cone(nb, lpt_order):
         assert rel_l2(to_np(sb_g["g2"]), sb_o["g2"]) < 1e-5 and rel_l2(to_np(sb_g["dg2dg"]), sb_o["dg2dg"]) < 1e-5
 
 
+@pytest.mark.parametrize("opts", [dict(paint_deconv=True), dict(grad_fd=4, lap_fd=2), dict(paint_deconv=True, grad_fd=2, lap_fd=4)])
+def test_nbody_bf_deconv_and_fd_kernels(nb, opts):
+    """nbody.py:967-1002 with the options the model leaves at their defaults: paint_deconv (:590-593) and the
+    finite-difference Laplace / gradient kernels (:125-163), forward state against the oracle."""
+    from montecosmo_amd import bricks, synth
+    n, n_steps = 16, 4
+    shape = (n, n, n)
+    spec = synth.init_mesh(n, seed=2, rms_disp=1.0)
+    pos = bricks.regular_pos(shape)
+    p_g, v_g = nb.nbody_bf(bricks.Planck18(), spec, pos, a0=0.1, a1=0.9, n_steps=n_steps, **opts)
+    p_o, v_o = o.nbody_bf(obg.Planck18(), spec.astype(np.complex128), pos, a0=0.1, a1=0.9, n_steps=n_steps, **opts)
+    assert rel_l2(to_np(p_g)[0] - pos, p_o[0] - pos) < 1e-5 and rel_l2(to_np(v_g)[0], v_o[0]) < 1e-5
+
+
 @pytest.mark.parametrize("snapshots", [3, [0.3, 0.55, 1.0]])
 def test_nbody_bf_snapshots(nb, snapshots):
     """SaveAt(ts=...) (nbody.py:990-997): linear interpolation of the Euler solution between steps."""
