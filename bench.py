@@ -45,6 +45,8 @@ def parse():
                     "(measures the slab path's own overhead: ghost planes, windowed passes, host calls)")
     ap.add_argument("--forward-only", action="store_true", help="time forward steps only (BASELINE config 2)")
     ap.add_argument("--ghost", type=int, default=8)
+    ap.add_argument("--fixed-ghost", action="store_true", help="slabs: always exchange all ghost planes (default: only the "
+                    "planes each step's displacements can reach)")
     ap.add_argument("--cpu-mesh", type=int, default=128)
     return ap.parse_args()
 
@@ -161,12 +163,12 @@ class Runner:
 class SlabRunner:
     """The same K forward + K adjoint steps on an x-slab of the mesh (one rank of N)."""
 
-    def __init__(self, n, K, device, ghost):
+    def __init__(self, n, K, device, ghost, adaptive_ghost=True):
         from montecosmo_amd import nbody, bricks, synth, dist
         self.n, self.K = n, K
         shape = (n, n, n)
         self.comm = dist.TorchComm() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else dist.LocalComm()
-        self.pm = dist.SlabPM(shape, self.comm, ghost, device)
+        self.pm = dist.SlabPM(shape, self.comm, ghost, device, adaptive_ghost=adaptive_ghost)
         pm = self.pm
         cosmo = bricks.Planck18()
         self.dg, self.alphas, self.betas, self.lpt_s = nbody._step_scalars(cosmo, 0.0, 1.0, K, "bullfrog")
@@ -184,6 +186,7 @@ class SlabRunner:
         self.vel_bar = torch.from_numpy(rng.standard_normal((pm.Nl, 3), dtype=np.float32)).to(device)
         self.xb, self.vb = torch.empty((pm.Nl, 3), **f32), torch.empty((pm.Nl, 3), **f32)
         self.sbar = torch.zeros((2 * K + 1,), dtype=torch.float64, device=device)
+        self.depths = [None] * K
 
     def forward(self, steps):
         K = self.K
@@ -191,6 +194,7 @@ class SlabRunner:
             tau = self.dg / 2 if i == K - 1 else self.dg
             self.pm.step(self.states[i, 0], self.states[i, 1], self.alphas[i], self.betas[i], tau, self.f3s[i],
                          self.states[i + 1, 0], self.states[i + 1, 1])
+            self.depths[i] = self.pm.ge
 
     def backward(self, steps):
         K = self.K
@@ -201,7 +205,7 @@ class SlabRunner:
             self.pm.step_vjp(self.states[i, 0], self.states[i, 1], self.f3s[i], self.alphas[i], self.betas[i], tau,
                              self.xb, self.vb, C.c_void_p(self.sbar.data_ptr() + 8 * i),
                              C.c_void_p(self.sbar.data_ptr() + 8 * (K + i)), 0.5 if i == K - 1 else 1.0,
-                             C.c_void_p(self.sbar.data_ptr() + 8 * 2 * K))
+                             C.c_void_p(self.sbar.data_ptr() + 8 * 2 * K), depth=self.depths[i])
 
     def run(self, steps):
         while steps > 0:
@@ -283,7 +287,7 @@ def main():
     K, W, n, NS = args.steps, args.warmup, args.mesh, args.n_steps
 
     slab = (dist and not args.replicas) or args.force_slab
-    r = SlabRunner(n, NS, device, args.ghost) if slab else Runner(n, NS, device)
+    r = SlabRunner(n, NS, device, args.ghost, not args.fixed_ghost) if slab else Runner(n, NS, device)
     if args.forward_only:
         assert not slab, "--forward-only is a single-GPU configuration"
         r.forward_only = True

@@ -21,6 +21,7 @@ all-to-all / y / z passes follow; the init_mesh cotangent is assembled with one 
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import numpy as np
 import torch
@@ -66,6 +67,9 @@ class LocalComm:
 
     def all_reduce_sum(self, t):
         return t
+
+    def all_reduce_max_float(self, v):
+        return float(v)
 
     def all_gather_cat(self, t):
         return t
@@ -130,6 +134,13 @@ class TorchComm:
         self.td.all_reduce(h, group=self.group)
         return h.to(t.device)
 
+    def all_reduce_max_float(self, v):
+        """Maximum over ranks of one device (or host) scalar, returned as a python float (synchronises the host)."""
+        t = v.detach().reshape(1).float() if isinstance(v, torch.Tensor) else torch.tensor([float(v)])
+        t = t.cpu() if self.stage else t.to(torch.device("cuda", torch.cuda.current_device()))
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
     def all_gather_cat(self, t):
         h = self._h(t).contiguous()
         outs = [torch.empty_like(h) for _ in range(self.world)]
@@ -140,19 +151,24 @@ class TorchComm:
 class HaloMixin:
     """Ghost-plane algebra of an x-slab (needs self.comm, self.G, self.nxl); meshes are (..., nxl + 2G, ny, nz)."""
 
+    def depth(self):
+        """Ghost planes the exchanges cover: all G, or the `self.ge` planes next to the interior that this step's
+        displacements can reach (SlabPM.set_depth)."""
+        return min(self.G, getattr(self, "ge", self.G))
+
     def halo_add(self, ext, async_op=False):
         """Adds my ghost planes into the neighbours' interiors (after a paint).  With async_op returns a handle
         whose wait() completes the exchange and does the additions."""
-        G, nxl = self.G, self.nxl
-        lo = ext[..., :G, :, :].contiguous()
-        hi = ext[..., G + nxl:, :, :].contiguous()
+        G, nxl, d = self.G, self.nxl, self.depth()
+        lo = ext[..., G - d:G, :, :].contiguous()
+        hi = ext[..., G + nxl:G + nxl + d, :, :].contiguous()
         from_l, from_r = torch.empty_like(hi), torch.empty_like(lo)
         h = self.comm.neighbour_exchange(lo, hi, from_l, from_r, async_op=async_op)
 
         def finish():
             h.wait()
-            ext[..., G:2 * G, :, :] += from_l          # the left neighbour's high ghost = my lowest interior planes
-            ext[..., nxl:nxl + G, :, :] += from_r      # the right neighbour's low ghost = my highest interior planes
+            ext[..., G:G + d, :, :] += from_l                  # the left neighbour's high ghost = my lowest interior planes
+            ext[..., G + nxl - d:G + nxl, :, :] += from_r      # the right neighbour's low ghost = my highest interior planes
 
         if async_op:
             return _Works([], finish)
@@ -162,16 +178,16 @@ class HaloMixin:
     def halo_fill(self, ext, async_op=False):
         """Fills my ghost planes from the neighbours' interiors (before a read).  With async_op returns a handle
         whose wait() completes the exchange and writes the ghosts (lets the next component's FFT passes overlap)."""
-        G, nxl = self.G, self.nxl
-        to_l = ext[..., G:2 * G, :, :].contiguous()          # becomes the left neighbour's high ghost
-        to_r = ext[..., nxl:nxl + G, :, :].contiguous()      # becomes the right neighbour's low ghost
+        G, nxl, d = self.G, self.nxl, self.depth()
+        to_l = ext[..., G:G + d, :, :].contiguous()                  # becomes the left neighbour's high ghost
+        to_r = ext[..., G + nxl - d:G + nxl, :, :].contiguous()      # becomes the right neighbour's low ghost
         from_l, from_r = torch.empty_like(to_r), torch.empty_like(to_l)
         h = self.comm.neighbour_exchange(to_l, to_r, from_l, from_r, async_op=async_op)
 
         def finish():
             h.wait()
-            ext[..., :G, :, :] = from_l
-            ext[..., G + nxl:, :, :] = from_r
+            ext[..., G - d:G, :, :] = from_l
+            ext[..., G + nxl:G + nxl + d, :, :] = from_r
 
         if async_op:
             return _Works([], finish)
@@ -182,7 +198,8 @@ class HaloMixin:
 class SlabPM(HaloMixin):
     """Slab-decomposed PM stepper for one rank."""
 
-    def __init__(self, mesh_shape, comm=None, ghost=16, device=None):
+    def __init__(self, mesh_shape, comm=None, ghost=16, device=None, adaptive_ghost=True):
+        self.adaptive_ghost = bool(adaptive_ghost)
         self.comm = comm if comm is not None else LocalComm()
         P, r = self.comm.world, self.comm.rank
         nx, ny, nz = (int(s) for s in mesh_shape)
@@ -243,10 +260,10 @@ class SlabPM(HaloMixin):
     def _windows(self, pending):
         """Plane windows in issue order.  With a halo exchange pending (or about to start) the passes are split into
         the G edge planes on each side, which the exchange touches, and the inner planes, which it does not."""
-        G, nxl = self.G, self.nxl
-        if not pending or nxl <= 2 * G:
+        d, nxl = self.depth(), self.nxl
+        if not pending or nxl <= 2 * d:
             return None, [(0, nxl)]
-        return (G, nxl - 2 * G), [(0, G), (nxl - G, G)]
+        return (d, nxl - 2 * d), [(0, d), (nxl - d, d)]
 
     def _win(self, w):
         self.call("mcpm_slab_set_window", int(w[0]), int(w[1]))
@@ -388,15 +405,37 @@ class SlabPM(HaloMixin):
         return out, np.array([sb[0], -sb[1], -sb[2]])
 
     # ---- one BullFrog step and its adjoint -----------------------------------------------------------------
+    def set_depth(self, x, paint_order=2, depth=None):
+        """Ghost depth of a step whose particles sit at displacements x: a CIC deposit / gather reaches at most
+        floor(max |d_x|) + 1 planes beyond the slab (order-3/4 stencils one more), so only those planes (plus one spare)
+        are exchanged instead of all G.  The maximum is taken over all ranks (one tiny all-reduce; synchronises the
+        host once per step).  adaptive_ghost=False keeps the full depth."""
+        if not self.adaptive_ghost:
+            self.ge = self.G
+            return
+        if depth is not None:       # the adjoint of a step revisits the forward step's positions: reuse its depth
+            self.ge = int(depth)
+            return
+        dmax = self.comm.all_reduce_max_float(x[:, 0].abs().max())
+        reach = int(math.floor(dmax)) + 1 + (1 if paint_order > 2 else 0)
+        self.ge = max(1, min(self.G, reach + 1))
+
     def step(self, x, v, alpha, beta, tau, f3_out, x_out, v_out, paint_order=2):
         """x, v: (Nl,3) local state; f3_out: (3, nxe, ny, nz) receives the ghost-filled force meshes."""
+        self.set_depth(x, paint_order)
+        if self.ge < self.G:      # ghost planes beyond the exchanged depth are never read, but keep checkpoints defined
+            f3_out[:, :self.G - self.ge].zero_()
+            f3_out[:, self.G + self.nxl + self.ge:].zero_()
         self.call("mcpm_paint_f32", _p(x), self.Nl, POS_LATTICE, None, 1, 1.0, paint_order, _p(self.rho), 0)
         self.force_meshes(self.rho, f3_out, rho_add=self.halo_add(self.rho, async_op=True))
         self.call("mcpm_kick_drift_f32", _p(x), _p(v), self.Nl, POS_LATTICE, _p(f3_out), paint_order, float(alpha),
                   float(beta), float(tau), _p(x_out), _p(v_out))
 
-    def step_vjp(self, x, v, f3, alpha, beta, tau, xb, vb, abar_ptr, bbar_ptr, dtau_ddg=1.0, dgbar_ptr=None, paint_order=2):
-        """Adjoint of `step`: xb, vb (cotangents of its outputs) are updated in place."""
+    def step_vjp(self, x, v, f3, alpha, beta, tau, xb, vb, abar_ptr, bbar_ptr, dtau_ddg=1.0, dgbar_ptr=None, paint_order=2,
+                 depth=None):
+        """Adjoint of `step`: xb, vb (cotangents of its outputs) are updated in place.  `depth`: the ghost depth the
+        forward step used (`self.ge` after `step`), saving its re-measurement."""
+        self.set_depth(x, paint_order, depth)
         self.call("mcpm_kick_f32", _p(vb), _p(xb), self.Nl, float(beta), float(beta * tau), _p(self.Fb))
         self.call("mcpm_paint3_f32", _p(x), self.Nl, POS_LATTICE, _p(self.Fb), paint_order, _p(self.f3), 0)
         adds = [self.halo_add(self.f3[c], async_op=True) for c in range(3)]   # overlap with the z / y passes below
@@ -425,14 +464,16 @@ def nbody_bf_slab(cosmo, init_mesh, a0=0., a1=1., n_steps=5, paint_order=2, lpt_
     f3s = torch.zeros((K, 3, pm.nxe) + shape[1:], dtype=torch.float32, device=spec.device) if return_ctx else None
     pm.lpt(spec, int(lpt_order), lpt_s[0], lpt_s[1], lpt_s[2], states[0, 0], states[0, 1])      # slab-decomposed LPT start
     states[0, 0] += states[0, 1] * (dg / 2)
+    depths = []
     for i in range(K):
         tau = dg / 2 if i == K - 1 else dg
         pm.step(states[i, 0], states[i, 1], alphas[i], betas[i], tau, f3s[i] if return_ctx else pm.f3,
                 states[i + 1, 0], states[i + 1, 1], paint_order)
+        depths.append(pm.ge)
     out = (states[K, 0], states[K, 1])
     if return_ctx:
         return out, SlabCtx(pm=pm, spec=spec, states=states, f3s=f3s, dg=dg, alphas=alphas, betas=betas, lpt_s=lpt_s,
-                            n_steps=K, lpt_order=int(lpt_order), paint_order=int(paint_order))
+                            n_steps=K, lpt_order=int(lpt_order), paint_order=int(paint_order), depths=depths)
     return out
 
 
@@ -448,7 +489,7 @@ def nbody_bf_slab_vjp(ctx, disp_bar, vel_bar):
         tau = ctx.dg / 2 if i == K - 1 else ctx.dg
         pm.step_vjp(ctx.states[i, 0], ctx.states[i, 1], ctx.f3s[i], ctx.alphas[i], ctx.betas[i], tau, xb, vb,
                     C.c_void_p(sbar.data_ptr() + 8 * i), C.c_void_p(sbar.data_ptr() + 8 * (K + i)),
-                    0.5 if i == K - 1 else 1.0, C.c_void_p(sbar.data_ptr() + 8 * 2 * K), ctx.paint_order)
+                    0.5 if i == K - 1 else 1.0, C.c_void_p(sbar.data_ptr() + 8 * 2 * K), ctx.paint_order, depth=ctx.depths[i])
     sbar[2 * K] += 0.5 * (xb.double() * ctx.states[0, 1].double()).sum()    # initial half drift x'_0 = x_0 + v_0 dg/2
     vb += xb * (ctx.dg / 2)
     sbar = pm.comm.all_reduce_sum(sbar).cpu().numpy()
