@@ -22,7 +22,7 @@ from ._lib import lib, check, POS_ABSOLUTE, POS_LATTICE
 from .utils import safe_div, ch2rshape, r2chshape, scale_shape, chreshape, chreshape_vjp  # noqa: F401 (re-exported like the reference)
 
 __all__ = [
-    "rfftk", "fftk", "invlaplace_hat", "gradient_hat", "gaussian_hat", "rectangular", "rectangular_hat",
+    "rfftk", "fftk", "invlaplace_hat", "gradient_hat", "gaussian_hat", "top_hat", "rectangular", "rectangular_hat", "k2ell", "ell2k",
     "paint", "read", "paint_vjp", "read_vjp", "pm_forces", "pm_forces_vjp", "pm_forces2", "lpt", "lpt_vjp",
     "a2g", "a2g2", "a2f", "a2f2", "a2dg2dg", "g2a", "g2g2", "g2f", "g2f2", "g2dg2dg", "a2chi", "chi2a",
     "bullfrog_vf", "nbody_bf", "nbody_bf_vjp", "cosmo_vjp", "alpha_bf", "alpha_fpm", "LatticePos", "get_plan",
@@ -224,6 +224,15 @@ def gaussian_hat(kvec, kcut=np.inf):
         return 1.
     rcut = 2 * np.pi / kcut
     return np.exp(-sum(k ** 2 for k in kvec) * rcut ** 2 / 2)
+
+
+def top_hat(kvec, kcut=np.inf):
+    """Top-hat kernel in the Fourier domain, isotropic (nbody.py:191-217): 1. for kcut = inf, else the boolean mask
+    k^2 < kcut^2."""
+    if kcut == np.inf:
+        return 1.
+    kk = sum(ki ** 2 for ki in kvec)
+    return np.where(kk < kcut ** 2, True, False)
 
 
 def rectangular(s, order):
@@ -663,6 +672,16 @@ def chi2a(cosmo, chi, log10_amin=dist_log10_amin, steps=dist_steps):
     """nbody.py:862-884"""
     c = _dist_cache(cosmo, log10_amin, steps)
     return _interp(chi, c["chi"][::-1], c["a"][::-1])
+
+
+def k2ell(cosmo, a, k):
+    """Comoving wavenumber k -> multipole ell in the Limber approximation (nbody.py:886-890)."""
+    return a2chi(cosmo, a) * k - 0.5
+
+
+def ell2k(cosmo, a, ell):
+    """Multipole ell -> comoving wavenumber k in the Limber approximation (nbody.py:892-896)."""
+    return (ell + 0.5) / a2chi(cosmo, a)
 
 
 # ------------------------------------------------------------------------------------------------
