@@ -60,7 +60,32 @@ def make_paint(n, N, seed):
     np.savez_compressed(os.path.join(HERE, "paint_read.npz"), **out)
 
 
+def make_evolve():
+    """FieldLevelModel.evolve fixture (model.py:686-838; oracle/bias_oracle.py::evolve): white noise + bias -> galaxy mesh,
+    for the light-cone 2LPT and the fixed-a_obs N-body branches, with the log density of one observed count mesh."""
+    from oracle import bias_oracle as bo
+    ks = np.logspace(-3, 1, 128)
+    kpow = (ks, 3.0e4 * (ks / 0.02) / (1 + (ks / 0.02) ** 2.6))
+    rng = np.random.default_rng(77)
+    out = {"ks": ks, "pows": kpow[1]}
+    bias = dict(b1=0.8, b2=0.2, bs2=-0.15, b3=0.1, bds2=0.1, bs3=-0.05, bn2=20.0, bnpar=5.0)
+    box = np.array([320., 320., 320.])
+    white = np.fft.rfftn(rng.standard_normal((12, 12, 12))) * (12 ** 3 / box.prod()) ** .5
+    out["white"] = white
+    out["bias_keys"], out["bias_vals"] = np.array(list(bias)), np.array(list(bias.values()))
+    for tag, evolution, a_obs in (("lpt_lc", "lpt", None), ("nbody", "nbody", 0.7)):
+        cfg = dict(init_shape=(12, 12, 12), evol_shape=(16, 16, 16), ptcl_shape=(16, 16, 16), paint_shape=(16, 16, 16), box_size=box,
+                   box_center=np.array([60., -40., 1400.]), box_rotvec=np.array([.1, .2, -.1]), a_obs=a_obs, curved_sky=True,
+                   evolution=evolution, nbody_a_start=0.1, nbody_n_steps=3, lpt_order=2, paint_order=2, paint_deconv=True,
+                   interlace_order=2, lin_kpow=kpow)
+        gxy, aux = bo.evolve(cfg, obg.Planck18(), bias, white)
+        out[f"gxy_{tag}"] = gxy
+        out[f"weights_{tag}"] = aux["weights"]
+    np.savez_compressed(os.path.join(HERE, "evolve_16.npz"), **out)
+
+
 if __name__ == "__main__":
+    make_evolve()
     make(16, 4, 0.1, 1.0, 0)
     make(32, 5, 0.0, 1.5, 1)
     make_paint(12, 3000, 2)
