@@ -557,10 +557,29 @@ def lpt(cosmo, init_mesh, pos, a, lpt_order: int = 2, read_order: int = 2, grad_
     init_mesh = torch.as_tensor(init_mesh)
     if not init_mesh.is_complex():
         init_mesh = rfftn(init_mesh)
+    scalar_a = not isinstance(a, torch.Tensor) and (np.ndim(a) == 0 or np.size(a) == 1)
+    if isinstance(pos, LatticePos) and pos.is_regular and int(read_order) == 1:
+        # the model's call (model.py:763-764: regular lattice, NGP): the fused library path -- force meshes of both
+        # orders accumulated straight onto the lattice (mcpm_lpt_f32), no separate read passes
+        spec = _c64(init_mesh)
+        plan = get_plan(ch2rshape(spec.shape), pos.ptcl_shape)
+        n = plan.N
+        dpos = torch.empty((n, 3), dtype=torch.float32, device=spec.device)
+        vel = torch.empty((n, 3), dtype=torch.float32, device=spec.device)
+        if scalar_a:
+            plan.call("mcpm_lpt_f32", _ptr(spec), int(lpt_order), float(a2g(cosmo, a)), float(a2g2(cosmo, a)), float(a2dg2dg(cosmo, a)),
+                      _fd(lap_fd), _fd(grad_fd), _ptr(dpos), _ptr(vel))
+            return dpos, vel
+        F2, F1 = dpos, vel                        # (g, g2, dg2dg) = (0, -1, 0): dpos = F2, vel = F1
+        plan.call("mcpm_lpt_f32", _ptr(spec), int(lpt_order), 0.0, -1.0, 0.0, _fd(lap_fd), _fd(grad_fd), _ptr(F2), _ptr(F1))
+        gt = _growth_tab3(cosmo, a, n)
+        dpos, vel = torch.empty_like(F1), torch.empty_like(F1)
+        plan.call("mcpm_lpt_combine_f32", _ptr(F1), _ptr(F2) if lpt_order == 2 else None, _ptr(gt), n, _ptr(dpos), _ptr(vel))
+        return dpos, vel
     force1 = pm_forces(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
     force2 = pm_forces2(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd) if lpt_order == 2 else None
     n = force1.shape[0]
-    if not isinstance(a, torch.Tensor) and (np.ndim(a) == 0 or np.size(a) == 1):
+    if scalar_a:
         dpos, vel = float(a2g(cosmo, a)) * force1, force1
         if force2 is not None:
             dpos = dpos - float(a2g2(cosmo, a)) * force2
