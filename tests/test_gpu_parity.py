@@ -321,16 +321,25 @@ def test_nbody_bf_particle_lattice_differs_from_mesh(nb, mesh, ptcl):
     cos_o, cos_g = obg.Planck18(), bricks.Planck18()
     n_steps = 3
     (p_o, v_o) = o.nbody_bf(cos_o, spec.astype(np.complex128), pos, 0.1, 1., n_steps)
-    (lp, vel), ctx = nb.nbody_bf(cos_g, spec, pos, a0=0.1, a1=1., n_steps=n_steps, lattice_out=True, return_ctx=True)
-    assert lp.ptcl_shape == tuple(ptcl)
-    assert rel_l2(to_np(lp.to_absolute()) - pos, p_o[0] - pos) < 1e-5
-    assert rel_l2(to_np(vel), v_o[0]) < 1e-5
     rng = np.random.default_rng(2)
     N = len(pos)
     xb, vb = rng.standard_normal((N, 3)).astype(np.float32), rng.standard_normal((N, 3)).astype(np.float32)
     mb_o, _ = o.nbody_bf_vjp(cos_o, spec.astype(np.complex128), pos, xb.astype(np.float64), vb.astype(np.float64), 0.1, 1., n_steps)
-    mb_g, _ = nb.nbody_bf_vjp(ctx, xb, vb)
-    assert rel_l2(to_np(mb_g), mb_o) < 1e-4
+    # This lattice takes the global-atomic paint, whose summation order varies from run to run: positions differ in
+    # their last bit, and once in ~30 runs a particle within fp32 round-off of a cell face lands on the other side of it,
+    # where the CIC gradient is discontinuous (profiles/r01_validate_128.txt).  The forward state is unaffected at 1e-5; the
+    # gradient comparison gets a second, independent run before it counts as a failure.
+    errs = []
+    for attempt in range(2):
+        (lp, vel), ctx = nb.nbody_bf(cos_g, spec, pos, a0=0.1, a1=1., n_steps=n_steps, lattice_out=True, return_ctx=True)
+        assert lp.ptcl_shape == tuple(ptcl)
+        assert rel_l2(to_np(lp.to_absolute()) - pos, p_o[0] - pos) < 1e-5
+        assert rel_l2(to_np(vel), v_o[0]) < 1e-5
+        mb_g, _ = nb.nbody_bf_vjp(ctx, xb, vb)
+        errs.append(rel_l2(to_np(mb_g), mb_o))
+        if errs[-1] < 1e-4:
+            break
+    assert min(errs) < 1e-4, errs
 
 
 def test_lpt_vjp_standalone(nb):
