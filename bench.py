@@ -205,7 +205,8 @@ class SlabRunner:
             self.pm.step_vjp(self.states[i, 0], self.states[i, 1], self.f3s[i], self.alphas[i], self.betas[i], tau,
                              self.xb, self.vb, C.c_void_p(self.sbar.data_ptr() + 8 * i),
                              C.c_void_p(self.sbar.data_ptr() + 8 * (K + i)), 0.5 if i == K - 1 else 1.0,
-                             C.c_void_p(self.sbar.data_ptr() + 8 * 2 * K), depth=self.depths[i])
+                             C.c_void_p(self.sbar.data_ptr() + 8 * 2 * K), depth=self.depths[i],
+                             next_beta_tau=(self.betas[i - 1], self.dg) if i > 0 else None)
 
     def run(self, steps):
         while steps > 0:

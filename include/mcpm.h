@@ -223,6 +223,10 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *plan, const float *pos_in, const float
    mcpm_bullfrog_step_vjp_f32 call skips its own pass over the cotangents IF it is given the same pos_bar / vel_bar
    pointers and exactly these scalars.  Only valid when the caller does not modify the cotangents in between. */
 int mcpm_plan_hint_next_adjoint(mcpm_plan *plan, double beta_next, double tau_next);
+/* After a hinted mcpm_step_adjoint_particles_f32: *fb = plan-owned F_bar = beta (v_bar + tau x_bar) (Np x 3 floats) of the
+   next adjoint step if (beta, tau, pos_bar, vel_bar) are the hinted ones, else NULL (then the caller forms it itself with
+   mcpm_kick_f32).  For callers that compose the adjoint step from the pieces (the slab-decomposed stepper). */
+int mcpm_plan_chained_fb(mcpm_plan *plan, double beta, double tau, const float *pos_bar, const float *vel_bar, float **fb);
 /* The particle half of that adjoint alone (fused gradient gather of the three force meshes and of rho_bar, kick /
    drift adjoints, scalar cotangents); used by the slab path, where the host exchanges ghost planes in between. */
 int mcpm_step_adjoint_particles_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in,

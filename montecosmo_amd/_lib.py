@@ -27,6 +27,7 @@ SIGNATURES = {
     "mcpm_last_error": (C.c_char_p, [C.c_void_p]),
     "mcpm_version": (C.c_char_p, []),
     "mcpm_plan_last_outliers": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mcpm_plan_chained_fb": (C.c_int, [C.c_void_p, C.c_double, C.c_double, _f32p, _f32p, C.POINTER(C.c_void_p)]),
     "mcpm_plan_set_halo": (C.c_int, [C.c_void_p, C.c_int]),
     "mcpm_plan_set_tile_order": (C.c_int, [C.c_void_p, C.c_int]),
     "mcpm_fft_r2c": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int]),

@@ -541,6 +541,19 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *v
                                   vel_bar, alpha_bar, beta_bar, dtau_ddg, dg_bar);
 }
 
+// The force cotangent F_bar = beta (v_bar + tau x_bar) of the NEXT adjoint step, if the previous
+// mcpm_step_adjoint_particles_f32 call was hinted (mcpm_plan_hint_next_adjoint) with exactly these (beta, tau) and
+// cotangent arrays: *fb then points at plan-owned memory (Np x 3 floats, valid until the next hinted call) and the caller
+// can skip forming it.  *fb = NULL otherwise.  Used by callers that compose the adjoint step themselves (slabs).
+int mcpm_plan_chained_fb(mcpm_plan *p, double beta, double tau, const float *pos_bar, const float *vel_bar, float **fb) {
+    if (!p || !fb) return MCPM_E_ARG;
+    *fb = nullptr;
+    if (p->fb_valid && p->fb_beta == (float)beta && p->fb_tau == (float)tau && p->fb_xb == pos_bar && p->fb_vb == vel_bar && p->pscratch)
+        *fb = p->pscratch + 6 * p->Np;
+    p->fb_valid = 0;
+    return MCPM_OK;
+}
+
 int mcpm_step_adjoint_particles_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes,
                                     const float *rho_bar, double alpha, double beta, double tau, int paint_order,
                                     float *pos_bar, float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg,

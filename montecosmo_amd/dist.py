@@ -432,14 +432,22 @@ class SlabPM(HaloMixin):
                   float(beta), float(tau), _p(x_out), _p(v_out))
 
     def step_vjp(self, x, v, f3, alpha, beta, tau, xb, vb, abar_ptr, bbar_ptr, dtau_ddg=1.0, dgbar_ptr=None, paint_order=2,
-                 depth=None):
+                 depth=None, next_beta_tau=None):
         """Adjoint of `step`: xb, vb (cotangents of its outputs) are updated in place.  `depth`: the ghost depth the
-        forward step used (`self.ge` after `step`), saving its re-measurement."""
+        forward step used (`self.ge` after `step`), saving its re-measurement.  `next_beta_tau`: (beta, tau) of the step
+        whose adjoint comes next (the previous step of the sweep): its force cotangent is then written by this call's
+        particle kernel and picked up by the next call instead of a separate pass."""
         self.set_depth(x, paint_order, depth)
-        self.call("mcpm_kick_f32", _p(vb), _p(xb), self.Nl, float(beta), float(beta * tau), _p(self.Fb))
-        self.call("mcpm_paint3_f32", _p(x), self.Nl, POS_LATTICE, _p(self.Fb), paint_order, _p(self.f3), 0)
+        fb = C.c_void_p()
+        self.call("mcpm_plan_chained_fb", float(beta), float(tau), _p(xb), _p(vb), C.byref(fb))
+        if not fb.value:
+            self.call("mcpm_kick_f32", _p(vb), _p(xb), self.Nl, float(beta), float(beta * tau), _p(self.Fb))
+            fb = _p(self.Fb)
+        self.call("mcpm_paint3_f32", _p(x), self.Nl, POS_LATTICE, fb, paint_order, _p(self.f3), 0)
         adds = [self.halo_add(self.f3[c], async_op=True) for c in range(3)]   # overlap with the z / y passes below
         self.force_meshes_vjp(self.f3, self.rho, adds, fill_ghosts=True)
+        if next_beta_tau is not None:
+            self.call("mcpm_plan_hint_next_adjoint", float(next_beta_tau[0]), float(next_beta_tau[1]))
         self.call("mcpm_step_adjoint_particles_f32", _p(x), _p(v), _p(f3), _p(self.rho), float(alpha), float(beta),
                   float(tau), paint_order, _p(xb), _p(vb), abar_ptr, bbar_ptr, float(dtau_ddg), dgbar_ptr)
 
@@ -489,7 +497,8 @@ def nbody_bf_slab_vjp(ctx, disp_bar, vel_bar):
         tau = ctx.dg / 2 if i == K - 1 else ctx.dg
         pm.step_vjp(ctx.states[i, 0], ctx.states[i, 1], ctx.f3s[i], ctx.alphas[i], ctx.betas[i], tau, xb, vb,
                     C.c_void_p(sbar.data_ptr() + 8 * i), C.c_void_p(sbar.data_ptr() + 8 * (K + i)),
-                    0.5 if i == K - 1 else 1.0, C.c_void_p(sbar.data_ptr() + 8 * 2 * K), ctx.paint_order, depth=ctx.depths[i])
+                    0.5 if i == K - 1 else 1.0, C.c_void_p(sbar.data_ptr() + 8 * 2 * K), ctx.paint_order, depth=ctx.depths[i],
+                    next_beta_tau=(ctx.betas[i - 1], ctx.dg) if i > 0 else None)
     sbar[2 * K] += 0.5 * (xb.double() * ctx.states[0, 1].double()).sum()    # initial half drift x'_0 = x_0 + v_0 dg/2
     vb += xb * (ctx.dg / 2)
     sbar = pm.comm.all_reduce_sum(sbar).cpu().numpy()
