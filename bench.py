@@ -167,7 +167,8 @@ class SlabRunner:
         from montecosmo_amd import nbody, bricks, synth, dist
         self.n, self.K = n, K
         shape = (n, n, n)
-        self.comm = dist.TorchComm() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else dist.LocalComm()
+        import torch.distributed as td
+        self.comm = dist.TorchComm() if (td.is_available() and td.is_initialized()) else dist.LocalComm()
         self.pm = dist.SlabPM(shape, self.comm, ghost, device, adaptive_ghost=adaptive_ghost)
         pm = self.pm
         cosmo = bricks.Planck18()
@@ -272,7 +273,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
+    # MCPM_BENCH_DIST=1 with one rank initialises the process group anyway: on a one-GPU box it drives the slab path
+    # through the real RCCL calls (self send/recv, one-rank all-to-all) instead of the local-copy communicator
+    dist = world > 1 or os.environ.get("MCPM_BENCH_DIST") == "1"
     ndev = max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank % ndev)
     device = torch.device("cuda", local_rank % ndev)
@@ -341,7 +344,7 @@ def main():
                                    f"rms displacement 2 cells; " + ("single GPU" if world == 1 else
                                                                     (f"x-slab decomposed over {world} GPUs (ghost {args.ghost} planes, RCCL all-to-all FFT transpose)"
                                                                      if slab else f"{world} independent replicas")),
-                       "mesh": n, "n_steps": NS, "parallelism": ("slab1 (local-copy communicator)" if slab else "single") if world == 1 else (f"slab{world}" if slab else f"replicas{world}")},
+                       "mesh": n, "n_steps": NS, "parallelism": (("slab1 (RCCL, one rank)" if dist else "slab1 (local-copy communicator)") if slab else "single") if world == 1 else (f"slab{world}" if slab else f"replicas{world}")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(stages[dom]["algorithmic_GBps"] / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic(dom, n) if world == 1 else None},

@@ -9,11 +9,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def _init(rank, world, port):
+def _init(rank, world, port, backend="gloo"):
     import torch.distributed as td
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    td.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        import torch
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        td.init_process_group(backend, rank=rank, world_size=world)
     return td
 
 
@@ -71,11 +75,13 @@ def cpu_comm_worker(rank, world, port, out_dir):
     open(os.path.join(out_dir, f"ok_{rank}"), "w").write("ok")
 
 
-def gpu_slab_worker(rank, world, port, out_dir, n, n_steps):
-    """Several ranks sharing cuda:0 (gloo, staged through the host): the slab path against the single-GPU path."""
+def gpu_slab_worker(rank, world, port, out_dir, n, n_steps, backend="gloo"):
+    """Several ranks sharing cuda:0 (gloo, staged through the host), or one rank through RCCL itself ("nccl": self
+    send/recv and a one-rank all-to-all, un-staged and asynchronous as on a multi-GPU node): the slab path against
+    the single-GPU path."""
     import torch
-    td = _init(rank, world, port)
     torch.cuda.set_device(0)
+    td = _init(rank, world, port, backend)
     from montecosmo_amd import nbody, bricks, synth, dist
     shape = (n, n, n)
     spec = synth.init_mesh(n, seed=3, rms_disp=1.5)

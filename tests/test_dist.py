@@ -71,6 +71,17 @@ def test_slab_path_multi_rank_shared_gpu(gpu, world):
 
 
 @pytest.mark.gpu
+def test_slab_path_one_rank_rccl(gpu):
+    """The communicator's RCCL branch (device tensors in place, asynchronous handles) with the one rank a one-GPU box
+    allows: self send/recv for the ghost planes, a one-rank all-to-all for the transposes."""
+    from _dist_worker import gpu_slab_worker
+    out = _spawn(gpu_slab_worker, 1, 64, 3, "nccl")
+    res = json.load(open(os.path.join(out, "result.json")))
+    assert res["disp"] < 2e-6 and res["vel"] < 2e-6, res
+    assert res["grad"] < 1e-5 and res["alpha"] < 1e-4 and res["beta"] < 1e-4 and res["lpt_scalars"] < 1e-4, res
+
+
+@pytest.mark.gpu
 def test_too_small_ghost_is_detected(gpu):
     """Deposits beyond the ghost planes are counted, so a too-narrow ghost region cannot pass silently."""
     import ctypes as C
