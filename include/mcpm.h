@@ -273,6 +273,9 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *plan, const float *init_mesh, int n_steps, 
 int mcpm_rg2cgh_f32(void *stream, const float *real, int nx, int ny, int nz, float *spec);
 int mcpm_rg2cgh_vjp_f32(void *stream, const float *spec_bar, int nx, int ny, int nz, float *real_bar);
 int mcpm_cgh2rg_f32(void *stream, const float *spec, int nx, int ny, int nz, float *real);
+/* cgh2rg with norm = "amp" (utils.py:916-918): the real AND the imaginary element of every mode take Re spec there,
+   unsigned and unweighted -- a per-mode amplitude laid out like the real tensor (model.py:1147, the 'kaiser' prior scale). */
+int mcpm_cgh2rg_amp_f32(void *stream, const float *spec, int nx, int ny, int nz, float *real);
 
 /* Lagrangian bias expansion (montecosmo/bricks.py:327-443, png_type = None).
    fields : lin_mesh (plain half-spectrum of the plan's mesh) -> fields7 = {delta, shear^2, 3 det(shear), laplacian(delta),

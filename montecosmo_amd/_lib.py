@@ -64,6 +64,7 @@ SIGNATURES = {
     "mcpm_rg2cgh_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
     "mcpm_rg2cgh_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
     "mcpm_cgh2rg_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
+    "mcpm_cgh2rg_amp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
     "mcpm_chreshape_c64": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int]),
     "mcpm_chreshape_vjp_c64": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int]),
     "mcpm_slab_spec_elems": (C.c_int64, [C.c_void_p]),

@@ -165,7 +165,10 @@ __global__ __launch_bounds__(256) void rg2cgh_kernel(int nx, int ny, int nz, flo
 }
 
 // out = cgh2rg(in complex): every real element takes the value of ONE stored mode (the mirrored one on the faces and
-// edges, as the reference's last assignment does); utils.py:839-889
+// edges, as the reference's last assignment does); utils.py:839-889.  AMP (norm="amp", utils.py:916-918): both the "real"
+// and the "imaginary" element of a mode take the REAL part of `in` there, unsigned and unweighted -- the layout of a
+// per-mode amplitude (model.py:1147).
+template <bool AMP>
 __global__ __launch_bounds__(256) void cgh2rg_kernel(int nx, int ny, int nz, float scale, const float *__restrict__ in,
                                                      float *__restrict__ out) {
     const int hx = nx / 2, hy = ny / 2, hz = nz / 2, nzc = hz + 1;
@@ -177,14 +180,14 @@ __global__ __launch_bounds__(256) void cgh2rg_kernel(int nx, int ny, int nz, flo
     auto at = [&](int a, int b, int c) { return 2 * (((int64_t)a * ny + b) * nzc + c); };
     float v;
     if (z != 0 && z != hz) {
-        v = z < hz ? in[at(x, y, z)] : in[at(x, y, z - hz) + 1];
+        v = z < hz ? in[at(x, y, z)] : (AMP ? in[at(x, y, z - hz)] : in[at(x, y, z - hz) + 1]);
     } else if (y != 0 && y != hy) {
         const int mx_ = x ? nx - x : 0;
-        v = y < hy ? in[at(mx_, ny - y, z)] : -in[at(mx_, ny + hy - y, z) + 1];
+        v = y < hy ? in[at(mx_, ny - y, z)] : (AMP ? in[at(mx_, ny + hy - y, z)] : -in[at(mx_, ny + hy - y, z) + 1]);
     } else if (x != 0 && x != hx) {
-        v = x < hx ? in[at(nx - x, y, z)] : -in[at(nx + hx - x, y, z) + 1];
+        v = x < hx ? in[at(nx - x, y, z)] : (AMP ? in[at(nx + hx - x, y, z)] : -in[at(nx + hx - x, y, z) + 1]);
     } else {
-        v = in[at(x, y, z)] * 0.70710678118654752f;
+        v = in[at(x, y, z)] * (AMP ? 1.f : 0.70710678118654752f);
     }
     out[idx] = scale * v;
 }
@@ -243,7 +246,14 @@ int mcpm_cgh2rg_f32(void *stream, const float *spec, int nx, int ny, int nz, flo
     if (int rc = check(spec, real, nx, ny, nz, nx, ny, nz)) return rc;
     const int64_t n = (int64_t)nx * ny * nz;
     const float scale = (float)sqrt(2.0 / ((double)nx * ny * nz));
-    cgh2rg_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(nx, ny, nz, scale, spec, real);
+    cgh2rg_kernel<false><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(nx, ny, nz, scale, spec, real);
+    return hipGetLastError() == hipSuccess ? MCPM_OK : MCPM_E_HIP;
+}
+
+int mcpm_cgh2rg_amp_f32(void *stream, const float *spec, int nx, int ny, int nz, float *real) {
+    if (int rc = check(spec, real, nx, ny, nz, nx, ny, nz)) return rc;
+    const int64_t n = (int64_t)nx * ny * nz;
+    cgh2rg_kernel<true><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(nx, ny, nz, 1.f, spec, real);
     return hipGetLastError() == hipSuccess ? MCPM_OK : MCPM_E_HIP;
 }
 

@@ -3,8 +3,9 @@
 
 Built branch (everything else stays in the reference): latents with a Normal prior -- in sample space
 `name_ ~ Normal((loc - loc_fid) / scale_fid, scale / scale_fid)` (model.py:1117-1119) with the affine
-reparametrisation `base = name_ * scale_fid + loc_fid` (bricks.py:270-276); initial conditions `white_mesh_ ~ N(0, 1)`
-per cell with the 'fourier' (rg2cgh) or 'real' (rfftn) preconditioning at unit scale (model.py:1131-1132, :1146);
+reparametrisation `base = name_ * scale_fid + loc_fid` (bricks.py:270-276); initial conditions `white_mesh_ ~ N(0, scale)`
+per cell with the 'fourier' (rg2cgh) or 'real' (rfftn) preconditioning at unit scale, or the reference's default 'kaiser'
+preconditioning (rg2cgh with the per-mode posterior width of the fiducial linear Kaiser model; model.py:1127-1148);
 `evolve`; the 'quad_gauss' likelihood (model.py:893-908) without mask, with unit selection, one radial bin and phi = 0:
     count = ngbar cell^3 * irfftn(chreshape(rfftn(gxy_mesh), final_shape));  delta = count / selec - 1
     obs ~ QuadGaussian(count, (|s_e + s_ed delta| + 1e-9) sqrt(selec), s_e2 sqrt(selec)),  selec = ngbar cell^3.
@@ -22,7 +23,7 @@ import numpy as np
 import torch
 
 from . import nbody, bricks
-from .utils import r2chshape, chreshape, chreshape_vjp, rg2cgh, rg2cgh_vjp
+from .utils import r2chshape, chreshape, chreshape_vjp, rg2cgh, rg2cgh_vjp, cgh2rg
 
 LOG2PI = math.log(2 * math.pi)
 
@@ -104,8 +105,8 @@ class FieldLevelLogDensity:
     STOCH = ("s_e", "s_ed", "s_e2")
 
     def __init__(self, fwd, count_obs, latents, fixed, precond="fourier", make_cosmo=None):
-        if precond not in ("fourier", "real"):
-            raise NotImplementedError("the 'kaiser' preconditioning (a fiducial-model transfer) is not built")
+        if precond not in ("fourier", "real", "kaiser"):
+            raise ValueError(f"Unknown preconditioning type: {precond}")
         self.fwd, self.precond = fwd, precond
         self.latents = {k: dict({"low": -math.inf, "high": math.inf}, **{kk: float(vv) for kk, vv in v.items()}) for k, v in latents.items()}
         self.fixed = dict(fixed)
@@ -117,8 +118,8 @@ class FieldLevelLogDensity:
             raise NotImplementedError("ngbars is kept fixed")
         self.final_shape = tuple(fwd.final_shape)
         self.count_obs = nbody._f32(count_obs, self.final_shape)
-        self.transfer = float(np.divide(fwd.init_shape, fwd.box_size).prod() ** .5)       # model.py:1146, scale = 1
         self.make_cosmo = make_cosmo or self._planck
+        self.scale, self.transfer = self._precond_scale_and_transfer()
 
     @staticmethod
     def _planck(base):
@@ -126,6 +127,56 @@ class FieldLevelLogDensity:
         c.Omega_c = float(base["Omega_m"]) - c.Omega_b
         c.sigma8 = float(base["sigma8"])
         return c
+
+    def fiducial(self):
+        """Fiducial base values: loc_fid of the latents, else the fixed value (model.py:1214-1223)."""
+        fid = dict(self.fixed)
+        fid.update({k: c["loc_fid"] for k, c in self.latents.items()})
+        return fid
+
+    def _fiducial_scale_factor(self, cosmo_fid):
+        """a_fid = g2a(mean a2g(a)) over the final-mesh cells (model.py:604-606)."""
+        fwd = self.fwd
+        if fwd.a_obs is not None:
+            a = fwd.a_obs
+        else:
+            p = bricks.cell2phys_pos(bricks.regular_pos(self.final_shape), fwd.box_center, fwd.box_rotvec, fwd.box_size,
+                                     self.final_shape)
+            if fwd.curved_sky:
+                r = np.linalg.norm(p, axis=-1)
+            else:
+                r = np.abs(p @ nbody.safe_div(fwd.box_center, np.linalg.norm(fwd.box_center)))
+            a = nbody.chi2a(cosmo_fid, r)
+        return float(nbody.g2a(cosmo_fid, np.mean(nbody.a2g(cosmo_fid, a))))
+
+    def _precond_scale_and_transfer(self):
+        """(scale, transfer) of the white-field preconditioning (model.py:1127-1148): `scale` is the prior std of
+        white_mesh_ (None = 1), `transfer` the factor taking rg2cgh / rfftn of it to unit-power white noise (a float, or
+        a per-mode device tensor).  'kaiser' (bricks.py:170-184, :96-106; uniform selection, selec_fid = 1): a one-off
+        host float64 set-up of two init_shape-sized meshes."""
+        fwd = self.fwd
+        unit = float(np.divide(fwd.init_shape, fwd.box_size).prod() ** .5)
+        if self.precond in ("real", "fourier"):
+            return None, unit
+        fid = self.fiducial()
+        cosmo_fid = self.make_cosmo(fid)
+        a_fid = self._fiducial_scale_factor(cosmo_fid)
+        los = nbody.safe_div(fwd.box_center, np.linalg.norm(fwd.box_center))
+        los_fid = bricks.rot_matrix(fwd.box_rotvec).T @ los                              # model.py:607-608, cell los
+        kvec = nbody.rfftk(fwd.init_shape, fwd.box_size)
+        kmesh = sum(ki ** 2 for ki in kvec) ** .5
+        mu = nbody.safe_div(sum(ki * li for ki, li in zip(kvec, los_fid)), kmesh)
+        boost = float(nbody.a2g(cosmo_fid, a_fid)) * ((1.0 + float(fid["b1"])) + float(nbody.a2f(cosmo_fid, a_fid)) * mu ** 2)
+        ks, pows = fwd.lin_kpow
+        pmesh = np.interp(kmesh.reshape(-1), ks, pows * float(fid["sigma8"]) ** 2, left=0., right=0.).reshape(kmesh.shape)
+        pmesh *= unit ** 2                                                                # power in cell units
+        var_fid = float(fid["s_e"]) / (float(fid["ngbars"]) * fwd.cell_length ** 3)        # model.py:1140, selec_fid = 1
+        scale_k = (1 + boost ** 2 / var_fid * pmesh) ** .5
+        cosmo_fid._workspace = {}
+        dev = self.count_obs.device
+        transfer = torch.from_numpy((unit / scale_k).astype(np.float32)).to(dev)
+        scale = cgh2rg(torch.from_numpy(scale_k.astype(np.complex64)).to(dev), norm="amp")
+        return scale, transfer
 
     def names(self):
         """Sample-space parameter names: scalars (in a fixed order) then 'white_mesh_'."""
@@ -163,8 +214,11 @@ class FieldLevelLogDensity:
                 lp += -0.5 * LOG2PI - math.log(sd) - 0.5 * ((x - mu) / sd) ** 2
                 grad[name + "_"], dbase[name] = -(x - mu) / sd ** 2, c["scale_fid"]
         w = nbody._f32(sample["white_mesh_"], fwd.init_shape)
-        lp += float(-0.5 * LOG2PI * w.numel() - 0.5 * (w.double() ** 2).sum())
-        white = (rg2cgh(w) if self.precond == "fourier" else nbody.rfftn(w)) * self.transfer
+        if self.scale is None:
+            lp += float(-0.5 * LOG2PI * w.numel() - 0.5 * (w.double() ** 2).sum())
+        else:      # white_mesh_ ~ Normal(0, scale) (model.py:666-672)
+            lp += float(-0.5 * LOG2PI * w.numel() - self.scale.double().log().sum() - 0.5 * ((w / self.scale).double() ** 2).sum())
+        white = (nbody.rfftn(w) if self.precond == "real" else rg2cgh(w)) * self.transfer
         cosmo = self.make_cosmo(base)
         bias = {k: base[k] for k in bricks.BIAS_KEYS}
         gxy, ctx = fwd.evolve(cosmo, bias, white, return_ctx=True)
@@ -197,14 +251,14 @@ class FieldLevelLogDensity:
             plan.call("mcpm_fft_c2r", nbody._ptr(kb), nbody._ptr(gxy_bar), 1)
         g = fwd.evolve_vjp(ctx, gxy_bar)
         wb = g["white_mesh"] * self.transfer
-        if self.precond == "fourier":
+        if self.precond != "real":
             wbar = rg2cgh_vjp(wb)
         else:
             wb = wb.clone()
             wb[..., 1:fwd.init_shape[-1] // 2] *= 0.5
             wbar = torch.empty(fwd.init_shape, dtype=torch.float32, device=wb.device)
             nbody.get_plan(fwd.init_shape).call("mcpm_fft_c2r", nbody._ptr(wb), nbody._ptr(wbar), 1)
-        grad["white_mesh_"] = wbar - w
+        grad["white_mesh_"] = wbar - (w if self.scale is None else w / self.scale ** 2)
         base_bar = dict(g["bias"])
         base_bar.update(stoch_bar)
         base_bar["sigma8"] = g["sigma8"]

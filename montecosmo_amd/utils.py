@@ -92,14 +92,16 @@ def rg2cgh_vjp(meshk_bar):
 
 def cgh2rg(meshk, norm="backward"):
     """Permute and reweight a complex Gaussian Hermitian tensor into a real Gaussian tensor (utils.py:909-921): the
-    inverse of rg2cgh.  HIP kernel mcpm_cgh2rg_f32."""
+    inverse of rg2cgh.  norm="amp" lays a per-mode amplitude (the real part of `meshk`) out like the real tensor.
+    HIP kernels mcpm_cgh2rg_f32 / mcpm_cgh2rg_amp_f32."""
     import torch
     from . import nbody
     from ._lib import lib, check
-    if norm != "backward":
-        raise NotImplementedError('only norm="backward" (the model\'s) is built')
+    if norm not in ("backward", "amp"):
+        raise NotImplementedError('only norm="backward" (the model\'s) and "amp" are built')
     k = nbody._c64(meshk)
     shape = ch2rshape(k.shape)
     out = torch.empty(shape, dtype=torch.float32, device=k.device)
-    check(lib.mcpm_cgh2rg_f32(_stream_of(k), nbody._ptr(k), *shape, nbody._ptr(out)), None, "mcpm_cgh2rg_f32")
+    fn = "mcpm_cgh2rg_f32" if norm == "backward" else "mcpm_cgh2rg_amp_f32"
+    check(getattr(lib, fn)(_stream_of(k), nbody._ptr(k), *shape, nbody._ptr(out)), None, fn)
     return out

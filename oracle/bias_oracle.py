@@ -285,10 +285,65 @@ def detrunc_truncnorm_log_prob(x, loc, scale, low, high, loc_fid, scale_fid, h=1
     return truncnorm.logpdf(y, a_, b_, loc=loc, scale=scale) + np.log(abs(jac))
 
 
+def kaiser_boost(cosmo, a, mesh_shape, box_size, b1E, los=(0., 0., 0.)):
+    """Eulerian Kaiser boost: linear growth, linear bias, RSD (bricks.py:170-184, png_type = None)."""
+    kvec = o.rfftk(mesh_shape, box_size)
+    kmesh = sum(ki ** 2 for ki in kvec) ** .5
+    mumesh = o.safe_div(sum(ki * li for ki, li in zip(kvec, los)), kmesh)
+    return o.a2g(cosmo, a) * (b1E + o.a2f(cosmo, a) * mumesh ** 2)
+
+
+def lin_power_mesh(sigma8, mesh_shape, box_size, kpow):
+    """bricks.py:69-106 with a tabulated kpow (normalised to sigma8 = 1): linear interpolation, 0 outside the table."""
+    kvec = o.rfftk(mesh_shape, box_size)
+    kmesh = sum(ki ** 2 for ki in kvec) ** .5
+    ks, pows = kpow
+    return np.interp(kmesh.reshape(-1), ks, np.asarray(pows) * sigma8 ** 2, left=0., right=0.).reshape(kmesh.shape)
+
+
+def fiducial_scale_factor(cfg, cosmo_fid):
+    """a_fid = g2a(mean a2g(a)) over the final-mesh cells (model.py:604-606; bricks.py:665-686, :760-778)."""
+    if cfg["a_obs"] is not None:
+        a = cfg["a_obs"]
+    else:
+        R = rotvec_matrix(cfg["box_rotvec"])
+        final = tuple(cfg["final_shape"])
+        pos = cell2phys_pos(o.regular_pos(final), cfg["box_center"], R, cfg["box_size"], final)
+        if cfg["curved_sky"]:
+            r = np.linalg.norm(pos, axis=-1)
+        else:
+            los = o.safe_div(np.asarray(cfg["box_center"], float), np.linalg.norm(cfg["box_center"]))
+            r = np.abs(pos @ los)
+        a = o.chi2a(cosmo_fid, r)
+    return float(o.g2a(cosmo_fid, np.mean(o.a2g(cosmo_fid, a))))
+
+
+def precond_scale_and_transfer(cfg, fiduc=None, cosmo_fid=None):
+    """Scale (real layout, prior std of white_mesh_) and transfer (per mode) of the white-field preconditioning
+    (model.py:1127-1148); 'kaiser' with a uniform selection (selec_fid = 1)."""
+    init_shape = tuple(cfg["init_shape"])
+    if cfg["precond"] in ("real", "fourier"):
+        scale = np.ones(o.r2chshape(init_shape))
+    else:
+        assert cfg["precond"] == "kaiser"
+        a_fid = fiducial_scale_factor(cfg, cosmo_fid)
+        c = np.asarray(cfg["box_center"], float)
+        los = o.safe_div(c, np.linalg.norm(c))
+        los_fid = rotvec_matrix(cfg["box_rotvec"]).T @ los
+        boost = kaiser_boost(cosmo_fid, a_fid, init_shape, cfg["box_size"], 1. + fiduc["b1"], los_fid)
+        pmesh = lin_power_mesh(fiduc["sigma8"], init_shape, cfg["box_size"], cfg["lin_kpow"])
+        pmesh = pmesh * np.divide(init_shape, cfg["box_size"]).prod()
+        count_fid = fiduc["ngbars"] * cfg["cell_length"] ** 3
+        var_fid = fiduc["s_e"] / count_fid
+        scale = (1 + boost ** 2 / var_fid * pmesh) ** .5
+    transfer = np.divide(init_shape, cfg["box_size"]).prod() ** .5 / scale
+    return o.cgh2rg(scale.astype(complex), norm="amp"), transfer
+
+
 def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo):
     """log p(sample params, count_obs) of the field-level model for Normal or truncated-Normal latents (model.py:1105-1125 prior in
-    sample space; bricks.py:255-287 affine reparametrisation; model.py:1127-1148 'fourier' / 'real' preconditioning with
-    unit scale; model.py:686-838 evolve; model.py:840-908 'quad_gauss' likelihood with no mask, unit selection, one radial
+    sample space; bricks.py:255-287 affine reparametrisation; model.py:1127-1148 'fourier' / 'real' / 'kaiser'
+    preconditioning; model.py:686-838 evolve; model.py:840-908 'quad_gauss' likelihood with no mask, unit selection, one radial
     bin and phi = 0).  `latents`: name -> dict(loc, scale, loc_fid, scale_fid); `fixed`: name -> value of the base
     parameters that are not sampled; `sample`: name_ -> value (scalars) and 'white_mesh_' (real, init_shape)."""
     lp = 0.0
@@ -304,8 +359,13 @@ def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo):
             lp += detrunc_truncnorm_log_prob(x, conf["loc"], conf["scale"], low, high, conf["loc_fid"], conf["scale_fid"])
             base[name] = std2trunc(x, conf["loc_fid"], conf["scale_fid"], low, high)
     w = np.asarray(sample["white_mesh_"], dtype=float)
-    lp += np.sum(-0.5 * np.log(2 * np.pi) - 0.5 * w ** 2)
-    transfer = np.divide(cfg["init_shape"], cfg["box_size"]).prod() ** .5
+    fiduc = cosmo_fid = None
+    if cfg["precond"] == "kaiser":      # fiducial values: loc_fid of the latents, else the fixed value (model.py:1214-1223)
+        fiduc = dict(fixed)
+        fiduc.update({k: v["loc_fid"] for k, v in latents.items()})
+        cosmo_fid = make_cosmo(fiduc)
+    scale, transfer = precond_scale_and_transfer(cfg, fiduc, cosmo_fid)
+    lp += np.sum(-0.5 * np.log(2 * np.pi) - np.log(scale) - 0.5 * (w / scale) ** 2)     # model.py:666-672
     white = (o.rg2cgh(w) if cfg["precond"] != "real" else np.fft.rfftn(w)) * transfer
     cosmo = make_cosmo(base)
     bias = {k: base[k] for k in BIAS_KEYS}

@@ -76,22 +76,26 @@ def _with_s8(c, s8):
     return c
 
 
-@pytest.mark.parametrize("evolution,s_e2", [("lpt", 0.0), ("nbody", 0.02)])
-def test_log_density_and_gradient(gpu, evolution, s_e2):
+@pytest.mark.parametrize("evolution,s_e2,precond,a_obs", [("lpt", 0.0, "fourier", 0.65), ("nbody", 0.02, "fourier", 0.65),
+                                                          ("nbody", 0.02, "kaiser", 0.65), ("lpt", 0.0, "kaiser", None)])
+def test_log_density_and_gradient(gpu, evolution, s_e2, precond, a_obs):
     """Prior + evolve + 'quad_gauss' likelihood (model.py:640-679, :840-908) on the HIP path against the float64
-    restatement; gradient w.r.t. every sampled parameter against central differences of that restatement."""
+    restatement; gradient w.r.t. every sampled parameter against central differences of that restatement.  'kaiser':
+    the reference's default preconditioning (model.py:1134-1147), once at fixed a_obs and once on the light cone."""
     from montecosmo_amd import model, logdensity
     rng = np.random.default_rng(41)
     fwd = model.FieldLevelForward(final_shape=(8, 8, 8), cell_length=40., box_center=(60., -40., 1400.), box_rotvec=(0.1, 0.2, -0.1),
                                   evolution=evolution, nbody_n_steps=3, lpt_order=2, init_oversamp=1.5, evol_oversamp=2.,
-                                  ptcl_oversamp=2., paint_oversamp=2., a_obs=0.65, curved_sky=True, lin_kpow=_kpow(), nbody_a_start=0.1)
-    cfg = dict(fwd.config(), final_shape=(8, 8, 8), cell_length=40., precond="fourier")
+                                  ptcl_oversamp=2., paint_oversamp=2., a_obs=a_obs, curved_sky=True, lin_kpow=_kpow(), nbody_a_start=0.1)
+    cfg = dict(fwd.config(), final_shape=(8, 8, 8), cell_length=40., precond=precond)
     lat = {"Omega_m": dict(loc=0.3111, scale=0.1, loc_fid=0.3111, scale_fid=1e-2, low=0.05, high=1.),   # model.py:76-83
            "sigma8": dict(loc=0.8102, scale=0.1, loc_fid=0.8102, scale_fid=1e-2, low=0., high=np.inf),   # model.py:100-111
            "b1": dict(loc=1., scale=1e2, loc_fid=1., scale_fid=1e-2), "b2": dict(loc=0., scale=1e2, loc_fid=0., scale_fid=3e-2),
            "bs2": dict(loc=0., scale=1e2, loc_fid=0., scale_fid=1e-1), "bn2": dict(loc=0., scale=1e3, loc_fid=0., scale_fid=1.),
            "s_ed": dict(loc=0., scale=1e1, loc_fid=0., scale_fid=1e-2)}
     fixed = dict(b3=0.1, bds2=0.1, bs3=-0.05, bnpar=5.0, ngbars=1e-3, s_e=1.0, s_e2=s_e2)
+    if a_obs is None:      # light cone: the cosmology dependence of the look-ups is not propagated -> Omega_m stays fixed
+        fixed["Omega_m"] = lat.pop("Omega_m")["loc_fid"]
     make_cosmo = lambda base: _cos(obg.Planck18(Omega_c=base["Omega_m"] - 0.0490), base["sigma8"])
     sample = {k + "_": float(rng.normal(0, 1.0)) for k in lat}
     sample["white_mesh_"] = rng.standard_normal((12, 12, 12))
@@ -103,7 +107,7 @@ def test_log_density_and_gradient(gpu, evolution, s_e2):
     rc = fixed["ngbars"] * 40. ** 3
     cm_t = rc * np.fft.irfftn(o.chreshape(np.fft.rfftn(gxy_t), o.r2chshape((8, 8, 8))), s=(8, 8, 8), axes=(0, 1, 2))
     obs = cm_t + rc ** .5 * rng.standard_normal((8, 8, 8))
-    ld = logdensity.FieldLevelLogDensity(fwd, obs, lat, fixed, precond="fourier")
+    ld = logdensity.FieldLevelLogDensity(fwd, obs, lat, fixed, precond=precond)
     lp, grad = ld.logdensity_and_grad({k: (v if np.ndim(v) == 0 else v.astype(np.float32)) for k, v in sample.items()})
     ref = lambda s: bo.log_density(cfg, lat, fixed, s, obs, make_cosmo)
     lp_o = ref(sample)

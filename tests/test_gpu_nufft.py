@@ -111,6 +111,8 @@ def test_rg2cgh_cgh2rg(nb, shape):
     assert rel_l2(utils.cgh2rg(X).cpu().numpy(), x) < 1e-6
     Z = rng.standard_normal(o.r2chshape(shape)) + 1j * rng.standard_normal(o.r2chshape(shape))   # not Hermitian on purpose
     assert rel_l2(utils.cgh2rg(Z.astype(np.complex64)).cpu().numpy(), o.cgh2rg(Z)) < 1e-6
+    assert np.array_equal(utils.cgh2rg(Z.astype(np.complex64), norm="amp").cpu().numpy(),
+                          o.cgh2rg(Z, "amp").astype(np.float32))             # a pure permutation of Re Z
     xb = utils.rg2cgh_vjp(Z.astype(np.complex64)).cpu().numpy()
     # transpose by linearity: <Z, rg2cgh(e)> over the stored modes
     d = rng.standard_normal(shape)

@@ -292,3 +292,33 @@ def test_rg2cgh_known_answers(rng, shape):
     assert np.allclose(o.cgh2rg(X), x)
     assert np.isclose((y ** 2).sum() * np.prod(shape), (x ** 2).sum() * np.prod(shape))
     assert np.isclose((y ** 2).sum(), (x ** 2).sum())
+
+
+def test_kaiser_preconditioning_known_answers():
+    """model.py:1127-1148, utils.py:909-921: with (scale, transfer) of the 'kaiser' preconditioning, rg2cgh(scale * N(0, I))
+    * transfer is unit-power white noise (every mode has variance M / V_cell, the law of rfftn of N(0, 1/V_cell) cells),
+    whatever the fiducial model; and the "amp" layout gives the real and imaginary element of a mode the same amplitude:
+    cgh2rg(A, "amp") = |cgh2rg(A, "backward")| / sqrt(2 / M) away from the eight self-conjugate modes."""
+    from oracle import bias_oracle as bo
+    ks = np.logspace(-3, 1, 64)
+    cfg = dict(init_shape=(8, 6, 10), final_shape=(4, 4, 6), cell_length=50., box_size=np.array([200., 200., 300.]),
+               box_center=np.array([60., -40., 1400.]), box_rotvec=np.array([0.1, 0.2, -0.1]), a_obs=None, curved_sky=True,
+               lin_kpow=(ks, 2e4 * ks / (1 + (ks / 0.02) ** 2.6)), precond="kaiser")
+    fid = dict(Omega_m=0.3111, sigma8=0.8102, b1=1., ngbars=1e-3, s_e=1.0)
+    cosmo = obg.Planck18(Omega_c=fid["Omega_m"] - 0.049)
+    scale, transfer = bo.precond_scale_and_transfer(cfg, fid, cosmo)
+    M = np.prod(cfg["init_shape"])
+    assert scale.shape == cfg["init_shape"] and scale.min() >= 1.0 and scale.max() > 1.5
+    a_fid = bo.fiducial_scale_factor(cfg, cosmo)
+    assert 1 / (1 + 0.7) < a_fid < 1 / (1 + 0.4)          # chi ~ 1400 Mpc/h is z ~ 0.5-0.6
+    rng = np.random.default_rng(0)
+    acc, n = 0., 400
+    for _ in range(n):
+        acc = acc + np.abs(o.rg2cgh(rng.standard_normal(cfg["init_shape"]) * scale) * transfer) ** 2
+    white = np.divide(cfg["init_shape"], cfg["box_size"]).prod() * M
+    assert abs((acc / n).mean() / white - 1) < 0.01
+    assert np.abs((acc / n) / white - 1).max() < 0.35     # per mode: chi^2 with 400 (800) degrees of freedom
+    A = rng.uniform(1, 2, o.r2chshape(cfg["init_shape"]))
+    amp, back = o.cgh2rg(A.astype(complex), "amp"), o.cgh2rg(A * (1 + 1j), "backward")
+    ratio = np.abs(back) / (2 / M) ** .5 / amp
+    assert np.isclose(np.sort(ratio.ravel())[8:], 1.0).all() and np.isclose(np.sort(ratio.ravel())[:8], 2 ** -.5).all()

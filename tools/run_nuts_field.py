@@ -1,6 +1,6 @@
 """End-to-end field-level NUTS on one MI355X (BASELINE config 5 in miniature or at size): synthetic truth -> observed
 counts -> `FieldLevelLogDensity` -> `samplers.nuts_sample`.
-usage: python tools/run_nuts_field.py [final_n=146] [n_warmup=200] [n_samples=200] [max_depth=6] [evolution=nbody] [out.json] [nuts|mclmc]"""
+usage: python tools/run_nuts_field.py [final_n=146] [n_warmup=200] [n_samples=200] [max_depth=6] [evolution=nbody] [out.json] [nuts|mclmc] [precond=fourier]"""
 import json, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -12,6 +12,7 @@ n_samp = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 depth = int(sys.argv[4]) if len(sys.argv) > 4 else 6
 evolution = sys.argv[5] if len(sys.argv) > 5 else "nbody"
 out_path = sys.argv[6] if len(sys.argv) > 6 else None
+precond = sys.argv[8] if len(sys.argv) > 8 else "fourier"
 
 ks = np.logspace(-3, 1, 128)
 kpow = (ks, 3.0e4 * (ks / 0.02) / (1 + (ks / 0.02) ** 2.6))
@@ -27,7 +28,9 @@ torch.manual_seed(0)
 truth = {k + "_": 0.0 for k in lat}
 truth["white_mesh_"] = torch.randn(fwd.init_shape, device="cuda")
 # observed counts: the model's own mean at the truth + its Gaussian noise (model.py:893-908 with s_ed = s_e2 = 0)
-ld0 = logdensity.FieldLevelLogDensity(fwd, torch.zeros(fwd.final_shape), lat, fixed)
+ld0 = logdensity.FieldLevelLogDensity(fwd, torch.zeros(fwd.final_shape), lat, fixed, precond=precond)
+prior_std = 1.0 if ld0.scale is None else ld0.scale          # white_mesh_ ~ Normal(0, scale): the truth is a prior draw
+truth["white_mesh_"] = truth["white_mesh_"] * prior_std
 base = ld0.base_params(truth)
 white = utils.rg2cgh(truth["white_mesh_"]) * ld0.transfer
 gxy = fwd.evolve(ld0.make_cosmo(base), {k: base[k] for k in bricks.BIAS_KEYS}, white)
@@ -35,10 +38,10 @@ rc = fixed["ngbars"] * fwd.cell_length ** 3
 cm = rc * nbody.irfftn(utils.chreshape(nbody.rfftn(gxy), utils.r2chshape(fwd.final_shape)))
 obs = cm + rc ** .5 * torch.randn(fwd.final_shape, device="cuda")
 print(f"truth: mean count {float(cm.mean()):.3f}, count contrast std {float((cm / rc - 1).std()):.3f}", flush=True)
-ld = logdensity.FieldLevelLogDensity(fwd, obs, lat, fixed)
+ld = logdensity.FieldLevelLogDensity(fwd, obs, lat, fixed, precond=precond)
 flat = samplers.FlatLogDensity(ld)
 start = dict(truth)
-start["white_mesh_"] = 0.1 * torch.randn(fwd.init_shape, device="cuda")      # away from the truth, near the prior mode
+start["white_mesh_"] = 0.1 * torch.randn(fwd.init_shape, device="cuda") * prior_std     # away from the truth, near the prior mode
 q0 = flat.pack(start)
 lp_truth = ld(truth)
 t0 = time.perf_counter()
@@ -71,7 +74,7 @@ torch.cuda.synchronize()
 wall = time.perf_counter() - t_run
 infos = res["infos"]
 draws = np.array(res["samples"])
-summary = {"sampler": sampler, "final_shape": fwd.final_shape, "evol_shape": fwd.evol_shape, "evolution": evolution, "dimension": int(q0.numel()),
+summary = {"sampler": sampler, "precond": precond, "final_shape": fwd.final_shape, "evol_shape": fwd.evol_shape, "evolution": evolution, "dimension": int(q0.numel()),
            "n_warmup": n_warm, "n_samples": n_samp, "max_tree_depth": depth, "wall_s": round(wall, 1),
            "gradient_evals": flat.n_eval, "ms_per_gradient": round(1e3 * wall / max(flat.n_eval - 1, 1), 2),
            "mean_leapfrogs": float(np.mean([i["n_leapfrog"] for i in infos])), "step_size": res["step_size"],
