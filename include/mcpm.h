@@ -74,6 +74,12 @@ int mcpm_plan_set_halo(mcpm_plan *plan, int halo);
 /* Tuning knob: order in which the tiled paints hand tiles to the 8 XCDs: 0 = one contiguous run of tiles per XCD
    (default), 1 = compact bricks of tiles (slower at 512^3; see particles.hip). */
 int mcpm_plan_set_tile_order(mcpm_plan *plan, int order);
+/* Accumulator of the tiled three-component paint (mcpm_paint3_f32, the adjoint of the force read): 1 = fixed point
+   (default: 32-bit fields in 64-bit integer LDS atomics, exact order-independent sums, overflow proven per tile by a
+   bound field, flagged tiles repainted in f64; particles.hip), 0 = f64 tiles.  mcpm_plan_last_redo returns how many
+   tiles the last fixed-point paint handed to the f64 kernel (host sync). */
+int mcpm_plan_set_paint3_fixed(mcpm_plan *plan, int fixed);
+int mcpm_plan_last_redo(mcpm_plan *plan, int64_t *count);
 
 /* Optional per-stage profile: HIP events on the plan's stream around every leaf stage (paint, FFTs, k-space,
    read, fused particle kernels).  mcpm_plan_profile_read synchronises, fills up to nmax entries of

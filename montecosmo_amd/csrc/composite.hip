@@ -147,15 +147,35 @@ __global__ __launch_bounds__(256) void lattice_dot_kernel(Geom g, const float *_
 // Adjoint of one fused step (see file header).  Inputs: x'_i, v_i (checkpoint), cotangents xb, vb of
 // (x'_{i+1}, v_{i+1}) (updated in place to those of (x'_i, v_i)), the step's three force meshes and
 // rho_bar = cotangent of the painted density.
+// max over the workgroup of |a|, |b|, |c| as float bits (any NaN / Inf gives >= 0x7f800000): what the fixed-point
+// three-component paint needs to choose its scale (particles.hip, paint3_fx_kernel).  One LDS atomic per wave, then ONE
+// L2-coherent read of a slot per workgroup and a global atomic only if the slot is smaller -- after the first few
+// workgroups none is: per-wave atomics on one address cost 20 ms per launch at 512^3.  Slots are a cache line apart.
+__device__ __forceinline__ void absmax_commit(float a, float b, float c, unsigned *__restrict__ out) {
+    __shared__ unsigned sh_max;
+    if (threadIdx.x == 0) sh_max = 0u;
+    __syncthreads();
+    unsigned m = max(max(__float_as_uint(a) & 0x7fffffffu, __float_as_uint(b) & 0x7fffffffu), __float_as_uint(c) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&sh_max, m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned *slot = out + (blockIdx.x & (MCPM_FX_SLOTS - 1)) * MCPM_FX_STRIDE;
+        if (sh_max > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, sh_max);
+    }
+}
+
 template <int ORDER, bool IL>
 __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *__restrict__ x, const float *__restrict__ v,
                                                            float *__restrict__ xb, float *__restrict__ vb,
                                                            const float *__restrict__ fm, const float *__restrict__ rho_bar,
                                                            int64_t M, float alpha, float beta, float tau,
                                                            double *slots, float *__restrict__ fb_next, float beta_next,
-                                                           float tau_next, float dtau_ddg) {
+                                                           float tau_next, float dtau_ddg, unsigned *__restrict__ fb_max) {
     PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
     double ra = 0., rb = 0., rc = 0.;
+    P3 fbn = {0.f, 0.f, 0.f};
     if (pi.valid) {
         const P3 d = load3(x, pi.i), vi = load3(v, pi.i);
         P3 xbi = load3(xb, pi.i), vbi = load3(vb, pi.i);
@@ -190,10 +210,13 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
         const P3 vnew = {alpha * vt.x, alpha * vt.y, alpha * vt.z};
         store3(xb, pi.i, xbi);
         store3(vb, pi.i, vnew);
-        if (fb_next)  // force cotangent of the PREVIOUS step, F_bar = beta' (v_bar + tau' x_bar)
-            store3(fb_next, pi.i, P3{beta_next * (vnew.x + tau_next * xbi.x), beta_next * (vnew.y + tau_next * xbi.y),
-                                     beta_next * (vnew.z + tau_next * xbi.z)});
+        if (fb_next) {  // force cotangent of the PREVIOUS step, F_bar = beta' (v_bar + tau' x_bar)
+            fbn = P3{beta_next * (vnew.x + tau_next * xbi.x), beta_next * (vnew.y + tau_next * xbi.y),
+                     beta_next * (vnew.z + tau_next * xbi.z)};
+            store3(fb_next, pi.i, fbn);
+        }
     }
+    if (fb_max) absmax_commit(fbn.x, fbn.y, fbn.z, fb_max);
     const int slot = blockIdx.x % MCPM_NSLOT;
     block_add2(ra, rb, slots + slot, slots + MCPM_NSLOT + slot);
     __syncthreads();
@@ -226,9 +249,14 @@ __global__ void fold256_kernel(double *out) {
 }
 
 __global__ void axpby_kernel(const float *__restrict__ x, const float *__restrict__ y, int64_t n, float a, float b,
-                             float *__restrict__ out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a * x[i] + b * y[i];
+                             float *__restrict__ out, unsigned *__restrict__ out_max) {
+    unsigned r = 0u;      // max |out| as bits: a NaN / Inf stays the maximum
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float o = a * x[i] + b * y[i];
+        out[i] = o;
+        r = max(r, __float_as_uint(o) & 0x7fffffffu);
+    }
+    if (out_max) absmax_commit(__uint_as_float(r), 0.f, 0.f, out_max);
 }
 
 static inline void lattice_launch(const Geom &g, dim3 &grid, dim3 &block) {
@@ -251,10 +279,17 @@ static int lattice_dot(mcpm_plan *p, const float *meshes3, const float *a, const
     return MCPM_OK;
 }
 
-static int axpby(mcpm_plan *p, const float *x, const float *y, int64_t n, float a, float b, float *out) {
+// out = a x + b y; with_max: also leaves max|out| for the fixed-point paint of `out` (plan->fx_wmax / fx_src)
+static int axpby(mcpm_plan *p, const float *x, const float *y, int64_t n, float a, float b, float *out, bool with_max = false) {
     StageTimer st_(p, ST_AXPY, 12.0 * n);
     unsigned nb = (unsigned)((n + 255) / 256);
-    axpby_kernel<<<nb, 256, 0, p->stream>>>(x, y, n, a, b, out);
+    with_max = with_max && p->paint3_variant == 4;
+    if (with_max && nb > 16384) nb = 16384;      // grid-stride: few workgroups commit the maximum
+    if (with_max) {
+        MCPM_HIP(p, hipMemsetAsync(p->fx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream));
+        p->fx_src = out;
+    }
+    axpby_kernel<<<nb, 256, 0, p->stream>>>(x, y, n, a, b, out, with_max ? p->fx_wmax : nullptr);
     MCPM_LAUNCH_CHECK(p, "axpby_kernel");
     return MCPM_OK;
 }
@@ -532,7 +567,7 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *v
     // force cotangent F_bar = beta (v_bar + tau x_bar), scattered onto three meshes (adjoint of read); already written
     // by the previous call's particle kernel when the caller chained the steps (mcpm_plan_hint_next_adjoint)
     if (!(p->fb_valid && p->fb_beta == b && p->fb_tau == t && p->fb_xb == pos_bar && p->fb_vb == vel_bar))
-        MCPM_TRY(axpby(p, vel_bar, pos_bar, 3 * N, b, b * t, Fb));
+        MCPM_TRY(axpby(p, vel_bar, pos_bar, 3 * N, b, b * t, Fb, true));
     p->fb_valid = 0;
     MCPM_TRY(mcpm_paint3_f32(p, pos_in, N, MCPM_POS_LATTICE, Fb, paint_order, p->fmesh, 0));
     // adjoint of 3 C2R + k-space + R2C: rho_bar = C2R( (1/M) sum_c conj(m_c) R2C(f_bar_c) )
@@ -588,14 +623,19 @@ static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float
         p->fb_xb = pos_bar;
         p->fb_vb = vel_bar;
         p->hint_set = 0;
+        if (p->paint3_variant == 4) {   // the fixed-point paint of fb_next needs max|fb_next|
+            MCPM_HIP(p, hipMemsetAsync(p->fx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream));
+            p->fx_src = fb_next;
+        }
     }
+    unsigned *fb_max = (fb_next && p->paint3_variant == 4) ? p->fx_wmax : nullptr;
     double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);
     MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 3 * MCPM_NSLOT, p->stream));
 #define ADJ(OR)                                                                                                                   \
     if (layout) step_adjoint_kernel<OR, true><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
-                                                           slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg);  \
+                                                           slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max);  \
     else step_adjoint_kernel<OR, false><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
-                                                           slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg)
+                                                           slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max)
     if (paint_order == 2) ADJ(2);
     else if (paint_order == 1) ADJ(1);
     else if (paint_order == 3) ADJ(3);

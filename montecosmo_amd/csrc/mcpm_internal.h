@@ -48,6 +48,9 @@ struct Geom {
     int tile_order;   // tiled paints: 0 = a contiguous run (pencil) of tiles per XCD, 1 = compact bricks of tiles per XCD
 };
 
+#define MCPM_FX_SLOTS 64
+#define MCPM_FX_STRIDE 32   // unsigned per slot: one 128-byte line each
+
 struct mcpm_plan {
     Geom g;
     hipStream_t stream;
@@ -56,7 +59,11 @@ struct mcpm_plan {
     int64_t Np;  // px*py*pz
     int halo;    // halo radius of the tiled paint
     int paint_variant;  // threads/unroll variant of the tiled paint (tuning)
-    int paint3_variant; // three-component tiled paint variant (tuning); < 0 disables it
+    int paint3_variant; // three-component tiled paint variant (tuning); < 0 disables it; 4 = fixed-point tile
+    unsigned *fx_wmax;  // fixed-point paint: bits of max|w|, maximum over MCPM_FX_SLOTS slots (device)
+    int *fx_redo;       // fixed-point paint: [0] = number of flagged tiles, then their indices (device)
+    int fx_tiles;       // capacity of fx_redo
+    const float *fx_src; // weights whose max|w| a producer kernel already left in fx_wmax (else NULL)
     // chaining of adjoint steps (mcpm_plan_hint_next_adjoint): the adjoint particle kernel of step i also writes the
     // force cotangent F_bar of step i-1, saving one pass over the cotangents
     int hint_set, fb_valid;

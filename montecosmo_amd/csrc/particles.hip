@@ -226,14 +226,190 @@ template <int B, int H, int THREADS, int U>
 __global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const float *__restrict__ disp,
                                                               const float *__restrict__ w3, float *__restrict__ mesh,
                                                               int64_t M, int accumulate, int *__restrict__ outliers,
-                                                              int *__restrict__ ocount) {
+                                                              int *__restrict__ ocount, const int *__restrict__ redo = nullptr) {
     constexpr int W = B + 2 * H + 1, NW = W * W * W, NT = B * B * B;
     __shared__ double tile[3 * NT];
     int tx, ty, tz;
-    tile_of_block(g.tile_order, g.nx / B, g.ny / B, g.nz / B, 32, tx, ty, tz);   // 96 KB of LDS: one workgroup per CU, 32 per XCD
+    if (redo) {   // second pass of the fixed-point paint: only the tiles it flagged (redo[0] = count, then tile indices);
+                  // their outliers are already on the list
+        if ((int)blockIdx.x >= redo[0]) return;
+        const int t = redo[1 + blockIdx.x], ntz = g.nz / B, nty = g.ny / B;
+        tz = t % ntz;
+        ty = (t / ntz) % nty;
+        tx = t / (ntz * nty);
+    } else
+        tile_of_block(g.tile_order, g.nx / B, g.ny / B, g.nz / B, 32, tx, ty, tz);   // 96 KB of LDS: one workgroup per CU, 32 per XCD
     const int x0 = tx * B, y0 = ty * B, z0 = tz * B;
     double2 *tile2 = reinterpret_cast<double2 *>(tile);
     for (int i = threadIdx.x; i < 3 * NT / 2; i += THREADS) tile2[i] = make_double2(0., 0.);
+    __syncthreads();
+
+    for (int j0 = threadIdx.x; j0 < NW; j0 += THREADS * U) {
+        P3 d[U], wt[U];
+        int rxs[U], rys[U], rzs[U], gis[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * THREADS;
+            bool ok = j < NW;
+            const int jz = j % W, r = j / W, jy = r % W, jx = r / W;
+            const int rx = jx - (H + 1), ry = jy - (H + 1), rz = jz - (H + 1);
+            int gx = x0 + rx, gy = y0 + ry, gz = z0 + rz;
+            bool inx = true;
+            if (g.xslab) {
+                gx -= g.xoff;
+                inx = (unsigned)gx < (unsigned)g.px;
+            } else {
+                gx += gx < 0 ? g.nx : 0;
+                gx -= gx >= g.nx ? g.nx : 0;
+            }
+            gy += gy < 0 ? g.ny : 0;
+            gy -= gy >= g.ny ? g.ny : 0;
+            gz += gz < 0 ? g.nz : 0;
+            gz -= gz >= g.nz ? g.nz : 0;
+            ok = ok && inx;
+            const int gi = ok ? (gx * g.ny + gy) * g.nz + gz : -1;
+            rxs[u] = rx;
+            rys[u] = ry;
+            rzs[u] = rz;
+            gis[u] = gi;
+            if (ok) {
+                d[u] = load3(disp, gi);
+                wt[u] = load3(w3, gi);
+            } else {
+                d[u] = P3{0.f, 0.f, 0.f};
+                wt[u] = P3{0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (gis[u] < 0) continue;
+            const int rx = rxs[u], ry = rys[u], rz = rzs[u];
+            const float fx = floorf(d[u].x), fy = floorf(d[u].y), fz = floorf(d[u].z);
+            const bool inl = fx >= (float)-H && fx <= (float)H && fy >= (float)-H && fy <= (float)H && fz >= (float)-H &&
+                             fz <= (float)H;
+            if (!inl) {
+                const bool home = (unsigned)rx < (unsigned)B && (unsigned)ry < (unsigned)B && (unsigned)rz < (unsigned)B;
+                if (home && !redo) {
+                    int k = atomicAdd(ocount, 1);
+                    outliers[k] = gis[u];
+                }
+                continue;
+            }
+            const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
+            if (cx < -1 || cx >= B || cy < -1 || cy >= B || cz < -1 || cz >= B) continue;
+            const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
+            const float kx[2] = {1.f - tx1, tx1}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int x = cx + a;
+                if ((unsigned)x >= (unsigned)B) continue;
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int y = cy + bb;
+                    if ((unsigned)y >= (unsigned)B) continue;
+                    const float kxy = kx[a] * ky[bb];
+                    double *row = tile + (x * B + y) * B;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int z = cz + e;
+                        if ((unsigned)z < (unsigned)B) {
+                            const float k = kxy * kz[e];
+                            atomicAdd(row + z, (double)(wt[u].x * k));
+                            atomicAdd(row + NT + z, (double)(wt[u].y * k));
+                            atomicAdd(row + 2 * NT + z, (double)(wt[u].z * k));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int i = threadIdx.x; i < 3 * NT / 4; i += THREADS) {
+        const int c = i / (NT / 4), ii = i - c * (NT / 4);
+        const int lz = (ii % (B / 4)) * 4, r = ii / (B / 4), ly = r % B, lx = r / B;
+        const double2 lo = tile2[2 * i], hi = tile2[2 * i + 1];
+        float4 v = make_float4((float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y);
+        float4 *dst = reinterpret_cast<float4 *>(mesh + c * M + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz);
+        if (accumulate) {
+            float4 o = *dst;
+            v.x += o.x;
+            v.y += o.y;
+            v.z += o.z;
+            v.w += o.w;
+        }
+        *dst = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fixed-point three-component paint.  An LDS f64 atomic costs about twice a 64-bit integer one under the bank
+// conflicts of real deposits and 24 of them per particle bound the f64 kernel above (tools/lds_atomic_bench.hip).
+// Here the three weighted corner contributions are rounded to 32-bit fixed point with a common power-of-two scale
+// S = 2^24 / 2^e (2^e <= max|w| < 2^(e+1), so one contribution is below 2^25 and a cell holds 64 maximal ones) and
+// travel in TWO 64-bit integer atomics per corner:
+//     word A = c0 + 2^32 c1        word B = c2 + 2^32 bound,   bound += max_c |contribution_c| / 2^11 + 1 (rounded up)
+// A signed low field added as a sign-extended 64-bit number leaves the high field exact as long as the low field's
+// true sum fits 32 bits, and modular arithmetic makes intermediate wrap-arounds harmless, so the sums are exact
+// integers and independent of the arrival order (bitwise reproducible).  `bound` proves it: a component field can only
+// leave the int32 range if sum |contribution| >= 2^31, i.e. bound >= 2^20; the bound field itself cannot overflow
+// (< 2^14 + 1 per deposit, < 2^17 deposits per cell).  A tile holding a cell with bound >= 2^19 is not written: it
+// is appended to the redo list and painted by the f64 kernel.  Non-finite or tiny (< 2^-97) max|w| sends every tile
+// there.  Rounding: half a unit per deposit = max|w| 2^-25, so the mesh differs from the exact sums by
+// ~1e-8 max|w| per cell (the f32 conversion of the output costs 6e-8 relative).
+__device__ __forceinline__ int cvt_rpi(float x) {   // floor(x + 0.5)
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ w, int64_t n, unsigned *__restrict__ out) {
+    float m = 0.f;
+    unsigned bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned b = __float_as_uint(w[i]) & 0x7fffffffu;
+        bad |= b >= 0x7f800000u;
+        m = fmaxf(m, __uint_as_float(b));
+    }
+    unsigned b = bad ? 0x7fc00000u : __float_as_uint(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out + (blockIdx.x & (MCPM_FX_SLOTS - 1)) * MCPM_FX_STRIDE, b);
+}
+
+template <int B, int H, int THREADS, int U>
+__global__ __launch_bounds__(THREADS) void paint3_fx_kernel(Geom g, const float *__restrict__ disp,
+                                                           const float *__restrict__ w3, float *__restrict__ mesh, int64_t M,
+                                                           int accumulate, int *__restrict__ outliers, int *__restrict__ ocount,
+                                                           const unsigned *__restrict__ wmax_bits, int *__restrict__ redo) {
+    constexpr int W = B + 2 * H + 1, NW = W * W * W, NT = B * B * B;
+    typedef unsigned long long u64;
+    __shared__ u64 tile[2 * NT];   // 64 KB: two workgroups per CU
+    __shared__ int flagged;
+    int tx, ty, tz;
+    tile_of_block(g.tile_order, g.nx / B, g.ny / B, g.nz / B, 64, tx, ty, tz);
+    const int x0 = tx * B, y0 = ty * B, z0 = tz * B;
+    unsigned wb = wmax_bits[(threadIdx.x & (MCPM_FX_SLOTS - 1)) * MCPM_FX_STRIDE];   // maximum over the slots, in every wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wb = max(wb, (unsigned)__shfl_xor((int)wb, o));
+    const unsigned be = wb >> 23;
+    if (be < 30u || be > 254u) {     // zero / tiny / non-finite weights: the f64 kernel paints this tile
+        if (wb == 0u) {              // all weights are zero: the tile is zero (or unchanged)
+            if (!accumulate)
+                for (int i = threadIdx.x; i < 3 * NT / 4; i += THREADS) {
+                    const int cc = i / (NT / 4), ii = i - cc * (NT / 4);
+                    const int lz = (ii % (B / 4)) * 4, r = ii / (B / 4), ly = r % B, lx = r / B;
+                    *reinterpret_cast<float4 *>(mesh + cc * M + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz) =
+                        make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            return;
+        }
+        if (threadIdx.x == 0) redo[1 + atomicAdd(redo, 1)] = (tx * (g.ny / B) + ty) * (g.nz / B) + tz;
+        return;
+    }
+    const float S = __uint_as_float((278u - be) << 23), Sinv = __uint_as_float((be - 24u) << 23);   // 2^(24-e), 2^(e-24)
+    if (threadIdx.x == 0) flagged = 0;
+    for (int i = threadIdx.x; i < 2 * NT; i += THREADS) tile[i] = 0ull;
     __syncthreads();
 
     for (int j0 = threadIdx.x; j0 < NW; j0 += THREADS * U) {
@@ -291,46 +467,75 @@ __global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const floa
             if (cx < -1 || cx >= B || cy < -1 || cy >= B || cz < -1 || cz >= B) continue;
             const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
             const float kx[2] = {1.f - tx1, tx1}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const float sx = wt[u].x * S, sy = wt[u].y * S, sz = wt[u].z * S;
+            const float mw = fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)) * (1.f / 2048.f);
+            const v2f s01 = {sx, sy}, s2m = {sz, mw}, c01 = {0.f, 1.f};     // packed f32 math: two products per instruction
+            // one LDS base address, corners at immediate offsets; a corner outside the tile is skipped
+            const bool vx[2] = {cx >= 0, cx < B - 1}, vy[2] = {cy >= 0, cy < B - 1}, vz[2] = {cz >= 0, cz < B - 1};
+            u64 *base = tile + ((cx * B + cy) * B + cz);
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int x = cx + a;
-                if ((unsigned)x >= (unsigned)B) continue;
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb) {
-                    const int y = cy + bb;
-                    if ((unsigned)y >= (unsigned)B) continue;
                     const float kxy = kx[a] * ky[bb];
-                    double *row = tile + (x * B + y) * B;
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int z = cz + e;
-                        if ((unsigned)z < (unsigned)B) {
+                    for (int e = 0; e < 2; ++e)
+                        if (vx[a] && vy[bb] && vz[e]) {
                             const float k = kxy * kz[e];
-                            atomicAdd(row + z, (double)(wt[u].x * k));
-                            atomicAdd(row + NT + z, (double)(wt[u].y * k));
-                            atomicAdd(row + 2 * NT + z, (double)(wt[u].z * k));
+                            const v2f kk = {k, k};
+                            const v2f p01 = s01 * kk, p2m = __builtin_elementwise_fma(s2m, kk, c01);
+                            const int i0 = cvt_rpi(p01.x), i1 = cvt_rpi(p01.y), i2 = cvt_rpi(p2m.x);
+                            const unsigned ib = (unsigned)p2m.y;
+                            const u64 wa = ((u64)(unsigned)(i1 + (i0 >> 31)) << 32) | (unsigned)i0;
+                            const u64 wbv = ((u64)(ib + (unsigned)(i2 >> 31)) << 32) | (unsigned)i2;
+                            u64 *q = base + ((a * B + bb) * B + e);
+                            atomicAdd(q, wa);
+                            atomicAdd(q + NT, wbv);
                         }
-                    }
                 }
-            }
         }
     }
     __syncthreads();
 
-    for (int i = threadIdx.x; i < 3 * NT / 4; i += THREADS) {
-        const int c = i / (NT / 4), ii = i - c * (NT / 4);
-        const int lz = (ii % (B / 4)) * 4, r = ii / (B / 4), ly = r % B, lx = r / B;
-        const double2 lo = tile2[2 * i], hi = tile2[2 * i + 1];
-        float4 v = make_float4((float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y);
-        float4 *dst = reinterpret_cast<float4 *>(mesh + c * M + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz);
-        if (accumulate) {
-            float4 o = *dst;
-            v.x += o.x;
-            v.y += o.y;
-            v.z += o.z;
-            v.w += o.w;
+    // overflow proof: bound field of every cell
+    int over = 0;
+    for (int i = threadIdx.x; i < NT; i += THREADS) {
+        const long long bw = (long long)tile[NT + i];
+        const int c2 = (int)(unsigned)bw;
+        over |= (unsigned)((bw - (long long)c2) >> 32) >= (1u << 19);
+    }
+    if (over) flagged = 1;
+    __syncthreads();
+    if (flagged) {
+        if (threadIdx.x == 0) redo[1 + atomicAdd(redo, 1)] = (tx * (g.ny / B) + ty) * (g.nz / B) + tz;
+        return;
+    }
+    for (int i = threadIdx.x; i < NT / 4; i += THREADS) {
+        const int lz = (i % (B / 4)) * 4, r = i / (B / 4), ly = r % B, lx = r / B;
+        float v[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long aw = (long long)tile[4 * i + q], bw = (long long)tile[NT + 4 * i + q];
+            const int c0 = (int)(unsigned)aw, c2 = (int)(unsigned)bw;
+            const int c1 = (int)((aw - (long long)c0) >> 32);
+            v[0][q] = (float)c0 * Sinv;
+            v[1][q] = (float)c1 * Sinv;
+            v[2][q] = (float)c2 * Sinv;
         }
-        *dst = v;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            float4 o = make_float4(v[cc][0], v[cc][1], v[cc][2], v[cc][3]);
+            float4 *dst = reinterpret_cast<float4 *>(mesh + cc * M + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz);
+            if (accumulate) {
+                const float4 old = *dst;
+                o.x += old.x;
+                o.y += old.y;
+                o.z += old.z;
+                o.w += old.w;
+            }
+            *dst = o;
+        }
     }
 }
 
@@ -673,6 +878,31 @@ int mcpm_paint3_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const f
     StageTimer st_(p, ST_PAINT3, 24.0 * n + (accumulate ? 24.0 : 12.0) * p->M);
     (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int), p->stream);
     const unsigned nb = (unsigned)((g.nx / 16) * (g.ny / 16) * (g.nz / 16));
+    if (p->paint3_variant == 4) {   // fixed-point tiles; the tiles they flag (and every tile if max|w| is unusable) in f64
+        MCPM_REQUIRE(p, p->fx_tiles >= (int)nb, MCPM_E_ARG, "mcpm_paint3_f32: redo list too small");
+        (void)hipMemsetAsync(p->fx_redo, 0, sizeof(int), p->stream);
+        if (p->fx_src != weights3) {   // max|w| not left behind by the kernel that produced the weights
+            (void)hipMemsetAsync(p->fx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream);
+            absmax_kernel<<<2048, 256, 0, p->stream>>>(weights3, 3 * n, p->fx_wmax);
+        }
+        p->fx_src = nullptr;
+#define CALLFX(HH)                                                                                                            \
+    {                                                                                                                         \
+        paint3_fx_kernel<16, HH, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, p->outliers, p->outlier_count, p->fx_wmax, p->fx_redo); \
+        paint3_tile_kernel<16, HH, 1024, 4><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, p->outliers, p->outlier_count, p->fx_redo); \
+    }
+        switch (H) {
+            case 1: CALLFX(1) break;
+            case 2: CALLFX(2) break;
+            case 3: CALLFX(3) break;
+            case 4: CALLFX(4) break;
+            default: CALLFX(6) break;
+        }
+#undef CALLFX
+        paint3_outlier_kernel<<<256, 256, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, p->outliers, p->outlier_count);
+        MCPM_LAUNCH_CHECK(p, "paint3_fx_kernel");
+        return MCPM_OK;
+    }
 #define CALL3(HH)                                                                                                             \
     {                                                                                                                         \
         if (p->paint3_variant == 1)                                                                                           \

@@ -94,12 +94,16 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->halo = 4;
     p->paint_variant = 0;
     if (const char *e = getenv("MCPM_PAINT_VARIANT")) p->paint_variant = atoi(e);
-    p->paint3_variant = 2;
+    p->paint3_variant = 4;   // fixed-point tiles (particles.hip); 2 = f64 tiles
     p->hint_set = 0;
     p->fb_valid = 0;
     if (const char *e = getenv("MCPM_PAINT3_VARIANT")) p->paint3_variant = atoi(e);
     p->rho = p->spec = p->fmesh = p->spec1 = p->fft_pad = nullptr;
     p->outliers = p->outlier_count = nullptr;
+    p->fx_wmax = nullptr;
+    p->fx_redo = nullptr;
+    p->fx_tiles = 0;
+    p->fx_src = nullptr;
     p->reduce = nullptr;
     p->pscratch = nullptr;
     p->vscratch = nullptr;
@@ -120,6 +124,9 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     alloc((void **)&p->spec1, sizeof(float) * 2 * p->Mh);
     alloc((void **)&p->outliers, sizeof(int) * p->Np);
     alloc((void **)&p->outlier_count, sizeof(int) * 4);
+    p->fx_tiles = (int)(p->M / 4096 + 2);
+    alloc((void **)&p->fx_wmax, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE);
+    alloc((void **)&p->fx_redo, sizeof(int) * (p->fx_tiles + 1));
     alloc((void **)&p->reduce, sizeof(double) * MCPM_NREDUCE);
     if (e != hipSuccess) {
         std::string msg = std::string("hipMalloc of plan scratch: ") + hipGetErrorString(e);
@@ -127,6 +134,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
         return mcpm_fail(nullptr, MCPM_E_NOMEM, msg);
     }
     (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int) * 4, p->stream);
+    (void)hipMemsetAsync(p->fx_redo, 0, sizeof(int), p->stream);
     *out = p;
     return MCPM_OK;
 }
@@ -152,6 +160,8 @@ int mcpm_plan_destroy(mcpm_plan *p) {
     (void)hipFree(p->fft_pad);
     (void)hipFree(p->outliers);
     (void)hipFree(p->outlier_count);
+    (void)hipFree(p->fx_wmax);
+    (void)hipFree(p->fx_redo);
     (void)hipFree(p->reduce);
     (void)hipFree(p->pscratch);
     (void)hipFree(p->vscratch);
@@ -171,6 +181,22 @@ int mcpm_plan_set_tile_order(mcpm_plan *p, int order) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, order == 0 || order == 1, MCPM_E_ARG, "tile order must be 0 (pencils) or 1 (bricks)");
     p->g.tile_order = order;
+    return MCPM_OK;
+}
+
+int mcpm_plan_set_paint3_fixed(mcpm_plan *p, int fixed) {
+    if (!p) return MCPM_E_ARG;
+    p->paint3_variant = fixed ? 4 : 2;
+    p->fx_src = nullptr;
+    return MCPM_OK;
+}
+
+int mcpm_plan_last_redo(mcpm_plan *p, int64_t *count) {
+    if (!p || !count) return MCPM_E_ARG;
+    int h = 0;
+    MCPM_HIP(p, hipMemcpyAsync(&h, p->fx_redo, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    MCPM_HIP(p, hipStreamSynchronize(p->stream));
+    *count = h;
     return MCPM_OK;
 }
 

@@ -311,6 +311,70 @@ def test_paint3_matches_three_paints(nb, n, sigma):
         assert rel_l2(to_np(out[c]), o.paint(pos64, shape, w3[:, c].astype(np.float64))) < 2e-6
 
 
+def test_paint3_fixed_point_tiles(nb):
+    """The fixed-point accumulator of the three-component paint (particles.hip, paint3_fx_kernel) against the float64
+    restatement and against the f64-tile kernel: heavy-tailed weights (the scale follows max|w|), bitwise reproducibility
+    (integer sums do not depend on the arrival order), accumulation, the overflow proof (a cell holding more than 32
+    maximal weights flags its tile, which the f64 kernel repaints), all-zero weights and NaN propagation."""
+    import ctypes as C
+    import torch
+    from montecosmo_amd._lib import lib
+    n = 64
+    shape, N = (n, n, n), n ** 3
+    rng = np.random.default_rng(33)
+    plan = nb.get_plan(shape)
+    disp = np.clip(rng.standard_normal((N, 3)) * 1.5, -3.9, 3.9).astype(np.float32)   # within the tile halo: no particle
+    pos64 = o.regular_pos(shape) + disp.astype(np.float64)                             # takes the float-atomic outlier path
+    lp = nb.LatticePos(disp, shape)
+    out = torch.empty((3,) + shape, dtype=torch.float32, device="cuda")
+
+    def paint3(w3, fixed, accumulate=0, d=lp):
+        assert lib.mcpm_plan_set_paint3_fixed(plan.h, fixed) == 0
+        wt = torch.from_numpy(np.ascontiguousarray(w3, dtype=np.float32)).cuda()
+        plan.call("mcpm_paint3_f32", C.c_void_p(d.disp.data_ptr()), N, 1, C.c_void_p(wt.data_ptr()), 2, C.c_void_p(out.data_ptr()),
+                  accumulate)
+        redo = C.c_int64()
+        assert lib.mcpm_plan_last_redo(plan.h, C.byref(redo)) == 0
+        return to_np(out).copy(), redo.value
+
+    try:
+        for tail in (0.0, 1.5):      # max|w| / rms|w| ~ 5 and ~ 1e3
+            w3 = (rng.standard_normal((N, 3)) * np.exp(tail * rng.standard_normal((N, 1)))).astype(np.float32)
+            fx, redo = paint3(w3, 1)
+            assert redo == 0
+            f64, _ = paint3(w3, 0)
+            ref = np.stack([o.paint(pos64, shape, w3[:, c].astype(np.float64)) for c in range(3)])
+            assert rel_l2(f64, ref) < 2e-6
+            assert rel_l2(fx, ref) < (2e-6 if tail == 0 else 2e-5), (tail, rel_l2(fx, ref))
+            assert np.array_equal(fx, paint3(w3, 1)[0])                       # reproducible bit for bit
+            acc, _ = paint3(w3, 1, accumulate=1)                               # out held fx: accumulate doubles it
+            assert rel_l2(acc, 2 * ref) < (2e-6 if tail == 0 else 2e-5)
+        # overflow proof: the 64 particles of every 4^3 block of lattice sites land on one mesh point with weight 1.5:
+        # 96 > 64 (the capacity of a cell in units of 2^floor(log2 max|w|)) / 2 flags every tile; half of it does not
+        g = np.indices(shape).reshape(3, -1).T
+        dc = (-(g % 4)).astype(np.float32)
+        lc = nb.LatticePos(dc, shape)
+        refc = o.paint(o.regular_pos(shape) + dc.astype(np.float64), shape, 1.0)
+        fx, redo = paint3(np.full((N, 3), 1.5, np.float32), 1, d=lc)
+        assert redo == (n // 16) ** 3
+        assert rel_l2(fx[0], 1.5 * refc) < 2e-6 and rel_l2(fx[2], 1.5 * refc) < 2e-6
+        wh = np.full((N, 3), 1.5, np.float32)
+        wh[g.sum(1) % 2 == 1] = 0.0                                            # 32 x 1.5 = 48 < 64: stays fixed point
+        fx, redo = paint3(wh, 1, d=lc)
+        assert redo == 0
+        assert rel_l2(fx[1], o.paint(o.regular_pos(shape) + dc.astype(np.float64), shape, wh[:, 1].astype(np.float64))) < 2e-6
+        # zero weights, then a NaN weight: every tile goes to the f64 kernel and the NaN reaches its 8 cells
+        z, redo = paint3(np.zeros((N, 3), np.float32), 1)
+        assert redo == 0 and not z.any()
+        wn = rng.standard_normal((N, 3)).astype(np.float32)
+        wn[12345, 1] = np.nan
+        fx, redo = paint3(wn, 1)
+        assert redo == (n // 16) ** 3
+        assert np.isnan(fx[1]).sum() == 8 and not np.isnan(fx[0]).any() and not np.isnan(fx[2]).any()
+    finally:
+        lib.mcpm_plan_set_paint3_fixed(plan.h, 1)
+
+
 @pytest.mark.parametrize("mesh,ptcl", [((32, 32, 32), (16, 16, 16)), ((16, 32, 16), (32, 32, 32))])
 def test_nbody_bf_particle_lattice_differs_from_mesh(nb, mesh, ptcl):
     """ptcl_shape != mesh_shape (model.py:738 with ptcl_oversamp != evol_oversamp): generic lattice path, forward
