@@ -312,10 +312,10 @@ __global__ __launch_bounds__(256) void zinv3_il_kernel(FGeom g, const cf *__rest
 
 // ------------------------------------------------------------------------------------------------
 // column passes (y or x): 16 adjacent kz columns per workgroup
-template <int N>
+template <int N, int ML = 16>
 struct ColShape {
     static constexpr int T = FftShape<N>::T;
-    static constexpr int LINES = (1024 / T) < 16 ? (1024 / T) : 16;
+    static constexpr int LINES = (1024 / T) < ML ? (1024 / T) : ML;
     static constexpr int THREADS = T * LINES;
 };
 
@@ -355,10 +355,10 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol_kernel(FGeom g, con
 // (ky = 0 at its Nyquist on the kz = 0 / Nyquist planes, kz = 0 at its Nyquist: the Hermitian projection).
 //   EXPAND  (inverse): in = {A, G} -> out = {IFFTy A, IFFTy(ky G), kz IFFTy G}
 //   CONTRACT (forward, adjoint): in = {a, b, c} -> out = {FFTy a, ky FFTy b + kz FFTy c}
-template <int N, bool EXPAND>
-__global__ __launch_bounds__(ColShape<N>::THREADS) void ycol2_kernel(
+template <int N, bool EXPAND, int ML>
+__global__ __launch_bounds__((ColShape<N, ML>::THREADS)) void ycol2_kernel(
     FGeom g, const cf *__restrict__ in, cf *__restrict__ out, YLayout li, YLayout lo, const cf *__restrict__ W, int parts) {
-    constexpr int T = ColShape<N>::T, LINES = ColShape<N>::LINES;
+    constexpr int T = ColShape<N, ML>::T, LINES = ColShape<N, ML>::LINES;
     typedef Tile<N, LINES, true> TL;
     __shared__ cf lds[TL::FLOATS2];
     const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
@@ -449,10 +449,10 @@ __device__ __forceinline__ float kfreq_i(int i, int n) {
 // (L = -scale/k^2; the y pass applies ky, kz: ycol2_kernel.)
 // The multiplier of component c at mode (kx, ky, kz) is s_c * (-i), s_c = k_c * (-scale/k^2), Hermitian-projected:
 // on the kz = 0 / Nyquist planes a component whose own index sits at Nyquist is dropped (kspace.hip header).
-template <int N, int MODE>
-__global__ __launch_bounds__(ColShape<N>::THREADS) void xfused_kernel(FGeom g, const cf *__restrict__ in, cf *__restrict__ out,
-                                                                      XLayout xl, float scale, const cf *__restrict__ W) {
-    constexpr int T = ColShape<N>::T, LINES = ColShape<N>::LINES;
+template <int N, int MODE, int ML>
+__global__ __launch_bounds__((ColShape<N, ML>::THREADS)) void xfused_kernel(FGeom g, const cf *__restrict__ in, cf *__restrict__ out,
+                                                                          XLayout xl, float scale, const cf *__restrict__ W) {
+    constexpr int T = ColShape<N, ML>::T, LINES = ColShape<N, ML>::LINES;
     typedef Tile<N, LINES, true> TL;
     __shared__ cf lds[TL::FLOATS2];
     const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
@@ -765,6 +765,18 @@ static YLayout ylayout(const mcpm_plan *p, bool packed) {
     return YLayout{spec_elems(p), (int64_t)nyl * nzp, (int64_t)p->nxl * nyl * nzp, nyl, p->nxl, lg(nyl), p->xw0, p->xwn};
 }
 
+// kz columns per workgroup of the register-heavy passes (ycol2, xfused; 75-118 VGPRs, so a 1024-thread workgroup is
+// alone on its CU): 8 columns (512 threads at N = 512, two independent workgroups per CU, 64-byte row segments) measured
+// 1 % faster per step than 16 at 512^3 (13.13 vs 13.26 ms, same box).  Tuning knob MCPM_COL_LINES = 8 | 16.
+static int col_lines() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MCPM_COL_LINES");
+        v = (e && atoi(e) == 16) ? 16 : 8;
+    }
+    return v;
+}
+
 static int y_columns(mcpm_plan *p, const cf *in, cf *out, int batch, int sign, bool in_packed, bool out_packed) {
     const FGeom g = fgeom(p);
     const YLayout li = ylayout(p, in_packed), lo = ylayout(p, out_packed);
@@ -787,15 +799,18 @@ static int y_columns2(mcpm_plan *p, const cf *in, cf *out, bool expand, bool in_
     const FGeom g = fgeom(p);
     const YLayout li = ylayout(p, in_packed), lo = ylayout(p, out_packed);
     StageTimer st_(p, expand ? ST_C2R : ST_R2C, pass_bytes(p, parts == 3 ? 3 : (parts == 1 ? 1 : 2)));
-#define CALL(NN)                                                                                       \
+#define CALLL(NN, ML)                                                                                  \
     {                                                                                                  \
-        constexpr int LINES = ColShape<NN>::LINES, TH = ColShape<NN>::THREADS;                         \
+        constexpr int LINES = ColShape<NN, ML>::LINES, TH = ColShape<NN, ML>::THREADS;                 \
         dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)p->xwn);                          \
-        if (expand) ycol2_kernel<NN, true><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1], parts);  \
-        else ycol2_kernel<NN, false><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1], parts);        \
+        if (expand) ycol2_kernel<NN, true, ML><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1], parts);  \
+        else ycol2_kernel<NN, false, ML><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1], parts);        \
     }
+#define CALL(NN)                                                                                       \
+    if (col_lines() == 8 && NN >= 512) CALLL(NN, 8) else CALLL(NN, 16)
     DISPATCH_N(g.ny, CALL)
 #undef CALL
+#undef CALLL
     MCPM_LAUNCH_CHECK(p, "ycol2_kernel");
     return MCPM_OK;
 }
@@ -811,15 +826,18 @@ static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
     const float scale = 1.f / ((float)g.nx * (float)g.ny * (float)g.nz);
     // one forward + one inverse x pass of (1 + 3) spectra and the k-space multiply
     StageTimer st_(p, ST_KSPACE, (32.0 * p->nxl * g.ny * g.nzh) + 4.0 * pass_bytes(p, 1));
-#define CALL(NN)                                                                                              \
+#define CALLL(NN, ML)                                                                                         \
     {                                                                                                         \
-        constexpr int LINES = ColShape<NN>::LINES, TH = ColShape<NN>::THREADS;                                \
+        constexpr int LINES = ColShape<NN, ML>::LINES, TH = ColShape<NN, ML>::THREADS;                        \
         dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)nyl);                                    \
-        if (mode == 0) xfused_kernel<NN, 0><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]); \
-        else xfused_kernel<NN, 1><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]);           \
+        if (mode == 0) xfused_kernel<NN, 0, ML><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]); \
+        else xfused_kernel<NN, 1, ML><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]);           \
     }
+#define CALL(NN)                                                                                              \
+    if (col_lines() == 8 && NN >= 512) CALLL(NN, 8) else CALLL(NN, 16)
     DISPATCH_N(g.nx, CALL)
 #undef CALL
+#undef CALLL
     MCPM_LAUNCH_CHECK(p, "xfused_kernel");
     return MCPM_OK;
 }
