@@ -3,13 +3,15 @@ usage: python tools/make_traffic_json.py <fetch_dir> <write_dir> <mesh> <out.jso
 import collections, csv, glob, json, sys
 
 fetch_dir, write_dir, mesh, out_json, out_txt = sys.argv[1:6]
-stage_of = [("paint3_", "paint3"), ("paint_tile_kernel", "paint"), ("paint_outlier_kernel", "paint"), ("paint_atomic_kernel", "paint"),
-            ("zfwd_kernel", "fft_r2c"), ("ycol2_kernel<512, false>", "fft_r2c"), ("ycol2_kernel<256, false>", "fft_r2c"),
-            ("ycol2_kernel<512, true>", "fft_c2r"), ("ycol2_kernel<256, true>", "fft_c2r"), ("ycol_kernel<512, -1>", "fft_r2c"), ("ycol_kernel<256, -1>", "fft_r2c"),
+stage_of = [("paint3_", "paint3"), ("absmax_kernel", "paint3"), ("paint_tile_kernel", "paint"), ("paint_outlier_kernel", "paint"), ("paint_atomic_kernel", "paint"),
+            ("zfwd_kernel", "fft_r2c"), ("ycol2_kernel<512, false", "fft_r2c"), ("ycol2_kernel<256, false", "fft_r2c"),
+            ("ycol2_kernel<512, true", "fft_c2r"), ("ycol2_kernel<256, true", "fft_c2r"), ("ycol_kernel<512, -1>", "fft_r2c"), ("ycol_kernel<256, -1>", "fft_r2c"),
             ("ycol_kernel<512, 1>", "fft_c2r"), ("ycol_kernel<256, 1>", "fft_c2r"), ("zinv_kernel", "fft_c2r"), ("zinv3_il_kernel", "fft_c2r"),
             ("xfused_kernel", "kspace"), ("kick_drift_kernel", "kick_drift"), ("step_adjoint_kernel", "step_adjoint"),
             ("axpby_kernel", "axpy"), ("axpy_kernel", "axpy")]
-outlier_kernels = ("paint_outlier_kernel", "paint3_outlier_kernel")
+# auxiliary kernels of a stage: their bytes count, their launches do not (the f64 repaint of the tiles the fixed-point
+# three-component paint flags is a separate, normally empty, launch)
+outlier_kernels = ("paint_outlier_kernel", "paint3_outlier_kernel", "paint3_tile_kernel", "absmax_kernel")
 
 
 def stage(name):
@@ -22,7 +24,8 @@ def stage(name):
 tot = collections.defaultdict(lambda: {"fetch_kb": 0.0, "write_kb": 0.0, "launches": 0})
 per_kernel = collections.defaultdict(lambda: {"fetch_kb": [], "write_kb": []})
 for d, key in ((fetch_dir, "fetch_kb"), (write_dir, "write_kb")):
-    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    import os
+    f = max(glob.glob(f"{d}/*/*counter_collection.csv"), key=os.path.getmtime)      # the latest pass
     for r in csv.DictReader(open(f)):
         nm, v = r["Kernel_Name"], float(r["Counter_Value"])
         per_kernel[nm.split("(")[0]][key].append(v)
