@@ -147,6 +147,19 @@ class _Rng:
             self._gens[key] = g
         return self._gens[key]
 
+    def get_state(self):
+        """Everything needed to continue the streams exactly (a chain resumed from a saved state repeats the draws an
+        uninterrupted chain would have made)."""
+        return {"seed": self._seed, "py": self._r.getstate(), "gens": {k: g.get_state() for k, g in self._gens.items()}}
+
+    @classmethod
+    def from_state(cls, st):
+        r = cls(st["seed"])
+        r._r.setstate(st["py"])
+        for k, gs in st["gens"].items():
+            r.torch_gen(torch.device(k)).set_state(gs)
+        return r
+
 
 def find_reasonable_step_size(fn, q, lp, g, rng, eps=1.0):
     """Heuristic of Hoffman & Gelman 2014, alg. 4: double / halve until the one-step acceptance crosses 1/2."""
@@ -167,12 +180,20 @@ def find_reasonable_step_size(fn, q, lp, g, rng, eps=1.0):
 
 
 def nuts_sample(logdensity_and_grad, q0, n_warmup=200, n_samples=200, max_tree_depth=10, target_accept=0.8, seed=0,
-                step_size=None, callback=None, keep=None):
+                step_size=None, callback=None, keep=None, state=None):
     """Runs warm-up (step-size adaptation by dual averaging) then sampling.  `logdensity_and_grad(q) -> (float, tensor)`.
     `keep(q)` maps a state to what is stored per draw (default: the state itself; pass a reducer for 10^7-dimensional
-    states).  Returns dict(samples=[...], step_size, infos=[...], seconds)."""
-    rng = _Rng(seed)
-    q = q0.clone()
+    states).  Returns dict(samples=[...], step_size, infos=[...], seconds, last_state).  `state` (a previous call's
+    `last_state`, see `save_run` / `load_state`) continues that chain: position, step size and random streams are taken
+    from it (q0, seed and step_size are ignored; pass n_warmup=0 to keep the adapted step size, as the reference does
+    with `post_warmup_state`, samplers.py:618-660)."""
+    if state is not None:
+        rng = _Rng.from_state(state["rng"])
+        q = state["q"].clone().to(q0.device if q0 is not None else state["q"].device)
+        step_size = state["step_size"]
+    else:
+        rng = _Rng(seed)
+        q = q0.clone()
     lp, g = logdensity_and_grad(q)
     eps = step_size if step_size is not None else find_reasonable_step_size(logdensity_and_grad, q, lp, g, rng)
     da = DualAveraging(eps, target=target_accept)
@@ -191,7 +212,58 @@ def nuts_sample(logdensity_and_grad, q0, n_warmup=200, n_samples=200, max_tree_d
         infos.append(info)
         if callback is not None:
             callback(it, info)
-    return {"samples": samples, "step_size": eps, "infos": infos, "seconds": time.perf_counter() - t0}
+    return {"samples": samples, "step_size": eps, "infos": infos, "seconds": time.perf_counter() - t0,
+            "last_state": {"sampler": "nuts", "q": q.clone(), "step_size": eps, "rng": rng.get_state()}}
+
+
+# ---- chains on disk (montecosmo/samplers.py:596-660: one .npz of draws per run + the last state, overwritten) ----
+def save_run(result, i_run, path, extra_fields=("n_evals", "accept_stat", "step_size", "logdensity", "diverging")):
+    """Writes `path_{i_run}.npz` (the kept draws stacked as 'samples' + the requested per-transition fields; n_evals is
+    the number of gradient evaluations, the reference's renamed `num_steps`) and overwrites `path_last_state.pt`."""
+    import numpy as np
+    infos = result["infos"]
+    out = {}
+    draws = result["samples"]
+    if len(draws):
+        out["samples"] = np.stack([np.asarray(d.detach().cpu()) if isinstance(d, torch.Tensor) else np.asarray(d) for d in draws])
+    for f in extra_fields:
+        key = "n_leapfrog" if (f == "n_evals" and infos and "n_evals" not in infos[0]) else f
+        if infos and key in infos[0]:
+            out[f] = np.asarray([i[key] for i in infos])
+    out["warmup"] = np.asarray([bool(i["warmup"]) for i in infos])
+    np.savez(f"{path}_{i_run}.npz", **out)
+    st = dict(result["last_state"])
+    st["q"] = st["q"].detach().cpu()
+    if "u" in st:
+        st["u"] = st["u"].detach().cpu()
+    torch.save(st, f"{path}_last_state.pt")
+
+
+def load_state(path, device=None):
+    """The state `save_run` left at `path_last_state.pt`, on `device`."""
+    st = torch.load(f"{path}_last_state.pt", weights_only=False)
+    if device is not None:
+        st["q"] = st["q"].to(device)
+        if "u" in st:
+            st["u"] = st["u"].to(device)
+    return st
+
+
+def sample_and_save(sampler, logdensity_and_grad, q0, path, start=0, end=1, n_warmup=200, n_samples=200, resume=False, **kw):
+    """Run `start` = warm-up (+ its draws), runs start+1..end = `n_samples` draws each, every run saved with `save_run`
+    (samplers.py:618-660).  `sampler` is nuts_sample or mclmc_sample.  resume=True continues from `path_last_state.pt`
+    without warm-up."""
+    import os
+    state = None
+    if resume and os.path.exists(f"{path}_last_state.pt"):
+        state = load_state(path, q0.device if q0 is not None else None)
+    res = None
+    for i_run in range(start, end + 1):
+        warm = n_warmup if (state is None) else 0
+        res = sampler(logdensity_and_grad, q0, n_warmup=warm, n_samples=n_samples, state=state, **kw)
+        save_run(res, i_run, path)
+        state = res["last_state"]
+    return res
 
 
 # ---- packing the model's parameter dict into one flat vector -----------------------------------------------------
@@ -272,18 +344,26 @@ def mclmc_step(fn, q, lp, g, u, eps, L, rng):
 
 
 def mclmc_sample(logdensity_and_grad, q0, n_warmup=200, n_samples=200, desired_energy_var=5e-4, L=None, step_size=None,
-                 seed=0, callback=None, keep=None):
+                 seed=0, callback=None, keep=None, state=None):
     """Warm-up: the step size is driven to an energy-error variance per dimension of `desired_energy_var`
     (E[dE^2] / d = C eps^6 for this second-order splitting: C is a down-weighted running average, eps = C^(-1/6)), L stays at its initial value (default sqrt(d), samplers.py:285-287) unless given.  Then
     `n_samples` transitions are recorded.  Two gradient evaluations per transition."""
-    rng = _Rng(seed)
-    q = q0.clone()
+    if state is not None:      # continue a chain: position, direction, step size, L and random streams (see nuts_sample)
+        rng = _Rng.from_state(state["rng"])
+        dev = q0.device if q0 is not None else state["q"].device
+        q, step_size, L = state["q"].clone().to(dev), state["step_size"], state["L"]
+    else:
+        rng = _Rng(seed)
+        q = q0.clone()
     d = q.numel()
     lp, g = logdensity_and_grad(q)
     L = float(L) if L is not None else math.sqrt(d)
     eps = float(step_size) if step_size is not None else math.sqrt(d) / 1e4 * 10.0
-    u = torch.randn(q.shape, dtype=q.dtype, device=q.device, generator=rng.torch_gen(q.device))
-    u = u / torch.linalg.vector_norm(u)
+    if state is not None:
+        u = state["u"].clone().to(q.device)
+    else:
+        u = torch.randn(q.shape, dtype=q.dtype, device=q.device, generator=rng.torch_gen(q.device))
+        u = u / torch.linalg.vector_norm(u)
     infos, samples = [], []
     # step-size predictor (the scheme of blackjax's mclmc adaptation): the energy-error variance per dimension scales as
     # xi = C eps^6; C is tracked as a weighted running average (outliers down-weighted in log space) and
@@ -314,4 +394,5 @@ def mclmc_sample(logdensity_and_grad, q0, n_warmup=200, n_samples=200, desired_e
         infos.append(info)
         if callback is not None:
             callback(it, info)
-    return {"samples": samples, "step_size": eps, "L": L, "infos": infos, "seconds": time.perf_counter() - t0}
+    return {"samples": samples, "step_size": eps, "L": L, "infos": infos, "seconds": time.perf_counter() - t0,
+            "last_state": {"sampler": "mclmc", "q": q.clone(), "u": u.clone(), "step_size": eps, "L": L, "rng": rng.get_state()}}

@@ -1,6 +1,7 @@
 """The host NUTS loop (montecosmo_amd/samplers.py) on targets with known answers (CPU tensors)."""
 import math
 import numpy as np
+import pytest
 import torch
 
 from montecosmo_amd import samplers
@@ -56,3 +57,34 @@ def test_mclmc_recovers_gaussian_moments():
     assert 5e-5 < mse < 5e-3                              # the step size was tuned to the energy-error target
     assert np.all(np.abs(x.std(0) / sd.numpy() - 1) < 0.25)
     assert np.all(np.abs(x.mean(0)) < 0.5 * sd.numpy())
+
+
+@pytest.mark.parametrize("which", ["nuts", "mclmc"])
+def test_chain_save_and_resume_continue_exactly(tmp_path, which):
+    """montecosmo/samplers.py:596-660 (`save_run`, `sample_and_save`): runs are written one .npz each plus the last
+    state; a chain resumed from the saved state repeats, bit for bit, what the uninterrupted chain draws."""
+    from montecosmo_amd import samplers
+    scale = torch.tensor([1.0, 0.5, 2.0, 1.5], dtype=torch.float64)
+
+    def logdf(q):
+        return float(-0.5 * ((q / scale) ** 2).sum()), -q / scale ** 2
+
+    sampler = samplers.nuts_sample if which == "nuts" else samplers.mclmc_sample
+    q0 = torch.zeros(4, dtype=torch.float64)
+    path = str(tmp_path / "chain")
+    whole = sampler(logdf, q0, n_warmup=30, n_samples=40, seed=3)
+    first = sampler(logdf, q0, n_warmup=30, n_samples=15, seed=3)
+    samplers.save_run(first, 0, path)
+    rest = sampler(logdf, None, n_warmup=0, n_samples=25, state=samplers.load_state(path))
+    samplers.save_run(rest, 1, path)
+    a = np.load(path + "_0.npz")
+    b = np.load(path + "_1.npz")
+    joined = np.concatenate([a["samples"], b["samples"]])
+    assert joined.shape == (40, 4) and a["warmup"].sum() == 30 and not b["warmup"].any()
+    assert np.array_equal(joined, torch.stack(whole["samples"]).numpy())
+    assert "n_evals" in a.files and len(a["n_evals"]) == 45
+    # the driver: warm-up run, two more runs, then a resumed fourth run
+    res = samplers.sample_and_save(sampler, logdf, q0, str(tmp_path / "drv"), start=0, end=2, n_warmup=20, n_samples=10, seed=1)
+    res2 = samplers.sample_and_save(sampler, logdf, q0, str(tmp_path / "drv"), start=3, end=3, n_samples=10, resume=True)
+    assert all((tmp_path / f"drv_{i}.npz").exists() for i in range(4))
+    assert res2["step_size"] == res["step_size"] and not any(i["warmup"] for i in res2["infos"])
