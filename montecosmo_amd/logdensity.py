@@ -6,9 +6,11 @@ Built branch (everything else stays in the reference): latents with a Normal pri
 reparametrisation `base = name_ * scale_fid + loc_fid` (bricks.py:270-276); initial conditions `white_mesh_ ~ N(0, scale)`
 per cell with the 'fourier' (rg2cgh) or 'real' (rfftn) preconditioning at unit scale, or the reference's default 'kaiser'
 preconditioning (rg2cgh with the per-mode posterior width of the fiducial linear Kaiser model; model.py:1127-1148);
-`evolve`; the 'quad_gauss' likelihood (model.py:893-908) without mask, with unit selection, one radial bin and phi = 0:
-    count = ngbar cell^3 * irfftn(chreshape(rfftn(gxy_mesh), final_shape));  delta = count / selec - 1
-    obs ~ QuadGaussian(count, (|s_e + s_ed delta| + 1e-9) sqrt(selec), s_e2 sqrt(selec)),  selec = ngbar cell^3.
+`evolve`; the 'quad_gauss' likelihood (model.py:852-866, :893-908) with phi = 0, an optional selection mesh (paint_shape),
+an optional mask over the final cells and radial shells with their own (fixed) mean densities:
+    count = rc * irfftn(chreshape(rfftn(gxy_mesh * selec_mesh), final_shape)),   rc = ngbars[shell(r)] cell^3 per cell
+    selec = |rc * irfftn(chreshape(rfftn(selec_mesh), final_shape))|  (or mean(ngbars) cell^3 without a selection mesh)
+    delta = count / selec - 1;   obs[mask] ~ QuadGaussian(count, (|s_e + s_ed delta| + 1e-9) sqrt(selec), s_e2 sqrt(selec)).
 Bounded latents (`low` / `high` in their config) use the reference's detruncated truncated-normal parametrisation
 (utils.py:189-226, :267-311) within |x| < 12 sigma.
 
@@ -30,8 +32,9 @@ LOG2PI = math.log(2 * math.pi)
 
 def quad_gaussian_log_prob_and_grad(value, loc, b, a):
     """QuadGaussian.log_prob (utils.py:497-510) per element and its derivatives w.r.t. (loc, scale1 = b, scale2 = a);
-    `a` is a python float (one value for the whole mesh), the rest device tensors."""
-    if abs(a) < 1e-8:
+    `a` is a python float (one value for the whole mesh; |a| < 1e-8 selects the Gaussian limit) or a device tensor
+    (nowhere near zero), the rest device tensors."""
+    if not torch.is_tensor(a) and abs(a) < 1e-8:
         z = (value - loc) / b
         lp = -0.5 * LOG2PI - torch.log(b) - 0.5 * z * z
         return lp, z / b, (z * z - 1.0) / b, torch.zeros_like(lp)
@@ -104,7 +107,11 @@ class FieldLevelLogDensity:
     COSMO = ("Omega_m", "sigma8")
     STOCH = ("s_e", "s_ed", "s_e2")
 
-    def __init__(self, fwd, count_obs, latents, fixed, precond="fourier", make_cosmo=None):
+    def __init__(self, fwd, count_obs, latents, fixed, precond="fourier", make_cosmo=None, selec_mesh=None, mask_mesh=None,
+                 redges=None):
+        """selec_mesh: real, fwd.paint_shape (None = 1); mask_mesh: bool, final_shape, True = observed cell (None = all);
+        fixed['ngbars']: a scalar or one mean density per radial shell; redges: shell edges (default: model.py:1087-1098,
+        equal-width shells over the observed cells).  count_obs is the full final mesh (only observed cells are used)."""
         if precond not in ("fourier", "real", "kaiser"):
             raise ValueError(f"Unknown preconditioning type: {precond}")
         self.fwd, self.precond = fwd, precond
@@ -119,6 +126,7 @@ class FieldLevelLogDensity:
         self.final_shape = tuple(fwd.final_shape)
         self.count_obs = nbody._f32(count_obs, self.final_shape)
         self.make_cosmo = make_cosmo or self._planck
+        self._setup_selection(selec_mesh, mask_mesh, redges)
         self.scale, self.transfer = self._precond_scale_and_transfer()
 
     @staticmethod
@@ -127,6 +135,54 @@ class FieldLevelLogDensity:
         c.Omega_c = float(base["Omega_m"]) - c.Omega_b
         c.sigma8 = float(base["sigma8"])
         return c
+
+    def _radius_mesh(self):
+        """Physical distance of the final-mesh cells (bricks.py:665-686); host float64, set-up only."""
+        fwd = self.fwd
+        p = bricks.cell2phys_pos(bricks.regular_pos(self.final_shape), fwd.box_center, fwd.box_rotvec, fwd.box_size, self.final_shape)
+        if fwd.curved_sky:
+            r = np.linalg.norm(p, axis=-1)
+        else:
+            r = np.abs(p @ nbody.safe_div(fwd.box_center, np.linalg.norm(fwd.box_center)))
+        return r.reshape(self.final_shape)
+
+    def _down(self, mesh):
+        """irfftn(chreshape(rfftn(mesh), final_shape)) (model.py:855, :861); identity when the shapes agree."""
+        if tuple(mesh.shape) == self.final_shape:
+            return mesh
+        return nbody.irfftn(chreshape(nbody.rfftn(mesh), r2chshape(self.final_shape)))
+
+    def _setup_selection(self, selec_mesh, mask_mesh, redges):
+        """Per-cell count multiplier rc (set_radial_count, bricks.py:1106-1122, with the fixed ngbars), the selection at
+        the final cells and the 0/1 mask, all as device tensors computed once."""
+        fwd, dev = self.fwd, self.count_obs.device
+        ngb = np.atleast_1d(np.asarray(self.fixed["ngbars"], dtype=np.float64))
+        rcounts = ngb * fwd.cell_length ** 3
+        mask = None if mask_mesh is None else np.asarray(mask_mesh, dtype=bool).reshape(self.final_shape)
+        rc = np.ones(self.final_shape)
+        if len(rcounts) == 1 and redges is None:
+            rc *= rcounts[0]
+        else:
+            rmesh = self._radius_mesh()
+            if redges is None:
+                r = rmesh if mask is None else rmesh[mask]
+                dr = 3 ** .5 * fwd.cell_length
+                redges = np.linspace(r.min() - dr / 1000, r.max() + dr / 1000, len(rcounts) + 1)
+            redges = np.asarray(redges, dtype=np.float64)
+            if len(redges) != len(rcounts) + 1:
+                raise ValueError("redges must have one more entry than ngbars")
+            for c, lo, hi in zip(rcounts, redges[:-1], redges[1:]):
+                rc[(lo < rmesh) & (rmesh <= hi)] *= c
+        self.rc = torch.from_numpy(rc.astype(np.float32)).to(dev)
+        self.mask = None if mask is None else torch.from_numpy(mask.astype(np.float32)).to(dev)
+        self.ngbar_mean = float(ngb.mean())
+        if selec_mesh is None:
+            self.selec_mesh, self.selec, self.selec_fid = None, float(rcounts.mean()), 1.0
+        else:
+            sm = np.asarray(selec_mesh, dtype=np.float64)
+            self.selec_fid = float((sm ** 2).mean() ** .5 / sm.mean())                 # model.py:609
+            self.selec_mesh = nbody._f32(selec_mesh, fwd.paint_shape)
+            self.selec = (self._down(self.selec_mesh) * self.rc).abs()
 
     def fiducial(self):
         """Fiducial base values: loc_fid of the latents, else the fixed value (model.py:1214-1223)."""
@@ -170,7 +226,7 @@ class FieldLevelLogDensity:
         ks, pows = fwd.lin_kpow
         pmesh = np.interp(kmesh.reshape(-1), ks, pows * float(fid["sigma8"]) ** 2, left=0., right=0.).reshape(kmesh.shape)
         pmesh *= unit ** 2                                                                # power in cell units
-        var_fid = float(fid["s_e"]) / (float(fid["ngbars"]) * fwd.cell_length ** 3)        # model.py:1140, selec_fid = 1
+        var_fid = float(fid["s_e"]) / (self.ngbar_mean * fwd.cell_length ** 3 * self.selec_fid)   # model.py:602, :609, :1140
         scale_k = (1 + boost ** 2 / var_fid * pmesh) ** .5
         cosmo_fid._workspace = {}
         dev = self.count_obs.device
@@ -222,25 +278,27 @@ class FieldLevelLogDensity:
         cosmo = self.make_cosmo(base)
         bias = {k: base[k] for k in bricks.BIAS_KEYS}
         gxy, ctx = fwd.evolve(cosmo, bias, white, return_ctx=True)
-        # likelihood (model.py:852-855, :893-908)
-        rcount = float(base["ngbars"]) * fwd.cell_length ** 3
-        selec = rcount
-        gk = chreshape(nbody.rfftn(gxy), r2chshape(self.final_shape)) if tuple(gxy.shape) != self.final_shape else None
-        cm = (nbody.irfftn(gk) if gk is not None else gxy) * rcount
+        # likelihood (model.py:852-866, :893-908)
+        selec = self.selec
+        gsel = gxy if self.selec_mesh is None else gxy * self.selec_mesh
+        resh = tuple(gxy.shape) != self.final_shape
+        cm = self._down(gsel) * self.rc
         delta = cm / selec - 1.0
         lin = base["s_e"] + base["s_ed"] * delta
         b = (lin.abs() + 1e-9) * selec ** .5
-        a = float(base["s_e2"]) * selec ** .5
+        a = 0.0 if abs(float(base["s_e2"])) < 1e-10 else float(base["s_e2"]) * selec ** .5
         lpe, g_loc, g_b, g_a = quad_gaussian_log_prob_and_grad(self.count_obs, cm, b, a)
+        if self.mask is not None:      # only the observed cells carry a likelihood term (mesh2masked, model.py:856)
+            lpe, g_loc, g_b, g_a = lpe * self.mask, g_loc * self.mask, g_b * self.mask, g_a * self.mask
         lp += float(lpe.double().sum())
         if not need_grad:
             return lp, None
         sgn = torch.sign(lin) * selec ** .5
         cm_bar = g_loc + g_b * sgn * (base["s_ed"] / selec)
         stoch_bar = {"s_e": float((g_b * sgn).double().sum()), "s_ed": float((g_b * sgn * delta).double().sum()),
-                     "s_e2": float(g_a.double().sum()) * selec ** .5}
-        gxy_bar = cm_bar * rcount
-        if gk is not None:      # adjoints of irfftn, chreshape, rfftn (real-pair convention)
+                     "s_e2": float((g_a * selec ** .5).double().sum())}
+        gxy_bar = cm_bar * self.rc
+        if resh:      # adjoints of irfftn, chreshape, rfftn (real-pair convention)
             Mf = float(np.prod(self.final_shape))
             kb = nbody.rfftn(gxy_bar) / Mf
             kb[..., 1:self.final_shape[-1] // 2] *= 2.0
@@ -249,6 +307,8 @@ class FieldLevelLogDensity:
             plan = nbody.get_plan(tuple(gxy.shape))
             gxy_bar = torch.empty(tuple(gxy.shape), dtype=torch.float32, device=kb.device)
             plan.call("mcpm_fft_c2r", nbody._ptr(kb), nbody._ptr(gxy_bar), 1)
+        if self.selec_mesh is not None:
+            gxy_bar = gxy_bar * self.selec_mesh
         g = fwd.evolve_vjp(ctx, gxy_bar)
         wb = g["white_mesh"] * self.transfer
         if self.precond != "real":

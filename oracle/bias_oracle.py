@@ -333,11 +333,42 @@ def precond_scale_and_transfer(cfg, fiduc=None, cosmo_fid=None):
         boost = kaiser_boost(cosmo_fid, a_fid, init_shape, cfg["box_size"], 1. + fiduc["b1"], los_fid)
         pmesh = lin_power_mesh(fiduc["sigma8"], init_shape, cfg["box_size"], cfg["lin_kpow"])
         pmesh = pmesh * np.divide(init_shape, cfg["box_size"]).prod()
-        count_fid = fiduc["ngbars"] * cfg["cell_length"] ** 3
-        var_fid = fiduc["s_e"] / count_fid
+        count_fid = np.mean(fiduc["ngbars"]) * cfg["cell_length"] ** 3                  # model.py:602
+        sel = cfg.get("selec_mesh")
+        selec_fid = 1.0 if sel is None else (np.asarray(sel) ** 2).mean() ** .5 / np.asarray(sel).mean()   # model.py:609
+        var_fid = fiduc["s_e"] / (count_fid * selec_fid)
         scale = (1 + boost ** 2 / var_fid * pmesh) ** .5
     transfer = np.divide(init_shape, cfg["box_size"]).prod() ** .5 / scale
     return o.cgh2rg(scale.astype(complex), norm="amp"), transfer
+
+
+def radius_mesh(cfg, shape):
+    """Physical distance of the cells of a mesh of `shape` spanning the box (bricks.py:665-686)."""
+    R = rotvec_matrix(cfg["box_rotvec"])
+    pos = cell2phys_pos(o.regular_pos(tuple(shape)), cfg["box_center"], R, cfg["box_size"], tuple(shape))
+    if cfg["curved_sky"]:
+        return np.linalg.norm(pos, axis=-1).reshape(shape)
+    los = o.safe_div(np.asarray(cfg["box_center"], float), np.linalg.norm(cfg["box_center"]))
+    return np.abs(pos @ los).reshape(shape)
+
+
+def radial_edges(cfg, n_rbins=None):
+    """Radial shell edges over the unmasked final-mesh cells (model.py:1087-1098)."""
+    r = radius_mesh(cfg, cfg["final_shape"])
+    if cfg.get("mask_mesh") is not None:
+        r = r[np.asarray(cfg["mask_mesh"], bool)]
+    dr = 3 ** .5 * cfg["cell_length"]
+    n = max(int((r.max() - r.min()) / dr), 1) if n_rbins is None else n_rbins
+    return np.linspace(r.min() - dr / 1000, r.max() + dr / 1000, n + 1)
+
+
+def set_radial_count(mesh, rmesh, redges, rcounts):
+    """bricks.py:1106-1122: cells of shell i are multiplied by rcounts[i]."""
+    out = np.array(mesh, dtype=float)
+    for c, lo, hi in zip(rcounts, redges[:-1], redges[1:]):
+        m = (lo < rmesh) & (rmesh <= hi)
+        out[m] = out[m] * c
+    return out
 
 
 def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo):
@@ -370,13 +401,21 @@ def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo):
     cosmo = make_cosmo(base)
     bias = {k: base[k] for k in BIAS_KEYS}
     gxy, _ = evolve(cfg, cosmo, bias, white)
+    # likelihood (model.py:852-866, :893-908): selection mesh (paint_shape or scalar 1), mask over the final cells,
+    # radial shells with their own mean densities; count_obs is the full final mesh (only its unmasked cells are used)
     final = tuple(cfg["final_shape"])
-    cm = np.fft.irfftn(o.chreshape(np.fft.rfftn(gxy), o.r2chshape(final)), s=final, axes=(0, 1, 2))
-    rcount = base["ngbars"] * cfg["cell_length"] ** 3
-    cm = cm * rcount
-    selec = rcount
+    down = lambda m: np.fft.irfftn(o.chreshape(np.fft.rfftn(m), o.r2chshape(final)), s=final, axes=(0, 1, 2))
+    sel = cfg.get("selec_mesh")
+    mask = np.ones(final, bool) if cfg.get("mask_mesh") is None else np.asarray(cfg["mask_mesh"], bool)
+    rcounts = np.atleast_1d(np.asarray(base["ngbars"], float)) * cfg["cell_length"] ** 3
+    redges = cfg.get("redges")
+    if redges is None:
+        redges = radial_edges(cfg, len(rcounts))
+    rmesh = radius_mesh(cfg, final)
+    cm = set_radial_count(down(gxy if sel is None else gxy * sel), rmesh, redges, rcounts)
+    selec = np.mean(rcounts) if sel is None else np.abs(set_radial_count(down(sel), rmesh, redges, rcounts))
     delta = cm / selec - 1
     scale1 = (np.abs(base["s_e"] + base["s_ed"] * delta) + 1e-9) * selec ** .5
-    scale2 = base["s_e2"] * selec ** .5
-    lp += np.sum(quad_gaussian_log_prob(count_obs, cm, scale1, scale2))
+    scale2 = base["s_e2"] * selec ** .5 * np.ones(final)
+    lp += np.sum(quad_gaussian_log_prob(np.asarray(count_obs)[mask], cm[mask], (scale1 * np.ones(final))[mask], scale2[mask]))
     return float(lp)
