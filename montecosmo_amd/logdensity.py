@@ -223,7 +223,7 @@ class FieldLevelLogDensity:
         kmesh = sum(ki ** 2 for ki in kvec) ** .5
         mu = nbody.safe_div(sum(ki * li for ki, li in zip(kvec, los_fid)), kmesh)
         boost = float(nbody.a2g(cosmo_fid, a_fid)) * ((1.0 + float(fid["b1"])) + float(nbody.a2f(cosmo_fid, a_fid)) * mu ** 2)
-        ks, pows = fwd.lin_kpow
+        ks, pows = fwd.kpow(cosmo_fid)
         pmesh = np.interp(kmesh.reshape(-1), ks, pows * float(fid["sigma8"]) ** 2, left=0., right=0.).reshape(kmesh.shape)
         pmesh *= unit ** 2                                                                # power in cell units
         var_fid = float(fid["s_e"]) / (self.ngbar_mean * fwd.cell_length ** 3 * self.selec_fid)   # model.py:602, :609, :1140

@@ -1,8 +1,9 @@
 """`FieldLevelModel.evolve` (montecosmo/model.py:686-838) on the HIP path, with its hand-written reverse sweep.
 
 Built branch: bias_type 'lagrangian', evolution 'lpt' (scalar a_obs or light cone) or 'nbody' (scalar a_obs, as the
-reference asserts), png_type None, ap_auto None, kernel_type 'rectangular', tabulated linear power (`lin_kpow`,
-bricks.py:75-77).  Everything else of the model (priors, likelihood, samplers, registers) stays in the reference.
+reference asserts), png_type None, ap_auto None, kernel_type 'rectangular', linear power from a table (`lin_kpow`,
+bricks.py:75-77) or, with lin_kpow = None, from the Eisenstein-Hu fit of the current cosmology (bricks.py:72-74; power.py).
+Priors, likelihood and samplers: logdensity.py, samplers.py.
 
     fwd = FieldLevelForward(final_shape=(64, 64, 64), cell_length=20., box_center=(0, 0, 2000.), evolution='nbody',
                             a_obs=0.7, lin_kpow=(ks, pows))
@@ -34,9 +35,6 @@ class FieldLevelForward:
                  a_obs=None, curved_sky=True, lin_kpow=None):
         if evolution not in ('lpt', 'nbody'):
             raise NotImplementedError("evolution must be 'lpt' or 'nbody' (the Kaiser model is not built)")
-        if lin_kpow is None:
-            raise NotImplementedError("a tabulated linear power spectrum lin_kpow = (ks, pows) normalised to sigma8 = 1 is "
-                                      "required (the Eisenstein-Hu emulation of jax_cosmo is not built)")
         self.final_shape = tuple(int(s) for s in final_shape)
         self.cell_length = float(cell_length)
         self.box_center = np.asarray(box_center, dtype=np.float64)
@@ -51,9 +49,10 @@ class FieldLevelForward:
         self.interlace_order, self.a_obs, self.curved_sky = int(interlace_order), a_obs, bool(curved_sky)
         if evolution == 'nbody' and a_obs is None:
             raise NotImplementedError("N-body light-cone not implemented (model.py:770)")
-        ks, pows = lin_kpow
-        self.lin_kpow = (np.asarray(ks, dtype=np.float64), np.asarray(pows, dtype=np.float64))
-        self._dev_kpow = None
+        # lin_kpow = (ks, pows) normalised to sigma8 = 1, or None: the Eisenstein-Hu power of the CURRENT cosmology
+        # (bricks.py:69-79; montecosmo_amd/power.py), re-tabulated whenever Omega_m / Omega_b / h / n_s change
+        self.lin_kpow = None if lin_kpow is None else (np.asarray(lin_kpow[0], dtype=np.float64), np.asarray(lin_kpow[1], dtype=np.float64))
+        self._dev_kpow = {}
         self._r0 = None
 
     def config(self):
@@ -67,16 +66,27 @@ class FieldLevelForward:
     def _kphys(self, shape):
         return [float(s) / float(b) for s, b in zip(shape, self.box_size)]
 
-    def _power_mult(self, spec, sigma8):
+    def kpow(self, cosmo):
+        """(ks, pows) normalised to sigma8 = 1 for this cosmology: the given table, or Eisenstein-Hu (power.py)."""
+        if self.lin_kpow is not None:
+            return self.lin_kpow
+        from . import power
+        return power.lin_power_table(cosmo)
+
+    def _power_mult(self, spec, cosmo):
         """white2lin (bricks.py:149-154): spec * sqrt(sigma8^2 P(|k|)); real multiplier, self-adjoint."""
-        if self._dev_kpow is None:
-            self._dev_kpow = torch.from_numpy(np.concatenate(self.lin_kpow)).to(spec.device)
-        nt = len(self.lin_kpow[0])
+        key = None if self.lin_kpow is not None else (float(cosmo.Omega_c), float(cosmo.Omega_b), float(cosmo.h), float(cosmo.n_s))
+        tab = self._dev_kpow.get(key)
+        if tab is None:
+            if len(self._dev_kpow) > 8:
+                self._dev_kpow.clear()
+            tab = self._dev_kpow[key] = torch.from_numpy(np.concatenate(self.kpow(cosmo))).to(spec.device)
+        nt = tab.numel() // 2
         plan = nbody.get_plan(self.init_shape)
         out = torch.empty_like(spec)
         kp = self._kphys(self.init_shape)
-        plan.call("mcpm_power_mult_f32", nbody._ptr(spec), kp[0], kp[1], kp[2], float(sigma8) ** 2, nbody._ptr(self._dev_kpow),
-                  nbody.C.c_void_p(self._dev_kpow.data_ptr() + 8 * nt), nt, nbody._ptr(out))
+        plan.call("mcpm_power_mult_f32", nbody._ptr(spec), kp[0], kp[1], kp[2], float(cosmo.sigma8) ** 2, nbody._ptr(tab),
+                  nbody.C.c_void_p(tab.data_ptr() + 8 * nt), nt, nbody._ptr(out))
         return out
 
     def _scale_factors(self, cosmo):
@@ -103,7 +113,7 @@ class FieldLevelForward:
         Lagrangian bias parameters; white_mesh: complex half-spectrum of shape r2chshape(init_shape) (what
         samp2base_mesh returns).  Returns gxy_mesh (paint_shape, float32 device tensor) = 1 + delta_obs."""
         white = nbody._c64(white_mesh, r2chshape(self.init_shape))
-        init_k = self._power_mult(white, cosmo.sigma8)
+        init_k = self._power_mult(white, cosmo)
         evol_k = chreshape(init_k, r2chshape(self.evol_shape))
         pos0 = nbody.LatticePos.regular(self.evol_shape, self.ptcl_shape)
         a = self._scale_factors(cosmo)
@@ -151,15 +161,17 @@ class FieldLevelForward:
             mb, growth = nbody.nbody_bf_vjp(ctx.nctx, xb, vb)
         mesh_b = mesh_b + mb
         init_b = chreshape_vjp(mesh_b, r2chshape(self.init_shape))
-        white_b = self._power_mult(init_b, cosmo.sigma8)
+        white_b = self._power_mult(init_b, cosmo)
         # d/d sigma8: init_mesh is linear in sigma8
-        init_k = self._power_mult(ctx.white, cosmo.sigma8)
+        init_k = self._power_mult(ctx.white, cosmo)
         s8b = float((init_b.conj() * init_k).real.sum().item()) / float(cosmo.sigma8)
-        return {"white_mesh": white_b, "bias": bias_bar, "sigma8": s8b, "growth": growth, "bias_growth": bg_bar, "gf": gfb}
+        return {"white_mesh": white_b, "bias": bias_bar, "sigma8": s8b, "growth": growth, "bias_growth": bg_bar, "gf": gfb,
+                "init_bar": init_b}
 
     def cosmo_vjp(self, ctx, grads, params=("Omega_m",), rel_eps=1e-5):
-        """Chains the growth cotangents of `evolve_vjp` to cosmological parameters (fixed a_obs): every place the
-        cosmology enters evolve besides sigma8 is a host float64 scalar looked up in the 128-point growth tables -- the
+        """Chains the growth cotangents of `evolve_vjp` to cosmological parameters (fixed a_obs): besides sigma8 and the
+        Eisenstein-Hu table (when no `lin_kpow` is given; central differences of the 256-point table, applied to the white
+        field on the device) the cosmology enters evolve through host float64 scalars looked up in the 128-point growth tables -- the
         BullFrog coefficients and the 2LPT start (nbody.cosmo_vjp), a2g(a_obs) in the bias weights, a2g a2f in the
         RSD -- so dL/dtheta = sum_s s_bar ds/dtheta with the table Jacobian taken by central finite differences.
         `params`: attribute names of the cosmology object; 'Omega_m' varies Omega_c at fixed Omega_b."""
@@ -190,11 +202,15 @@ class FieldLevelForward:
             attr = "Omega_c" if name == "Omega_m" else name
             base = float(getattr(cosmo, attr))
             h = rel_eps * max(abs(base), 1e-2)
-            vals = []
+            vals, inits = [], []
             for sgn in (+1, -1):
                 c = copy.copy(cosmo)
                 setattr(c, attr, base + sgn * h)
                 vals.append(scalars(c))
+                if self.lin_kpow is None:      # the Eisenstein-Hu shape moves with the cosmology: init_mesh = white sqrt(P)
+                    inits.append(self._power_mult(ctx.white, c))
             out[name] = float(np.dot(bars, (vals[0] - vals[1]) / (2 * h)))
+            if inits:
+                out[name] += float((grads["init_bar"].conj() * (inits[0] - inits[1])).real.sum().item()) / (2 * h)
         cosmo._workspace = {}
         return out

@@ -217,7 +217,11 @@ def evolve(cfg, cosmo, bias, white_mesh):
     galaxy mesh 1 + delta_obs of shape paint_shape, and the intermediates a test may want."""
     R = rotvec_matrix(cfg["box_rotvec"])
     box, ctr = cfg["box_size"], cfg["box_center"]
-    init_mesh = white2lin(cosmo.sigma8, white_mesh, cfg["init_shape"], box, cfg["lin_kpow"])
+    kpow = cfg["lin_kpow"]
+    if kpow is None:      # bricks.py:69-79 with kpow = None: Eisenstein-Hu power of this cosmology (oracle/power_oracle.py)
+        from . import power_oracle
+        kpow = power_oracle.lin_power_table(cosmo)
+    init_mesh = white2lin(cosmo.sigma8, white_mesh, cfg["init_shape"], box, kpow)
     init_mesh = o.chreshape(init_mesh, o.r2chshape(cfg["evol_shape"]))
     pos = o.regular_pos(cfg["evol_shape"], cfg["ptcl_shape"])
     _, a = los_scalefactor_pos(pos, ctr, R, box, cfg["evol_shape"], cosmo, cfg["a_obs"], cfg["curved_sky"])
@@ -331,7 +335,11 @@ def precond_scale_and_transfer(cfg, fiduc=None, cosmo_fid=None):
         los = o.safe_div(c, np.linalg.norm(c))
         los_fid = rotvec_matrix(cfg["box_rotvec"]).T @ los
         boost = kaiser_boost(cosmo_fid, a_fid, init_shape, cfg["box_size"], 1. + fiduc["b1"], los_fid)
-        pmesh = lin_power_mesh(fiduc["sigma8"], init_shape, cfg["box_size"], cfg["lin_kpow"])
+        kpow = cfg["lin_kpow"]
+        if kpow is None:
+            from . import power_oracle
+            kpow = power_oracle.lin_power_table(cosmo_fid)
+        pmesh = lin_power_mesh(fiduc["sigma8"], init_shape, cfg["box_size"], kpow)
         pmesh = pmesh * np.divide(init_shape, cfg["box_size"]).prod()
         count_fid = np.mean(fiduc["ngbars"]) * cfg["cell_length"] ** 3                  # model.py:602
         sel = cfg.get("selec_mesh")

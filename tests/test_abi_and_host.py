@@ -120,3 +120,17 @@ def test_synthetic_initial_conditions():
     F = o.pm_forces(o.regular_pos((16,) * 3), s.astype(np.complex128), 1)
     assert abs(np.sqrt((F ** 2).sum(-1).mean()) - 2.0) < 0.02
     assert np.array_equal(s, synth.init_mesh(16, seed=0, rms_disp=2.0))
+
+
+def test_eisenstein_hu_power_table_matches_restatement():
+    """montecosmo_amd/power.py (host numpy, vectorised) against the scalar restatement of the published fit in
+    oracle/power_oracle.py: the sigma8 = 1 table on logspace(-4, 1, 256) h/Mpc (bricks.py:69-79 with kpow = None)."""
+    from montecosmo_amd import power, bricks
+    from oracle import power_oracle as po, background as obg
+    for kw in (dict(), dict(Omega_c=0.20, h=0.72, n_s=0.93), dict(Omega_b=0.03, Omega_c=0.35)):
+        ks, pows = power.lin_power_table(bricks.Planck18(**kw))
+        ko, po_ = po.lin_power_table(obg.Planck18(**kw))
+        assert np.array_equal(ks, ko) and np.allclose(pows, po_, rtol=1e-8)
+        assert abs(power.sigma_r(ks, pows) - 1.0) < 1e-3
+    c = bricks.Planck18()
+    assert np.allclose(power.eisenstein_hu_transfer(c, [0.0, 1e-7]), 1.0, atol=1e-6)

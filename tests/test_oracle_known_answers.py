@@ -322,3 +322,37 @@ def test_kaiser_preconditioning_known_answers():
     amp, back = o.cgh2rg(A.astype(complex), "amp"), o.cgh2rg(A * (1 + 1j), "backward")
     ratio = np.abs(back) / (2 / M) ** .5 / amp
     assert np.isclose(np.sort(ratio.ravel())[8:], 1.0).all() and np.isclose(np.sort(ratio.ravel())[:8], 2 ** -.5).all()
+
+
+def test_eisenstein_hu_known_answers():
+    """Eisenstein & Hu 1998 (the fit behind jax_cosmo's linear_matter_power, bricks.py:69-79): large-scale limit T -> 1;
+    without baryons the fit is its own zero-baryon form T0(q) = L / (L + C q^2) with q = k / (13.41 k_eq); the sound
+    horizon of a Planck-like cosmology is ~150 Mpc and the baryon wiggles of T have that period; Silk damping suppresses
+    the baryon branch; the table is normalised to sigma8 = 1 under an independent quadrature."""
+    from oracle import power_oracle as po
+    c = obg.Planck18()
+    assert abs(po.eisenstein_hu(c, [1e-6])[0] - 1.0) < 1e-6
+    T = po.eisenstein_hu(c, np.logspace(-4, 1, 200))
+    assert np.all(np.diff(T[:60]) < 0) and T[-1] < 1e-3 and np.all(T > 0)
+    # zero-baryon limit (fb -> 0: alpha_c, beta_c -> 1 and the CDM branch is T0(k, 1, 1))
+    nb = obg.Planck18(Omega_b=1e-9, Omega_c=0.3097)
+    ks = np.logspace(-3, 0.5, 40)
+    k_eq = 0.0746 * nb.Omega_m * nb.h ** 2 * (po.TCMB / 2.7) ** -2
+    q = ks * nb.h / (13.41 * k_eq)
+    L, C = np.log(np.e + 1.8 * q), 14.2 + 386.0 / (1.0 + 69.9 * q ** 1.08)
+    assert np.allclose(po.eisenstein_hu(nb, ks), L / (L + C * q * q), rtol=2e-6)
+    s = po.sound_horizon(c)
+    assert 145.0 < s < 156.0
+    # wiggles: T(with baryons) / T(smooth CDM-like envelope) oscillates with period 2 pi / s in k [1/Mpc]
+    kk = np.linspace(0.03, 0.3, 4000)                                   # h/Mpc
+    ratio = po.eisenstein_hu(c, kk) / po.eisenstein_hu(obg.Planck18(Omega_b=1e-9, Omega_c=c.Omega_m - 1e-9), kk)
+    osc = ratio - np.convolve(ratio, np.ones(801) / 801, mode="same")
+    zc = kk[1:][(osc[1:] * osc[:-1] < 0)][3:-3]                          # zero crossings away from the window edges
+    period = 2 * np.mean(np.diff(zc)) * c.h                              # 1/Mpc
+    assert abs(period / (2 * np.pi / s) - 1) < 0.08
+    ks, pows = po.lin_power_table(c)
+    from scipy.integrate import quad
+    f = lambda lk: np.exp(lk) ** 3 * np.interp(np.exp(lk), ks, pows) * (3 * (np.sin(8 * np.exp(lk)) - 8 * np.exp(lk) * np.cos(8 * np.exp(lk))) / (8 * np.exp(lk)) ** 3) ** 2
+    sig = np.sqrt(quad(f, np.log(1e-4), np.log(10.0), limit=400)[0] / (2 * np.pi ** 2))
+    assert abs(sig - 1.0) < 2e-3
+    assert 0.012 < ks[np.argmax(pows)] < 0.022                           # turnover at k_eq
