@@ -74,13 +74,29 @@ torch.cuda.synchronize()
 wall = time.perf_counter() - t_run
 infos = res["infos"]
 draws = np.array(res["samples"])
+
+
+def field_correlation(q_end):
+    """Cross-correlation of the last state's initial field with the truth's, over all modes and over |k| < k_Nyquist / 4
+    (in units of the prior width of each mode, i.e. of white_mesh_ / scale)."""
+    w_end = q_end[ns:].reshape(fwd.init_shape) / prior_std
+    w_tr = truth["white_mesh_"] / prior_std
+    a, b = utils.rg2cgh(w_end), utils.rg2cgh(w_tr)
+    kv = nbody.rfftk(fwd.init_shape)
+    low = torch.from_numpy((sum(k ** 2 for k in kv) ** .5 < np.pi / 4)).to(a.device)
+    cc = lambda m: float(((a.conj() * b).real * m).sum() / (((a.abs() ** 2) * m).sum() * ((b.abs() ** 2) * m).sum()).sqrt())
+    return {"all_modes": round(cc(torch.ones_like(low)), 4), "k_below_quarter_nyquist": round(cc(low), 4)}
+
+
+corr = field_correlation(res["last_state"]["q"])
+print("correlation of the last state's initial field with the truth:", corr, flush=True)
 summary = {"sampler": sampler, "precond": precond, "final_shape": fwd.final_shape, "evol_shape": fwd.evol_shape, "evolution": evolution, "dimension": int(q0.numel()),
            "n_warmup": n_warm, "n_samples": n_samp, "max_tree_depth": depth, "wall_s": round(wall, 1),
            "gradient_evals": flat.n_eval, "ms_per_gradient": round(1e3 * wall / max(flat.n_eval - 1, 1), 2),
            "mean_leapfrogs": float(np.mean([i["n_leapfrog"] for i in infos])), "step_size": res["step_size"],
            "accept_stat_sampling": float(np.mean([i["accept_stat"] for i in infos[n_warm:]])) if n_samp else None,
            "divergences": int(sum(i["diverging"] for i in infos)), "logdensity_start": lp0, "logdensity_truth": lp_truth,
-           "logdensity_end": infos[-1]["logdensity"],
+           "logdensity_end": infos[-1]["logdensity"], "field_correlation_with_truth": corr,
            "posterior_mean_sample_space": dict(zip(flat.scalars + ["white_std"], draws.mean(0).round(4).tolist())) if n_samp else None}
 print(json.dumps(summary), flush=True)
 if out_path:
