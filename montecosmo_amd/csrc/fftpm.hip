@@ -18,15 +18,25 @@
 // Spectra live in a padded internal layout [nx][ny][nzp], nzp = nz/2 + 16, so that those segments are aligned.
 #include "mcpm_internal.h"
 
-typedef float2 cf;
+// A complex number is a native two-float vector: the compiler then keeps (re, im) in one aligned register pair and
+// maps complex adds to v_pk_add_f32 and complex multiplies to v_pk_mul_f32 + v_pk_fma_f32 (swaps and sign flips ride
+// the op_sel / neg modifiers) instead of pairing unrelated scalars and shuffling them with v_mov.
+typedef float cf __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cf mkc(float x, float y) {
+    cf r = {x, y};
+    return r;
+}
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    const cf bs = {-b.y, b.x};
+    return __builtin_elementwise_fma(a.yy, bs, a.xx * b);
+}
 // multiply by exp(SIGN * i * pi/2): SIGN = -1 (forward) -> -i, +1 (inverse) -> +i
 template <int SIGN>
 __device__ __forceinline__ cf mul_i(cf a) {
-    return SIGN < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+    return SIGN < 0 ? mkc(a.y, -a.x) : mkc(-a.y, a.x);
 }
 
 template <int SIGN>
@@ -47,9 +57,9 @@ __device__ __forceinline__ void fft8(cf (&v)[8]) {
     fft4<SIGN>(o0, o1, o2, o3);
     const float h = 0.70710678118654752f;
     // w8^1 = (1 + SIGN i)/sqrt2, w8^2 = SIGN i, w8^3 = (-1 + SIGN i)/sqrt2
-    cf w1 = SIGN < 0 ? make_float2(h * (o1.x + o1.y), h * (o1.y - o1.x)) : make_float2(h * (o1.x - o1.y), h * (o1.y + o1.x));
+    cf w1 = SIGN < 0 ? mkc(h * (o1.x + o1.y), h * (o1.y - o1.x)) : mkc(h * (o1.x - o1.y), h * (o1.y + o1.x));
     cf w2 = mul_i<SIGN>(o2);
-    cf w3 = SIGN < 0 ? make_float2(h * (o3.y - o3.x), -h * (o3.x + o3.y)) : make_float2(-h * (o3.x + o3.y), h * (o3.x - o3.y));
+    cf w3 = SIGN < 0 ? mkc(h * (o3.y - o3.x), -h * (o3.x + o3.y)) : mkc(-h * (o3.x + o3.y), h * (o3.x - o3.y));
     v[0] = cadd(e0, o0);
     v[4] = csub(e0, o0);
     v[1] = cadd(e1, w1);
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(256) void zfwd_kernel(FGeom g, const float *__restr
     const float *a = real + bi * zb.real_bstride + lm * N, *b = a + N;
     cf v[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = ok ? make_float2(a[u + T * m], b[u + T * m]) : make_float2(0.f, 0.f);
+    for (int m = 0; m < 8; ++m) v[m] = ok ? mkc(a[u + T * m], b[u + T * m]) : mkc(0.f, 0.f);
     TL tile{pl};
     fft_line<N, -1>(v, lds, W, u, tile);
     __syncthreads();
@@ -208,13 +218,13 @@ __global__ __launch_bounds__(256) void zfwd_kernel(FGeom g, const float *__restr
     for (int m = 0; m < 4; ++m) {
         const int k = u + T * m;
         const cf z = v[m], zm = lds[tile((N - k) & (N - 1))];
-        oa[k] = make_float2(0.5f * (z.x + zm.x), 0.5f * (z.y - zm.y));
-        ob[k] = make_float2(0.5f * (z.y + zm.y), 0.5f * (zm.x - z.x));
+        oa[k] = mkc(0.5f * (z.x + zm.x), 0.5f * (z.y - zm.y));
+        ob[k] = mkc(0.5f * (z.y + zm.y), 0.5f * (zm.x - z.x));
     }
     if (u == 0) {  // Nyquist: Z[N/2] is its own mirror
         const cf z = v[4];
-        oa[N / 2] = make_float2(z.x, 0.f);
-        ob[N / 2] = make_float2(z.y, 0.f);
+        oa[N / 2] = mkc(z.x, 0.f);
+        ob[N / 2] = mkc(z.y, 0.f);
     }
 }
 
@@ -234,17 +244,17 @@ __global__ __launch_bounds__(256) void zinv_kernel(FGeom g, const cf *__restrict
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int k = u + T * m;
-        cf A = ok ? ia[k] : make_float2(0.f, 0.f), B = ok ? ib[k] : make_float2(0.f, 0.f);
+        cf A = ok ? ia[k] : mkc(0.f, 0.f), B = ok ? ib[k] : mkc(0.f, 0.f);
         if (k == 0) {
-            lds[tile(0)] = make_float2(A.x, B.x);
+            lds[tile(0)] = mkc(A.x, B.x);
         } else {
-            lds[tile(k)] = make_float2(A.x - B.y, A.y + B.x);
-            lds[tile(N - k)] = make_float2(A.x + B.y, B.x - A.y);
+            lds[tile(k)] = mkc(A.x - B.y, A.y + B.x);
+            lds[tile(N - k)] = mkc(A.x + B.y, B.x - A.y);
         }
     }
     if (u == 0) {
-        cf A = ok ? ia[N / 2] : make_float2(0.f, 0.f), B = ok ? ib[N / 2] : make_float2(0.f, 0.f);
-        lds[tile(N / 2)] = make_float2(A.x, B.x);
+        cf A = ok ? ia[N / 2] : mkc(0.f, 0.f), B = ok ? ib[N / 2] : mkc(0.f, 0.f);
+        lds[tile(N / 2)] = mkc(A.x, B.x);
     }
     __syncthreads();
     cf v[8];
@@ -281,17 +291,17 @@ __global__ __launch_bounds__(256) void zinv3_il_kernel(FGeom g, const cf *__rest
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int k = u + T * m;
-            cf A = ok ? ia[k] : make_float2(0.f, 0.f), B = ok ? ib[k] : make_float2(0.f, 0.f);
+            cf A = ok ? ia[k] : mkc(0.f, 0.f), B = ok ? ib[k] : mkc(0.f, 0.f);
             if (k == 0) {
-                lds[tile(0)] = make_float2(A.x, B.x);
+                lds[tile(0)] = mkc(A.x, B.x);
             } else {
-                lds[tile(k)] = make_float2(A.x - B.y, A.y + B.x);
-                lds[tile(N - k)] = make_float2(A.x + B.y, B.x - A.y);
+                lds[tile(k)] = mkc(A.x - B.y, A.y + B.x);
+                lds[tile(N - k)] = mkc(A.x + B.y, B.x - A.y);
             }
         }
         if (u == 0) {
-            cf A = ok ? ia[N / 2] : make_float2(0.f, 0.f), B = ok ? ib[N / 2] : make_float2(0.f, 0.f);
-            lds[tile(N / 2)] = make_float2(A.x, B.x);
+            cf A = ok ? ia[N / 2] : mkc(0.f, 0.f), B = ok ? ib[N / 2] : mkc(0.f, 0.f);
+            lds[tile(N / 2)] = mkc(A.x, B.x);
         }
         __syncthreads();
 #pragma unroll
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol_kernel(FGeom g, con
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int y = u + T * m, yb = y >> li.lgYB;
-        v[m] = ok ? ib[yb * li.SB + (int64_t)(y & (li.YB - 1)) * g.nzp] : make_float2(0.f, 0.f);
+        v[m] = ok ? ib[yb * li.SB + (int64_t)(y & (li.YB - 1)) * g.nzp] : mkc(0.f, 0.f);
     }
     TL tile{l};
     fft_line<N, SIGN>(v, lds, W, u, tile);
@@ -374,7 +384,7 @@ __global__ __launch_bounds__((ColShape<N, ML>::THREADS)) void ycol2_kernel(
 #define ioff(m) ((uint32_t)((u + T * (m)) >> li.lgYB) * (uint32_t)li.SB + (uint32_t)((u + T * (m)) & (li.YB - 1)) * (uint32_t)g.nzp)
 #define ooff(m) ((uint32_t)((u + T * (m)) >> lo.lgYB) * (uint32_t)lo.SB + (uint32_t)((u + T * (m)) & (lo.YB - 1)) * (uint32_t)g.nzp)
 #define fy(m) ((special && (u + T * (m)) == N / 2) ? 0.f : MCPM_TWO_PI * (float)((u + T * (m)) < N / 2 ? (u + T * (m)) : (u + T * (m)) - N) / (float)N)
-    const cf zero = make_float2(0.f, 0.f);
+    const cf zero = mkc(0.f, 0.f);
     TL tile{l};
     cf v[8];
     // parts (uniform): bit 0 = the spectrum-0 transform, bit 1 = the other two (they travel in separate all-to-alls)
@@ -394,7 +404,7 @@ __global__ __launch_bounds__((ColShape<N, ML>::THREADS)) void ycol2_kernel(
         for (int m = 0; m < 8; ++m) {
             gq[m] = ok ? ib[li.BS + ioff(m)] : zero;
             const float f = fy(m);
-            v[m] = make_float2(f * gq[m].x, f * gq[m].y);
+            v[m] = mkc(f * gq[m].x, f * gq[m].y);
         }
         fft_line<N, +1>(v, lds, W, u, tile);
         if (ok) {
@@ -404,7 +414,7 @@ __global__ __launch_bounds__((ColShape<N, ML>::THREADS)) void ycol2_kernel(
         fft_line<N, +1>(gq, lds, W, u, tile);
         if (ok) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) ob[2 * lo.BS + ooff(m)] = make_float2(fz * gq[m].x, fz * gq[m].y);
+            for (int m = 0; m < 8; ++m) ob[2 * lo.BS + ooff(m)] = mkc(fz * gq[m].x, fz * gq[m].y);
         }
     } else {
         if (parts & 1) {
@@ -429,7 +439,7 @@ __global__ __launch_bounds__((ColShape<N, ML>::THREADS)) void ycol2_kernel(
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const float f = fy(m);
-                ob[lo.BS + ooff(m)] = make_float2(f * v[m].x + fz * c[m].x, f * v[m].y + fz * c[m].y);
+                ob[lo.BS + ooff(m)] = mkc(f * v[m].x + fz * c[m].x, f * v[m].y + fz * c[m].y);
             }
         }
     }
@@ -481,18 +491,18 @@ __global__ __launch_bounds__((ColShape<N, ML>::THREADS)) void xfused_kernel(FGeo
     if (MODE == 0) {
         cf v[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = ok ? in[o1[m]] : make_float2(0.f, 0.f);
+        for (int m = 0; m < 8; ++m) v[m] = ok ? in[o1[m]] : mkc(0.f, 0.f);
         fft_line<N, -1>(v, lds, W, u, tile);
         cf w[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) w[m] = make_float2(sx[m] * v[m].y, -sx[m] * v[m].x);  // (a + i b)(-i s_x)
+        for (int m = 0; m < 8; ++m) w[m] = mkc(sx[m] * v[m].y, -sx[m] * v[m].x);  // (a + i b)(-i s_x)
         fft_line<N, +1>(w, lds, W, u, tile);
         if (ok) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) out[o3[m]] = w[m];
         }
 #pragma unroll
-        for (int m = 0; m < 8; ++m) w[m] = make_float2(L[m] * v[m].y, -L[m] * v[m].x);  // (a + i b)(-i L)
+        for (int m = 0; m < 8; ++m) w[m] = mkc(L[m] * v[m].y, -L[m] * v[m].x);  // (a + i b)(-i L)
         fft_line<N, +1>(w, lds, W, u, tile);
         if (ok) {  // G: the y pass turns it into the y and z components (ycol2_kernel)
             cf *og = out + xl.SC;
@@ -503,15 +513,15 @@ __global__ __launch_bounds__((ColShape<N, ML>::THREADS)) void xfused_kernel(FGeo
         cf a[8], b[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) {  // b = ky FFTy(f_bar_y) + kz FFTy(f_bar_z), formed by the y pass (ycol2_kernel)
-            a[m] = ok ? in[o3[m]] : make_float2(0.f, 0.f);
-            b[m] = ok ? in[xl.SC + o3[m]] : make_float2(0.f, 0.f);
+            a[m] = ok ? in[o3[m]] : mkc(0.f, 0.f);
+            b[m] = ok ? in[xl.SC + o3[m]] : mkc(0.f, 0.f);
         }
         fft_line<N, -1>(a, lds, W, u, tile);
         fft_line<N, -1>(b, lds, W, u, tile);
         cf acc[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m)  // (a + i b)(+i s): conj of the forward multipliers
-            acc[m] = make_float2(-sx[m] * a[m].y - L[m] * b[m].y, sx[m] * a[m].x + L[m] * b[m].x);
+            acc[m] = mkc(-sx[m] * a[m].y - L[m] * b[m].y, sx[m] * a[m].x + L[m] * b[m].x);
         fft_line<N, +1>(acc, lds, W, u, tile);
         if (ok) {
 #pragma unroll
@@ -576,14 +586,14 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xspec_kernel(FGeom g, co
     if (MODE == 2 || MODE == 3) {
         cf v[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = ok ? in[os[m]] : make_float2(0.f, 0.f);
+        for (int m = 0; m < 8; ++m) v[m] = ok ? in[os[m]] : mkc(0.f, 0.f);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             cf w[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const float f = factor(c, m);
-                w[m] = NC == 3 ? make_float2(f * v[m].y, -f * v[m].x) : make_float2(f * v[m].x, f * v[m].y);
+                w[m] = NC == 3 ? mkc(f * v[m].y, -f * v[m].x) : mkc(f * v[m].x, f * v[m].y);
             }
             fft_line<N, +1>(w, lds, W, u, tile);
             if (ok) {
@@ -595,13 +605,13 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xspec_kernel(FGeom g, co
     } else {
         cf acc[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) acc[m] = make_float2(0.f, 0.f);
+        for (int m = 0; m < 8; ++m) acc[m] = mkc(0.f, 0.f);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             cf v[8];
             const cf *ic = in + c * xl.SC;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = ok ? ic[o3[m]] : make_float2(0.f, 0.f);
+            for (int m = 0; m < 8; ++m) v[m] = ok ? ic[o3[m]] : mkc(0.f, 0.f);
             fft_line<N, -1>(v, lds, W, u, tile);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
@@ -648,7 +658,7 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xplain_kernel(FGeom g, c
     for (int m = 0; m < 8; ++m) {
         const int x = u + T * m;
         const uint32_t op = ((uint32_t)x * g.ny + iy) * g.nzh + kzi, oq = ((uint32_t)x * g.ny + iy) * g.nzp + kzi;
-        v[m] = ok ? in[DIR > 0 ? op : oq] : make_float2(0.f, 0.f);
+        v[m] = ok ? in[DIR > 0 ? op : oq] : mkc(0.f, 0.f);
     }
     fft_line<N, DIR>(v, lds, W, u, tile);
     if (!ok) return;
