@@ -191,11 +191,13 @@ class SlabRunner:
 
     def forward(self, steps):
         K = self.K
+        self.pm.reset_depth()           # a new trajectory: first step at full ghost depth, then predicted depths
         for i in range(steps):
             tau = self.dg / 2 if i == K - 1 else self.dg
             self.pm.step(self.states[i, 0], self.states[i, 1], self.alphas[i], self.betas[i], tau, self.f3s[i],
                          self.states[i + 1, 0], self.states[i + 1, 1])
             self.depths[i] = self.pm.ge
+        self.pm.finish_depth()          # verifies the last prediction (the only host stop of the trajectory)
 
     def backward(self, steps):
         K = self.K

@@ -52,6 +52,18 @@ class _Works:
             self.after()
 
 
+def _pinned_slot(owner):
+    """A (pinned one-float tensor, event) pair from a small ring owned by the communicator: a pinned allocation per step
+    costs more host time than the step's launches."""
+    ring = getattr(owner, "_pin_ring", None)
+    if ring is None:
+        ring = owner._pin_ring = [[torch.empty(1, dtype=torch.float32, pin_memory=True), torch.cuda.Event()] for _ in range(4)]
+        owner._pin_next = 0
+    slot = ring[owner._pin_next % len(ring)]
+    owner._pin_next += 1
+    return slot[0], slot[1]
+
+
 class LocalComm:
     """Single-rank communicator: every exchange is a local copy (used to validate the slab code path itself)."""
     world, rank = 1, 0
@@ -71,6 +83,14 @@ class LocalComm:
     def all_reduce_max_float(self, v):
         return float(v)
 
+    def all_reduce_max_async(self, v):
+        """Maximum over ranks of one device scalar without stopping the host: returns (pinned host tensor, event); the
+        value is in the tensor once the event has completed."""
+        host, ev = _pinned_slot(self)
+        host.copy_(v.detach().reshape(1).float(), non_blocking=True)
+        ev.record()
+        return host, ev
+
     def all_gather_cat(self, t):
         return t
 
@@ -80,11 +100,12 @@ class TorchComm:
     the single-GPU test box) device tensors are staged through host memory; with "nccl" (RCCL) they are used
     in place."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, stage=None):
         import torch.distributed as td
         self.td, self.group = td, group
         self.world, self.rank = td.get_world_size(group), td.get_rank(group)
-        self.stage = td.get_backend(group) == "gloo"
+        # stage=False with gloo and CPU tensors runs the un-staged (RCCL) code path of the exchanges in the CPU tests
+        self.stage = (td.get_backend(group) == "gloo") if stage is None else bool(stage)
 
     def _h(self, t):
         return t.cpu() if (self.stage and t.is_cuda) else t
@@ -106,6 +127,31 @@ class TorchComm:
     def neighbour_exchange(self, to_left, to_right, from_left, from_right, async_op=False):
         td, P, r = self.td, self.world, self.rank
         left, right = (r - 1) % P, (r + 1) % P
+        if not self.stage:
+            # RCCL: ONE all_to_all_single with split sizes instead of four point-to-point operations (the batched
+            # isend / irecv costs ~86 us of host time per exchange, eight exchanges per forward+adjoint step).  Chunks
+            # are ordered by peer rank; with one or two ranks both chunks travel to the same peer, [to_left, to_right].
+            n = to_left.numel()
+            first_left = left <= right
+            send = torch.cat((to_left.reshape(-1), to_right.reshape(-1)) if first_left else (to_right.reshape(-1), to_left.reshape(-1)))
+            recv = torch.empty_like(send)
+            splits = [0] * P
+            splits[left] += n
+            splits[right] += n
+            w = td.all_to_all_single(recv, send, splits, splits, group=self.group, async_op=True)
+            # the chunk from rank `left` is its to_right (my from_left); from one peer only: [its to_left, its to_right]
+            a, b = recv[:n], recv[n:]
+            fl, fr = (b, a) if left == right else ((a, b) if first_left else (b, a))
+
+            def finish():
+                from_left.copy_(fl.view_as(from_left))
+                from_right.copy_(fr.view_as(from_right))
+
+            h = _Works([w], finish)
+            if async_op:
+                return h
+            h.wait()
+            return _Done()
         sl, sr = self._h(to_left), self._h(to_right)
         rl = torch.empty(from_left.shape, dtype=from_left.dtype) if (self.stage and from_left.is_cuda) else from_left
         rr = torch.empty(from_right.shape, dtype=from_right.dtype) if (self.stage and from_right.is_cuda) else from_right
@@ -140,6 +186,19 @@ class TorchComm:
         t = t.cpu() if self.stage else t.to(torch.device("cuda", torch.cuda.current_device()))
         self.td.all_reduce(t, op=self.td.ReduceOp.MAX, group=self.group)
         return float(t.item())
+
+    def all_reduce_max_async(self, v):
+        """See LocalComm.all_reduce_max_async.  RCCL: the all-reduce runs on the communicator's stream, the current stream
+        (not the host) waits for it and copies the result to pinned memory.  Staged (gloo) communicators have to stop the
+        host anyway: the value is returned with no event."""
+        if self.stage:
+            return torch.tensor([self.all_reduce_max_float(v)], dtype=torch.float32), None
+        t = v.detach().reshape(1).float().clone()
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX, group=self.group, async_op=True).wait()
+        host, ev = _pinned_slot(self)
+        host.copy_(t, non_blocking=True)
+        ev.record()
+        return host, ev
 
     def all_gather_cat(self, t):
         h = self._h(t).contiguous()
@@ -405,20 +464,61 @@ class SlabPM(HaloMixin):
         return out, np.array([sb[0], -sb[1], -sb[2]])
 
     # ---- one BullFrog step and its adjoint -----------------------------------------------------------------
+    def reset_depth(self):
+        """Forget the displacement history (call before the first step of a new trajectory: its depth is then the full G)."""
+        self._dhist, self._dpending, self._dused = [], None, []
+
+    def _harvest_depth(self):
+        """Collects the measurement enqueued by the previous `set_depth` (its device work was enqueued a whole step ago, so
+        the wait is normally free) and checks that the depth that step USED covered what its particles needed."""
+        if getattr(self, "_dpending", None) is None:
+            return
+        host, ev, order = self._dpending
+        self._dpending = None
+        if ev is not None:
+            ev.synchronize()
+        dmax = float(host[0])
+        self._dhist.append(dmax)
+        need = min(self.G, int(math.floor(dmax)) + 1 + (1 if order > 2 else 0))
+        if self._dused and self._dused[-1] < need:
+            raise RuntimeError(f"ghost depth {self._dused[-1]} was predicted for a step whose particles reach {need} planes "
+                               f"beyond the slab (max |d_x| = {dmax:.2f}): the result of that step is wrong; use "
+                               f"adaptive_ghost=False or restart the trajectory with reset_depth()")
+
     def set_depth(self, x, paint_order=2, depth=None):
         """Ghost depth of a step whose particles sit at displacements x: a CIC deposit / gather reaches at most
-        floor(max |d_x|) + 1 planes beyond the slab (order-3/4 stencils one more), so only those planes (plus one spare)
-        are exchanged instead of all G.  The maximum is taken over all ranks (one tiny all-reduce; synchronises the
-        host once per step).  adaptive_ghost=False keeps the full depth."""
+        floor(max |d_x|) + 1 planes beyond the slab (order-3/4 stencils one more), so only those planes (plus spares) are
+        exchanged instead of all G.  The host is NOT stopped to learn max |d_x| of this step: the maximum over ranks is
+        enqueued (tiny all-reduce + pinned copy) and read one step later, and this step's depth is PREDICTED from the
+        previous steps' maxima (last value + twice its last increase + one plane).  Every rank predicts from the same
+        all-reduced numbers, so the depths agree.  The prediction is verified when the measurement arrives
+        (`_harvest_depth` raises if it was too small); the first step of a trajectory uses the full depth.
+        adaptive_ghost=False keeps the full depth always."""
         if not self.adaptive_ghost:
             self.ge = self.G
             return
         if depth is not None:       # the adjoint of a step revisits the forward step's positions: reuse its depth
             self.ge = int(depth)
             return
-        dmax = self.comm.all_reduce_max_float(x[:, 0].abs().max())
-        reach = int(math.floor(dmax)) + 1 + (1 if paint_order > 2 else 0)
-        self.ge = max(1, min(self.G, reach + 1))
+        if not hasattr(self, "_dhist"):
+            self.reset_depth()
+        self._harvest_depth()
+        host, ev = self.comm.all_reduce_max_async(x[:, 0].abs().max())
+        self._dpending = (host, ev, paint_order)
+        h = self._dhist
+        if not h:
+            self.ge = self.G
+        else:
+            growth = max(h[-1] - h[-2], 0.0) if len(h) > 1 else 0.5 * h[-1]
+            pred = h[-1] + 2.0 * growth + 1.0
+            reach = int(math.floor(pred)) + 1 + (1 if paint_order > 2 else 0)
+            self.ge = max(1, min(self.G, reach + 1))
+        self._dused.append(self.ge)
+
+    def finish_depth(self):
+        """Verifies the last step's predicted depth (stops the host once; call at the end of a forward trajectory)."""
+        if self.adaptive_ghost:
+            self._harvest_depth()
 
     def step(self, x, v, alpha, beta, tau, f3_out, x_out, v_out, paint_order=2):
         """x, v: (Nl,3) local state; f3_out: (3, nxe, ny, nz) receives the ghost-filled force meshes."""
@@ -473,11 +573,13 @@ def nbody_bf_slab(cosmo, init_mesh, a0=0., a1=1., n_steps=5, paint_order=2, lpt_
     pm.lpt(spec, int(lpt_order), lpt_s[0], lpt_s[1], lpt_s[2], states[0, 0], states[0, 1])      # slab-decomposed LPT start
     states[0, 0] += states[0, 1] * (dg / 2)
     depths = []
+    pm.reset_depth()
     for i in range(K):
         tau = dg / 2 if i == K - 1 else dg
         pm.step(states[i, 0], states[i, 1], alphas[i], betas[i], tau, f3s[i] if return_ctx else pm.f3,
                 states[i + 1, 0], states[i + 1, 1], paint_order)
         depths.append(pm.ge)
+    pm.finish_depth()
     out = (states[K, 0], states[K, 1])
     if return_ctx:
         return out, SlabCtx(pm=pm, spec=spec, states=states, f3s=f3s, dg=dg, alphas=alphas, betas=betas, lpt_s=lpt_s,

@@ -71,6 +71,35 @@ def test_slab_path_multi_rank_shared_gpu(gpu, world):
 
 
 @pytest.mark.gpu
+def test_predicted_ghost_depth_is_verified(gpu):
+    """The exchanged ghost depth of a step is predicted from the previous steps' displacement maxima (no host stop per
+    step) and verified one step later: smooth growth stays within the prediction with a spare plane, a jump beyond it is
+    reported loudly instead of silently dropping deposits."""
+    import torch
+    from montecosmo_amd import dist
+    pm = dist.SlabPM((32, 32, 32), ghost=8)
+    x = torch.zeros((pm.Nl, 3), device="cuda")
+    pm.reset_depth()
+    used = []
+    for amp in (0.4, 0.9, 1.5, 2.2, 3.0):          # displacement maxima of successive steps
+        x[:, 0] = amp * torch.sin(torch.arange(pm.Nl, device="cuda") * 0.01)
+        pm.set_depth(x)
+        used.append(pm.ge)
+    pm.finish_depth()
+    assert used[0] == 8                            # first step of a trajectory: the full depth
+    need = [int(np.floor(a)) + 1 for a in (0.4, 0.9, 1.5, 2.2, 3.0)]
+    assert all(u >= n for u, n in zip(used, need)) and used[3] < 8
+    pm.reset_depth()
+    x[:, 0] = 0.3
+    pm.set_depth(x)
+    pm.set_depth(x)
+    x[:, 0] = 6.5                                  # a jump no smooth trajectory makes
+    pm.set_depth(x)
+    with pytest.raises(RuntimeError, match="ghost depth"):
+        pm.finish_depth()
+
+
+@pytest.mark.gpu
 def test_slab_path_one_rank_rccl(gpu):
     """The communicator's RCCL branch (device tensors in place, asynchronous handles) with the one rank a one-GPU box
     allows: self send/recv for the ghost planes, a one-rank all-to-all for the transposes."""
