@@ -777,7 +777,8 @@ static YLayout ylayout(const mcpm_plan *p, bool packed) {
 
 // kz columns per workgroup of the register-heavy passes (ycol2, xfused; 75-118 VGPRs, so a 1024-thread workgroup is
 // alone on its CU): 8 columns (512 threads at N = 512, two independent workgroups per CU, 64-byte row segments) measured
-// 1 % faster per step than 16 at 512^3 (13.13 vs 13.26 ms, same box).  Tuning knob MCPM_COL_LINES = 8 | 16.
+// 1 % faster per step than 16 at 512^3 (13.13 vs 13.26 ms, same box); 4 columns (32-byte segments) are 2.3x SLOWER (fused x
+// pass 1.15 vs 0.49 ms): a row segment must stay a whole 64-byte access.  Tuning knob MCPM_COL_LINES = 8 | 16.
 static int col_lines() {
     static int v = -1;
     if (v < 0) {
