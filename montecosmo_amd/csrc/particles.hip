@@ -106,6 +106,14 @@ __device__ __forceinline__ void tile_of_block(int order, int ntx, int nty, int n
     tx = tt / nty;
 }
 
+// c in (-n, 2n) -> [0, n): a mask on power-of-two sizes (the condition is uniform, the compiler branches on it once)
+__device__ __forceinline__ int wrap_once(int c, int n) {
+    if ((n & (n - 1)) == 0) return c & (n - 1);
+    c += c < 0 ? n : 0;
+    c -= c >= n ? n : 0;
+    return c;
+}
+
 __device__ __forceinline__ int cvt_rpi(float x) {   // floor(x + 0.5)
     int r;
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
@@ -153,13 +161,10 @@ __global__ __launch_bounds__(THREADS) void paint_tile_kernel(Geom g, const float
                 gx -= g.xoff;
                 inx = (unsigned)gx < (unsigned)g.px;
             } else {
-                gx += gx < 0 ? g.nx : 0;
-                gx -= gx >= g.nx ? g.nx : 0;
+                gx = wrap_once(gx, g.nx);
             }
-            gy += gy < 0 ? g.ny : 0;
-            gy -= gy >= g.ny ? g.ny : 0;
-            gz += gz < 0 ? g.nz : 0;
-            gz -= gz >= g.nz ? g.nz : 0;
+            gy = wrap_once(gy, g.ny);
+            gz = wrap_once(gz, g.nz);
             ok = ok && inx;
             const int gi = ok ? (gx * g.ny + gy) * g.nz + gz : -1;
             rxs[u] = rx;
@@ -278,13 +283,10 @@ __global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const floa
                 gx -= g.xoff;
                 inx = (unsigned)gx < (unsigned)g.px;
             } else {
-                gx += gx < 0 ? g.nx : 0;
-                gx -= gx >= g.nx ? g.nx : 0;
+                gx = wrap_once(gx, g.nx);
             }
-            gy += gy < 0 ? g.ny : 0;
-            gy -= gy >= g.ny ? g.ny : 0;
-            gz += gz < 0 ? g.nz : 0;
-            gz -= gz >= g.nz ? g.nz : 0;
+            gy = wrap_once(gy, g.ny);
+            gz = wrap_once(gz, g.nz);
             ok = ok && inx;
             const int gi = ok ? (gx * g.ny + gy) * g.nz + gz : -1;
             rxs[u] = rx;
@@ -440,13 +442,10 @@ __global__ __launch_bounds__(THREADS) void paint3_fx_kernel(Geom g, const float 
                 gx -= g.xoff;
                 inx = (unsigned)gx < (unsigned)g.px;
             } else {
-                gx += gx < 0 ? g.nx : 0;
-                gx -= gx >= g.nx ? g.nx : 0;
+                gx = wrap_once(gx, g.nx);
             }
-            gy += gy < 0 ? g.ny : 0;
-            gy -= gy >= g.ny ? g.ny : 0;
-            gz += gz < 0 ? g.nz : 0;
-            gz -= gz >= g.nz ? g.nz : 0;
+            gy = wrap_once(gy, g.ny);
+            gz = wrap_once(gz, g.nz);
             ok = ok && inx;
             const int gi = ok ? (gx * g.ny + gy) * g.nz + gz : -1;
             rxs[u] = rx;
