@@ -43,9 +43,12 @@ class _Done:
 
 class _Works:
     def __init__(self, works, after=None):
-        self.works, self.after = works, after
+        self.works, self.after, self.done = works, after, False
 
     def wait(self):
+        if self.done:      # several consumers may wait on one exchange (the three components of a batched ghost add)
+            return
+        self.done = True
         for w in self.works:
             w.wait()
         if self.after:
@@ -362,14 +365,24 @@ class SlabPM(HaloMixin):
         hG = self.comm.all_to_all(self.s3b[ss:2 * ss], self.s3a[ss:2 * ss], async_op=True)
         hA.wait()
         self.call("mcpm_slab_ycol2", _p(self.s3b), _p(self.s3a), 1, 1, 0, 1)          # A -> force spectrum 0 (s3a[0])
-        fills = [self._zinv_fill(self.s3a, 0, f3_ext[0], fill_ghosts)]
+        self._zinv_fill(self.s3a, 0, f3_ext[0], False)                                # all of component 0 under G's transfer
         hG.wait()
         self.call("mcpm_slab_ycol2", _p(self.s3b), _p(self.s3a), 1, 1, 0, 2)          # G -> force spectra 1, 2
+        # ONE ghost fill for the three components: the edge planes of components 1, 2 first, the exchange (async) under
+        # their inner planes
+        inner, edges = self._windows(fill_ghosts)
         for c in (1, 2):
-            fills.append(self._zinv_fill(self.s3a, c, f3_ext[c], fill_ghosts))
-        for f in fills:
-            if f is not None:
-                f.wait()
+            for w in edges:
+                self._win(w)
+                self.call("mcpm_slab_zinv", self._spec(self.s3a, c), self._interior(f3_ext[c]), self.Me, 1)
+        h = self.halo_fill(f3_ext, async_op=True) if fill_ghosts else None
+        if inner is not None:
+            self._win(inner)
+            for c in (1, 2):
+                self.call("mcpm_slab_zinv", self._spec(self.s3a, c), self._interior(f3_ext[c]), self.Me, 1)
+        self._win((0, self.nxl))
+        if h is not None:
+            h.wait()
 
     def force_meshes_vjp(self, fbar3_ext, rhobar_ext, ghost_adds=None, fill_ghosts=False):
         """fbar3_ext: three cotangent meshes (ghosts added, or `ghost_adds[c]` handles still in flight).  Writes the
@@ -544,8 +557,8 @@ class SlabPM(HaloMixin):
             self.call("mcpm_kick_f32", _p(vb), _p(xb), self.Nl, float(beta), float(beta * tau), _p(self.Fb))
             fb = _p(self.Fb)
         self.call("mcpm_paint3_f32", _p(x), self.Nl, POS_LATTICE, fb, paint_order, _p(self.f3), 0)
-        adds = [self.halo_add(self.f3[c], async_op=True) for c in range(3)]   # overlap with the z / y passes below
-        self.force_meshes_vjp(self.f3, self.rho, adds, fill_ghosts=True)
+        add = self.halo_add(self.f3, async_op=True)      # ONE exchange for the three components, under the inner planes' passes
+        self.force_meshes_vjp(self.f3, self.rho, [add, add, add], fill_ghosts=True)
         if next_beta_tau is not None:
             self.call("mcpm_plan_hint_next_adjoint", float(next_beta_tau[0]), float(next_beta_tau[1]))
         self.call("mcpm_step_adjoint_particles_f32", _p(x), _p(v), _p(f3), _p(self.rho), float(alpha), float(beta),
