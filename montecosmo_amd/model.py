@@ -1,7 +1,7 @@
 """`FieldLevelModel.evolve` (montecosmo/model.py:686-838) on the HIP path, with its hand-written reverse sweep.
 
-Built branch: bias_type 'lagrangian', evolution 'lpt' (scalar a_obs or light cone) or 'nbody' (scalar a_obs, as the
-reference asserts), png_type None, ap_auto None, kernel_type 'rectangular', linear power from a table (`lin_kpow`,
+Built branch: bias_type 'lagrangian', evolution 'lpt' (scalar a_obs or light cone), 'nbody' (scalar a_obs, as the
+reference asserts) or 'kaiser' (flat sky, scalar a_obs: bricks.py:170-198), png_type None, ap_auto None, kernel_type 'rectangular', linear power from a table (`lin_kpow`,
 bricks.py:75-77) or, with lin_kpow = None, from the Eisenstein-Hu fit of the current cosmology (bricks.py:72-74; power.py).
 Priors, likelihood and samplers: logdensity.py, samplers.py.
 
@@ -33,8 +33,11 @@ class FieldLevelForward:
                  evolution='lpt', nbody_a_start=0., nbody_n_steps=10, lpt_order=2, paint_order=2, paint_deconv=True,
                  init_oversamp=3 / 2, evol_oversamp=7 / 4, ptcl_oversamp=7 / 4, paint_oversamp=7 / 4, interlace_order=2,
                  a_obs=None, curved_sky=True, lin_kpow=None):
-        if evolution not in ('lpt', 'nbody'):
-            raise NotImplementedError("evolution must be 'lpt' or 'nbody' (the Kaiser model is not built)")
+        if evolution not in ('kaiser', 'lpt', 'nbody'):
+            raise ValueError("evolution must be 'kaiser', 'lpt' or 'nbody'")
+        if evolution == 'kaiser' and (curved_sky or a_obs is None):
+            raise NotImplementedError("the Kaiser model is built for the flat sky at fixed a_obs (bricks.py:194-198); "
+                                      "its curved-sky / light-cone forms (bricks.py:200-231) are not")
         self.final_shape = tuple(int(s) for s in final_shape)
         self.cell_length = float(cell_length)
         self.box_center = np.asarray(box_center, dtype=np.float64)
@@ -107,6 +110,44 @@ class FieldLevelForward:
         d = nbody._dist_cache(cosmo)
         return nbody.interp_dev(self._r0, d["chi"][::-1], d["a"][::-1]).reshape(-1, 1)
 
+    # ---- Kaiser model (bricks.py:170-198, flat sky, fixed a): growth, Eulerian linear bias and RSD, diagonal in k -------
+    def _mu2_mesh(self, device):
+        """(k . los)^2 / k^2 on the half-spectrum of the evolution mesh, los = the box centre's direction in cell axes."""
+        if getattr(self, "_mu2", None) is None:
+            los = bricks.rot_matrix(self.box_rotvec).T @ nbody.safe_div(self.box_center, np.linalg.norm(self.box_center))
+            kvec = nbody.rfftk(self.evol_shape, self.box_size)
+            kk = sum(k ** 2 for k in kvec)
+            mu2 = nbody.safe_div(sum(k * l for k, l in zip(kvec, los)) ** 2, kk)
+            self._mu2 = torch.from_numpy(np.ascontiguousarray(mu2, dtype=np.float32)).to(device)
+        return self._mu2
+
+    def _kaiser(self, cosmo, bias, white, evol_k, return_ctx):
+        D, f = float(nbody.a2g(cosmo, self.a_obs)), float(nbody.a2f(cosmo, self.a_obs))
+        mu2 = self._mu2_mesh(evol_k.device)
+        boost = D * ((1.0 + float(bias["b1"])) + f * mu2)                 # b1E = 1 + b1 (bricks.py:454)
+        gxy = nbody.irfftn(evol_k * boost) + 1.0
+        cosmo._workspace = {}
+        if return_ctx:
+            return gxy, EvolveCtx(cosmo=cosmo, white=white, evol_k=evol_k, kaiser=(D, f, float(bias["b1"]), boost))
+        return gxy
+
+    def _kaiser_vjp(self, ctx, gxy_bar):
+        cosmo = ctx.cosmo
+        D, f, b1, boost = ctx.kaiser
+        gb = nbody._f32(gxy_bar, self.evol_shape)
+        kb = nbody.rfftn(gb) / float(np.prod(self.evol_shape))           # irfftn adjoint (real-pair convention)
+        kb[..., 1:self.evol_shape[-1] // 2] *= 2.0
+        prod = kb.conj() * ctx.evol_k
+        c0 = float(prod.real.double().sum())                              # d/d(D b1E)
+        c1 = float((prod.real * self._mu2_mesh(kb.device)).double().sum())    # d/d(D f)
+        init_b = chreshape_vjp(kb * boost, r2chshape(self.init_shape))
+        white_b = self._power_mult(init_b, cosmo)
+        s8b = float((init_b.conj() * self._power_mult(ctx.white, cosmo)).real.sum().item()) / float(cosmo.sigma8)
+        bias_bar = {k: 0.0 for k in bricks.BIAS_KEYS}
+        bias_bar["b1"] = D * c0
+        return {"white_mesh": white_b, "bias": bias_bar, "sigma8": s8b, "init_bar": init_b,
+                "kaiser": {"g": (1.0 + b1) * c0 + f * c1, "f": D * c1}}
+
     # ---- forward -----------------------------------------------------------------------------------------
     def evolve(self, cosmo, bias, white_mesh, return_ctx=False):
         """cosmo: duck-typed cosmology (Omega_m, Omega_de, Omega_k, w0, wa, sigma8, _workspace); bias: dict of the
@@ -115,6 +156,8 @@ class FieldLevelForward:
         white = nbody._c64(white_mesh, r2chshape(self.init_shape))
         init_k = self._power_mult(white, cosmo)
         evol_k = chreshape(init_k, r2chshape(self.evol_shape))
+        if self.evolution == 'kaiser':      # gxy_mesh lives on the evolution mesh (model.py:690-696: no oversampling needed)
+            return self._kaiser(cosmo, bias, white, evol_k, return_ctx)
         pos0 = nbody.LatticePos.regular(self.evol_shape, self.ptcl_shape)
         a = self._scale_factors(cosmo)
         (w, dvel, _), bctx = bricks.lagrangian_bias(cosmo, pos0, a, self.box_size, evol_k, bias, read_order=1, return_ctx=True)
@@ -144,6 +187,8 @@ class FieldLevelForward:
         """Cotangent of gxy_mesh (real, paint_shape) -> {'white_mesh': complex64 cotangent (real-pair convention),
         'bias': dict, 'sigma8': float, 'growth': cotangents of the growth scalars (see nbody.lpt_vjp / nbody_bf_vjp),
         'bias_growth': cotangent(s) of a2g(a) through the bias weights, 'gf': cotangent of a2g(a_obs) a2f(a_obs) through rsd}."""
+        if self.evolution == 'kaiser':
+            return self._kaiser_vjp(ctx, gxy_bar)
         cosmo = ctx.cosmo
         gb = nbody._f32(gxy_bar, self.paint_shape)
         # irfftn adjoint: X_bar = (w / M) rfftn(y_bar)
@@ -182,6 +227,8 @@ class FieldLevelForward:
 
         def scalars(c):
             c._workspace = {}
+            if self.evolution == 'kaiser':
+                return np.array([float(nbody.a2g(c, a)), float(nbody.a2f(c, a))])
             out = [float(nbody.a2g(c, a)), float(nbody.a2g(c, a) * nbody.a2f(c, a))]
             if self.evolution == 'lpt':
                 out += [float(nbody.a2g(c, a)), float(nbody.a2g2(c, a)), float(nbody.a2dg2dg(c, a))]
@@ -190,9 +237,14 @@ class FieldLevelForward:
                 out += [dg] + list(al) + list(be) + list(ls)
             return np.array(out)
 
-        g = grads["growth"]
-        bars = [float(np.asarray(grads["bias_growth"]).sum()), float(grads["gf"])]
-        if self.evolution == 'lpt':
+        if self.evolution == 'kaiser':
+            g, bars = None, [float(grads["kaiser"]["g"]), float(grads["kaiser"]["f"])]
+        else:
+            g = grads["growth"]
+            bars = [float(np.asarray(grads["bias_growth"]).sum()), float(grads["gf"])]
+        if self.evolution == 'kaiser':
+            pass
+        elif self.evolution == 'lpt':
             bars += [float(g["g"]), float(g["g2"]), float(g["dg2dg"])]
         else:
             bars += [float(g["dg"])] + list(g["alpha"]) + list(g["beta"]) + [float(g["g"]), float(g["g2"]), float(g["dg2dg"])]

@@ -223,6 +223,13 @@ def evolve(cfg, cosmo, bias, white_mesh):
         kpow = power_oracle.lin_power_table(cosmo)
     init_mesh = white2lin(cosmo.sigma8, white_mesh, cfg["init_shape"], box, kpow)
     init_mesh = o.chreshape(init_mesh, o.r2chshape(cfg["evol_shape"]))
+    if cfg["evolution"] == "kaiser":      # model.py:690-696 with bricks.py:186-198: flat sky, fixed a -> diagonal in k
+        assert not cfg["curved_sky"] and cfg["a_obs"] is not None
+        c = np.asarray(ctr, float)
+        los = R.T @ o.safe_div(c, np.linalg.norm(c))
+        boost = kaiser_boost(cosmo, cfg["a_obs"], cfg["evol_shape"], box, 1. + bias["b1"], los)
+        cosmo._workspace = {}
+        return 1. + np.fft.irfftn(init_mesh * boost, s=tuple(cfg["evol_shape"]), axes=(0, 1, 2)), None
     pos = o.regular_pos(cfg["evol_shape"], cfg["ptcl_shape"])
     _, a = los_scalefactor_pos(pos, ctr, R, box, cfg["evol_shape"], cosmo, cfg["a_obs"], cfg["curved_sky"])
     w, dvel = lagrangian_bias(o.a2g(cosmo, a), pos, box, init_mesh, bias, read_order=1)

@@ -79,24 +79,26 @@ def _with_s8(c, s8):
 @pytest.mark.parametrize("evolution,s_e2,precond,a_obs,survey", [("lpt", 0.0, "fourier", 0.65, False), ("nbody", 0.02, "fourier", 0.65, False),
                                                                  ("nbody", 0.02, "kaiser", 0.65, False), ("lpt", 0.0, "kaiser", None, False),
                                                                  ("lpt", 0.02, "kaiser", 0.65, True), ("nbody", 0.0, "fourier", 0.65, True),
-                                                                 ("lpt", 0.0, "kaiser", 0.65, "eh")])
+                                                                 ("lpt", 0.0, "kaiser", 0.65, "eh"),
+                                                                 ("kaiser", 0.02, "kaiser", 0.65, "flat")])
 def test_log_density_and_gradient(gpu, evolution, s_e2, precond, a_obs, survey):
     """Prior + evolve + 'quad_gauss' likelihood (model.py:640-679, :840-908) on the HIP path against the float64
     restatement; gradient w.r.t. every sampled parameter against central differences of that restatement.  'kaiser':
     the reference's default preconditioning (model.py:1134-1147), once at fixed a_obs and once on the light cone.
-    "eh": lin_kpow = None, the linear power is the Eisenstein-Hu fit of the sampled cosmology.
+    "eh": lin_kpow = None, the linear power is the Eisenstein-Hu fit of the sampled cosmology.  evolution "kaiser": the linear
+    Kaiser model on the flat sky (bricks.py:170-198), gradients w.r.t. b1 and the cosmology through its growth and growth rate.
     survey: a selection mesh on the paint mesh, a mask over the final cells and two radial shells with their own mean
     densities (model.py:855-866, :1087-1098; bricks.py:1106-1122)."""
     from montecosmo_amd import model, logdensity
     rng = np.random.default_rng(41)
     fwd = model.FieldLevelForward(final_shape=(8, 8, 8), cell_length=40., box_center=(60., -40., 1400.), box_rotvec=(0.1, 0.2, -0.1),
                                   evolution=evolution, nbody_n_steps=3, lpt_order=2, init_oversamp=1.5, evol_oversamp=2.,
-                                  ptcl_oversamp=2., paint_oversamp=2., a_obs=a_obs, curved_sky=True,
+                                  ptcl_oversamp=2., paint_oversamp=2., a_obs=a_obs, curved_sky=survey != "flat",
                                   lin_kpow=None if survey == "eh" else _kpow(), nbody_a_start=0.1)
     cfg = dict(fwd.config(), final_shape=(8, 8, 8), cell_length=40., precond=precond)
     extra = {}
-    if survey == "eh":      # no tabulated power: Eisenstein-Hu of the sampled cosmology (bricks.py:69-79), Omega_m moves its shape
-        survey = False
+    if survey in ("eh", "flat"):      # "eh": no tabulated power, Eisenstein-Hu of the sampled cosmology (bricks.py:69-79), Omega_m
+        survey = False                # moves its shape; "flat": flat sky (the Kaiser model's built branch)
     if survey:
         gsel = np.indices(fwd.paint_shape).astype(float)
         extra["selec_mesh"] = 0.7 + 0.3 * np.cos(2 * np.pi * gsel[0] / fwd.paint_shape[0]) * np.sin(2 * np.pi * gsel[2] / fwd.paint_shape[2]) \
