@@ -12,7 +12,8 @@ an optional mask over the final cells and radial shells with their own (fixed) m
     selec = |rc * irfftn(chreshape(rfftn(selec_mesh), final_shape))|  (or mean(ngbars) cell^3 without a selection mesh)
     delta = count / selec - 1;   obs[mask] ~ QuadGaussian(count, (|s_e + s_ed delta| + 1e-9) sqrt(selec), s_e2 sqrt(selec)).
 Bounded latents (`low` / `high` in their config) use the reference's detruncated truncated-normal parametrisation
-(utils.py:189-226, :267-311) within |x| < 12 sigma.
+(utils.py:189-226, :267-311) within |x| < 12 sigma; latents without `loc` / `scale` have a uniform prior on [low, high] in the
+same parametrisation (DetruncUnif, utils.py:314-353).
 
 The gradient is hand-derived end to end: elementwise likelihood / prior terms here (device tensors), the mesh and
 particle operators through their `*_vjp` twins -- no autodiff framework.
@@ -93,6 +94,13 @@ def detrunc_truncnorm_log_prob_and_grad(x, c):
     return lp, -z / c["scale"] * d1 + d2 / d1, y, d1
 
 
+def detrunc_unif_log_prob_and_grad(x, c):
+    """DetruncUnif.log_prob (utils.py:314-353): Uniform(low, high).log_prob(std2trunc(x; fid)) + log |d std2trunc / dx|, its
+    d/dx, the base value and d base / dx."""
+    y, d1, d2 = std2trunc_and_derivs(x, c["loc_fid"], c["scale_fid"], c["low"], c["high"])
+    return -math.log(c["high"] - c["low"]) + math.log(abs(d1)), d2 / d1, y, d1
+
+
 class FieldLevelLogDensity:
     """log p(sample params, observed counts) and its gradient.
 
@@ -115,7 +123,15 @@ class FieldLevelLogDensity:
         if precond not in ("fourier", "real", "kaiser"):
             raise ValueError(f"Unknown preconditioning type: {precond}")
         self.fwd, self.precond = fwd, precond
-        self.latents = {k: dict({"low": -math.inf, "high": math.inf}, **{kk: float(vv) for kk, vv in v.items()}) for k, v in latents.items()}
+        self.latents = {k: dict({"low": -math.inf, "high": math.inf}, **{kk: float(vv) for kk, vv in v.items() if vv is not None})
+                        for k, v in latents.items()}
+        for k, c in self.latents.items():      # no loc / scale: a uniform prior on [low, high] (model.py:1122-1123)
+            if "loc" not in c or "scale" not in c:
+                if not (math.isfinite(c["low"]) and math.isfinite(c["high"])):
+                    raise ValueError(f"latent '{k}' not valid: low and high must be finite for uniform distribution")
+                c.pop("loc", None), c.pop("scale", None)
+                c.setdefault("loc_fid", (c["low"] + c["high"]) / 2)              # model.py:1081-1084
+                c.setdefault("scale_fid", (c["high"] - c["low"]) / 12 ** .5)
         self.fixed = dict(fixed)
         need = set(self.COSMO) | set(bricks.BIAS_KEYS) | {"ngbars"} | set(self.STOCH)
         missing = need - set(self.latents) - set(self.fixed)
@@ -261,7 +277,11 @@ class FieldLevelLogDensity:
         lp, grad, dbase = 0.0, {}, {}
         for name, c in self.latents.items():
             x = float(sample[name + "_"])
-            if self._bounded(c):      # truncated-normal latent (model.py:1120-1121, bricks.py:271-273)
+            if "loc" not in c:        # uniform latent (model.py:1122-1123)
+                l, gl, _, d1 = detrunc_unif_log_prob_and_grad(x, c)
+                lp += l
+                grad[name + "_"], dbase[name] = gl, d1
+            elif self._bounded(c):    # truncated-normal latent (model.py:1120-1121, bricks.py:271-273)
                 l, gl, _, d1 = detrunc_truncnorm_log_prob_and_grad(x, c)
                 lp += l
                 grad[name + "_"], dbase[name] = gl, d1

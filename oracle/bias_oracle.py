@@ -397,7 +397,12 @@ def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo):
     for name, conf in latents.items():
         x = sample[name + "_"]
         low, high = conf.get("low", -np.inf), conf.get("high", np.inf)
-        if low == -np.inf and high == np.inf:
+        if conf.get("loc") is None:      # uniform prior (model.py:1122-1123; utils.py:314-353 DetruncUnif), central-difference Jacobian
+            lf, sf, h = conf.get("loc_fid", (low + high) / 2), conf.get("scale_fid", (high - low) / 12 ** .5), 1e-6
+            jac = (std2trunc(x + h, lf, sf, low, high) - std2trunc(x - h, lf, sf, low, high)) / (2 * h)
+            lp += -np.log(high - low) + np.log(abs(jac))
+            base[name] = std2trunc(x, lf, sf, low, high)
+        elif low == -np.inf and high == np.inf:
             mu, sd = (conf["loc"] - conf["loc_fid"]) / conf["scale_fid"], conf["scale"] / conf["scale_fid"]
             lp += -0.5 * np.log(2 * np.pi) - np.log(sd) - 0.5 * ((x - mu) / sd) ** 2
             base[name] = x * conf["scale_fid"] + conf["loc_fid"]

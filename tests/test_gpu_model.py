@@ -109,8 +109,9 @@ def test_log_density_and_gradient(gpu, evolution, s_e2, precond, a_obs, survey):
            "sigma8": dict(loc=0.8102, scale=0.1, loc_fid=0.8102, scale_fid=1e-2, low=0., high=np.inf),   # model.py:100-111
            "b1": dict(loc=1., scale=1e2, loc_fid=1., scale_fid=1e-2), "b2": dict(loc=0., scale=1e2, loc_fid=0., scale_fid=3e-2),
            "bs2": dict(loc=0., scale=1e2, loc_fid=0., scale_fid=1e-1), "bn2": dict(loc=0., scale=1e3, loc_fid=0., scale_fid=1.),
-           "s_ed": dict(loc=0., scale=1e1, loc_fid=0., scale_fid=1e-2)}
-    fixed = dict(b3=0.1, bds2=0.1, bs3=-0.05, bnpar=5.0, ngbars=(np.array([1e-3, 1.4e-3]) if survey else 1e-3), s_e=1.0, s_e2=s_e2)
+           "s_ed": dict(loc=0., scale=1e1, loc_fid=0., scale_fid=1e-2),
+           "bnpar": dict(low=-10., high=20., loc_fid=5., scale_fid=30. / 12 ** .5)}                                                            # uniform (DetruncUnif)
+    fixed = dict(b3=0.1, bds2=0.1, bs3=-0.05, ngbars=(np.array([1e-3, 1.4e-3]) if survey else 1e-3), s_e=1.0, s_e2=s_e2)
     if a_obs is None:      # light cone: the cosmology dependence of the look-ups is not propagated -> Omega_m stays fixed
         fixed["Omega_m"] = lat.pop("Omega_m")["loc_fid"]
     make_cosmo = lambda base: _cos(obg.Planck18(Omega_c=base["Omega_m"] - 0.0490), base["sigma8"])
