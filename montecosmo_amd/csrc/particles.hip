@@ -733,7 +733,7 @@ static inline void flat_launch(int64_t n, dim3 &grid, dim3 &block) {
 
 static int check_particles(mcpm_plan *p, const void *pos, int64_t n, int mode, int order, const char *who) {
     if (!p) return MCPM_E_ARG;
-    MCPM_REQUIRE(p, pos != nullptr, MCPM_E_ARG, std::string(who) + ": null particle array");
+    MCPM_REQUIRE(p, pos != nullptr || n == 0, MCPM_E_ARG, std::string(who) + ": null particle array");   // empty input is valid
     MCPM_REQUIRE(p, n >= 0 && n < ((int64_t)1 << 31), MCPM_E_ARG, std::string(who) + ": bad particle count");
     MCPM_REQUIRE(p, mode == MCPM_POS_ABSOLUTE || mode == MCPM_POS_LATTICE, MCPM_E_ARG, std::string(who) + ": bad pos_mode");
     MCPM_REQUIRE(p, mode != MCPM_POS_LATTICE || n == p->Np, MCPM_E_SHAPE,
@@ -940,7 +940,7 @@ int mcpm_paint3_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const f
 int mcpm_read_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *meshes, int ncomp, int order,
                   float *out) {
     MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_read_f32"));
-    MCPM_REQUIRE(p, meshes && out, MCPM_E_ARG, "mcpm_read_f32: null buffer");
+    MCPM_REQUIRE(p, meshes && (out || n == 0), MCPM_E_ARG, "mcpm_read_f32: null buffer");
     MCPM_REQUIRE(p, ncomp == 1 || ncomp == 3, MCPM_E_ARG, "mcpm_read_f32: ncomp must be 1 or 3");
     StageTimer st_(p, ST_READ, 12.0 * n + 4.0 * ncomp * (p->M + n));
     if (n == 0) return MCPM_OK;
@@ -958,7 +958,7 @@ int mcpm_read_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const flo
 int mcpm_read_vjp_pos_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *meshes, int ncomp,
                           int order, const float *out_bar, float *pos_bar) {
     MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_read_vjp_pos_f32"));
-    MCPM_REQUIRE(p, meshes && out_bar && pos_bar, MCPM_E_ARG, "mcpm_read_vjp_pos_f32: null buffer");
+    MCPM_REQUIRE(p, meshes && ((out_bar && pos_bar) || n == 0), MCPM_E_ARG, "mcpm_read_vjp_pos_f32: null buffer");
     MCPM_REQUIRE(p, ncomp == 1 || ncomp == 3, MCPM_E_ARG, "mcpm_read_vjp_pos_f32: ncomp must be 1 or 3");
     StageTimer st_(p, ST_READ, 24.0 * n + 4.0 * ncomp * (p->M + n));
     if (n == 0) return MCPM_OK;
@@ -978,7 +978,7 @@ int mcpm_read_vjp_pos_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, c
 int mcpm_paint_vjp_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *weights, int64_t wstride,
                        float wscalar, int order, const float *mesh_bar, float *pos_bar, float *weights_bar) {
     MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_paint_vjp_f32"));
-    MCPM_REQUIRE(p, mesh_bar && pos_bar, MCPM_E_ARG, "mcpm_paint_vjp_f32: null buffer");
+    MCPM_REQUIRE(p, mesh_bar && (pos_bar || n == 0), MCPM_E_ARG, "mcpm_paint_vjp_f32: null buffer");
     if (weights && wstride < 1) return mcpm_fail(p, MCPM_E_ARG, "mcpm_paint_vjp_f32: wstride must be >= 1");
     StageTimer st_(p, ST_READ, 28.0 * n + 4.0 * p->M);
     if (n == 0) return MCPM_OK;

@@ -85,6 +85,29 @@ def test_paint_read_absolute(nb, order):
     assert rel_l2(r, o.read(pos.astype(np.float64), mesh.astype(np.float64), order)) < 2e-6
 
 
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
+def test_paint_read_edge_cases(nb, order):
+    """Empty input, particles exactly on mesh points and on cell faces (round-half-to-even for the odd orders,
+    nbody.py:369-371), many periods outside the box on both sides, and all particles in one cell."""
+    shape = (8, 12, 16)
+    rng = np.random.default_rng(11)
+    empty = np.zeros((0, 3), np.float32)
+    assert not to_np(nb.paint(empty, shape, 1., order)).any()
+    assert to_np(nb.read(empty, rng.standard_normal(shape).astype(np.float32), order)).shape == (0,)
+    grid = np.stack(np.meshgrid(*[np.arange(-2, 4) * 0.5] * 3, indexing="ij"), -1).reshape(-1, 3)      # 0, +-0.5, +-1, 1.5
+    far = grid + np.array([8 * 37, -12 * 41, 16 * 29])                                                  # whole periods away
+    pile = np.tile(np.array([[3.25, 7.75, 9.5]]), (500, 1))
+    pos = np.concatenate([grid, far, pile]).astype(np.float32)
+    assert np.array_equal(to_np(nb.cell_index(pos, shape, order)), o.cell_index(pos.astype(np.float64), shape, order))
+    w = rng.standard_normal(len(pos)).astype(np.float32)
+    got = to_np(nb.paint(pos, shape, w, order))
+    want = o.paint(pos.astype(np.float64), shape, w.astype(np.float64), order)
+    assert np.abs(got - want).max() < 2e-5 * np.abs(want).max()
+    mesh = rng.standard_normal(shape).astype(np.float32)
+    r = to_np(nb.read(pos, mesh, order))
+    assert np.allclose(r, o.read(pos.astype(np.float64), mesh.astype(np.float64), order), atol=2e-6 * np.abs(mesh).max() * 8)
+
+
 @pytest.mark.parametrize("n,halo,sigma", [(32, 4, 1.0), (64, 2, 1.5), (64, 4, 2.5), (16, 4, 1.0), (48, 4, 1.0)])
 def test_paint_tiled_lattice(nb, n, halo, sigma):
     """LDS-tiled paint (incl. its outlier path, sigma ~ halo) against the oracle; also the weighted form."""
