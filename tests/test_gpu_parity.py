@@ -302,6 +302,27 @@ def test_nbody_bf_vjp(nb, n, n_steps, lpt_order, integrator):
         assert np.isclose(sb_g[k], sb_o[k], rtol=1e-3, atol=1e-3 * abs(sb_o["g"])), k
 
 
+@pytest.mark.parametrize("shape,n_steps,a0", [((16, 16, 16), 1, 0.0), ((24, 24, 24), 2, 0.0), ((16, 32, 48), 3, 0.05)])
+def test_nbody_bf_edge_configurations(nb, shape, n_steps, a0):
+    """One single (half-drift) step, the model's default start a0 = 0 (the growth table is clamped there, nbody.py:984-985
+    note in SURVEY 8a-12), a mesh that is neither a power of two nor a multiple of the tile size (rocFFT + atomic paint
+    fallbacks) and a non-cubic mesh: forward state and reverse sweep against the oracle."""
+    from montecosmo_amd import bricks, synth
+    spec = synth.init_mesh(shape, seed=8, rms_disp=1.0)
+    pos = bricks.regular_pos(shape)
+    cos_o, cos_g = obg.Planck18(), bricks.Planck18()
+    N = len(pos)
+    p_o, v_o = o.nbody_bf(cos_o, spec.astype(np.complex128), pos, a0, 1., n_steps)
+    (p_g, v_g), ctx = nb.nbody_bf(cos_g, spec, pos, a0=a0, a1=1., n_steps=n_steps, return_ctx=True)
+    assert rel_l2(to_np(p_g).reshape(-1, 3) - pos, p_o.reshape(-1, 3) - pos) < 2e-5
+    assert rel_l2(to_np(v_g).reshape(-1, 3), v_o.reshape(-1, 3)) < 2e-5
+    rng = np.random.default_rng(3)
+    xb, vb = rng.standard_normal((N, 3)).astype(np.float32), rng.standard_normal((N, 3)).astype(np.float32)
+    mb_o, _ = o.nbody_bf_vjp(cos_o, spec.astype(np.complex128), pos, xb.astype(np.float64), vb.astype(np.float64), a0, 1., n_steps)
+    mb_g, _ = nb.nbody_bf_vjp(ctx, xb, vb)
+    assert rel_l2(to_np(mb_g), mb_o) < 2e-4
+
+
 def test_errors_are_loud(nb):
     from montecosmo_amd._lib import McpmError
     with pytest.raises(McpmError):
