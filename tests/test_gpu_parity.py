@@ -302,11 +302,13 @@ def test_nbody_bf_vjp(nb, n, n_steps, lpt_order, integrator):
         assert np.isclose(sb_g[k], sb_o[k], rtol=1e-3, atol=1e-3 * abs(sb_o["g"])), k
 
 
-@pytest.mark.parametrize("shape,n_steps,a0", [((16, 16, 16), 1, 0.0), ((24, 24, 24), 2, 0.0), ((16, 32, 48), 3, 0.05)])
+@pytest.mark.parametrize("shape,n_steps,a0", [((16, 16, 16), 1, 0.0), ((24, 24, 24), 2, 0.0), ((16, 32, 48), 3, 0.05),
+                                                ((4, 4, 4), 2, 0.1), ((8, 6, 4), 2, 0.1)])
 def test_nbody_bf_edge_configurations(nb, shape, n_steps, a0):
     """One single (half-drift) step, the model's default start a0 = 0 (the growth table is clamped there, nbody.py:984-985
     note in SURVEY 8a-12), a mesh that is neither a power of two nor a multiple of the tile size (rocFFT + atomic paint
-    fallbacks) and a non-cubic mesh: forward state and reverse sweep against the oracle."""
+    fallbacks), a non-cubic mesh and meshes smaller than any tile or stencil halo: forward state and reverse sweep against
+    the oracle."""
     from montecosmo_amd import bricks, synth
     spec = synth.init_mesh(shape, seed=8, rms_disp=1.0)
     pos = bricks.regular_pos(shape)
