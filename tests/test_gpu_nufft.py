@@ -53,7 +53,8 @@ def test_nufft_vjp(nb):
 
 
 CHRESHAPES = [((16, 16, 16), (8, 8, 8)), ((8, 8, 8), (16, 16, 16)), ((16, 12, 8), (8, 20, 12)), ((12, 12, 12), (12, 12, 12)),
-              ((16, 16, 16), (16, 16, 8)), ((8, 16, 16), (16, 8, 16))]
+              ((16, 16, 16), (16, 16, 8)), ((8, 16, 16), (16, 8, 16)), ((2, 2, 2), (4, 4, 4)), ((4, 6, 2), (2, 2, 4)),
+              ((2, 2, 2), (2, 2, 2))]
 
 
 @pytest.mark.parametrize("ishape,oshape", CHRESHAPES)
@@ -99,7 +100,7 @@ def test_nufft_oversampled_paint_shape(nb):
     assert rel_l2(got, ref) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(8, 8, 8), (16, 12, 20), (6, 10, 4)])
+@pytest.mark.parametrize("shape", [(8, 8, 8), (16, 12, 20), (6, 10, 4), (2, 2, 2), (2, 4, 6), (4, 2, 2)])
 def test_rg2cgh_cgh2rg(nb, shape):
     """utils.py:785-921 (norm "backward"): the white-noise parametrisation of the initial conditions; forward, inverse and
     VJP against the slice-by-slice restatement."""
