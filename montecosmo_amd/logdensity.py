@@ -116,13 +116,18 @@ class FieldLevelLogDensity:
     STOCH = ("s_e", "s_ed", "s_e2")
 
     def __init__(self, fwd, count_obs, latents, fixed, precond="fourier", make_cosmo=None, selec_mesh=None, mask_mesh=None,
-                 redges=None):
+                 redges=None, n_rbins=None):
         """selec_mesh: real, fwd.paint_shape (None = 1); mask_mesh: bool, final_shape, True = observed cell (None = all);
-        fixed['ngbars']: a scalar or one mean density per radial shell; redges: shell edges (default: model.py:1087-1098,
-        equal-width shells over the observed cells).  count_obs is the full final mesh (only observed cells are used)."""
+        ngbars: fixed (a scalar or one mean density per radial shell) or a latent whose config entries are broadcast to the
+        n_rbins shells (model.py:1087-1103; sample key 'ngbars_' is then an array); redges: shell edges (default: equal-width
+        shells over the observed cells); n_rbins: number of shells of a sampled ngbars (default: the reference's
+        max(int((rmax - rmin) / (sqrt(3) cell)), 1)).  count_obs is the full final mesh (only observed cells are used)."""
         if precond not in ("fourier", "real", "kaiser"):
             raise ValueError(f"Unknown preconditioning type: {precond}")
         self.fwd, self.precond = fwd, precond
+        latents = dict(latents)
+        self._ngb_conf = latents.pop("ngbars", None)
+        self._n_rbins = n_rbins
         self.latents = {k: dict({"low": -math.inf, "high": math.inf}, **{kk: float(vv) for kk, vv in v.items() if vv is not None})
                         for k, v in latents.items()}
         for k, c in self.latents.items():      # no loc / scale: a uniform prior on [low, high] (model.py:1122-1123)
@@ -134,11 +139,9 @@ class FieldLevelLogDensity:
                 c.setdefault("scale_fid", (c["high"] - c["low"]) / 12 ** .5)
         self.fixed = dict(fixed)
         need = set(self.COSMO) | set(bricks.BIAS_KEYS) | {"ngbars"} | set(self.STOCH)
-        missing = need - set(self.latents) - set(self.fixed)
+        missing = need - set(self.latents) - set(self.fixed) - ({"ngbars"} if self._ngb_conf is not None else set())
         if missing:
             raise ValueError(f"parameters neither sampled nor fixed: {sorted(missing)}")
-        if "ngbars" in self.latents:
-            raise NotImplementedError("ngbars is kept fixed")
         self.final_shape = tuple(fwd.final_shape)
         self.count_obs = nbody._f32(count_obs, self.final_shape)
         self.make_cosmo = make_cosmo or self._planck
@@ -169,41 +172,58 @@ class FieldLevelLogDensity:
         return nbody.irfftn(chreshape(nbody.rfftn(mesh), r2chshape(self.final_shape)))
 
     def _setup_selection(self, selec_mesh, mask_mesh, redges):
-        """Per-cell count multiplier rc (set_radial_count, bricks.py:1106-1122, with the fixed ngbars), the selection at
-        the final cells and the 0/1 mask, all as device tensors computed once."""
+        """Radial shells as a per-cell index (set_radial_count, bricks.py:1106-1122: cell -> its shell's count), the
+        down-sampled selection and the 0/1 mask as device tensors computed once; a sampled ngbars gets its per-shell
+        prior configuration (model.py:1099-1103)."""
         fwd, dev = self.fwd, self.count_obs.device
-        ngb = np.atleast_1d(np.asarray(self.fixed["ngbars"], dtype=np.float64))
-        rcounts = ngb * fwd.cell_length ** 3
         mask = None if mask_mesh is None else np.asarray(mask_mesh, dtype=bool).reshape(self.final_shape)
-        rc = np.ones(self.final_shape)
-        if len(rcounts) == 1 and redges is None:
-            rc *= rcounts[0]
+        rmesh = self._radius_mesh()
+        if self._ngb_conf is None:
+            nb = len(np.atleast_1d(self.fixed["ngbars"]))
+        elif redges is not None:
+            nb = len(redges) - 1
+        elif self._n_rbins is not None:
+            nb = int(self._n_rbins)
         else:
-            rmesh = self._radius_mesh()
-            if redges is None:
-                r = rmesh if mask is None else rmesh[mask]
-                dr = 3 ** .5 * fwd.cell_length
-                redges = np.linspace(r.min() - dr / 1000, r.max() + dr / 1000, len(rcounts) + 1)
-            redges = np.asarray(redges, dtype=np.float64)
-            if len(redges) != len(rcounts) + 1:
-                raise ValueError("redges must have one more entry than ngbars")
-            for c, lo, hi in zip(rcounts, redges[:-1], redges[1:]):
-                rc[(lo < rmesh) & (rmesh <= hi)] *= c
-        self.rc = torch.from_numpy(rc.astype(np.float32)).to(dev)
+            r = rmesh if mask is None else rmesh[mask]
+            nb = max(int((r.max() - r.min()) / (3 ** .5 * fwd.cell_length)), 1)            # model.py:1095
+        if redges is None:
+            r = rmesh if mask is None else rmesh[mask]
+            dr = 3 ** .5 * fwd.cell_length
+            redges = np.linspace(r.min() - dr / 1000, r.max() + dr / 1000, nb + 1)
+        redges = np.asarray(redges, dtype=np.float64)
+        if len(redges) != nb + 1:
+            raise ValueError("redges must have one more entry than ngbars")
+        shell = np.full(self.final_shape, nb, dtype=np.int64)          # nb: in no shell (count multiplier 1)
+        for i, (lo, hi) in enumerate(zip(redges[:-1], redges[1:])):
+            shell[(lo < rmesh) & (rmesh <= hi)] = i
+        self.n_rbins, self.shell = nb, torch.from_numpy(shell).to(dev)
+        if self._ngb_conf is not None:
+            c = {k: v for k, v in self._ngb_conf.items() if v is not None and k in ("loc", "scale", "loc_fid", "scale_fid", "low", "high")}
+            c.setdefault("low", -math.inf), c.setdefault("high", math.inf)
+            self.ngb_lat = {k: np.broadcast_to(np.asarray(v, dtype=np.float64), (nb,)).copy() for k, v in c.items()}
+            self.ngbar_mean = float(self.ngb_lat["loc_fid"].mean())
+        else:
+            self.ngb_lat = None
+            self.ngbar_mean = float(np.mean(self.fixed["ngbars"]))
         self.mask = None if mask is None else torch.from_numpy(mask.astype(np.float32)).to(dev)
-        self.ngbar_mean = float(ngb.mean())
         if selec_mesh is None:
-            self.selec_mesh, self.selec, self.selec_fid = None, float(rcounts.mean()), 1.0
+            self.selec_mesh, self.sel_down, self.selec_fid = None, None, 1.0
         else:
             sm = np.asarray(selec_mesh, dtype=np.float64)
             self.selec_fid = float((sm ** 2).mean() ** .5 / sm.mean())                 # model.py:609
             self.selec_mesh = nbody._f32(selec_mesh, fwd.paint_shape)
-            self.selec = (self._down(self.selec_mesh) * self.rc).abs()
+            self.sel_down = self._down(self.selec_mesh)
+
+    def _ngb_elem(self, i):
+        return {k: float(v[i]) for k, v in self.ngb_lat.items()}
 
     def fiducial(self):
         """Fiducial base values: loc_fid of the latents, else the fixed value (model.py:1214-1223)."""
         fid = dict(self.fixed)
         fid.update({k: c["loc_fid"] for k, c in self.latents.items()})
+        if self.ngb_lat is not None:
+            fid["ngbars"] = self.ngb_lat["loc_fid"].copy()
         return fid
 
     def _fiducial_scale_factor(self, cosmo_fid):
@@ -252,7 +272,7 @@ class FieldLevelLogDensity:
 
     def names(self):
         """Sample-space parameter names: scalars (in a fixed order) then 'white_mesh_'."""
-        return [k + "_" for k in self.latents] + ["white_mesh_"]
+        return [k + "_" for k in self.latents] + (["ngbars_"] if self.ngb_lat is not None else []) + ["white_mesh_"]
 
     @staticmethod
     def _bounded(c):
@@ -264,6 +284,14 @@ class FieldLevelLogDensity:
             x = float(sample[name + "_"])
             base[name] = std2trunc_and_derivs(x, c["loc_fid"], c["scale_fid"], c["low"], c["high"])[0] if self._bounded(c) \
                 else x * c["scale_fid"] + c["loc_fid"]
+        if self.ngb_lat is not None:
+            xs = np.atleast_1d(np.asarray(sample["ngbars_"], dtype=np.float64))
+            out = np.empty(self.n_rbins)
+            for i in range(self.n_rbins):
+                c = self._ngb_elem(i)
+                out[i] = std2trunc_and_derivs(float(xs[i]), c["loc_fid"], c["scale_fid"], c["low"], c["high"])[0] if self._bounded(c) \
+                    else float(xs[i]) * c["scale_fid"] + c["loc_fid"]
+            base["ngbars"] = out
         return base
 
     def __call__(self, sample):
@@ -289,6 +317,21 @@ class FieldLevelLogDensity:
                 mu, sd = (c["loc"] - c["loc_fid"]) / c["scale_fid"], c["scale"] / c["scale_fid"]
                 lp += -0.5 * LOG2PI - math.log(sd) - 0.5 * ((x - mu) / sd) ** 2
                 grad[name + "_"], dbase[name] = -(x - mu) / sd ** 2, c["scale_fid"]
+        ngb_prior_grad = ngb_dbase = None
+        if self.ngb_lat is not None:      # one latent per radial shell, same priors as the scalars (model.py:1105-1125)
+            xs = np.atleast_1d(np.asarray(sample["ngbars_"], dtype=np.float64))
+            ngb_prior_grad, ngb_dbase = np.empty(self.n_rbins), np.empty(self.n_rbins)
+            for i in range(self.n_rbins):
+                c, x = self._ngb_elem(i), float(xs[i])
+                if "loc" not in c:
+                    l, gl, _, d1 = detrunc_unif_log_prob_and_grad(x, c)
+                elif self._bounded(c):
+                    l, gl, _, d1 = detrunc_truncnorm_log_prob_and_grad(x, c)
+                else:
+                    mu, sd = (c["loc"] - c["loc_fid"]) / c["scale_fid"], c["scale"] / c["scale_fid"]
+                    l, gl, d1 = -0.5 * LOG2PI - math.log(sd) - 0.5 * ((x - mu) / sd) ** 2, -(x - mu) / sd ** 2, c["scale_fid"]
+                lp += l
+                ngb_prior_grad[i], ngb_dbase[i] = gl, d1
         w = nbody._f32(sample["white_mesh_"], fwd.init_shape)
         if self.scale is None:
             lp += float(-0.5 * LOG2PI * w.numel() - 0.5 * (w.double() ** 2).sum())
@@ -298,11 +341,15 @@ class FieldLevelLogDensity:
         cosmo = self.make_cosmo(base)
         bias = {k: base[k] for k in bricks.BIAS_KEYS}
         gxy, ctx = fwd.evolve(cosmo, bias, white, return_ctx=True)
-        # likelihood (model.py:852-866, :893-908)
-        selec = self.selec
+        # likelihood (model.py:852-866, :893-908): per-cell count multiplier from the shells' mean densities
+        rcounts = np.atleast_1d(np.asarray(base["ngbars"], dtype=np.float64)) * fwd.cell_length ** 3
+        rc_ext = torch.from_numpy(np.append(rcounts, 1.0).astype(np.float32)).to(gxy.device)
+        rc = rc_ext[self.shell]
+        selec = float(rcounts.mean()) if self.sel_down is None else (self.sel_down * rc).abs()
         gsel = gxy if self.selec_mesh is None else gxy * self.selec_mesh
         resh = tuple(gxy.shape) != self.final_shape
-        cm = self._down(gsel) * self.rc
+        dn = self._down(gsel)
+        cm = dn * rc
         delta = cm / selec - 1.0
         lin = base["s_e"] + base["s_ed"] * delta
         b = (lin.abs() + 1e-9) * selec ** .5
@@ -317,7 +364,21 @@ class FieldLevelLogDensity:
         cm_bar = g_loc + g_b * sgn * (base["s_ed"] / selec)
         stoch_bar = {"s_e": float((g_b * sgn).double().sum()), "s_ed": float((g_b * sgn * delta).double().sum()),
                      "s_e2": float((g_a * selec ** .5).double().sum())}
-        gxy_bar = cm_bar * self.rc
+        gxy_bar = cm_bar * rc
+        ngb_bar = None
+        if self.ngb_lat is not None:      # d/d rcounts: through count = dn rc and through selec (|S rc| per cell, or mean(rcounts))
+            wsel = g_b * (lin.abs() + 1e-9) + (g_a * float(base["s_e2"]) if torch.is_tensor(g_a) else 0.0)   # d lp / d sqrt(selec)
+            if self.sel_down is not None:
+                # delta = count / selec does not move with rc; selec = |S| |rc|
+                rc_bar = g_loc * dn + wsel * 0.5 * selec ** -.5 * self.sel_down.abs() * torch.sign(rc)
+                per = torch.bincount(self.shell.reshape(-1), weights=rc_bar.double().reshape(-1), minlength=self.n_rbins + 1)[:self.n_rbins]
+                rcounts_bar = per.cpu().numpy()
+            else:
+                rc_bar = cm_bar * dn
+                per = torch.bincount(self.shell.reshape(-1), weights=rc_bar.double().reshape(-1), minlength=self.n_rbins + 1)[:self.n_rbins]
+                common = float((-(g_b * sgn * base["s_ed"]) * cm / selec ** 2 + wsel * 0.5 * selec ** -.5).double().sum())
+                rcounts_bar = per.cpu().numpy() + common / self.n_rbins
+            ngb_bar = rcounts_bar * fwd.cell_length ** 3
         if resh:      # adjoints of irfftn, chreshape, rfftn (real-pair convention)
             Mf = float(np.prod(self.final_shape))
             kb = nbody.rfftn(gxy_bar) / Mf
@@ -339,6 +400,8 @@ class FieldLevelLogDensity:
             wbar = torch.empty(fwd.init_shape, dtype=torch.float32, device=wb.device)
             nbody.get_plan(fwd.init_shape).call("mcpm_fft_c2r", nbody._ptr(wb), nbody._ptr(wbar), 1)
         grad["white_mesh_"] = wbar - (w if self.scale is None else w / self.scale ** 2)
+        if ngb_bar is not None:
+            grad["ngbars_"] = ngb_prior_grad + ngb_bar * ngb_dbase
         base_bar = dict(g["bias"])
         base_bar.update(stoch_bar)
         base_bar["sigma8"] = g["sigma8"]

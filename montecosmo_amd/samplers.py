@@ -274,29 +274,38 @@ class FlatLogDensity:
     def __init__(self, ld):
         self.ld = ld
         self.scalars = [n for n in ld.names() if n != "white_mesh_"]
+        # 'ngbars_' is one value per radial shell (model.py:1099-1103); every other scalar latent is one number
+        self.sizes = [getattr(ld, "n_rbins", 1) if n == "ngbars_" else 1 for n in self.scalars]
+        self.ns = int(sum(self.sizes))
         self.shape = tuple(ld.fwd.init_shape)
         self.n_eval = 0
 
     def pack(self, sample):
         from . import nbody
+        import numpy as np
         w = nbody._f32(sample["white_mesh_"], self.shape).reshape(-1)
-        s = torch.tensor([float(sample[n]) for n in self.scalars], dtype=torch.float32, device=w.device)
-        return torch.cat([s, w])
+        vals = np.concatenate([np.atleast_1d(np.asarray(sample[n], dtype=np.float64)).reshape(-1) for n in self.scalars]) \
+            if self.scalars else np.zeros(0)
+        return torch.cat([torch.tensor(vals, dtype=torch.float32, device=w.device), w])
 
     def unpack(self, q):
-        ns = len(self.scalars)
-        vals = q[:ns].tolist()
-        out = {n: v for n, v in zip(self.scalars, vals)}
-        out["white_mesh_"] = q[ns:].reshape(self.shape)
+        vals = q[:self.ns].tolist()
+        out, k = {}, 0
+        for n, sz in zip(self.scalars, self.sizes):
+            out[n] = vals[k] if n != "ngbars_" else vals[k:k + sz]
+            k += sz
+        out["white_mesh_"] = q[self.ns:].reshape(self.shape)
         return out
 
     def __call__(self, q):
+        import numpy as np
         self.n_eval += 1
         lp, grad = self.ld.logdensity_and_grad(self.unpack(q))
         if not math.isfinite(lp):
             return -math.inf, torch.zeros_like(q)
-        g = torch.cat([torch.tensor([grad[n] for n in self.scalars], dtype=torch.float32, device=q.device),
-                       grad["white_mesh_"].reshape(-1)])
+        gs = np.concatenate([np.atleast_1d(np.asarray(grad[n], dtype=np.float64)).reshape(-1) for n in self.scalars]) \
+            if self.scalars else np.zeros(0)
+        g = torch.cat([torch.tensor(gs, dtype=torch.float32, device=q.device), grad["white_mesh_"].reshape(-1)])
         return lp, g
 
 

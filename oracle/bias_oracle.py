@@ -394,26 +394,40 @@ def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo):
     parameters that are not sampled; `sample`: name_ -> value (scalars) and 'white_mesh_' (real, init_shape)."""
     lp = 0.0
     base = dict(fixed)
-    for name, conf in latents.items():
-        x = sample[name + "_"]
+    scalar_items = []
+    for name, conf in latents.items():      # a per-shell latent (ngbars, model.py:1099-1103): one scalar latent per element
+        xs = np.atleast_1d(np.asarray(sample[name + "_"], dtype=float))
+        if name == "ngbars":
+            n = len(xs)
+            el = lambda k, i: None if conf.get(k) is None else float(np.broadcast_to(np.asarray(conf[k], float), (n,))[i])
+            for i in range(n):
+                scalar_items.append((name, i, {k: el(k, i) for k in ("loc", "scale", "loc_fid", "scale_fid", "low", "high") if k in conf}, xs[i]))
+            base[name] = np.zeros(n)
+        else:
+            scalar_items.append((name, None, conf, float(xs[0])))
+    for name, idx, conf, x in scalar_items:
         low, high = conf.get("low", -np.inf), conf.get("high", np.inf)
         if conf.get("loc") is None:      # uniform prior (model.py:1122-1123; utils.py:314-353 DetruncUnif), central-difference Jacobian
             lf, sf, h = conf.get("loc_fid", (low + high) / 2), conf.get("scale_fid", (high - low) / 12 ** .5), 1e-6
             jac = (std2trunc(x + h, lf, sf, low, high) - std2trunc(x - h, lf, sf, low, high)) / (2 * h)
             lp += -np.log(high - low) + np.log(abs(jac))
-            base[name] = std2trunc(x, lf, sf, low, high)
+            val = std2trunc(x, lf, sf, low, high)
         elif low == -np.inf and high == np.inf:
             mu, sd = (conf["loc"] - conf["loc_fid"]) / conf["scale_fid"], conf["scale"] / conf["scale_fid"]
             lp += -0.5 * np.log(2 * np.pi) - np.log(sd) - 0.5 * ((x - mu) / sd) ** 2
-            base[name] = x * conf["scale_fid"] + conf["loc_fid"]
+            val = x * conf["scale_fid"] + conf["loc_fid"]
         else:      # model.py:1120-1121, bricks.py:271-273
             lp += detrunc_truncnorm_log_prob(x, conf["loc"], conf["scale"], low, high, conf["loc_fid"], conf["scale_fid"])
-            base[name] = std2trunc(x, conf["loc_fid"], conf["scale_fid"], low, high)
+            val = std2trunc(x, conf["loc_fid"], conf["scale_fid"], low, high)
+        if idx is None:
+            base[name] = val
+        else:
+            base[name][idx] = val
     w = np.asarray(sample["white_mesh_"], dtype=float)
     fiduc = cosmo_fid = None
     if cfg["precond"] == "kaiser":      # fiducial values: loc_fid of the latents, else the fixed value (model.py:1214-1223)
         fiduc = dict(fixed)
-        fiduc.update({k: v["loc_fid"] for k, v in latents.items()})
+        fiduc.update({k: (np.asarray(v["loc_fid"], float) if k == "ngbars" else v["loc_fid"]) for k, v in latents.items()})
         cosmo_fid = make_cosmo(fiduc)
     scale, transfer = precond_scale_and_transfer(cfg, fiduc, cosmo_fid)
     lp += np.sum(-0.5 * np.log(2 * np.pi) - np.log(scale) - 0.5 * (w / scale) ** 2)     # model.py:666-672

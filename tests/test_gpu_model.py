@@ -80,7 +80,8 @@ def _with_s8(c, s8):
                                                                  ("nbody", 0.02, "kaiser", 0.65, False), ("lpt", 0.0, "kaiser", None, False),
                                                                  ("lpt", 0.02, "kaiser", 0.65, True), ("nbody", 0.0, "fourier", 0.65, True),
                                                                  ("lpt", 0.0, "kaiser", 0.65, "eh"),
-                                                                 ("kaiser", 0.02, "kaiser", 0.65, "flat")])
+                                                                 ("kaiser", 0.02, "kaiser", 0.65, "flat"),
+                                                                 ("lpt", 0.02, "kaiser", 0.65, "ngbars"), ("lpt", 0.0, "fourier", 0.65, "ngbars+survey")])
 def test_log_density_and_gradient(gpu, evolution, s_e2, precond, a_obs, survey):
     """Prior + evolve + 'quad_gauss' likelihood (model.py:640-679, :840-908) on the HIP path against the float64
     restatement; gradient w.r.t. every sampled parameter against central differences of that restatement.  'kaiser':
@@ -97,6 +98,9 @@ def test_log_density_and_gradient(gpu, evolution, s_e2, precond, a_obs, survey):
                                   lin_kpow=None if survey == "eh" else _kpow(), nbody_a_start=0.1)
     cfg = dict(fwd.config(), final_shape=(8, 8, 8), cell_length=40., precond=precond)
     extra = {}
+    sampled_ngbars = isinstance(survey, str) and survey.startswith("ngbars")      # ngbars as a per-shell latent (model.py:205-214, :1099-1103)
+    if sampled_ngbars:
+        survey = survey.endswith("survey")
     if survey in ("eh", "flat"):      # "eh": no tabulated power, Eisenstein-Hu of the sampled cosmology (bricks.py:69-79), Omega_m
         survey = False                # moves its shape; "flat": flat sky (the Kaiser model's built branch)
     if survey:
@@ -112,26 +116,37 @@ def test_log_density_and_gradient(gpu, evolution, s_e2, precond, a_obs, survey):
            "s_ed": dict(loc=0., scale=1e1, loc_fid=0., scale_fid=1e-2),
            "bnpar": dict(low=-10., high=20., loc_fid=5., scale_fid=30. / 12 ** .5)}                                                            # uniform (DetruncUnif)
     fixed = dict(b3=0.1, bds2=0.1, bs3=-0.05, ngbars=(np.array([1e-3, 1.4e-3]) if survey else 1e-3), s_e=1.0, s_e2=s_e2)
+    if sampled_ngbars:
+        fixed.pop("ngbars")
+        lat["ngbars"] = dict(loc=np.array([1e-3, 1.4e-3]), scale=1e-2, loc_fid=np.array([1e-3, 1.4e-3]), scale_fid=1e-5, low=0., high=np.inf)
+        extra["n_rbins"] = 2
     if a_obs is None:      # light cone: the cosmology dependence of the look-ups is not propagated -> Omega_m stays fixed
         fixed["Omega_m"] = lat.pop("Omega_m")["loc_fid"]
     make_cosmo = lambda base: _cos(obg.Planck18(Omega_c=base["Omega_m"] - 0.0490), base["sigma8"])
-    sample = {k + "_": float(rng.normal(0, 1.0)) for k in lat}
+    sample = {k + "_": (float(rng.normal(0, 1.0)) if k != "ngbars" else rng.normal(0, 1.0, 2)) for k in lat}
     sample["white_mesh_"] = rng.standard_normal((12, 12, 12))
     truth = dict(sample, **{"b1_": 20.0})
     base_t = dict(fixed, **{k: (bo.std2trunc(truth[k + "_"], c["loc_fid"], c["scale_fid"], c["low"], c["high"]) if "low" in c
-                                else truth[k + "_"] * c["scale_fid"] + c["loc_fid"]) for k, c in lat.items()})
+                                else truth[k + "_"] * c["scale_fid"] + c["loc_fid"]) for k, c in lat.items() if k != "ngbars"})
+    base_t.setdefault("ngbars", 1e-3)
     white_t = o.rg2cgh(truth["white_mesh_"]) * np.divide(cfg["init_shape"], cfg["box_size"]).prod() ** .5
     gxy_t, _ = bo.evolve(cfg, make_cosmo(base_t), {k: base_t[k] for k in bo.BIAS_KEYS}, white_t)
-    rc = float(np.mean(fixed["ngbars"])) * 40. ** 3
+    rc = float(np.mean(base_t["ngbars"])) * 40. ** 3
     cm_t = rc * np.fft.irfftn(o.chreshape(np.fft.rfftn(gxy_t), o.r2chshape((8, 8, 8))), s=(8, 8, 8), axes=(0, 1, 2))
     obs = cm_t + rc ** .5 * rng.standard_normal((8, 8, 8))
     ld = logdensity.FieldLevelLogDensity(fwd, obs, lat, fixed, precond=precond, **extra)
-    lp, grad = ld.logdensity_and_grad({k: (v if np.ndim(v) == 0 else v.astype(np.float32)) for k, v in sample.items()})
+    lp, grad = ld.logdensity_and_grad({k: (v if (np.ndim(v) == 0 or k == "ngbars_") else v.astype(np.float32)) for k, v in sample.items()})
     ref = lambda s: bo.log_density(cfg, lat, fixed, s, obs, make_cosmo)
     lp_o = ref(sample)
     assert np.isfinite(lp_o) and abs(lp - lp_o) < 2e-4 * abs(lp_o) + 0.05, (lp, lp_o)
     for k in lat:
         h = 1e-4
+        if k == "ngbars":
+            for i in range(2):
+                e = np.eye(2)[i] * h
+                fd = (ref(dict(sample, ngbars_=sample["ngbars_"] + e)) - ref(dict(sample, ngbars_=sample["ngbars_"] - e))) / (2 * h)
+                assert abs(fd - grad["ngbars_"][i]) < 1e-2 * abs(fd) + 1e-3, (k, i, fd, grad["ngbars_"])
+            continue
         fd = (ref(dict(sample, **{k + "_": sample[k + "_"] + h})) - ref(dict(sample, **{k + "_": sample[k + "_"] - h}))) / (2 * h)
         assert abs(fd - grad[k + "_"]) < 1e-2 * abs(fd) + 1e-3, (k, fd, grad[k + "_"])
     d = rng.standard_normal((12, 12, 12))

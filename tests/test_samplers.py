@@ -88,3 +88,34 @@ def test_chain_save_and_resume_continue_exactly(tmp_path, which):
     res2 = samplers.sample_and_save(sampler, logdf, q0, str(tmp_path / "drv"), start=3, end=3, n_samples=10, resume=True)
     assert all((tmp_path / f"drv_{i}.npz").exists() for i in range(4))
     assert res2["step_size"] == res["step_size"] and not any(i["warmup"] for i in res2["infos"])
+
+
+def test_flat_log_density_packs_per_shell_latents():
+    """`FlatLogDensity` lays the scalar latents, the per-shell 'ngbars_' array and the white mesh out in one vector and
+    routes the gradient back in the same order."""
+    class Fwd:
+        init_shape = (2, 2, 2)
+
+    class Stub:
+        fwd, n_rbins = Fwd(), 3
+
+        def names(self):
+            return ["b1_", "ngbars_", "s_e_", "white_mesh_"]
+
+        def logdensity_and_grad(self, s):
+            assert isinstance(s["b1_"], float) and len(s["ngbars_"]) == 3 and tuple(s["white_mesh_"].shape) == (2, 2, 2)
+            lp = -0.5 * (s["b1_"] ** 2 + sum(v ** 2 for v in s["ngbars_"]) + s["s_e_"] ** 2 + float((s["white_mesh_"] ** 2).sum()))
+            return lp, {"b1_": -s["b1_"], "ngbars_": [-v for v in s["ngbars_"]], "s_e_": -s["s_e_"], "white_mesh_": -s["white_mesh_"]}
+
+    flat = samplers.FlatLogDensity(Stub())
+    import montecosmo_amd.nbody as nbody
+    nbody_f32 = nbody._f32
+    nbody._f32 = lambda x, shape=None: torch.as_tensor(np.asarray(x), dtype=torch.float32).reshape(shape)   # CPU stand-in
+    try:
+        q = flat.pack({"b1_": 1.0, "ngbars_": [2.0, 3.0, 4.0], "s_e_": 5.0, "white_mesh_": np.arange(8.).reshape(2, 2, 2)})
+    finally:
+        nbody._f32 = nbody_f32
+    assert q.tolist() == [1.0, 2.0, 3.0, 4.0, 5.0] + list(np.arange(8.))
+    lp, g = flat(q)
+    assert np.isclose(lp, -0.5 * float((q ** 2).sum())) and torch.allclose(g, -q)
+    assert flat.unpack(q)["ngbars_"] == [2.0, 3.0, 4.0]
