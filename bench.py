@@ -365,6 +365,7 @@ def main():
         if slab:
             out["comm_and_host_ms_per_step"] = round(dt / K * 1e3 - step_ms, 3)   # wall minus rank-0 kernel stages
             out["deposits_beyond_ghost_rank0"] = r.pm.out_of_ghost()                # must be 0
+            out["ghost_planes_exchanged_per_step"] = [int(d) for d in r.depths if d is not None]   # of --ghost allocated
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_mesh, n)
     if dist:
