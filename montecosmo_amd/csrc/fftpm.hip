@@ -781,15 +781,22 @@ static YLayout ylayout(const mcpm_plan *p, bool packed) {
 }
 
 // kz columns per workgroup of the register-heavy passes (ycol2, xfused; 75-118 VGPRs, so a 1024-thread workgroup is
-// alone on its CU): 8 columns (512 threads at N = 512, two independent workgroups per CU, 64-byte row segments) measured
-// 1 % faster per step than 16 at 512^3 (13.13 vs 13.26 ms, same box); 4 columns (32-byte segments) are 2.3x SLOWER (fused x
-// pass 1.15 vs 0.49 ms): a row segment must stay a whole 64-byte access.  Tuning knob MCPM_COL_LINES = 8 | 16.
-static int col_lines() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("MCPM_COL_LINES");
-        v = (e && atoi(e) == 16) ? 16 : 8;
-    }
+// alone on its CU).  Fused x pass: 8 columns (512 threads at N = 512, two independent workgroups per CU, 64-byte row
+// segments) beat 16 (0.51 vs 0.53 ms); 4 columns (32-byte segments) are 2.3x SLOWER: a row segment must stay a whole
+// 64-byte access.  Factor-carrying y pass: with streaming stores 16 columns (128-byte segments) win (stage 0.423 vs 0.440
+// ms).  Knobs: MCPM_XCOL_LINES, MCPM_YCOL_LINES = 8 | 16 (MCPM_COL_LINES sets both).
+static int col_lines(const char *name, int dflt) {
+    const char *e = getenv(name);
+    if (!e) e = getenv("MCPM_COL_LINES");
+    const int v = e ? atoi(e) : dflt;
+    return (v == 8 || v == 16) ? v : dflt;
+}
+static int col_lines_x() {
+    static const int v = col_lines("MCPM_XCOL_LINES", 8);
+    return v;
+}
+static int col_lines_y() {
+    static const int v = col_lines("MCPM_YCOL_LINES", 16);
     return v;
 }
 
@@ -823,7 +830,7 @@ static int y_columns2(mcpm_plan *p, const cf *in, cf *out, bool expand, bool in_
         else ycol2_kernel<NN, false, ML><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1], parts);        \
     }
 #define CALL(NN)                                                                                       \
-    if (col_lines() == 8 && NN >= 512) CALLL(NN, 8) else CALLL(NN, 16)
+    if (col_lines_y() == 8 && NN >= 512) CALLL(NN, 8) else CALLL(NN, 16)
     DISPATCH_N(g.ny, CALL)
 #undef CALL
 #undef CALLL
@@ -850,7 +857,7 @@ static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
         else xfused_kernel<NN, 1, ML><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]);           \
     }
 #define CALL(NN)                                                                                              \
-    if (col_lines() == 8 && NN >= 512) CALLL(NN, 8) else CALLL(NN, 16)
+    if (col_lines_x() == 8 && NN >= 512) CALLL(NN, 8) else CALLL(NN, 16)
     DISPATCH_N(g.nx, CALL)
 #undef CALL
 #undef CALLL
