@@ -8,10 +8,13 @@ N = n^3 particles on an n^3 mesh, synthetic inputs of SURVEY.md 8(d).  The timed
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mesh n]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL): the SAME mesh is x-slab decomposed over the
-ranks (montecosmo_amd/dist.py: ghost planes point-to-point, one all-to-all per FFT transpose), so the total work
-is fixed and scaling is "strong".  `--replicas` instead runs N independent copies (the reference's own
-multi-device mode: independent chains, script.py:13-20; "weak", no collective on the data path).
+N > 1 runs one rank per GPU (RCCL): the SAME mesh is x-slab decomposed over the ranks (montecosmo_amd/dist.py: ghost
+planes point-to-point, one all-to-all per FFT transpose), so the total work is fixed and scaling is "strong".  The ranks
+come from `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (WORLD_SIZE / RANK / LOCAL_RANK in
+the environment), or, when WORLD_SIZE is unset, `python bench.py --gpus N` starts the N rank processes itself (fresh
+children, before this process touches the GPU) and relays rank 0's JSON line.  `--gpus` must equal the world size; the
+line reports the world size the communicator observed (`rccl_world`).  `--replicas` instead runs N independent copies
+(the reference's own multi-device mode: independent chains, script.py:13-20; "weak", no collective on the data path).
 """
 import argparse
 import ctypes as C
@@ -48,6 +51,8 @@ def parse():
     ap.add_argument("--fixed-ghost", action="store_true", help="slabs: always exchange all ghost planes (default: only the "
                     "planes each step's displacements can reach)")
     ap.add_argument("--cpu-mesh", type=int, default=128)
+    ap.add_argument("--rehearse", action="store_true", help="launch path only: start / join the ranks, rendezvous over gloo on the "
+                    "CPU, barrier + max-over-ranks, print the JSON skeleton; touches no GPU (CPU test of --gpus N)")
     return ap.parse_args()
 
 
@@ -270,11 +275,51 @@ def cpu_baseline(n_cpu, n_gpu):
                       f"(host has {os.cpu_count()} cores); scaled by cell count x{scale:.0f} to {n_gpu}^3"}
 
 
+def spawn_ranks(nproc):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this process has not touched the GPU
+    and never will), one per GPU, rendezvous on 127.0.0.1, and relay their output.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(nproc):
+        env = dict(os.environ, WORLD_SIZE=str(nproc), RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(nproc),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch with --nproc-per-node {args.gpus}, "
+                 f"or leave WORLD_SIZE unset and let bench.py start the ranks")
+    if args.rehearse:
+        import torch.distributed as td
+        if world > 1:
+            td.init_process_group(backend="gloo")
+            td.barrier()
+            t = torch.tensor([float(rank)], dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            seen, top = td.get_world_size(), float(t.item())
+            td.barrier()
+            td.destroy_process_group()
+        else:
+            seen, top = 1, 0.0
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "n_gpus": world, "rccl_world": seen, "comm_backend": "gloo" if world > 1 else None,
+                              "max_rank_seen": top, "steps": args.steps, "warmup": args.warmup}))
+        return
     # MCPM_BENCH_DIST=1 with one rank initialises the process group anyway: on a one-GPU box it drives the slab path
     # through the real RCCL calls (self send/recv, one-rank all-to-all) instead of the local-copy communicator
     dist = world > 1 or os.environ.get("MCPM_BENCH_DIST") == "1"
@@ -340,7 +385,8 @@ def main():
         step_ms = (fwd_ms + bwd_ms) / NS
         out = {
             "metric": "PM forward steps/sec" if args.forward_only else "PM forward+adjoint steps/sec", "value": round(steps_per_s, 3), "unit": "steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
+            "n_gpus": world, "rccl_world": (td.get_world_size() if dist else 1), "comm_backend": (td.get_backend() if dist else None),
+            "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
             "higher_is_better": True, "scaling": "weak" if args.replicas else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}^3 mesh, {n}^3 particles, {NS}-step BullFrog {'forward only' if args.forward_only else 'forward+VJP'}, CIC, 2LPT start (untimed), "
                                    f"rms displacement 2 cells; " + ("single GPU" if world == 1 else

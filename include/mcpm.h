@@ -66,6 +66,8 @@ int mcpm_plan_create_slab(int nx, int ny, int nz, int nranks, int rank, int ghos
 int mcpm_plan_slab_oob(mcpm_plan *plan, int64_t *count);
 int mcpm_plan_destroy(mcpm_plan *plan);
 const char *mcpm_last_error(const mcpm_plan *plan); /* plan may be NULL: last error of a failed create */
+/* ABI revision string; the Python loader (montecosmo_amd/_lib.py) refuses a library that reports another one. */
+#define MCPM_ABI_VERSION "mcpm 0.2 (gfx950)"
 const char *mcpm_version(void);
 /* Number of particles the last tiled paint routed through the global-atomic outlier path (host sync). */
 int mcpm_plan_last_outliers(mcpm_plan *plan, int64_t *count);

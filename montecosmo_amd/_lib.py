@@ -104,19 +104,30 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = "mcpm 0.2 (gfx950)"   # must equal mcpm_version() of the loaded library (include/mcpm.h MCPM_ABI_VERSION)
+
+
 def _load():
+    build_log = ""
     if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
         # a fresh checkout (the .so is git-ignored): build the HIP library in-tree once; there is still no fallback
         import subprocess
-        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        r = subprocess.run(["make", "-j8", "-C", os.path.join(_HERE, "csrc")], check=False, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            build_log = "\n--- tail of the failed `make -C montecosmo_amd/csrc` ---\n" + "\n".join(r.stdout.splitlines()[-30:])
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension is the product and there is no CPU fallback. "
-            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C montecosmo_amd/csrc`.")
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C montecosmo_amd/csrc`." + build_log)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
+    got = lib.mcpm_version().decode()
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} reports ABI '{got}' but this package was written against '{ABI_VERSION}': "
+                          "stale library, rebuild it with `make -C montecosmo_amd/csrc`.")
     return lib
 
 

@@ -11,23 +11,6 @@
 // straight into the checkpoint as well, so the adjoint needs no force recomputation.
 #include "particles_dev.h"
 
-// ------------------------------------------------------------------------------------------------
-// NGP cell of a lattice point (read_order = 1 at pos = regular_pos, nbody.py:984-985): exact integer
-// round-half-even of ip*n/p.
-__device__ __forceinline__ int lattice_ngp(int ip, int n, int p, int same) {
-    if (same) return ip;
-    int qn = ip * n, qi = qn / p, qr = qn - qi * p;
-    int c = qi + ((2 * qr > p || (2 * qr == p && (qi & 1))) ? 1 : 0);
-    return c >= n ? c - n : c;
-}
-
-__device__ __forceinline__ int64_t lattice_cell(const Geom &g, const PIdx &pi) {
-    int cx = lattice_ngp(pi.ipx, g.nx, g.px, g.same_lattice) + g.xoff;
-    int cy = lattice_ngp(pi.ipy, g.ny, g.py, g.same_lattice);
-    int cz = lattice_ngp(pi.ipz, g.nz, g.pz, g.same_lattice);
-    return ((int64_t)cx * g.ny + cy) * g.nz + cz;
-}
-
 // dpos = (init ? 0 : dpos) + ad * F(q), vel likewise with av; F from three contiguous meshes.
 __global__ __launch_bounds__(256) void lpt_accum_kernel(Geom g, const float *__restrict__ meshes, int64_t M, float ad,
                                                         float av, int init, float *__restrict__ dpos,
@@ -47,8 +30,8 @@ __global__ __launch_bounds__(256) void lpt_accum_kernel(Geom g, const float *__r
     store3(vel, pi.i, v);
 }
 
-// Adjoint of the NGP lattice read: out_c[cell(i)] (+)= a*xb[i][c] + b*vb[i][c].  On the identity
-// lattice every cell is hit exactly once (plain store); otherwise float atomics onto zeroed meshes.
+// Adjoint of the NGP lattice read on the identity lattice: out_c[cell(i)] = a*xb[i][c] + b*vb[i][c], every cell is hit
+// exactly once (plain store).  Other lattices: mcpm_lattice_scatter_fx (particles.hip), order-independent fixed-point sums.
 __global__ __launch_bounds__(256) void lattice_scatter_kernel(Geom g, const float *__restrict__ xb,
                                                               const float *__restrict__ vb, float a, float b,
                                                               float *__restrict__ out, int64_t M) {
@@ -56,12 +39,9 @@ __global__ __launch_bounds__(256) void lattice_scatter_kernel(Geom g, const floa
     if (!pi.valid) return;
     int64_t c = lattice_cell(g, pi);
     P3 x = load3(xb, pi.i), v = load3(vb, pi.i);
-    float o0 = a * x.x + b * v.x, o1 = a * x.y + b * v.y, o2 = a * x.z + b * v.z;
-    if (g.same_lattice) {
-        out[c] = o0; out[M + c] = o1; out[2 * M + c] = o2;
-    } else {
-        atomicAdd(out + c, o0); atomicAdd(out + M + c, o1); atomicAdd(out + 2 * M + c, o2);
-    }
+    out[c] = a * x.x + b * v.x;
+    out[M + c] = a * x.y + b * v.y;
+    out[2 * M + c] = a * x.z + b * v.z;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -266,6 +246,16 @@ static inline void lattice_launch(const Geom &g, dim3 &grid, dim3 &block) {
     grid = dim3((unsigned)((int64_t)g.px * g.py * cpr));
 }
 
+// adjoint of the NGP lattice read: a plain store per cell on the identity lattice, fixed-point sums otherwise
+static int lattice_scatter(mcpm_plan *p, const float *xb, const float *vb, float a, float b, float *meshes3) {
+    if (!p->g.same_lattice) return mcpm_lattice_scatter_fx(p, xb, vb, a, b, meshes3);
+    dim3 grid, block;
+    lattice_launch(p->g, grid, block);
+    lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, a, b, meshes3, p->M);
+    MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
+    return MCPM_OK;
+}
+
 // out0 += sum_i a[i].F(q_i), out1 += sum_i b[i].F(q_i) through MCPM_NSLOT spread partial sums
 static int lattice_dot(mcpm_plan *p, const float *meshes3, const float *a, const float *b, double *out0, double *out1) {
     dim3 grid, block;
@@ -357,9 +347,7 @@ static int lpt_vjp_device(mcpm_plan *p, const float *init_mesh, int lpt_order, c
     const float g = (float)lpt_scalars[0], g2 = (float)lpt_scalars[1], c2 = (float)lpt_scalars[2];
     MCPM_TRY(spec_to_force_meshes(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, p->fmesh));
     MCPM_TRY(lattice_dot(p, p->fmesh, xb, nullptr, sb + 0, nullptr));
-    if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(p->fmesh, 0, sizeof(float) * 3 * M, p->stream));
-    lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, g, 1.f, p->fmesh, M);
-    MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
+    MCPM_TRY(lattice_scatter(p, xb, vb, g, 1.f, p->fmesh));
     const bool custom = spec_custom(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF);
     if (custom) {
         MCPM_TRY(mcpm_fftpm_spec_meshes_vjp(p, p->fmesh, init_mesh_bar, 3));
@@ -372,9 +360,7 @@ static int lpt_vjp_device(mcpm_plan *p, const float *init_mesh, int lpt_order, c
         MCPM_TRY(spec_to_delta2_real(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF));        // h in fmesh[0:6], delta2 in rho
         MCPM_TRY(delta2_to_force_meshes(p, MCPM_FD_INF, MCPM_FD_INF, f2));            // F2 meshes
         MCPM_TRY(lattice_dot(p, f2, xb, vb, sb + 1, sb + 2));  // negated on the host
-        if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(f2, 0, sizeof(float) * 3 * M, p->stream));
-        lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, -g2, -c2, f2, M);
-        MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
+        MCPM_TRY(lattice_scatter(p, xb, vb, -g2, -c2, f2));
         MCPM_TRY(mcpm_force_meshes_vjp_f32(p, f2, p->rho));                           // delta2_bar
         MCPM_TRY(mcpm_hessian_combine_vjp_f32(p, h, p->rho, h));                      // in place: h -> h_bar
         if (custom) {
@@ -499,13 +485,8 @@ int mcpm_lpt_accum_f32(mcpm_plan *p, const float *meshes3, float ad, float av, i
 int mcpm_lattice_scatter_f32(mcpm_plan *p, const float *xb, const float *vb, float a, float b, float *meshes3) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, xb && vb && meshes3, MCPM_E_ARG, "mcpm_lattice_scatter_f32: null buffer");
-    dim3 grid, block;
-    lattice_launch(p->g, grid, block);
-    if (!p->g.same_lattice) MCPM_HIP(p, hipMemsetAsync(meshes3, 0, sizeof(float) * 3 * p->M, p->stream));
     StageTimer st_(p, ST_LPT, 12.0 * p->M + 24.0 * p->Np);
-    lattice_scatter_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, a, b, meshes3, p->M);
-    MCPM_LAUNCH_CHECK(p, "lattice_scatter_kernel");
-    return MCPM_OK;
+    return lattice_scatter(p, xb, vb, a, b, meshes3);
 }
 
 int mcpm_lattice_dot_f32(mcpm_plan *p, const float *meshes3, const float *a, const float *b, double *out2) {

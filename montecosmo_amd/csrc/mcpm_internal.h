@@ -64,6 +64,8 @@ struct mcpm_plan {
     int *fx_redo;       // fixed-point paint: [0] = number of flagged tiles, then their indices (device)
     int fx_tiles;       // capacity of fx_redo
     const float *fx_src; // weights whose max|w| a producer kernel already left in fx_wmax (else NULL)
+    long long *gx_acc;  // generic (order-independent) paint: int64 fixed-point accumulator mesh, all-zero between calls; allocated on first use
+    unsigned *gx_wmax;  // generic paint: bits of max|w| (MCPM_FX_SLOTS slots)
     // chaining of adjoint steps (mcpm_plan_hint_next_adjoint): the adjoint particle kernel of step i also writes the
     // force cotangent F_bar of step i-1, saving one pass over the cotangents
     int hint_set, fb_valid;
@@ -147,6 +149,9 @@ int mcpm_fftpm_c2r(mcpm_plan *p, const float *spec, float *real, int batch);
 // (spec_bar overwritten for nc = 3, accumulated into for nc = 6)
 int mcpm_fftpm_spec_meshes(mcpm_plan *p, const float *spec, float *meshes, int nc);
 int mcpm_fftpm_spec_meshes_vjp(mcpm_plan *p, const float *meshes_bar, float *spec_bar, int nc);
+
+// adjoint of the NGP lattice read on a lattice != mesh: order-independent fixed-point sums (particles.hip)
+int mcpm_lattice_scatter_fx(mcpm_plan *p, const float *xb, const float *vb, float a, float b, float *meshes3);
 
 #define MCPM_HIP(plan, expr)                                                                         \
     do {                                                                                             \

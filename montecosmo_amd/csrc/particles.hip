@@ -30,11 +30,64 @@ __global__ __launch_bounds__(256) void cell_index_kernel(Geom g, const float *__
 }
 
 // ------------------------------------------------------------------------------------------------
-// generic paint: one thread per particle, global float atomics
+// generic paint: one thread per particle, arbitrary positions / NGP / TSC / PCS / any mesh size.
+// Deposits are ORDER-INDEPENDENT: every contribution w * kx * ky * kz (an f32 product, as in the tiled kernels) is
+// rounded once to fixed point with the power-of-two scale S = 2^(q - e), 2^e <= max|w| < 2^(e+1), and added with a
+// 64-bit INTEGER global atomic into the plan's accumulator mesh `acc` (int64 per cell, kept all-zero between calls);
+// paint_fxg_flush_kernel then adds acc / S to the f32 mesh and zeroes acc again.  Integer sums are exact, so two
+// launches give bitwise identical meshes whatever the arrival order (f32 float atomics did not: a last-bit change of
+// the density moved a particle across a cell face a few steps later).  q = min(40, 61 - ceil(log2(n ORDER^3))) keeps
+// the sum of |contribution| S below 2^62 even if every particle lands in one cell; one deposit is rounded by at most
+// 2^-(q+1) max|w| <= 2^-25 max|w| (n < 2^31, PCS), below the f32 rounding of the product itself.
+// Non-finite weights (max|w| = inf / NaN) fall back to f32 float atomics so that NaN / inf reach the mesh as before.
+struct FxgScale {
+    double S, Sinv;   // 0 / 0: all weights are zero, nothing to deposit
+    bool flt;         // non-finite weights: f32 float atomics straight into the mesh
+};
+__device__ __forceinline__ FxgScale fxg_scale(const unsigned *__restrict__ wmax_bits, int q) {
+    unsigned wb = wmax_bits[(threadIdx.x & (MCPM_FX_SLOTS - 1)) * MCPM_FX_STRIDE];   // maximum over the slots, in every wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wb = max(wb, (unsigned)__shfl_xor((int)wb, o));
+    FxgScale r;
+    int be = (int)(wb >> 23);
+    r.flt = be >= 255;
+    if (wb == 0u || r.flt) {
+        r.S = r.Sinv = 0.;
+        return r;
+    }
+    if (be == 0) be = 1;   // subnormal maximum
+    const int e = be - 127;
+    r.S = __longlong_as_double((long long)(1023 + q - e) << 52);
+    r.Sinv = __longlong_as_double((long long)(1023 - q + e) << 52);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void absmax_strided_kernel(const float *__restrict__ w, int64_t stride, int64_t n,
+                                                             unsigned *__restrict__ out) {
+    float m = 0.f;
+    unsigned bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned b = __float_as_uint(w[i * stride]) & 0x7fffffffu;
+        bad |= b >= 0x7f800000u;
+        m = fmaxf(m, __uint_as_float(b));
+    }
+    unsigned b = bad ? 0x7fc00000u : __float_as_uint(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+    if ((threadIdx.x & 63) == 0 && b) atomicMax(out + (blockIdx.x & (MCPM_FX_SLOTS - 1)) * MCPM_FX_STRIDE, b);
+}
+
+__global__ __launch_bounds__(64) void fxg_set_unit_kernel(unsigned *__restrict__ out) {   // max|w| = 1 (unweighted paint)
+    out[threadIdx.x * MCPM_FX_STRIDE] = 0x3f800000u;
+}
+
 template <int MODE, int ORDER>
 __global__ __launch_bounds__(256) void paint_atomic_kernel(Geom g, const float *__restrict__ pos, int64_t n,
                                                            const float *__restrict__ w, int64_t wstride,
-                                                           float wscalar, float *__restrict__ mesh, int *__restrict__ oob) {
+                                                           float *__restrict__ mesh, unsigned long long *__restrict__ acc,
+                                                           const unsigned *__restrict__ wmax_bits, int q, int *__restrict__ oob) {
+    const FxgScale sc = fxg_scale(wmax_bits, q);
+    if (sc.S == 0. && !sc.flt) return;
     PIdx pi = particle_index<MODE>(g, n);
     if (!pi.valid) return;
     P3 d = load3(pos, pi.i);
@@ -42,10 +95,14 @@ __global__ __launch_bounds__(256) void paint_atomic_kernel(Geom g, const float *
     float f[3];
     locate<MODE, ORDER>(g, pi, d, c, f);
     if (g.xslab && (c[0] < 0 || c[0] > g.nx - ORDER)) atomicAdd(oob, 1);  // beyond the ghost planes: clamped + counted
-    float wt = w ? w[pi.i * wstride] : wscalar;
+    const float wt = w ? w[pi.i * wstride] : 1.f;   // unweighted: the scalar weight is applied by the flush
     Stencil<ORDER> s(g, c);
+    auto deposit = [&](int64_t cell, float v) {
+        if (sc.flt) atomicAdd(mesh + cell, v);
+        else atomicAdd(acc + cell, (unsigned long long)__double2ll_rn((double)v * sc.S));
+    };
     if (ORDER == 1) {
-        atomicAdd(mesh + s.xo[0] + s.yo[0] + s.zo[0], wt);
+        deposit(s.xo[0] + s.yo[0] + s.zo[0], wt);
         return;
     }
     if (ORDER >= 3) {
@@ -59,7 +116,7 @@ __global__ __launch_bounds__(256) void paint_atomic_kernel(Geom g, const float *
 #pragma unroll
             for (int b = 0; b < NPG; ++b)
 #pragma unroll
-                for (int e = 0; e < NPG; ++e) atomicAdd(mesh + s.xo[a] + s.yo[b] + s.zo[e], wt * wx[a] * wy[b] * wz[e]);
+                for (int e = 0; e < NPG; ++e) deposit(s.xo[a] + s.yo[b] + s.zo[e], wt * wx[a] * wy[b] * wz[e]);
         return;
     }
     float kx[2] = {1.f - f[0], f[0]}, ky[2] = {1.f - f[1], f[1]}, kz[2] = {1.f - f[2], f[2]};
@@ -68,7 +125,72 @@ __global__ __launch_bounds__(256) void paint_atomic_kernel(Geom g, const float *
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) atomicAdd(mesh + s.xo[a] + s.yo[b] + s.zo[e], wt * kx[a] * ky[b] * kz[e]);
+            for (int e = 0; e < 2; ++e) deposit(s.xo[a] + s.yo[b] + s.zo[e], wt * kx[a] * ky[b] * kz[e]);
+}
+
+// mesh += wscalar * acc / S; acc = 0 (the accumulator is all-zero again for the next paint)
+__global__ __launch_bounds__(256) void paint_fxg_flush_kernel(long long *__restrict__ acc, float *__restrict__ mesh, int64_t M,
+                                                              const unsigned *__restrict__ wmax_bits, int q, float wscalar,
+                                                              int vec) {
+    const FxgScale sc = fxg_scale(wmax_bits, q);
+    if (sc.S == 0.) return;   // nothing was deposited in fixed point
+    const double s = sc.Sinv * (double)wscalar;
+    if (!vec) {   // mesh pointer not 8-byte aligned
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+            const long long a = acc[i];
+            if (a) {
+                mesh[i] += (float)((double)a * s);
+                acc[i] = 0;
+            }
+        }
+        return;
+    }
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; i < M; i += (int64_t)gridDim.x * 512) {
+        if (i + 1 < M) {
+            longlong2 a = *reinterpret_cast<longlong2 *>(acc + i);
+            if (a.x | a.y) {
+                float2 m = *reinterpret_cast<float2 *>(mesh + i);
+                m.x += (float)((double)a.x * s);
+                m.y += (float)((double)a.y * s);
+                *reinterpret_cast<float2 *>(mesh + i) = m;
+                *reinterpret_cast<longlong2 *>(acc + i) = make_longlong2(0, 0);
+            }
+        } else {
+            const long long a = acc[i];
+            if (a) {
+                mesh[i] += (float)((double)a * s);
+                acc[i] = 0;
+            }
+        }
+    }
+}
+
+// Adjoint of the NGP lattice read on a lattice that is not the mesh (several lattice points per cell): component C of
+// out[cell(i)] += a*xb[i] + b*vb[i], through the same fixed-point accumulator as the generic paint.
+__global__ __launch_bounds__(256) void absmax_axpby3_kernel(const float *__restrict__ x, const float *__restrict__ y, int64_t n3,
+                                                            float a, float b, unsigned *__restrict__ out) {
+    unsigned m = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n3; i += (int64_t)gridDim.x * 256) {
+        const unsigned v = __float_as_uint(a * x[i] + b * y[i]) & 0x7fffffffu;
+        m = max(m, v >= 0x7f800000u ? 0x7fc00000u : v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out + (blockIdx.x & (MCPM_FX_SLOTS - 1)) * MCPM_FX_STRIDE, m);
+}
+
+__global__ __launch_bounds__(256) void lattice_scatter_fx_kernel(Geom g, const float *__restrict__ xb, const float *__restrict__ vb,
+                                                                 float a, float b, int comp, float *__restrict__ out,
+                                                                 unsigned long long *__restrict__ acc,
+                                                                 const unsigned *__restrict__ wmax_bits, int q) {
+    const FxgScale sc = fxg_scale(wmax_bits, q);
+    if (sc.S == 0. && !sc.flt) return;
+    PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
+    if (!pi.valid) return;
+    const int64_t c = lattice_cell(g, pi);
+    const float o = a * xb[3 * pi.i + comp] + b * vb[3 * pi.i + comp];
+    if (sc.flt) atomicAdd(out + c, o);
+    else atomicAdd(acc + c, (unsigned long long)__double2ll_rn((double)o * sc.S));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -726,6 +848,8 @@ static inline void lattice_launch(const Geom &g, dim3 &grid, dim3 &block) {
     block = dim3(bs);
     grid = dim3((unsigned)((int64_t)g.px * g.py * cpr));
 }
+static int fxg_prepare(mcpm_plan *p);
+static inline int fxg_q(int64_t deposits);
 static inline void flat_launch(int64_t n, dim3 &grid, dim3 &block) {
     block = dim3(256);
     grid = dim3((unsigned)((n + 255) / 256));
@@ -865,11 +989,20 @@ int mcpm_paint_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const fl
     }
     if (!accumulate) MCPM_HIP(p, hipMemsetAsync(mesh, 0, sizeof(float) * p->M, p->stream));
     if (n == 0) return MCPM_OK;
+    MCPM_TRY(fxg_prepare(p));
+    if (weights) {
+        MCPM_HIP(p, hipMemsetAsync(p->gx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream));
+        absmax_strided_kernel<<<2048, 256, 0, p->stream>>>(weights, wstride, n, p->gx_wmax);
+    } else {
+        fxg_set_unit_kernel<<<1, MCPM_FX_SLOTS, 0, p->stream>>>(p->gx_wmax);
+    }
+    const int q = fxg_q(n * order * order * order);
     dim3 grid, block;
     if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
-#define CALL(MO, OR) paint_atomic_kernel<MO, OR><<<grid, block, 0, p->stream>>>(p->g, pos, n, weights, wstride, wscalar, mesh, p->outlier_count + 2)
+#define CALL(MO, OR) paint_atomic_kernel<MO, OR><<<grid, block, 0, p->stream>>>(p->g, pos, n, weights, wstride, mesh, (unsigned long long *)p->gx_acc, p->gx_wmax, q, p->outlier_count + 2)
     DISPATCH_MODE_ORDER(mode, order, CALL);
 #undef CALL
+    paint_fxg_flush_kernel<<<2048, 256, 0, p->stream>>>(p->gx_acc, mesh, p->M, p->gx_wmax, q, weights ? 1.f : wscalar, (((uintptr_t)mesh) & 7) ? 0 : 1);
     MCPM_LAUNCH_CHECK(p, "paint_atomic_kernel");
     return MCPM_OK;
 }
@@ -1025,6 +1158,36 @@ int mcpm_kick_drift_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, 
 }
 
 }  // extern "C"
+
+static int fxg_prepare(mcpm_plan *p) {   // the int64 accumulator mesh of the order-independent sums (all-zero between calls)
+    if (!p->gx_acc) {
+        MCPM_HIP(p, hipMalloc((void **)&p->gx_acc, sizeof(long long) * p->M));
+        MCPM_HIP(p, hipMemsetAsync(p->gx_acc, 0, sizeof(long long) * p->M, p->stream));
+    }
+    return MCPM_OK;
+}
+static inline int fxg_q(int64_t deposits) {   // sum of |contribution| S < 2^62 whatever the collisions
+    int nb = 1;
+    while (nb < 62 && ((int64_t)1 << nb) < deposits) ++nb;
+    return 61 - nb < 40 ? 61 - nb : 40;
+}
+
+int mcpm_lattice_scatter_fx(mcpm_plan *p, const float *xb, const float *vb, float a, float b, float *meshes3) {
+    MCPM_TRY(fxg_prepare(p));
+    MCPM_HIP(p, hipMemsetAsync(meshes3, 0, sizeof(float) * 3 * p->M, p->stream));
+    MCPM_HIP(p, hipMemsetAsync(p->gx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream));
+    absmax_axpby3_kernel<<<2048, 256, 0, p->stream>>>(xb, vb, 3 * p->Np, a, b, p->gx_wmax);
+    const int q = fxg_q(p->Np);
+    dim3 grid, block;
+    lattice_launch(p->g, grid, block);
+    for (int c = 0; c < 3; ++c) {
+        float *out = meshes3 + c * p->M;
+        lattice_scatter_fx_kernel<<<grid, block, 0, p->stream>>>(p->g, xb, vb, a, b, c, out, (unsigned long long *)p->gx_acc, p->gx_wmax, q);
+        paint_fxg_flush_kernel<<<2048, 256, 0, p->stream>>>(p->gx_acc, out, p->M, p->gx_wmax, q, 1.f, (((uintptr_t)out) & 7) ? 0 : 1);
+    }
+    MCPM_LAUNCH_CHECK(p, "lattice_scatter_fx_kernel");
+    return MCPM_OK;
+}
 
 // three-component read of an interleaved [cell][3] force mesh (internal: pm_forces)
 int mcpm_read3_il(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *fm_il, int order, float *out) {

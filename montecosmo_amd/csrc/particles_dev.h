@@ -123,6 +123,23 @@ __device__ __forceinline__ void locate(const Geom &g, const PIdx &pi, P3 d, int 
     axis_cell<ORDER>(qz, fz + d.z, c[2], f[2]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// NGP cell of a lattice point (read_order = 1 at pos = regular_pos, nbody.py:984-985): exact integer
+// round-half-even of ip*n/p.
+__device__ __forceinline__ int lattice_ngp(int ip, int n, int p, int same) {
+    if (same) return ip;
+    int qn = ip * n, qi = qn / p, qr = qn - qi * p;
+    int c = qi + ((2 * qr > p || (2 * qr == p && (qi & 1))) ? 1 : 0);
+    return c >= n ? c - n : c;
+}
+
+__device__ __forceinline__ int64_t lattice_cell(const Geom &g, const PIdx &pi) {
+    int cx = lattice_ngp(pi.ipx, g.nx, g.px, g.same_lattice) + g.xoff;
+    int cy = lattice_ngp(pi.ipy, g.ny, g.py, g.same_lattice);
+    int cz = lattice_ngp(pi.ipz, g.nz, g.pz, g.same_lattice);
+    return ((int64_t)cx * g.ny + cy) * g.nz + cz;
+}
+
 // Flat mesh offsets of the ORDER^3 stencil (NGP 1, CIC 2, TSC 3, PCS 4 points per axis), periodic.  The stencil
 // starts at id0 - (ORDER-1)/2 (nbody.py:376).
 template <int ORDER>

@@ -31,7 +31,11 @@ static int make_fft(mcpm_plan *p, bool forward, int batch) {
     rocfft_execution_info_create(&info);
     void *work = nullptr;
     if (wsz) {
-        if (hipMalloc(&work, wsz) != hipSuccess) return mcpm_fail(p, MCPM_E_NOMEM, "rocFFT work buffer");
+        if (hipMalloc(&work, wsz) != hipSuccess) {
+            rocfft_execution_info_destroy(info);
+            rocfft_plan_destroy(plan);
+            return mcpm_fail(p, MCPM_E_NOMEM, "rocFFT work buffer");
+        }
         rocfft_execution_info_set_work_buffer(info, work, wsz);
     }
     rocfft_execution_info_set_stream(info, p->stream);
@@ -43,7 +47,7 @@ static int make_fft(mcpm_plan *p, bool forward, int batch) {
 
 extern "C" {
 
-const char *mcpm_version(void) { return "mcpm 0.1 (gfx950)"; }
+const char *mcpm_version(void) { return MCPM_ABI_VERSION; }
 
 const char *mcpm_last_error(const mcpm_plan *plan) { return plan ? plan->err.c_str() : g_mcpm_create_error.c_str(); }
 
@@ -104,6 +108,8 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->fx_redo = nullptr;
     p->fx_tiles = 0;
     p->fx_src = nullptr;
+    p->gx_acc = nullptr;
+    p->gx_wmax = nullptr;
     p->reduce = nullptr;
     p->pscratch = nullptr;
     p->vscratch = nullptr;
@@ -127,6 +133,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->fx_tiles = (int)(p->M / 4096 + 2);
     alloc((void **)&p->fx_wmax, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE);
     alloc((void **)&p->fx_redo, sizeof(int) * (p->fx_tiles + 1));
+    alloc((void **)&p->gx_wmax, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE);
     alloc((void **)&p->reduce, sizeof(double) * MCPM_NREDUCE);
     if (e != hipSuccess) {
         std::string msg = std::string("hipMalloc of plan scratch: ") + hipGetErrorString(e);
@@ -162,6 +169,8 @@ int mcpm_plan_destroy(mcpm_plan *p) {
     (void)hipFree(p->outlier_count);
     (void)hipFree(p->fx_wmax);
     (void)hipFree(p->fx_redo);
+    (void)hipFree(p->gx_acc);
+    (void)hipFree(p->gx_wmax);
     (void)hipFree(p->reduce);
     (void)hipFree(p->pscratch);
     (void)hipFree(p->vscratch);

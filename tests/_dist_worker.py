@@ -123,3 +123,42 @@ def gpu_slab_worker(rank, world, port, out_dir, n, n_steps, backend="gloo"):
         json.dump(res, open(os.path.join(out_dir, "result.json"), "w"))
     td.barrier()
     td.destroy_process_group()
+
+
+def gpu_slab_golden_worker(rank, world, port, out_dir, name, backend="gloo"):
+    """The slab path with `world` ranks against the ORACLE's committed fixture tests/golden/<name> (final state, final
+    density, gradient and scalar cotangents of BASELINE config 4's workload at fixture size), not against the single-GPU
+    HIP path."""
+    import json
+    import torch
+    torch.cuda.set_device(0)
+    td = _init(rank, world, port, backend)
+    from montecosmo_amd import nbody, bricks, dist
+    g = np.load(os.path.join(ROOT, "tests", "golden", name))
+    n, n_steps, a0 = int(g["n"]), int(g["n_steps"]), float(g["a0"])
+    shape = (n, n, n)
+    comm = dist.TorchComm()
+    (d, v), ctx = dist.nbody_bf_slab(bricks.Planck18(), g["init_mesh"], a0=a0, a1=1.0, n_steps=n_steps, comm=comm, ghost=8,
+                                     return_ctx=True)
+    Nl = n ** 3 // world
+    mb, sb = dist.nbody_bf_slab_vjp(ctx, g["pos_bar"][rank * Nl:(rank + 1) * Nl], g["vel_bar"][rank * Nl:(rank + 1) * Nl])
+    d_all, v_all = comm.all_gather_cat(d), comm.all_gather_cat(v)
+    oob = ctx.pm.out_of_ghost()
+    if rank == 0:
+        def rel(a, b):
+            a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+            dt = np.complex128 if np.iscomplexobj(b) else np.float64
+            return float(np.linalg.norm(a.astype(dt) - b.astype(dt)) / np.linalg.norm(b.astype(dt)))
+        lp = nbody.LatticePos(d_all, shape)
+        res = {"disp": rel(d_all, g["final_disp"]), "vel": rel(v_all, g["final_vel"]),
+               "density": rel(nbody.paint(lp, shape), g["final_density"]),
+               "cell_mismatch": float(np.mean(np.any(nbody.cell_index(lp, shape).cpu().numpy() != g["final_cell"], axis=1))),
+               "grad": rel(mb, g["init_mesh_bar"]),
+               "alpha": float(np.abs(sb["alpha"] - g["alpha_bar"]).max() / np.abs(g["alpha_bar"]).max()),
+               "beta": float(np.abs(sb["beta"] - g["beta_bar"]).max() / np.abs(g["beta_bar"]).max()),
+               "lpt_scalars": float(np.abs(np.array([sb["g"], sb["g2"], sb["dg2dg"]]) - g["lpt_scalar_bars"]).max()
+                                    / np.abs(g["lpt_scalar_bars"]).max()),
+               "oob": int(oob)}
+        json.dump(res, open(os.path.join(out_dir, "result.json"), "w"))
+    td.barrier()
+    td.destroy_process_group()

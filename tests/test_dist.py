@@ -33,6 +33,56 @@ def test_comm_and_halo_gloo_cpu(world):
     assert all(os.path.exists(os.path.join(out, f"ok_{r}")) for r in range(world))
 
 
+def _run_bench(extra, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=e, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_gpus_launches_ranks_cpu(world):
+    """`python bench.py --gpus N` with WORLD_SIZE unset starts N rank processes itself (--gpus was ignored):
+    the launch / rendezvous / max-over-ranks path rehearsed over gloo on the CPU, no GPU touched."""
+    r, line = _run_bench(["--gpus", str(world), "--rehearse"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == world and line["rccl_world"] == world and line["max_rank_seen"] == world - 1
+    # a launcher that disagrees with --gpus is an error, not a silent one-GPU run
+    r, line = _run_bench(["--gpus", "2", "--rehearse"], env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and line is None and "WORLD_SIZE is 1" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_gloo_shared_gpu(gpu):
+    """The whole `bench.py --gpus 2` line (slab-decomposed, strong scaling) with two ranks sharing cuda:0 over gloo: a
+    rehearsal of the multi-GPU launch, never a measurement."""
+    r, line = _run_bench(["--gpus", "2", "--mesh", "64", "--steps", "3", "--warmup", "1", "--n-steps", "3", "--no-cpu-baseline"],
+                         env={"MCPM_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["rccl_world"] == 2 and line["comm_backend"] == "gloo"
+    assert line["scaling"] == "strong" and line["value"] > 0 and line["deposits_beyond_ghost_rank0"] == 0
+    assert line["config"]["parallelism"] == "slab2"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2])
+def test_slab_path_against_oracle_fixture(gpu, world):
+    """BASELINE config 4's workload at fixture size: the slab-decomposed run (2 ranks) against the float64 ORACLE's
+    golden vectors (tests/golden/nbody_32.npz), with the single-GPU tolerances of test_gpu_golden.py."""
+    from _dist_worker import gpu_slab_golden_worker
+    out = _spawn(gpu_slab_golden_worker, world, "nbody_32.npz")
+    res = json.load(open(os.path.join(out, "result.json")))
+    assert res["oob"] == 0
+    assert res["disp"] < 1e-5 and res["vel"] < 1e-5 and res["density"] < 1e-5 and res["cell_mismatch"] < 1e-4, res
+    assert res["grad"] < 1e-4 and res["alpha"] < 1e-3 and res["beta"] < 1e-3 and res["lpt_scalars"] < 1e-3, res
+
+
 @pytest.mark.gpu
 def test_slab_path_single_rank(gpu):
     """One rank, local-copy communicator: exercises ghost-extended paint/read, the packed FFT layouts and the
