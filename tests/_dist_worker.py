@@ -126,15 +126,16 @@ def gpu_slab_worker(rank, world, port, out_dir, n, n_steps, backend="gloo"):
 
 
 def gpu_slab_golden_worker(rank, world, port, out_dir, name, backend="gloo"):
-    """The slab path with `world` ranks against the ORACLE's committed fixture tests/golden/<name> (final state, final
-    density, gradient and scalar cotangents of BASELINE config 4's workload at fixture size), not against the single-GPU
-    HIP path."""
+    """The slab path with `world` ranks against float64 ORACLE vectors in the layout of tests/golden/nbody_*.npz (final
+    state, final density, gradient and scalar cotangents of BASELINE config 4's workload at test size), not against the
+    single-GPU HIP path.  `name`: a file under tests/golden/ or an absolute path (the slab FFT needs axes >= 64, so the
+    test writes 64^3 oracle vectors to a temporary file)."""
     import json
     import torch
     torch.cuda.set_device(0)
     td = _init(rank, world, port, backend)
     from montecosmo_amd import nbody, bricks, dist
-    g = np.load(os.path.join(ROOT, "tests", "golden", name))
+    g = np.load(name if os.path.isabs(name) else os.path.join(ROOT, "tests", "golden", name))
     n, n_steps, a0 = int(g["n"]), int(g["n_steps"]), float(g["a0"])
     shape = (n, n, n)
     comm = dist.TorchComm()

@@ -75,6 +75,18 @@ def test_growth_tables_match_oracle(libmod):
             assert np.isclose(nbody.alpha_fpm(cg, g0, 0.1), o.alpha_fpm(co, g0, 0.1), rtol=1e-10)
 
 
+def test_product_growth_table_matches_valid_precond_notebook(libmod):
+    """The product's host float64 RK4 (csrc/growth.cpp, mcpm_growth_table) against the reference-printed numbers of
+    tests_old/valid_precond.ipynb:76-84 (see tests/test_oracle_known_answers.py for how they pin the table)."""
+    from test_oracle_known_answers import PRECOND_DG
+    steps = 256
+    arrs = [np.zeros(steps) for _ in range(7)]
+    rc = libmod.lib.mcpm_growth_table(0.31, 0.69, 0., -1., 0., -4., steps, *[a.ctypes.data_as(C.POINTER(C.c_double)) for a in arrs])
+    assert rc == 0
+    for a_obs, dg in PRECOND_DG.items():
+        assert np.isclose(np.interp(a_obs, arrs[0], arrs[1]) / 20, dg, rtol=1e-13, atol=0), a_obs
+
+
 def test_step_scalars_follow_the_euler_time_grid():
     from montecosmo_amd import nbody, bricks
     cg, co = bricks.Planck18(), obg.Planck18()

@@ -101,6 +101,49 @@ def test_planck18_growth_matches_reference_notebook():
     assert np.isclose(o.a2g(c, 0.0), o.growth_table(c)["g"][0])     # a0 = 0 is table-clamped, not 0
 
 
+# tests_old/valid_precond.ipynb:76-84 (cell 3 output): `dg = a2g(a_obs) / 20` printed to 16 digits for a_obs = 0.1, 0.5 with
+# the notebook's truth cosmology Omega_m = 0.31 (cell 3 source) and g0 = 0 (a_obs = 1 prints dg = 0.05 exactly).
+# That notebook ran an older revision whose growth table was logspace(-4, 0, 256) -- today's module constants are
+# (-3, 128) (nbody.py:675-676) -- found by scanning (log10_amin, steps): (-4, 256) reproduces BOTH numbers to the last
+# printed digit, which pins the restated jax_cosmo background (Omega_m(a), Omega_de(a), w), its RK4 `odeint`, the growth
+# ODE of nbody.py:703-716, the normalisation and the linear interpolation, at 1e-15.
+PRECOND_DG = {0.1: 0.0063675511943792435, 0.5: 0.03041908411253382, 1.0: 0.05}
+
+
+def test_growth_matches_valid_precond_notebook_to_16_digits():
+    c = obg.Planck18(Omega_c=0.31 - 0.049)
+    t = o.growth_table(c, log10_amin=-4., steps=256)
+    for a_obs, dg in PRECOND_DG.items():
+        assert np.isclose(np.interp(a_obs, t["a"], t["g"]) / 20, dg, rtol=2e-15, atol=0), a_obs
+    # with today's table (-3, 128) the same quantities differ by the interpolation error of the coarser table only
+    c._workspace.clear()
+    assert abs(float(o.a2g(c, 0.5)) / 20 / PRECOND_DG[0.5] - 1) < 1e-4
+    assert abs(float(o.a2g(c, 0.1)) / 20 / PRECOND_DG[0.1] - 1) < 2e-6
+
+
+def test_rg2cgh_unique_counts_of_valid_fourier_notebook():
+    """tests/valid_fourier.ipynb cells 4-5: on a real (6,6,6) field, rfftn and rg2cgh both give a (6,6,4) spectrum with
+    144 distinct complex entries, 112 distinct real parts and 105 distinct |imaginary parts| (zero included): the
+    Hermitian redundancy of the kz = 0 and kz = 3 planes (2 x (4 self-conjugate + 16 pairs)) + 72 free entries; and
+    cgh2rg inverts rg2cgh (assert_allclose(spatial, spatial2) in cell 5)."""
+    rng = np.random.default_rng(66)          # own generator: the module-scoped one feeds order-sensitive tests
+    x = rng.standard_normal((6, 6, 6))
+    for X in (np.fft.rfftn(x), o.rg2cgh(x)):
+        assert X.shape == (6, 6, 4)
+        r, i = np.round(X.real, 9), np.round(np.abs(X.imag), 9)
+        assert len(np.unique(np.round(X, 9))) == 144 and len(np.unique(r)) == 112 and len(np.unique(i)) == 105
+        assert len(np.unique(r)) + len(np.unique(i)) == 6 * 6 * (2 * (4 - 1)) + 1
+    assert np.allclose(o.cgh2rg(o.rg2cgh(x)), x, rtol=1e-5)
+    # same second moments as rfftn (cell 5's assert on the covariances): per-mode variance of the real / imaginary parts
+    xs = rng.standard_normal((4000, 6, 6, 6))
+    F = np.fft.rfftn(xs, axes=(1, 2, 3))
+    G = np.stack([o.rg2cgh(v) for v in xs])
+    assert np.allclose((F.real ** 2).mean(0), (G.real ** 2).mean(0), rtol=0.15, atol=2.)
+    assert np.allclose((F.imag ** 2).mean(0), (G.imag ** 2).mean(0), rtol=0.15, atol=2.)
+    assert np.array_equal((F.imag ** 2).mean(0) < 1e-20, (G.imag ** 2).mean(0) < 1e-20)      # the same 8 purely real modes
+    assert ((G.imag ** 2).mean(0) < 1e-20).sum() == 8
+
+
 def test_zeldovich_plane_wave():
     """Item 5: a single plane wave before shell crossing: PM stepping stays on x = q + D psi(q) to integrator
     and CIC-force accuracy (1-D collapse, amplitude well below shell crossing).  A floor-based CIC paint of a
