@@ -32,13 +32,18 @@ LOG2PI = math.log(2 * math.pi)
 
 
 def quad_gaussian_log_prob_and_grad(value, loc, b, a):
-    """QuadGaussian.log_prob (utils.py:497-510) per element and its derivatives w.r.t. (loc, scale1 = b, scale2 = a);
-    `a` is a python float (one value for the whole mesh; |a| < 1e-8 selects the Gaussian limit) or a device tensor
-    (nowhere near zero), the rest device tensors."""
+    """QuadGaussian.log_prob (utils.py:497-510) per element and its derivatives w.r.t. (loc, scale1 = b, scale2 = a).
+    `a` is a python float (one value for the whole mesh) or a device tensor; as in the reference the Gaussian limit is
+    selected PER ELEMENT where |a| < 1e-8 (utils.py:510), with a_safe = 1 there so that nothing non-finite is formed."""
+    z = (value - loc) / b
+    lp_g = -0.5 * LOG2PI - torch.log(b) - 0.5 * z * z
     if not torch.is_tensor(a) and abs(a) < 1e-8:
-        z = (value - loc) / b
-        lp = -0.5 * LOG2PI - torch.log(b) - 0.5 * z * z
-        return lp, z / b, (z * z - 1.0) / b, torch.zeros_like(lp)
+        return lp_g, z / b, (z * z - 1.0) / b, torch.zeros_like(lp_g)
+    if torch.is_tensor(a):
+        small = a.abs() < 1e-8
+        a = torch.where(small, torch.ones_like(a), a)
+    else:
+        small = None
     r = value - loc + a
     D = b * b + 4.0 * a * r
     ok = D > 0
@@ -59,17 +64,38 @@ def quad_gaussian_log_prob_and_grad(value, loc, b, a):
     g_loc = -dD_dloc / (2 * Ds) - t * dD_dloc / (2 * sq)
     g_b = -dD_db / (2 * Ds) - t * dD_db / (2 * sq) + s
     g_a = -dD_da / (2 * Ds) - t * dD_da / (2 * sq) + (wp * ep * ep + wm * em * em) / a
-    z = torch.zeros_like(D)
-    return lp, torch.where(ok, g_loc, z), torch.where(ok, g_b, z), torch.where(ok, g_a, z)
+    zero = torch.zeros_like(D)
+    g_loc, g_b, g_a = torch.where(ok, g_loc, zero), torch.where(ok, g_b, zero), torch.where(ok, g_a, zero)
+    if small is not None:
+        lp, g_loc, g_b, g_a = (torch.where(small, lp_g, lp), torch.where(small, z / b, g_loc),
+                               torch.where(small, (z * z - 1.0) / b, g_b), torch.where(small, zero, g_a))
+    return lp, g_loc, g_b, g_a
+
+
+_TAIL_TEMP = 1 / 6.2842226 / 2      # utils.py:190, :195: "best temperature at 12 sigma"
+_TAIL_LIM = 12.0                     # utils.py:222
 
 
 def std2trunc_and_derivs(x, loc, scale, low, high):
-    """std2trunc (utils.py:189-226, |x| < 12) with its first two derivatives, host float64:
-    y = Phi^-1(c_l + (c_h - c_l) Phi(x)) (and the mirrored form for x >= 0); dy/dx = phi(x) (c_h - c_l) / phi(y)."""
+    """std2trunc (utils.py:189-226) with its first two derivatives, host float64.
+    Body: y = Phi^-1(c_l + (c_h - c_l) Phi(x)) (and the mirrored form for x >= 0); dy/dx = phi(x) (c_h - c_l) / phi(y).
+    Beyond 12 sigma, when the bound on that side is beyond 12 sigma too (utils.py:223), the reference switches to
+    lowtail = T logsumexp([x, low] / T) (a soft maximum) and hightail = -T logsumexp(-[x, high] / T) (a soft minimum)."""
     from scipy.special import ndtr, ndtri
-    if abs(x) >= 12:
-        raise NotImplementedError("the 12-sigma tail approximations of std2trunc are not built")
     lo, hi = (low - loc) / scale, (high - loc) / scale
+    T = _TAIL_TEMP
+    if x < -_TAIL_LIM and lo < -_TAIL_LIM:
+        m = max(x, lo)
+        ex, el = math.exp((x - m) / T), math.exp((lo - m) / T)
+        y = m + T * math.log(ex + el)
+        d1 = ex / (ex + el)
+        return loc + scale * y, scale * d1, scale * d1 * (1.0 - d1) / T
+    if x > _TAIL_LIM and hi > _TAIL_LIM:
+        m = min(x, hi)
+        ex, eh = math.exp(-(x - m) / T), math.exp(-(hi - m) / T)
+        y = m - T * math.log(ex + eh)
+        d1 = ex / (ex + eh)
+        return loc + scale * y, scale * d1, -scale * d1 * (1.0 - d1) / T
     phi = lambda t: math.exp(-0.5 * t * t) / math.sqrt(2 * math.pi)
     if x < 0:
         cl, ch = ndtr(lo), ndtr(hi)
@@ -206,7 +232,7 @@ class FieldLevelLogDensity:
         else:
             self.ngb_lat = None
             self.ngbar_mean = float(np.mean(self.fixed["ngbars"]))
-        self.mask = None if mask is None else torch.from_numpy(mask.astype(np.float32)).to(dev)
+        self.mask = None if mask is None else torch.from_numpy(np.asarray(mask).astype(bool)).to(dev)
         if selec_mesh is None:
             self.selec_mesh, self.sel_down, self.selec_fid = None, None, 1.0
         else:
@@ -350,13 +376,24 @@ class FieldLevelLogDensity:
         resh = tuple(gxy.shape) != self.final_shape
         dn = self._down(gsel)
         cm = dn * rc
-        delta = cm / selec - 1.0
+        # Only the observed cells carry a likelihood term: the reference extracts them first (mesh2masked, model.py:856-863).
+        # Here every cell is evaluated, so the unobserved ones are given safe inputs (selection 1, count 0 -- a cut-sky
+        # selection is exactly 0 there and count / selec would be NaN) and are removed with `where`, never by multiplying.
+        obs, cmu = self.count_obs, cm
+        if self.mask is not None:
+            if torch.is_tensor(selec):
+                selec = torch.where(self.mask, selec, torch.ones_like(selec))
+            cmu = torch.where(self.mask, cm, torch.zeros_like(cm))
+            obs = torch.where(self.mask, obs, torch.zeros_like(obs))
+        delta = cmu / selec - 1.0
         lin = base["s_e"] + base["s_ed"] * delta
         b = (lin.abs() + 1e-9) * selec ** .5
         a = 0.0 if abs(float(base["s_e2"])) < 1e-10 else float(base["s_e2"]) * selec ** .5
-        lpe, g_loc, g_b, g_a = quad_gaussian_log_prob_and_grad(self.count_obs, cm, b, a)
-        if self.mask is not None:      # only the observed cells carry a likelihood term (mesh2masked, model.py:856)
-            lpe, g_loc, g_b, g_a = lpe * self.mask, g_loc * self.mask, g_b * self.mask, g_a * self.mask
+        lpe, g_loc, g_b, g_a = quad_gaussian_log_prob_and_grad(obs, cmu, b, a)
+        if self.mask is not None:
+            zero = torch.zeros_like(lpe)
+            lpe, g_loc, g_b = torch.where(self.mask, lpe, zero), torch.where(self.mask, g_loc, zero), torch.where(self.mask, g_b, zero)
+            g_a = torch.where(self.mask, g_a, zero) if torch.is_tensor(g_a) else g_a
         lp += float(lpe.double().sum())
         if not need_grad:
             return lp, None
@@ -376,7 +413,7 @@ class FieldLevelLogDensity:
             else:
                 rc_bar = cm_bar * dn
                 per = torch.bincount(self.shell.reshape(-1), weights=rc_bar.double().reshape(-1), minlength=self.n_rbins + 1)[:self.n_rbins]
-                common = float((-(g_b * sgn * base["s_ed"]) * cm / selec ** 2 + wsel * 0.5 * selec ** -.5).double().sum())
+                common = float((-(g_b * sgn * base["s_ed"]) * cmu / selec ** 2 + wsel * 0.5 * selec ** -.5).double().sum())
                 rcounts_bar = per.cpu().numpy() + common / self.n_rbins
             ngb_bar = rcounts_bar * fwd.cell_length ** 3
         if resh:      # adjoints of irfftn, chreshape, rfftn (real-pair convention)

@@ -301,7 +301,10 @@ class FlatLogDensity:
         import numpy as np
         self.n_eval += 1
         lp, grad = self.ld.logdensity_and_grad(self.unpack(q))
-        if not math.isfinite(lp):
+        if math.isnan(lp):      # never a legitimate value: a silent -inf would freeze the chain at its current state
+            raise FloatingPointError("log density is NaN at this state (non-finite inputs to the likelihood?)")
+        if not math.isfinite(lp):      # outside the support (QuadGaussian's is bounded, utils.py:476-477): rejected, and counted
+            self.n_nonfinite = getattr(self, "n_nonfinite", 0) + 1
             return -math.inf, torch.zeros_like(q)
         gs = np.concatenate([np.atleast_1d(np.asarray(grad[n], dtype=np.float64)).reshape(-1) for n in self.scalars]) \
             if self.scalars else np.zeros(0)

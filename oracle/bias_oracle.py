@@ -271,12 +271,17 @@ def quad_gaussian_log_prob(value, loc, scale1, scale2):
 
 
 def std2trunc(x, loc=0., scale=1., low=-np.inf, high=np.inf):
-    """montecosmo/utils.py:189-226: transport a standard normal variable to a truncated normal one; |x| < 12 (the
-    12-sigma tail approximations lowtail / hightail are not restated: they raise)."""
+    """montecosmo/utils.py:189-226: transport a standard normal variable to a truncated normal one, with the 12-sigma
+    tail forms lowtail / hightail (temperature 1 / 6.2842226 / 2, utils.py:189-198) where both x and the bound on that
+    side lie beyond 12 sigma (utils.py:222-225)."""
     from scipy.stats import norm
+    from scipy.special import logsumexp
     lo, hi = (low - loc) / scale, (high - loc) / scale
-    if abs(x) >= 12:
-        raise NotImplementedError("12-sigma tails")
+    temp = 1 / 6.2842226 / 2
+    if x < -12 and lo < -12:
+        return loc + scale * temp * logsumexp(np.array([x, lo]) / temp)
+    if x > 12 and hi > 12:
+        return loc + scale * (-temp * logsumexp(-np.array([x, hi]) / temp))
     if x < 0:
         cl, ch = norm.cdf(lo), norm.cdf(hi)
         y = norm.ppf(cl + (ch - cl) * norm.cdf(x))

@@ -19,6 +19,71 @@ import numpy as np
 
 from . import background
 
+# --------------------------------------------------------------------------- optional multi-threaded back end
+# `set_threads(n)` with n > 1 switches (a) every FFT to scipy.fft (pocketfft, float64) with `workers = n` and (b) paint / read
+# and their VJPs to the OpenMP float64 kernels of oracle/csrc/pm_kernels.c (oracle/_build/libpmo.so, built by
+# `make -C oracle`).  The arithmetic restated is the same (same index semantics, same kernels, float64); sums are
+# accumulated in a different order, so results agree with the single-threaded numpy path to ~1e-14 (checked in
+# tests/test_oracle_threads.py).  Used for the parity cases at 128^3 / 256^3 and for bench.py's cpu_baseline.
+_THREADS = 1
+_CLIB = None
+
+
+def _load_clib():
+    global _CLIB
+    if _CLIB is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libpmo.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `make -C oracle` (or __graft_entry__.build())")
+        lib = C.CDLL(path)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int16)
+        lib.pmo_paint.argtypes = [dp, C.c_int64, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        lib.pmo_read.argtypes = [dp, C.c_int64, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, dp]
+        lib.pmo_cell_index.argtypes = [dp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, ip]
+        for f in (lib.pmo_paint, lib.pmo_read, lib.pmo_cell_index):
+            f.restype = None
+        _CLIB = lib
+    return _CLIB
+
+
+def set_threads(n):
+    """n > 1: threaded FFTs (scipy.fft workers) and OpenMP particle kernels; 1: plain numpy (the default, which
+    generated the golden fixtures).  Returns the previous setting."""
+    global _THREADS
+    import os
+    prev, n = _THREADS, max(1, int(n))
+    if n > 1:
+        _load_clib()
+        os.environ["OMP_NUM_THREADS"] = str(n)
+        try:
+            import ctypes as C
+            C.CDLL("libgomp.so.1").omp_set_num_threads(n)
+        except OSError:
+            pass
+    _THREADS = n
+    return prev
+
+
+def _dptr(a):
+    import ctypes as C
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _rfftn(x):
+    if _THREADS > 1:
+        import scipy.fft
+        return scipy.fft.rfftn(x, workers=_THREADS)
+    return np.fft.rfftn(x)
+
+
+def _irfftn(X, s=None, axes=None):
+    if _THREADS > 1:
+        import scipy.fft
+        return scipy.fft.irfftn(X, s=s, axes=axes, workers=_THREADS)
+    return np.fft.irfftn(X, s=s, axes=axes) if s is not None else np.fft.irfftn(X)
+
 
 # --------------------------------------------------------------------------- helpers
 def safe_div(x, y):
@@ -169,6 +234,12 @@ def _id0_shifts(pos, ndim, order):
 
 def cell_index(pos, shape, order=2):
     """Wrapped base-cell index of every particle, (N,3) int16: `wrap(id0)` of nbody.py:372-375."""
+    if _THREADS > 1 and len(shape) == 3:
+        import ctypes as C
+        p = np.ascontiguousarray(pos, dtype=np.float64)
+        idx = np.empty((len(p), 3), np.int16)
+        _load_clib().pmo_cell_index(_dptr(p), len(p), order, *(int(v) for v in shape), idx.ctypes.data_as(C.POINTER(C.c_int16)))
+        return idx
     shape16 = np.asarray(shape, dtype=np.int16)
     id0, _ = _id0_shifts(np.asarray(pos, dtype=np.float64), len(shape), order)
     return id0 % shape16
@@ -195,6 +266,11 @@ def paint(pos, shape, weights=1., order=2):
     size = int(np.prod(shape))
     mesh = np.zeros(size)
     n = len(pos)
+    if _THREADS > 1 and len(shape) == 3 and 1 <= order <= 4:
+        p = np.ascontiguousarray(pos, dtype=np.float64)
+        w = None if np.ndim(weights) == 0 else np.ascontiguousarray(np.broadcast_to(weights, (n,)), dtype=np.float64)
+        _load_clib().pmo_paint(_dptr(p), n, _dptr(w), float(weights) if w is None else 0.0, order, *shape, _dptr(mesh))
+        return mesh.reshape(shape)
     weights = np.broadcast_to(np.asarray(weights, dtype=np.float64), (n,))
     for flat, ker, _ in stencil(pos, shape, order):
         mesh += np.bincount(flat, weights=weights * ker.prod(-1), minlength=size)
@@ -204,6 +280,11 @@ def paint(pos, shape, weights=1., order=2):
 def read(pos, mesh, order=2):
     """montecosmo/nbody.py:398-427"""
     mesh = np.asarray(mesh)
+    if _THREADS > 1 and mesh.ndim == 3 and mesh.dtype == np.float64 and 1 <= order <= 4:
+        p, m = np.ascontiguousarray(pos, dtype=np.float64), np.ascontiguousarray(mesh)
+        out = np.empty(len(p))
+        _load_clib().pmo_read(_dptr(p), len(p), _dptr(m), order, *m.shape, _dptr(out), None, 0.0, None)
+        return out
     out = np.zeros(len(pos), dtype=mesh.dtype)
     flatmesh = mesh.reshape(-1)
     for flat, ker, _ in stencil(pos, mesh.shape, order):
@@ -227,6 +308,12 @@ def paint_vjp(pos, shape, weights, mesh_bar, order=2):
     """VJP of paint w.r.t. (pos, weights).  weights may be a scalar (its bar is then summed)."""
     n = len(pos)
     w = np.broadcast_to(np.asarray(weights, dtype=np.float64), (n,))
+    if _THREADS > 1 and len(shape) == 3 and 1 <= order <= 4:
+        p, mb = np.ascontiguousarray(pos, dtype=np.float64), np.ascontiguousarray(mesh_bar, dtype=np.float64)
+        wc = np.ascontiguousarray(w)
+        pos_bar, w_bar = np.zeros((n, 3)), np.empty(n)
+        _load_clib().pmo_read(_dptr(p), n, _dptr(mb), order, *(int(v) for v in shape), _dptr(w_bar), _dptr(wc), 0.0, _dptr(pos_bar))
+        return pos_bar, (w_bar.sum() if np.ndim(weights) == 0 else w_bar)
     flatbar = np.asarray(mesh_bar).reshape(-1)
     pos_bar = np.zeros((n, len(shape)))
     w_bar = np.zeros(n)
@@ -242,6 +329,12 @@ def paint_vjp(pos, shape, weights, mesh_bar, order=2):
 def read_vjp(pos, mesh, out_bar, order=2):
     """VJP of read w.r.t. (pos, mesh)."""
     mesh = np.asarray(mesh)
+    if _THREADS > 1 and mesh.ndim == 3 and mesh.dtype == np.float64 and 1 <= order <= 4:
+        p, m = np.ascontiguousarray(pos, dtype=np.float64), np.ascontiguousarray(mesh)
+        ob = np.ascontiguousarray(np.broadcast_to(out_bar, (len(p),)), dtype=np.float64)
+        pos_bar = np.zeros((len(p), 3))
+        _load_clib().pmo_read(_dptr(p), len(p), _dptr(m), order, *m.shape, None, _dptr(ob), 0.0, _dptr(pos_bar))
+        return pos_bar, paint(pos, mesh.shape, weights=out_bar, order=order)
     flatmesh = mesh.reshape(-1)
     pos_bar = np.zeros((len(pos), mesh.ndim))
     for flat, ker, dker in stencil(pos, mesh.shape, order):
@@ -255,7 +348,7 @@ def deconv_paint(mesh, order=2):
     """montecosmo/nbody.py:315-334 (kernel_type='rectangular')."""
     if np.isrealobj(mesh):
         kvec = rfftk(mesh.shape)
-        return np.fft.irfftn(np.fft.rfftn(mesh) / rectangular_hat(kvec, order), s=mesh.shape, axes=(0, 1, 2))
+        return _irfftn(_rfftn(mesh) / rectangular_hat(kvec, order), s=mesh.shape, axes=(0, 1, 2))
     return mesh / rectangular_hat(rfftk(ch2rshape(mesh.shape)), order)
 
 
@@ -265,7 +358,7 @@ def interlace(pos, shape, weights=1., paint_order=2, interlace_order=2):
     mesh = np.zeros(r2chshape(shape), dtype=complex)
     for shift in np.arange(interlace_order) / interlace_order:
         m = paint(pos + shift, shape, weights, paint_order)
-        mesh = mesh + np.fft.rfftn(m) * np.exp(1j * shift * sum(kvec)) / interlace_order
+        mesh = mesh + _rfftn(m) * np.exp(1j * shift * sum(kvec)) / interlace_order
     return mesh
 
 
@@ -528,20 +621,20 @@ def _zweights(shape_r):
 def irfftn_vjp(real_bar):
     """y = irfftn(X) (numpy: ifft over leading axes, c2r over last)  ->  X_bar = (w/M) rfftn(y_bar)."""
     M = real_bar.size
-    return np.fft.rfftn(real_bar) * (_zweights(real_bar.shape) / M)
+    return _rfftn(real_bar) * (_zweights(real_bar.shape) / M)
 
 
 def rfftn_vjp(spec_bar, shape_r):
     """X = rfftn(rho), rho real  ->  rho_bar = M * irfftn(X_bar / w)."""
     M = int(np.prod(shape_r))
-    return np.fft.irfftn(spec_bar / _zweights(shape_r), s=shape_r, axes=tuple(range(len(shape_r)))) * M
+    return _irfftn(spec_bar / _zweights(shape_r), s=shape_r, axes=tuple(range(len(shape_r)))) * M
 
 
 # --------------------------------------------------------------------------- forces
 def pm_forces(pos, mesh, read_order=2, paint_deconv=False, grad_fd=np.inf, lap_fd=np.inf, kcut=np.inf):
     """montecosmo/nbody.py:583-604.  `mesh` a shape tuple (paint first) or a half-spectrum."""
     if isinstance(mesh, tuple):
-        mesh = np.fft.rfftn(paint(pos, mesh, order=read_order))
+        mesh = _rfftn(paint(pos, mesh, order=read_order))
         if paint_deconv:
             kvec = rfftk(ch2rshape(mesh.shape))
             mesh = mesh / rectangular_hat(kvec, order=read_order) ** 2
@@ -549,7 +642,7 @@ def pm_forces(pos, mesh, read_order=2, paint_deconv=False, grad_fd=np.inf, lap_f
     pot = mesh * invlaplace_hat(kvec, lap_fd)
     if kcut != np.inf:
         pot = pot * gaussian_hat(kvec, kcut)
-    return np.stack([read(pos, np.fft.irfftn(-gradient_hat(kvec, i, grad_fd) * pot), read_order)
+    return np.stack([read(pos, _irfftn(-gradient_hat(kvec, i, grad_fd) * pot), read_order)
                      for i in range(len(kvec))], axis=-1)
 
 
@@ -557,7 +650,7 @@ def force_meshes(mesh_k, grad_fd=np.inf, lap_fd=np.inf):
     """The three real force meshes irfftn(-(i k_c) * (-1/k^2) * mesh_k) of nbody.py:597-603."""
     kvec = rfftk(ch2rshape(mesh_k.shape))
     pot = mesh_k * invlaplace_hat(kvec, lap_fd)
-    return [np.fft.irfftn(-gradient_hat(kvec, i, grad_fd) * pot) for i in range(3)]
+    return [_irfftn(-gradient_hat(kvec, i, grad_fd) * pot) for i in range(3)]
 
 
 def pm_forces_vjp(pos, mesh, forces_bar, read_order=2, paint_deconv=False, grad_fd=np.inf, lap_fd=np.inf,
@@ -567,7 +660,7 @@ def pm_forces_vjp(pos, mesh, forces_bar, read_order=2, paint_deconv=False, grad_
     painted = isinstance(mesh, tuple)
     if painted:
         shape = mesh
-        spec = np.fft.rfftn(paint(pos, shape, order=read_order))
+        spec = _rfftn(paint(pos, shape, order=read_order))
     else:
         spec = mesh
         shape = ch2rshape(mesh.shape)
@@ -582,7 +675,7 @@ def pm_forces_vjp(pos, mesh, forces_bar, read_order=2, paint_deconv=False, grad_
     pot_bar = np.zeros_like(pot)
     for c in range(3):
         gk = -gradient_hat(kvec, c, grad_fd)
-        fmesh = np.fft.irfftn(gk * pot)
+        fmesh = _irfftn(gk * pot)
         pb, mb = read_vjp(pos, fmesh, forces_bar[:, c], read_order)
         pos_bar += pb
         pot_bar += np.conj(gk) * irfftn_vjp(mb)
@@ -602,12 +695,12 @@ def delta2_mesh(mesh_k, grad_fd=np.inf, lap_fd=np.inf, return_hess=False):
     hesses = 0.
     hess = {}
     for i in range(3):
-        hess_ii = np.fft.irfftn(gradient_hat(kvec, i, grad_fd) ** 2 * pot)
+        hess_ii = _irfftn(gradient_hat(kvec, i, grad_fd) ** 2 * pot)
         hess[(i, i)] = hess_ii
         delta2 = delta2 + hess_ii * hesses
         hesses = hesses + hess_ii
         for j in range(i + 1, 3):
-            hess_ij = np.fft.irfftn(gradient_hat(kvec, i, grad_fd) * gradient_hat(kvec, j, grad_fd) * pot)
+            hess_ij = _irfftn(gradient_hat(kvec, i, grad_fd) * gradient_hat(kvec, j, grad_fd) * pot)
             hess[(i, j)] = hess_ij
             delta2 = delta2 - hess_ij ** 2
     return (delta2, hess) if return_hess else delta2
@@ -616,7 +709,7 @@ def delta2_mesh(mesh_k, grad_fd=np.inf, lap_fd=np.inf, return_hess=False):
 def pm_forces2(pos, mesh_k, read_order=2, grad_fd=np.inf, lap_fd=np.inf):
     """montecosmo/nbody.py:607-631"""
     delta2 = delta2_mesh(mesh_k, grad_fd, lap_fd)
-    return pm_forces(pos, np.fft.rfftn(delta2), read_order, grad_fd=grad_fd, lap_fd=lap_fd)
+    return pm_forces(pos, _rfftn(delta2), read_order, grad_fd=grad_fd, lap_fd=lap_fd)
 
 
 def pm_forces2_vjp(pos, mesh_k, forces_bar, read_order=2, grad_fd=np.inf, lap_fd=np.inf):
@@ -624,7 +717,7 @@ def pm_forces2_vjp(pos, mesh_k, forces_bar, read_order=2, grad_fd=np.inf, lap_fd
     shape = ch2rshape(mesh_k.shape)
     kvec = rfftk(shape)
     delta2, hess = delta2_mesh(mesh_k, grad_fd, lap_fd, return_hess=True)
-    pos_bar, d2k_bar = pm_forces_vjp(pos, np.fft.rfftn(delta2), forces_bar, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
+    pos_bar, d2k_bar = pm_forces_vjp(pos, _rfftn(delta2), forces_bar, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
     d2_bar = rfftn_vjp(d2k_bar, shape)
     pot_bar = 0.
     for i in range(3):
@@ -639,7 +732,7 @@ def pm_forces2_vjp(pos, mesh_k, forces_bar, read_order=2, grad_fd=np.inf, lap_fd
 def lpt(cosmo, init_mesh, pos, a, lpt_order=2, read_order=2, grad_fd=np.inf, lap_fd=np.inf):
     """montecosmo/nbody.py:634-667"""
     if np.isrealobj(init_mesh):
-        init_mesh = np.fft.rfftn(init_mesh)
+        init_mesh = _rfftn(init_mesh)
     force1 = pm_forces(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
     dpos = a2g(cosmo, a) * force1
     vel = force1

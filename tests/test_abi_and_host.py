@@ -146,3 +146,21 @@ def test_eisenstein_hu_power_table_matches_restatement():
         assert abs(power.sigma_r(ks, pows) - 1.0) < 1e-3
     c = bricks.Planck18()
     assert np.allclose(power.eisenstein_hu_transfer(c, [0.0, 1e-7]), 1.0, atol=1e-6)
+
+
+def test_std2trunc_body_and_12_sigma_tails_match_restatement():
+    """utils.py:189-226 incl. the lowtail / hightail soft-max forms beyond 12 sigma (the tails raised):
+    product host code (value + two analytic derivatives) against the oracle restatement and central differences; the map
+    is continuous across the switch at 12 sigma to the accuracy the reference's temperature gives (~1e-7 sigma)."""
+    from montecosmo_amd.logdensity import std2trunc_and_derivs as f
+    from oracle import bias_oracle as bo
+    loc, sc = 0.8102, 0.01
+    for low, high in ((0., np.inf), (-np.inf, np.inf), (0.6, 0.95), (0.75, np.inf)):
+        for x in (-40., -13., -12.5, -12.0001, -11.9, -3., 0., 2., 11.9, 12.0001, 12.5, 30.):
+            y, d1, d2 = f(x, loc, sc, low, high)
+            assert abs(y - bo.std2trunc(x, loc, sc, low, high)) < 1e-13
+            h = 1e-5
+            assert abs(d1 - (f(x + h, loc, sc, low, high)[0] - f(x - h, loc, sc, low, high)[0]) / (2 * h)) < 1e-6 * abs(d1) + 1e-13
+            assert abs(d2 - (f(x + h, loc, sc, low, high)[1] - f(x - h, loc, sc, low, high)[1]) / (2 * h)) < 1e-4 * abs(d2) + 1e-10
+            assert low <= y <= high
+        assert abs(f(-12.0 - 1e-9, loc, sc, low, high)[0] - f(-12.0 + 1e-9, loc, sc, low, high)[0]) < 1e-6 * sc

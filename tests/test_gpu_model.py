@@ -161,3 +161,62 @@ def test_log_density_and_gradient(gpu, evolution, s_e2, precond, a_obs, survey):
 def _cos(c, s8):
     c.sigma8 = s8
     return c
+
+
+@pytest.mark.parametrize("s_e2", [0.0, 0.005])
+def test_cut_sky_selection_exactly_zero_outside_the_mask(gpu, s_e2):
+    """ADVICE r1 (logdensity.py): a cut-sky selection is exactly 0 in the unobserved cells (the normal output of
+    cutsky2selection, bricks.py:1054-1103); the reference extracts the observed cells first (mesh2masked, model.py:856-863).
+    Here count / selec in the unobserved cells must not poison the sum or the gradient (NaN * 0 = NaN): value against the
+    float64 restatement, gradient against its central differences, everything finite."""
+    from montecosmo_amd import model, logdensity, samplers
+    rng = np.random.default_rng(43)
+    fwd = model.FieldLevelForward(final_shape=(8, 8, 8), cell_length=40., box_center=(60., -40., 1400.), box_rotvec=(0.1, 0.2, -0.1),
+                                  evolution="lpt", lpt_order=2, init_oversamp=1.5, evol_oversamp=2., ptcl_oversamp=2.,
+                                  paint_oversamp=1., a_obs=0.65, curved_sky=True, lin_kpow=_kpow())
+    assert tuple(fwd.paint_shape) == (8, 8, 8)          # the selection reaches the final mesh unchanged: exact zeros stay exact
+    g = np.indices((8, 8, 8)).astype(float)
+    sel = (0.6 + 0.3 * np.cos(2 * np.pi * g[1] / 8)) * (g[0] < 5)              # exactly 0 for x >= 5
+    mask = sel > 0
+    extra = dict(selec_mesh=sel, mask_mesh=mask)
+    cfg = dict(fwd.config(), final_shape=(8, 8, 8), cell_length=40., precond="fourier", **extra)
+    lat = {"sigma8": dict(loc=0.8102, scale=0.1, loc_fid=0.8102, scale_fid=1e-2, low=0., high=np.inf),
+           "b1": dict(loc=1., scale=1e2, loc_fid=1., scale_fid=1e-2), "s_ed": dict(loc=0., scale=1e1, loc_fid=0., scale_fid=1e-2)}
+    fixed = dict(Omega_m=0.3111, b2=0.1, bs2=-0.1, bn2=0., b3=0., bds2=0., bs3=0., bnpar=0., ngbars=1e-3, s_e=1.0, s_e2=s_e2)
+    make_cosmo = lambda base: _cos(obg.Planck18(Omega_c=base["Omega_m"] - 0.0490), base["sigma8"])
+    sample = {k + "_": float(rng.normal(0, 1.0)) for k in lat}
+    sample["white_mesh_"] = rng.standard_normal((12, 12, 12))
+    obs = 60. + 8. * rng.standard_normal((8, 8, 8))
+    obs[~mask] = np.nan                                                          # never read: a NaN here must not matter
+    ld = logdensity.FieldLevelLogDensity(fwd, np.where(mask, obs, 0.), lat, fixed, precond="fourier", **extra)
+    lp, grad = ld.logdensity_and_grad({k: (v if np.ndim(v) == 0 else v.astype(np.float32)) for k, v in sample.items()})
+    with np.errstate(all="ignore"):
+        ref = lambda s: bo.log_density(cfg, lat, fixed, s, obs, make_cosmo)
+        lp_o = ref(sample)
+        assert np.isfinite(lp_o) and np.isfinite(lp) and abs(lp - lp_o) < 2e-4 * abs(lp_o) + 0.05, (lp, lp_o)
+        assert all(np.isfinite(grad[k + "_"]) for k in lat) and bool(torch_isfinite(grad["white_mesh_"]))
+        for k in lat:
+            h = 1e-4
+            fd = (ref(dict(sample, **{k + "_": sample[k + "_"] + h})) - ref(dict(sample, **{k + "_": sample[k + "_"] - h}))) / (2 * h)
+            assert abs(fd - grad[k + "_"]) < 1e-2 * abs(fd) + 1e-3, (k, fd, grad[k + "_"])
+        d = rng.standard_normal((12, 12, 12))
+        h = 1e-4
+        fd = (ref(dict(sample, white_mesh_=sample["white_mesh_"] + h * d)) - ref(dict(sample, white_mesh_=sample["white_mesh_"] - h * d))) / (2 * h)
+    gw = grad["white_mesh_"].double().cpu().numpy()
+    typical = np.linalg.norm(gw) * np.linalg.norm(d) / np.sqrt(d.size)
+    assert abs(fd - float((gw * d).sum())) < 5e-3 * max(abs(fd), typical)
+    # and the flat adapter refuses a NaN log density instead of turning it into a frozen chain
+    flat = samplers.FlatLogDensity(ld)
+    q = flat.pack({k: (v if np.ndim(v) == 0 else v.astype(np.float32)) for k, v in sample.items()})
+    assert abs(flat(q)[0] - lp) < 1e-3 * abs(lp) + 0.05       # float32 packing of the scalars
+    ld.count_obs[0, 0, 0] = float("nan")                 # an observed cell this time
+    if s_e2 == 0.0:
+        with pytest.raises(FloatingPointError):
+            flat(q)
+    else:      # the quadratic branch maps a NaN discriminant to "outside the support" (utils.py:507): rejected and counted
+        assert flat(q)[0] == -np.inf and flat.n_nonfinite == 1
+
+
+def torch_isfinite(t):
+    import torch
+    return torch.isfinite(t).all()

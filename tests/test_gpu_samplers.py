@@ -1,0 +1,80 @@
+"""BASELINE config 5 in miniature under -m gpu: short seeded NUTS and MCLMC chains over
+`FieldLevelLogDensity` -- the HIP log density and its hand-written gradient (montecosmo/model.py:350-363, the contract
+samplers.py:44 / :311-315 consumes) -- checking reproducibility of a seeded chain, bounded energy errors, and the log
+density of the states the chain visits against the float64 restatement (oracle/bias_oracle.py::log_density)."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import bias_oracle as bo, background as obg  # checker only
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(evolution="nbody"):
+    import torch
+    from montecosmo_amd import model, logdensity, samplers
+    rng = np.random.default_rng(7)
+    ks = np.logspace(-3, 1, 128)
+    kpow = (ks, 3.0e4 * (ks / 0.02) / (1 + (ks / 0.02) ** 2.6))
+    fwd = model.FieldLevelForward(final_shape=(8, 8, 8), cell_length=40., box_center=(60., -40., 1400.), box_rotvec=(0.1, 0.2, -0.1),
+                                  evolution=evolution, nbody_n_steps=3, lpt_order=2, init_oversamp=1.5, evol_oversamp=2.,
+                                  ptcl_oversamp=2., paint_oversamp=2., a_obs=0.65, curved_sky=True, lin_kpow=kpow, nbody_a_start=0.1)
+    cfg = dict(fwd.config(), final_shape=(8, 8, 8), cell_length=40., precond="kaiser")
+    lat = {"sigma8": dict(loc=0.8102, scale=0.1, loc_fid=0.8102, scale_fid=1e-2, low=0., high=np.inf),
+           "b1": dict(loc=1., scale=1e2, loc_fid=1., scale_fid=1e-2), "b2": dict(loc=0., scale=1e2, loc_fid=0., scale_fid=3e-2)}
+    fixed = dict(Omega_m=0.3111, bs2=0., bn2=0., b3=0., bds2=0., bs3=0., bnpar=0., ngbars=1e-3, s_e=1.0, s_ed=0., s_e2=0.)
+    make_cosmo = lambda base: _cos(obg.Planck18(Omega_c=base["Omega_m"] - 0.0490), base["sigma8"])
+    obs = 64. + 8. * rng.standard_normal((8, 8, 8))
+    ld = logdensity.FieldLevelLogDensity(fwd, obs, lat, fixed, precond="kaiser")
+    flat = samplers.FlatLogDensity(ld)
+    start = {k + "_": 0.0 for k in lat}
+    start["white_mesh_"] = (0.3 * rng.standard_normal(fwd.init_shape)).astype(np.float32)
+    q0 = flat.pack(start)
+    ref = lambda q: bo.log_density(cfg, lat, fixed, {k: (np.asarray(v.cpu(), np.float64) if torch.is_tensor(v) else v)
+                                                     for k, v in flat.unpack(q).items()}, obs, make_cosmo)
+    return samplers, flat, q0, ref
+
+
+def _cos(c, s8):
+    c.sigma8 = s8
+    return c
+
+
+def test_nuts_chain_over_the_hip_log_density(gpu):
+    samplers, flat, q0, ref = _setup()
+    run = lambda: samplers.nuts_sample(flat, q0, n_warmup=12, n_samples=8, max_tree_depth=4, seed=3)
+    r1 = run()
+    infos = r1["infos"]
+    assert len(r1["samples"]) == 8 and all(math.isfinite(i["logdensity"]) for i in infos)
+    assert not any(i["diverging"] for i in infos[12:])                      # bounded energy error over the sampling phase
+    assert np.mean([i["accept_stat"] for i in infos[12:]]) > 0.4
+    assert r1["samples"][-1].ne(q0).any()                                   # the chain moved
+    # log density of visited states against the float64 restatement
+    for q in (q0, r1["samples"][0], r1["samples"][-1]):
+        lp, lp_o = flat(q)[0], ref(q)
+        assert abs(lp - lp_o) < 2e-4 * abs(lp_o) + 0.05, (lp, lp_o)
+    assert abs(infos[-1]["logdensity"] - ref(r1["samples"][-1])) < 2e-4 * abs(infos[-1]["logdensity"]) + 0.05
+    # a seeded chain is reproducible: same decisions, same states
+    r2 = run()
+    assert [i["n_leapfrog"] for i in r2["infos"]] == [i["n_leapfrog"] for i in infos]
+    assert np.allclose(r2["samples"][-1].cpu().numpy(), r1["samples"][-1].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    assert abs(r2["step_size"] - r1["step_size"]) < 1e-6 * r1["step_size"]
+
+
+def test_mclmc_chain_over_the_hip_log_density(gpu):
+    samplers, flat, q0, ref = _setup("lpt")
+    d = q0.numel()
+    run = lambda: samplers.mclmc_sample(flat, q0, n_warmup=40, n_samples=20, seed=5)
+    r1 = run()
+    infos = r1["infos"]
+    assert len(r1["samples"]) == 20 and all(math.isfinite(i["logdensity"]) for i in infos)
+    de = np.array([i["energy_change"] for i in infos[40:]])
+    assert np.all(np.isfinite(de))
+    assert np.mean(de ** 2) / d < 20 * 5e-4                                 # energy-error variance per dimension near its target
+    lp, lp_o = flat(r1["samples"][-1])[0], ref(r1["samples"][-1])
+    assert abs(lp - lp_o) < 2e-4 * abs(lp_o) + 0.05, (lp, lp_o)
+    r2 = run()
+    assert np.allclose(r2["samples"][-1].cpu().numpy(), r1["samples"][-1].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    assert abs(r2["step_size"] - r1["step_size"]) < 1e-5 * r1["step_size"]
