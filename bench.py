@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--ghost", type=int, default=8)
     ap.add_argument("--fixed-ghost", action="store_true", help="slabs: always exchange all ghost planes (default: only the "
                     "planes each step's displacements can reach)")
-    ap.add_argument("--cpu-mesh", type=int, default=128)
+    ap.add_argument("--cpu-mesh", type=int, default=256, help="mesh of the second GPU record and of the CPU baseline (unscaled)")
     ap.add_argument("--rehearse", action="store_true", help="launch path only: start / join the ranks, rendezvous over gloo on the "
                     "CPU, barrier + max-over-ranks, print the JSON skeleton; touches no GPU (CPU test of --gpus N)")
     return ap.parse_args()
@@ -256,23 +256,61 @@ def pmc_traffic(stage, n):
         return None
 
 
-def cpu_baseline(n_cpu, n_gpu):
-    """The numpy float64 oracle (a port of the reference's algorithm; the JAX reference itself cannot run here)
-    timed on one forward+adjoint DKD step at n_cpu^3, scaled by cell count to the benchmark mesh."""
-    from oracle import pm_oracle as o
-    shape = (n_cpu,) * 3
-    N = n_cpu ** 3
-    rng = np.random.default_rng(0)
-    pos = o.regular_pos(shape) + rng.standard_normal((N, 3))
-    vel = rng.standard_normal((N, 3))
-    xb, vb = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
+def host_threads():
+    """CPU threads this process may use (the GPU box gives one GPU's share of the host, not all of its cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(runner, n_sample_steps=2):
+    """The reference-equivalent CPU path (the float64 oracle with its threaded back end: scipy.fft on all allowed host
+    threads + the OpenMP paint / read kernels of oracle/csrc/pm_kernels.c; the JAX reference itself cannot run here), timed
+    on forward+adjoint DKD steps of the SAME trajectory the GPU just ran at runner.n^3: the GPU's checkpoint of step i is
+    handed to the oracle, which runs the step and its adjoint in float64.  Not scaled: value is steps/s at runner.n^3."""
+    from oracle import pm_oracle as o, background as obg
+    n, K, N = runner.n, runner.K, runner.N
+    shape = (n, n, n)
+    threads = host_threads()
+    prev = o.set_threads(threads)
+    try:
+        cos = obg.Planck18()
+        pos = o.regular_pos(shape)
+        rng = np.random.default_rng(1)
+        xb, vb = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
+        dg = float(runner.dg)
+        g0 = float(o.a2g(cos, 0.0))
+        steps = list(range(K // 2, min(K // 2 + n_sample_steps, K)))
+        states = [(runner.states[i, 0].double().cpu().numpy(), runner.states[i, 1].double().cpu().numpy()) for i in steps]
+        t0 = time.perf_counter()
+        for i, (xh, v) in zip(steps, states):
+            t = g0 + i * dg
+            o.dkd_vjp(pos + xh - v * (dg / 2), v, xb, vb, dg, float(o.alpha_bf(cos, t, dg)), t + dg / 2, shape)
+        dt = time.perf_counter() - t0
+    finally:
+        o.set_threads(prev)
+    return {"value": round(len(steps) / dt, 4), "unit": "steps/s", "cores": threads, "kind": "port", "mesh": n,
+            "sample": f"{len(steps)} forward+adjoint DKD steps (steps {steps[0]}..{steps[-1]} of {K}) of the {n}^3 bench trajectory, "
+                      f"float64 oracle with scipy.fft workers + OpenMP paint/read on {threads} threads, took {dt:.1f} s "
+                      f"(host reports {os.cpu_count()} cores); not scaled"}
+
+
+def sub_record(n, NS, K, W, device):
+    """The same measurement at a second mesh (the metric names 256^3 and 512^3): timed region + pm_forces."""
+    r = Runner(n, NS, device)
+    r.run(W)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    o.dkd_vjp(pos, vel, xb, vb, 0.1, 0.5, 0.3, shape)
+    r.run(K)
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    scale = (n_gpu / n_cpu) ** 3
-    return {"value": 1.0 / (dt * scale), "unit": "steps/s", "cores": 1, "kind": "port",
-            "sample": f"1 forward+adjoint DKD step of the numpy float64 oracle at {n_cpu}^3 took {dt:.2f} s on 1 thread "
-                      f"(host has {os.cpu_count()} cores); scaled by cell count x{scale:.0f} to {n_gpu}^3"}
+    pmf = r.force_cycle_ms()
+    M = float(n) ** 3
+    return r, {"mesh": n, "value": round(K / dt, 3), "unit": "steps/s", "steps": K, "ms_per_step": round(dt / K * 1e3, 4),
+               "pm_forces_ms": round(pmf, 4), "pm_forces_frac_of_hbm_peak": round(B_PER_CELL_CYCLE * M / (pmf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "fwd_adj_step_frac_of_hbm_peak": round(B_PER_CELL_STEP * M / (dt / K) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def spawn_ranks(nproc):
@@ -412,8 +450,14 @@ def main():
             out["comm_and_host_ms_per_step"] = round(dt / K * 1e3 - step_ms, 3)   # wall minus rank-0 kernel stages
             out["deposits_beyond_ghost_rank0"] = r.pm.out_of_ghost()                # must be 0
             out["ghost_planes_exchanged_per_step"] = [int(d) for d in r.depths if d is not None]   # of --ghost allocated
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_mesh, n)
+        if world == 1 and not slab and not args.forward_only:
+            # the metric names 256^3 as well: a second, smaller record in the same line, and the CPU baseline on ITS trajectory
+            if n != args.cpu_mesh:
+                r2, out[f"mesh_{args.cpu_mesh}"] = sub_record(args.cpu_mesh, NS, K, W, device)
+            else:
+                r2 = r
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(r2)
     if dist:
         td.barrier()
         td.destroy_process_group()

@@ -69,12 +69,17 @@ const char *mcpm_last_error(const mcpm_plan *plan); /* plan may be NULL: last er
 /* ABI revision string; the Python loader (montecosmo_amd/_lib.py) refuses a library that reports another one. */
 #define MCPM_ABI_VERSION "mcpm 0.2 (gfx950)"
 const char *mcpm_version(void);
-/* Number of particles the last tiled paint routed through the global-atomic outlier path (host sync). */
+/* Tiled CIC paints (montecosmo_amd/csrc/paint_tiled.hip).  A tile's window is (16 + 2 halo + 1)^3 lattice points wide,
+   centred on the tile (or, optionally, on the local bulk displacement); what a window misses travels through per-tile
+   buckets (integer LDS sums, so the paint stays bitwise reproducible).  mcpm_plan_last_bucketed: (particle, tile) pairs the last tiled paint routed through
+   the buckets.  mcpm_plan_last_outliers: particles / pairs it had to deposit with f32 global atomics instead (non-finite or
+   absurd displacements, bucket overflow).  Both synchronise the host. */
 int mcpm_plan_last_outliers(mcpm_plan *plan, int64_t *count);
-/* Tuning knob: halo radius (cells) of the LDS-tiled paint; displacements beyond it take the outlier path. */
+int mcpm_plan_last_bucketed(mcpm_plan *plan, int64_t *count);
+/* Tuning knobs: halo radius (1, 2, 3, 4 or 6 cells; default 3) and whether windows are centred on the local bulk
+   displacement (default 1; 0 = on the tile itself, which needs halo 4 at the benchmark's 2-cell rms displacement). */
 int mcpm_plan_set_halo(mcpm_plan *plan, int halo);
-/* Tuning knob: order in which the tiled paints hand tiles to the 8 XCDs: 0 = one contiguous run of tiles per XCD
-   (default), 1 = compact bricks of tiles (slower at 512^3; see particles.hip). */
+int mcpm_plan_set_centre(mcpm_plan *plan, int centre);
 int mcpm_plan_set_tile_order(mcpm_plan *plan, int order);
 /* Accumulator of the tiled three-component paint (mcpm_paint3_f32, the adjoint of the force read): 1 = fixed point
    (default: 32-bit fields in 64-bit integer LDS atomics, exact order-independent sums, overflow proven per tile by a
@@ -182,6 +187,8 @@ int mcpm_slab_ycol2(mcpm_plan *plan, const float *in, float *out, int expand, in
 int mcpm_slab_set_window(mcpm_plan *plan, int x0, int count);
 int mcpm_slab_xfused(mcpm_plan *plan, const float *in, float *out, int mode);
 int mcpm_slab_zinv(mcpm_plan *plan, const float *spec, float *real, int64_t real_bstride, int batch);
+/* z C2R of three spectra (spec_elems apart) into ONE interleaved real mesh [x][y][z][3] (window of local planes as above). */
+int mcpm_slab_zinv3_il(mcpm_plan *plan, const float *spec3, float *real_il);
 
 /* ---- forces (nbody.py:583-631) -------------------------------------------------------------- */
 /* pm_forces with mesh = shape tuple: paint -> R2C -> k-space -> 3 C2R -> read; forces[N][3].
@@ -212,6 +219,15 @@ int mcpm_kick_f32(mcpm_plan *plan, const float *vel_in, const float *forces, int
 int mcpm_kick_drift_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in, int64_t n, int pos_mode,
                         const float *meshes3, int order, float alpha, float beta, float dt, float *pos_out,
                         float *vel_out);
+/* The same on ONE interleaved force mesh [x][y][z][3] (a CIC corner is one 12-byte gather for the three components; what
+   mcpm_slab_zinv3_il writes). */
+int mcpm_kick_drift_il_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in, int64_t n, int pos_mode,
+                           const float *mesh_il, int order, float alpha, float beta, float dt, float *pos_out,
+                           float *vel_out);
+/* slots: 64 x 32 device unsigned (zeroed by each kick_drift call) or NULL.  While set, every mcpm_kick_drift*_f32 leaves
+   max_i |pos_out[i][0]| there as float bits (maximum over the 64 slots at stride 32): the slab stepper's ghost depth for
+   the next step, without a pass of its own over the positions. */
+int mcpm_plan_track_dmax(mcpm_plan *plan, unsigned *slots);
 /* lpt (nbody.py:634-667) on the plan's particle lattice, read_order = 1, scalar a:
    dpos = g F1 - g2 F2, vel = F1 - dg2dg F2 (lpt_order 2) from the half-spectrum init_mesh. */
 /* One BullFrog/FastPM step in the fused form x' -> paint -> forces -> v1 = alpha v + beta F(x'), x1 = x' + v1 tau
@@ -241,6 +257,11 @@ int mcpm_step_adjoint_particles_f32(mcpm_plan *plan, const float *pos_in, const 
                                     const float *force_meshes, const float *rho_bar, double alpha, double beta,
                                     double tau, int paint_order, float *pos_bar, float *vel_bar, double *alpha_bar,
                                     double *beta_bar, double dtau_ddg, double *dg_bar);
+/* The same with the step's force meshes as ONE interleaved mesh [x][y][z][3]. */
+int mcpm_step_adjoint_particles_il_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in,
+                                       const float *force_mesh_il, const float *rho_bar, double alpha, double beta,
+                                       double tau, int paint_order, float *pos_bar, float *vel_bar, double *alpha_bar,
+                                       double *beta_bar, double dtau_ddg, double *dg_bar);
 int mcpm_lpt_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg,
                  int lap_fd, int grad_fd, float *dpos, float *vel);
 /* Lattice-point pieces of lpt (read_order = 1 at pos = regular_pos, nbody.py:984-985), exposed for the slab path:

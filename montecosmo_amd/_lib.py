@@ -27,6 +27,8 @@ SIGNATURES = {
     "mcpm_last_error": (C.c_char_p, [C.c_void_p]),
     "mcpm_version": (C.c_char_p, []),
     "mcpm_plan_last_outliers": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mcpm_plan_last_bucketed": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mcpm_plan_set_centre": (C.c_int, [C.c_void_p, C.c_int]),
     "mcpm_plan_chained_fb": (C.c_int, [C.c_void_p, C.c_double, C.c_double, _f32p, _f32p, C.POINTER(C.c_void_p)]),
     "mcpm_plan_set_halo": (C.c_int, [C.c_void_p, C.c_int]),
     "mcpm_plan_set_tile_order": (C.c_int, [C.c_void_p, C.c_int]),
@@ -84,12 +86,16 @@ SIGNATURES = {
     "mcpm_drift_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_float, _f32p]),
     "mcpm_kick_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_float, C.c_float, _f32p]),
     "mcpm_kick_drift_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_float, C.c_float, C.c_float, _f32p, _f32p]),
+    "mcpm_kick_drift_il_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_float, C.c_float, C.c_float, _f32p, _f32p]),
+    "mcpm_plan_track_dmax": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mcpm_slab_zinv3_il": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "mcpm_plan_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "mcpm_plan_profile_read": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p, C.POINTER(C.c_int64)]),
     "mcpm_stage_name": (C.c_char_p, [C.c_int]),
     "mcpm_bullfrog_step_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, _f32p]),
     "mcpm_bullfrog_step_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "mcpm_plan_hint_next_adjoint": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "mcpm_step_adjoint_particles_il_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "mcpm_step_adjoint_particles_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "mcpm_lpt_accum_f32": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_float, C.c_int, _f32p, _f32p]),
     "mcpm_lattice_scatter_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, _f32p]),

@@ -582,6 +582,14 @@ int mcpm_step_adjoint_particles_f32(mcpm_plan *p, const float *pos_in, const flo
 
 // layout 0: three force meshes M apart (public entry point); 1: interleaved [cell][3] (what the steppers checkpoint on
 // plans served by the hand-written Poisson solve)
+extern "C" int mcpm_step_adjoint_particles_il_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_mesh_il,
+                                                  const float *rho_bar, double alpha, double beta, double tau, int paint_order,
+                                                  float *pos_bar, float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg,
+                                                  double *dg_bar) {
+    return step_adjoint_particles(p, pos_in, vel_in, force_mesh_il, 1, rho_bar, alpha, beta, tau, paint_order, pos_bar, vel_bar,
+                                  alpha_bar, beta_bar, dtau_ddg, dg_bar);
+}
+
 static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes, int layout,
                                   const float *rho_bar, double alpha, double beta, double tau, int paint_order, float *pos_bar,
                                   float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg, double *dg_bar) {

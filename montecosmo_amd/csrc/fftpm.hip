@@ -1012,6 +1012,14 @@ int mcpm_slab_zinv(mcpm_plan *p, const float *spec, float *real, int64_t real_bs
     return z_inverse(p, (const cf *)spec, real, real_bstride, batch);
 }
 
+int mcpm_slab_zinv3_il(mcpm_plan *p, const float *spec3, float *real_il) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, real_il && spec3, MCPM_E_ARG, "mcpm_slab_zinv3_il: bad argument");
+    MCPM_REQUIRE(p, mcpm_fftpm_supported(p), MCPM_E_UNSUPPORTED, "slab FFT needs power-of-two axes in [64, 1024]");
+    MCPM_TRY(ensure_twiddles(p));
+    return z_inverse3_il(p, (const cf *)spec3, real_il);
+}
+
 int mcpm_slab_ycol(mcpm_plan *p, const float *in, float *out, int batch, int sign, int in_packed, int out_packed) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, in && out && batch >= 1 && (sign == 1 || sign == -1), MCPM_E_ARG, "mcpm_slab_ycol: bad argument");

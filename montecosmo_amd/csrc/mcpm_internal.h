@@ -57,7 +57,13 @@ struct mcpm_plan {
     int64_t M;   // nx*ny*nz
     int64_t Mh;  // nx*ny*nzh
     int64_t Np;  // px*py*pz
-    int halo;    // halo radius of the tiled paint
+    int halo;    // halo radius H of the tiled paints: a tile's window is (16 + 2H + 1)^3 lattice points
+    int centre;  // tiled paints: windows centred on the local bulk displacement (paint_tiled.hip); 0 = on the tile itself
+    int *tile_off;    // packed window offsets per 16^3 tile (device; NULL if the mesh cannot be tiled)
+    int *bucket_cnt;  // per-tile bucket fill counts
+    int *bucket;      // [tile][bucket_cap] particles a tile's window misses
+    int bucket_cap;
+    int *bucket_tiles; // list of tiles with a non-empty bucket (built by the duty, walked by the bucket kernels)
     int paint_variant;  // threads/unroll variant of the tiled paint (tuning)
     int paint3_variant; // three-component tiled paint variant (tuning); < 0 disables it; 4 = fixed-point tile
     unsigned *fx_wmax;  // fixed-point paint: bits of max|w|, maximum over MCPM_FX_SLOTS slots (device)
@@ -73,6 +79,7 @@ struct mcpm_plan {
     const void *fb_xb, *fb_vb;
     // x-slab decomposition (mcpm_plan_create_slab): this rank owns global planes [rank*nxl, (rank+1)*nxl)
     int nranks, rank, ghost, nx_global, nxl;
+    unsigned *dmax; // caller's MCPM_FX_SLOTS x MCPM_FX_STRIDE slots: kick_drift leaves max |d_x| (as float bits) there; NULL = off
     int xw0, xwn;  // window of local planes the slab z / y passes work on (mcpm_slab_set_window; default all nxl)
 
     // rocFFT plans keyed by batch
@@ -87,7 +94,7 @@ struct mcpm_plan {
     float *spec1;    // 1 half-spectrum scratch
     float *fft_pad;  // 1 padded spectrum: scratch of the generic hand-written R2C / C2R (allocated on first use)
     int *outliers;   // outlier particle list of the tiled paint (Np ints)
-    int *outlier_count;  // device counter (2 ints: live counter, copy of last)
+    int *outlier_count;  // device counters (8 ints, see paint_tiled.hip: wild, last, slab oob, overflow pairs, dropped, bucketed)
     double *reduce;  // device accumulators for scalar cotangents (MCPM_NREDUCE doubles)
     float *pscratch; // 9*Np floats, allocated on first VJP (adjoint state + force cotangent)
     float *vscratch;  // variable-size particle scratch (pm_forces_vjp)
@@ -149,6 +156,10 @@ int mcpm_fftpm_c2r(mcpm_plan *p, const float *spec, float *real, int batch);
 // (spec_bar overwritten for nc = 3, accumulated into for nc = 6)
 int mcpm_fftpm_spec_meshes(mcpm_plan *p, const float *spec, float *meshes, int nc);
 int mcpm_fftpm_spec_meshes_vjp(mcpm_plan *p, const float *meshes_bar, float *spec_bar, int nc);
+
+// tiled CIC paints (paint_tiled.hip); false: geometry not tileable, the caller takes the generic path
+bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t wstride, float wscalar, float *mesh, int accumulate);
+bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, float *meshes3, int accumulate);
 
 // adjoint of the NGP lattice read on a lattice != mesh: order-independent fixed-point sums (particles.hip)
 int mcpm_lattice_scatter_fx(mcpm_plan *p, const float *xb, const float *vb, float a, float b, float *meshes3);

@@ -1,0 +1,1001 @@
+// LDS-tiled paints of libmcpm.so for gfx950 (CIC, lattice displacements, particle lattice == mesh):
+//   mcpm_paint_tiled   the density paint of the force cycle            (montecosmo/nbody.py:365-396 `paint`)
+//   mcpm_paint3_tiled  three weighted paints at once, the adjoint of the three-component force read (`read` :398-427, x3)
+//
+// Design (MI355X-first; the reference runs 8 scatter-add passes with global atomics):
+//   * PULL, not scatter.  One workgroup owns one 16^3 Eulerian tile of the mesh in LDS and pulls the lattice particles that
+//     can land in it: coalesced 12-byte loads, lanes along z, 4 loads in flight per thread.  Only stencil points inside the
+//     tile are deposited (LDS integer atomics); the tile is written with plain 16-byte stores.  No global atomics, no sort.
+//   * BULK-CENTRED WINDOWS.  Particles are stored in Lagrangian order as displacements from their lattice point, and the
+//     displacement field is smooth: the particles that land in tile T come from lattice points around T - o_T, where o_T is
+//     the (rounded) mean displacement near T.  `tile_offset_kernel` samples 64 particles per tile for o_T (25 MB of reads at
+//     512^3), and the window of T is the (16 + 2H + 1)^3 lattice points  T - o_T - (H+1) ... T - o_T + 15 + H  with H = 2:
+//     2.3 window visits per particle instead of the 3.8 of an uncentred H = 4 window (which the 2-cell rms displacement of
+//     the benchmark needed), for the same outlier rate.
+//   * BUCKETS for what the windows miss.  Every workgroup also watches the particles of its own Lagrangian block (they lie
+//     in its window whenever |o_T| <= H; a second short loop covers them otherwise): a particle whose floor(d) leaves the
+//     interval in which every neighbouring window is sure to contain it (six compares, the cost of the round-1 outlier
+//     test) is appended to a SUSPECT list.  `coverage_duty_kernel` then runs the exact test on the suspects only: for each
+//     of the (up to 8) tiles T' the stencil touches, with the same integer predicate the consumer uses, is the lattice
+//     point in T's window?  If not the particle goes to T's bucket (a fixed-capacity list per tile).  A second kernel deposits every bucket through an LDS integer tile and adds it to the mesh with plain
+//     read-modify-writes of the touched cells (one workgroup per tile: no races).  A bucket that overflows (displacement
+//     fields with no bulk flow to follow: nothing a PM run produces) is dropped as a whole and a repair pass over the
+//     particles deposits that tile's pairs with f32 global atomics: no input can lose mass.
+//   * INTEGER ACCUMULATORS everywhere: 2^-30 fixed point (unweighted), max|w| 2^-28 fixed point (weighted; max|w| from a
+//     reduction pass) in 64-bit LDS integer atomics; the three-component kernel packs 32-bit fields with an overflow-proof
+//     bound (below).  Integer sums do not depend on arrival order, so every paint is bitwise reproducible.  Only particles
+//     with non-finite / absurd displacements ("wild") and bucket overflows take f32 global atomics; both are counted
+//     (mcpm_plan_last_outliers).
+#include "particles_dev.h"
+
+typedef unsigned long long u64;
+
+#define MCPM_TILE 16
+#define MCPM_TAME 16384.f   // |d| beyond this (or NaN) on any axis: "wild", deposited by the global-atomic kernel
+
+// counters (device ints): [0] wild particles, [1] copy of last wild + overflow pairs (host query), [2] slab deposits beyond
+// the ghost planes (cumulative), [3] appends that found their bucket full, [4] tiles with a non-empty bucket, [5] bucketed pairs, [6] suspects (particles handed to the exact coverage test)
+enum { C_WILD = 0, C_LAST = 1, C_OOB = 2, C_PAIRS = 3, C_NTILES = 4, C_BUCKETED = 5, C_SUSPECTS = 6 };
+
+__device__ __forceinline__ int pack_off(int ox, int oy, int oz) { return (ox & 0xff) | ((oy & 0xff) << 8) | ((oz & 0xff) << 16); }
+__device__ __forceinline__ void unpack_off(int v, int &ox, int &oy, int &oz) {
+    ox = (int)(signed char)(v & 0xff);
+    oy = (int)(signed char)((v >> 8) & 0xff);
+    oz = (int)(signed char)((v >> 16) & 0xff);
+}
+__device__ __forceinline__ int pymod(int a, int n) {
+    int r = a % n;
+    return r < 0 ? r + n : r;
+}
+__device__ __forceinline__ int wrap_once(int c, int n) {   // c in (-n, 2n) -> [0, n)
+    if ((n & (n - 1)) == 0) return c & (n - 1);
+    c += c < 0 ? n : 0;
+    c -= c >= n ? n : 0;
+    return c;
+}
+__device__ __forceinline__ int cvt_rpi(float x) {   // floor(x + 0.5)
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// Tile of this workgroup.  Blocks b, b+8, ... run on the same XCD (and share its 4 MB L2): each XCD works through one
+// contiguous run of tiles, z fastest (a pencil of tiles whose flushes and particle reads are contiguous in memory; compact
+// bricks of tiles per XCD measured 4-15 % slower).
+__device__ __forceinline__ void tile_of_block(int ntx, int nty, int ntz, int &tx, int &ty, int &tz) {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int t = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+    tz = t % ntz;
+    const int tt = t / ntz;
+    ty = tt % nty;
+    tx = tt / nty;
+}
+
+// ------------------------------------------------------------------------------------------------
+// o_T: rounded mean displacement of 64 lattice points (a 4x4x4 sub-grid) of the Lagrangian block at tile T
+__global__ __launch_bounds__(256) void tile_offset_kernel(Geom g, const float *__restrict__ disp, int *__restrict__ toff, int ntiles,
+                                                          int maxoff) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= ntiles) return;
+    const int ntz = g.nz / MCPM_TILE, nty = g.ny / MCPM_TILE;
+    const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
+    int gx = tx * MCPM_TILE + 2 + 4 * (lane >> 4) - g.xoff;
+    const int gy = ty * MCPM_TILE + 2 + 4 * ((lane >> 2) & 3), gz = tz * MCPM_TILE + 2 + 4 * (lane & 3);
+    if (g.xslab) gx = min(max(gx, 0), g.px - 1);   // ghost tiles: the nearest lattice plane
+    const P3 d = load3(disp, ((int64_t)gx * g.ny + gy) * g.nz + gz);
+    float sx = d.x, sy = d.y, sz = d.z;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o);
+        sy += __shfl_xor(sy, o);
+        sz += __shfl_xor(sz, o);
+    }
+    if (lane == 0) {
+        const float m = (float)maxoff;   // fmaxf / fminf return the non-NaN operand: a NaN mean gives a finite offset
+        toff[tile] = pack_off((int)rintf(fminf(fmaxf(sx * (1.f / 64.f), -m), m)), (int)rintf(fminf(fmaxf(sy * (1.f / 64.f), -m), m)),
+                              (int)rintf(fminf(fmaxf(sz * (1.f / 64.f), -m), m)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scale of the weighted fixed-point accumulators: S = 2^(28 - e), 2^e <= max|w| < 2^(e+1): one deposit is below 2^29, an
+// int64 cell holds 2^34 of them (n < 2^31 particles x 8 corners).  mode: 0 = all weights zero, 1 = fixed point, 2 = non-finite
+struct TScale {
+    float S;
+    double Sinv;
+    int mode;
+};
+__device__ __forceinline__ TScale tile_scale(const unsigned *__restrict__ wmax_bits) {
+    unsigned wb = wmax_bits[(threadIdx.x & (MCPM_FX_SLOTS - 1)) * MCPM_FX_STRIDE];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wb = max(wb, (unsigned)__shfl_xor((int)wb, o));
+    TScale r;
+    int be = (int)(wb >> 23);
+    r.mode = wb == 0u ? 0 : (be >= 255 ? 2 : 1);
+    be = min(max(be, 30), 254);            // tiny maxima (< 2^-97): the scale is capped, absolute resolution 2^-125
+    const int e = be - 127;
+    r.S = __uint_as_float((unsigned)(127 + 28 - e) << 23);
+    r.Sinv = __longlong_as_double((long long)(1023 - 28 + e) << 52);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lists shared by the kernels below
+struct TileLists {
+    const int *toff;   // packed window offsets per tile
+    int *bcnt;         // bucket fill counts per tile (zeroed by the host before the paint)
+    int *bucket;       // [tile][cap] particle indices
+    int cap;
+    int *nonempty;     // tiles whose bucket received something (cnts[C_NTILES] of them): what the bucket kernels walk
+    int *list;         // wild particles from the front, suspects from the back (a particle is one or the other: capacity Np)
+    int listcap;
+    int *cnts;
+};
+
+__device__ __forceinline__ void append_wild(const TileLists &L, int gi) {
+    const int k = atomicAdd(L.cnts + C_WILD, 1);
+    if (k < L.listcap) L.list[k] = gi;      // at most one entry per particle: cannot overflow
+}
+
+// Suspects are staged in LDS (one global atomic per workgroup instead of one per suspect: a single global counter serialised
+// the kernel as soon as a few per cent of the particles were suspects); `sus`: MCPM_SUS ints + the count in sus[MCPM_SUS].
+#define MCPM_SUS 1024
+__device__ __forceinline__ void append_suspect(const TileLists &L, int *sus, int gi) {
+    const int k = atomicAdd(sus + MCPM_SUS, 1);
+    if (k < MCPM_SUS) sus[k] = gi;
+    else {
+        const int kg = atomicAdd(L.cnts + C_SUSPECTS, 1);
+        if (kg < L.listcap) L.list[L.listcap - 1 - kg] = gi;
+    }
+}
+// after a barrier: moves the staged suspects to the global list (sus[MCPM_SUS + 1]: scratch word for the base index)
+__device__ __forceinline__ void flush_suspects(const TileLists &L, int *sus) {
+    const int n = min(sus[MCPM_SUS], MCPM_SUS);
+    if (n == 0) return;
+    if (threadIdx.x == 0) sus[MCPM_SUS + 1] = atomicAdd(L.cnts + C_SUSPECTS, n);
+    __syncthreads();
+    const int base = sus[MCPM_SUS + 1];
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        if (base + i < L.listcap) L.list[L.listcap - 1 - (base + i)] = sus[i];
+}
+
+// The tiles the CIC stencil of one particle touches whose window does NOT contain its lattice point.  (tx, ty, tz): home
+// tile of the lattice point, (r): lattice point relative to that tile's origin, (i): floor of the displacement.
+// f(tile index, base cell relative to that tile's origin) is called for each such tile.
+template <int H, class F>
+__device__ __forceinline__ void for_uncovered(const Geom &g, const TileLists &L, int tx, int ty, int tz, int ntx, int nty, int ntz,
+                                              int oself, int rx, int ry, int rz, int ix, int iy, int iz, F f) {
+    constexpr int W = MCPM_TILE + 2 * H + 1;
+    const int cx = rx + ix, cy = ry + iy, cz = rz + iz;
+    const int d0x = cx >> 4, d0y = cy >> 4, d0z = cz >> 4, mx = cx & 15, my = cy & 15, mz = cz & 15;
+    const int nax = mx == 15 ? 2 : 1, nay = my == 15 ? 2 : 1, naz = mz == 15 ? 2 : 1;
+    for (int a = 0; a < nax; ++a) {
+        const int dtx = d0x + a, rlx = a ? -1 - ix : mx - ix;
+        int Tx = tx + dtx;
+        if (g.xslab) {
+            if (Tx < 0 || Tx >= ntx) continue;   // beyond the ghost planes: such particles are "wild" (see the callers)
+        } else
+            Tx = pymod(Tx, ntx);
+        for (int b = 0; b < nay; ++b) {
+            const int dty = d0y + b, rly = b ? -1 - iy : my - iy;
+            const int Ty = pymod(ty + dty, nty);
+            for (int e = 0; e < naz; ++e) {
+                const int dtz = d0z + e, rlz = e ? -1 - iz : mz - iz;
+                const int Tz = pymod(tz + dtz, ntz);
+                const int tidx = (Tx * nty + Ty) * ntz + Tz;
+                int ox, oy, oz;
+                unpack_off((dtx | dty | dtz) == 0 || !L.toff ? oself : L.toff[tidx], ox, oy, oz);
+                const bool covered = (unsigned)(rlx + ox + H + 1) < (unsigned)W && (unsigned)(rly + oy + H + 1) < (unsigned)W &&
+                                     (unsigned)(rlz + oz + H + 1) < (unsigned)W;
+                if (!covered) f(tidx, a ? -1 : mx, b ? -1 : my, e ? -1 : mz);
+            }
+        }
+    }
+}
+
+// particles the tiled kernels leave to the global-atomic kernel: non-finite / absurd displacements, and (slab mode) base
+// cells beyond the ghost planes (clamped and counted there)
+__device__ __forceinline__ bool is_wild(const Geom &g, const P3 &d, int x0, int rx) {
+    const bool tame = fabsf(d.x) < MCPM_TAME && fabsf(d.y) < MCPM_TAME && fabsf(d.z) < MCPM_TAME;   // NaN compares false
+    if (!tame) return true;
+    if (g.xslab) {
+        const int cxg = x0 + rx + (int)floorf(d.x);
+        return cxg < 0 || cxg > g.nx - 2;
+    }
+    return false;
+}
+
+// Exact coverage test of the suspects: append each to the bucket of every tile whose window misses it.  A full bucket keeps
+// counting (bcnt > cap marks the tile for the repair pass, which then deposits ALL of that tile's pairs).
+template <int H>
+__global__ __launch_bounds__(256) void coverage_duty_kernel(Geom g, const float *__restrict__ disp, TileLists L) {
+    const int ns = min(L.cnts[C_SUSPECTS], L.listcap);
+    const int ntx = g.nx / MCPM_TILE, nty = g.ny / MCPM_TILE, ntz = g.nz / MCPM_TILE;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < ns; k += gridDim.x * blockDim.x) {
+        const int gi = L.list[L.listcap - 1 - k];
+        const int qz = gi % g.nz, r = gi / g.nz, qy = r % g.ny, qx = r / g.ny + g.xoff;   // lattice == mesh
+        const int tx = qx >> 4, ty = qy >> 4, tz = qz >> 4;
+        const P3 d = load3(disp, gi);
+        if (is_wild(g, d, tx * MCPM_TILE, qx & 15)) {
+            append_wild(L, gi);
+            continue;
+        }
+        for_uncovered<H>(g, L, tx, ty, tz, ntx, nty, ntz, L.toff ? L.toff[(tx * nty + ty) * ntz + tz] : 0, qx & 15, qy & 15, qz & 15,
+                         (int)floorf(d.x), (int)floorf(d.y), (int)floorf(d.z), [&](int tidx, int, int, int) {
+                             const int kb = atomicAdd(L.bcnt + tidx, 1);
+                             if (kb == 0) L.nonempty[atomicAdd(L.cnts + C_NTILES, 1)] = tidx;
+                             if (kb < L.cap) L.bucket[(int64_t)tidx * L.cap + kb] = gi;
+                             else atomicAdd(L.cnts + C_PAIRS, 1);
+                         });
+    }
+}
+
+// Range of the window offsets over the 27 tiles around (tx, ty, tz) (the destinations of every home particle displaced by
+// less than a tile): min in omin[3], max in omax[3].  Reduced by the first wave, broadcast through six LDS words.
+__device__ __forceinline__ void neighbour_offset_range(const Geom &g, const TileLists &L, int tx, int ty, int tz, int ntx, int nty,
+                                                       int ntz, int *sh27, int (&omin)[3], int (&omax)[3]) {
+    if (threadIdx.x < 64) {
+        int lo[3] = {127, 127, 127}, hi[3] = {-127, -127, -127};
+        if (threadIdx.x < 27) {
+            const int a = (int)threadIdx.x / 9 - 1, b = ((int)threadIdx.x / 3) % 3 - 1, e = (int)threadIdx.x % 3 - 1;
+            const int Tx = g.xslab ? min(max(tx + a, 0), ntx - 1) : pymod(tx + a, ntx);
+            unpack_off(L.toff[(Tx * nty + pymod(ty + b, nty)) * ntz + pymod(tz + e, ntz)], lo[0], lo[1], lo[2]);
+            hi[0] = lo[0]; hi[1] = lo[1]; hi[2] = lo[2];
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                lo[c] = min(lo[c], __shfl_xor(lo[c], o));
+                hi[c] = max(hi[c], __shfl_xor(hi[c], o));
+            }
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sh27[c] = lo[c];
+                sh27[3 + c] = hi[c];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        omin[c] = sh27[c];
+        omax[c] = sh27[3 + c];
+    }
+}
+
+// Conservative form of the coverage test, as cheap as the round-1 outlier test: a particle of the home block is covered by
+// EVERY tile its stencil touches if |floor(d)_a - o_T',a| <= H on each axis for each of them, which holds if
+// |floor(d)_a - o_a| <= H - D_a with o the home tile's offset and D_a the largest difference between o_a and the offsets of
+// the 27 neighbours (0 everywhere when the windows are not centred).  lo / hi: that interval as floats, per axis.
+template <int H>
+__device__ __forceinline__ void sure_interval(int o, int omin, int omax, float &lo, float &hi) {
+    const int D = max(omax - o, o - omin);
+    lo = (float)(o - (H - D));
+    hi = (float)(o + (H - D));
+}
+
+// window point j (flat, z fastest) of a tile whose window offset is (ox, oy, oz): lattice point relative to the tile (r),
+// flat lattice index gi (-1: no such lattice point)
+template <int H>
+__device__ __forceinline__ int window_point(const Geom &g, int j, int x0, int y0, int z0, int ox, int oy, int oz, int &rx, int &ry,
+                                            int &rz) {
+    constexpr int W = MCPM_TILE + 2 * H + 1;
+    const int jz = j % W, r = j / W, jy = r % W, jx = r / W;
+    rx = jx - (H + 1) - ox;
+    ry = jy - (H + 1) - oy;
+    rz = jz - (H + 1) - oz;
+    int gx = x0 + rx;
+    if (g.xslab) {  // ghost-extended slab: lattice planes are mesh planes [xoff, xoff + px), no wrap
+        gx -= g.xoff;
+        if ((unsigned)gx >= (unsigned)g.px) return -1;
+    } else
+        gx = wrap_once(gx, g.nx);      // |window offset| <= 8 + H + 1 < n: one wrap suffices
+    const int gy = wrap_once(y0 + ry, g.ny), gz = wrap_once(z0 + rz, g.nz);
+    return (gx * g.ny + gy) * g.nz + gz;
+}
+
+// ------------------------------------------------------------------------------------------------
+// density paint.  WMODE 0: unweighted (2^-30 fixed point, scalar weight applied at the flush); 1: weighted, fixed point with
+// the max|w| scale; 2: weighted, f64 accumulators (non-finite weights only: runs when tile_scale().mode == 2, WMODE 1 otherwise)
+// (amdgpu_num_sgpr: with more than 80 scalar registers a CU admits 7 waves per SIMD instead of 8, i.e. three of these
+// 512-thread workgroups instead of four -- measured +45 % on the kernel; MI355X_MICROARCH.md "Residency")
+template <int H, int WMODE, int THREADS, int U>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void paint_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
+                                                             int64_t wstride, float wscalar, float *__restrict__ mesh,
+                                                             int accumulate, TileLists L, const unsigned *__restrict__ wmax_bits,
+                                                             int duty) {
+    constexpr int B = MCPM_TILE, W = B + 2 * H + 1, NW = W * W * W, NT = B * B * B;
+    __shared__ u64 tile[NT];
+    __shared__ int sh27[27];
+    __shared__ int sus[MCPM_SUS + 2];
+    double *dtile = reinterpret_cast<double *>(tile);
+    TScale sc = {1073741824.f, 9.313225746154785e-10, 1};
+    if (WMODE != 0) {
+        sc = tile_scale(wmax_bits);
+        if ((WMODE == 1 && sc.mode == 2) || (WMODE == 2 && sc.mode != 2)) return;   // the other instantiation paints
+    }
+    const int ntx = g.nx / B, nty = g.ny / B, ntz = g.nz / B;
+    int tx, ty, tz;
+    tile_of_block(ntx, nty, ntz, tx, ty, tz);
+    const int x0 = tx * B, y0 = ty * B, z0 = tz * B;
+    for (int i = threadIdx.x; i < NT; i += THREADS) tile[i] = 0ull;
+    if (threadIdx.x == 0) sus[MCPM_SUS] = 0;
+    int ox = 0, oy = 0, oz = 0;
+    float slo[3] = {(float)-H, (float)-H, (float)-H}, shi[3] = {(float)H, (float)H, (float)H};
+    if (L.toff) {   // windows centred on the bulk displacement (optional)
+        unpack_off(L.toff[(tx * nty + ty) * ntz + tz], ox, oy, oz);
+        int omin[3], omax[3];
+        neighbour_offset_range(g, L, tx, ty, tz, ntx, nty, ntz, sh27, omin, omax);
+        sure_interval<H>(ox, omin[0], omax[0], slo[0], shi[0]);
+        sure_interval<H>(oy, omin[1], omax[1], slo[1], shi[1]);
+        sure_interval<H>(oz, omin[2], omax[2], slo[2], shi[2]);
+    }
+    __syncthreads();
+
+    for (int j0 = threadIdx.x; j0 < NW; j0 += THREADS * U) {
+        P3 d[U];
+        float wt[U];
+        int rxs[U], rys[U], rzs[U], gis[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * THREADS;
+            gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
+            if (gis[u] >= 0) {
+                d[u] = load3(disp, gis[u]);
+                wt[u] = WMODE ? w[(int64_t)gis[u] * wstride] : 1.f;
+            } else {
+                d[u] = P3{0.f, 0.f, 0.f};
+                wt[u] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (gis[u] < 0) continue;
+            const int rx = rxs[u], ry = rys[u], rz = rzs[u];
+            const float fx = floorf(d[u].x), fy = floorf(d[u].y), fz = floorf(d[u].z);
+            // Coverage duty: six compares (what the round-1 outlier test cost; NaN fails them).  What they cannot clear goes
+            // to the suspect list of the home tile, for the exact test of coverage_duty_kernel (400 instructions: inlined in
+            // this unrolled loop, and entered by most waves, they doubled the kernel's time).
+            if (!(fx >= slo[0] && fx <= shi[0] && fy >= slo[1] && fy <= shi[1] && fz >= slo[2] && fz <= shi[2])) {
+                if (duty && (unsigned)rx < (unsigned)B && (unsigned)ry < (unsigned)B && (unsigned)rz < (unsigned)B) append_suspect(L, sus, gis[u]);
+                if (!(fabsf(d[u].x) < MCPM_TAME && fabsf(d[u].y) < MCPM_TAME && fabsf(d[u].z) < MCPM_TAME)) continue;   // wild
+            }
+            const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
+            if (g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2)) continue;   // beyond the ghost planes: wild (clamped + counted there)
+            if (cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
+                const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
+                const float s0 = WMODE == 2 ? wt[u] : (WMODE == 1 ? wt[u] * sc.S : sc.S);   // exact power-of-two scaling
+                const float kx[2] = {(1.f - tx1) * s0, tx1 * s0}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
+                // one LDS base address, corners at immediate offsets; a corner outside the tile is skipped
+                const bool vx[2] = {cx >= 0, cx < B - 1}, vy[2] = {cy >= 0, cy < B - 1}, vz[2] = {cz >= 0, cz < B - 1};
+                const int base = (cx * B + cy) * B + cz;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const float wxy = kx[a] * ky[bb];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            if (vx[a] && vy[bb] && vz[e]) {
+                                const int q = base + (a * B + bb) * B + e;
+                                if (WMODE == 2) atomicAdd(dtile + q, (double)(wxy * kz[e]));
+                                else if (WMODE == 1) atomicAdd(tile + q, (u64)(long long)cvt_rpi(wxy * kz[e]));
+                                else atomicAdd(tile + q, (u64)(unsigned)cvt_rpi(wxy * kz[e]));
+                            }
+                    }
+            }
+        }
+    }
+    // home lattice points outside the own window (|o| > H on some axis): all of them are suspects
+    if (duty && (abs(ox) > H || abs(oy) > H || abs(oz) > H)) {
+        for (int j = threadIdx.x; j < NT; j += THREADS) {
+            const int rz = j % B, rr = j / B, ry = rr % B, rx = rr / B;
+            const bool inwin = (unsigned)(rx + ox + H + 1) < (unsigned)W && (unsigned)(ry + oy + H + 1) < (unsigned)W &&
+                               (unsigned)(rz + oz + H + 1) < (unsigned)W;
+            if (inwin) continue;
+            int gx = x0 + rx;
+            if (g.xslab) {
+                gx -= g.xoff;
+                if ((unsigned)gx >= (unsigned)g.px) continue;
+            }
+            const int gi = (gx * g.ny + y0 + ry) * g.nz + z0 + rz;
+            append_suspect(L, sus, gi);
+        }
+    }
+    __syncthreads();
+    flush_suspects(L, sus);
+
+    const double s = WMODE == 0 ? (double)wscalar * sc.Sinv : sc.Sinv;
+    for (int i = threadIdx.x; i < NT / 4; i += THREADS) {
+        const int lz = (i % (B / 4)) * 4, r = i / (B / 4), ly = r % B, lx = r / B;
+        float4 v;
+        if (WMODE == 2) v = make_float4((float)dtile[4 * i], (float)dtile[4 * i + 1], (float)dtile[4 * i + 2], (float)dtile[4 * i + 3]);
+        else if (WMODE == 1)
+            v = make_float4((float)((double)(long long)tile[4 * i] * s), (float)((double)(long long)tile[4 * i + 1] * s),
+                            (float)((double)(long long)tile[4 * i + 2] * s), (float)((double)(long long)tile[4 * i + 3] * s));
+        else
+            v = make_float4((float)((double)tile[4 * i] * s), (float)((double)tile[4 * i + 1] * s), (float)((double)tile[4 * i + 2] * s),
+                            (float)((double)tile[4 * i + 3] * s));
+        float4 *dst = reinterpret_cast<float4 *>(mesh + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz);
+        if (accumulate) {
+            const float4 o = *dst;
+            v.x += o.x;
+            v.y += o.y;
+            v.z += o.z;
+            v.w += o.w;
+        }
+        *dst = v;
+    }
+}
+
+// base cell of a bucketed particle relative to the tile origin, brought into [-1, n-1) (the tile sees it at c in [-1, 16))
+__device__ __forceinline__ bool bucket_cell(const Geom &g, int gi, const P3 &d, int x0, int y0, int z0, int &cx, int &cy, int &cz) {
+    const int qz = gi % g.nz, r = gi / g.nz, qy = r % g.ny, qx = r / g.ny;   // lattice == mesh
+    cx = qx + g.xoff + (int)floorf(d.x) - x0;
+    if (!g.xslab) cx = pymod(cx + 1, g.nx) - 1;
+    cy = pymod(qy + (int)floorf(d.y) - y0 + 1, g.ny) - 1;
+    cz = pymod(qz + (int)floorf(d.z) - z0 + 1, g.nz) - 1;
+    return cx >= -1 && cx < MCPM_TILE && cy >= -1 && cy < MCPM_TILE && cz >= -1 && cz < MCPM_TILE;
+}
+
+// deposits the bucket of every tile through an LDS integer tile and adds the touched cells to the mesh
+template <int WMODE>
+__global__ __launch_bounds__(256) void paint_bucket_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
+                                                           int64_t wstride, float wscalar, float *__restrict__ mesh, TileLists L,
+                                                           const unsigned *__restrict__ wmax_bits) {
+    constexpr int B = MCPM_TILE, NT = B * B * B;
+    const int ntl = L.cnts[C_NTILES];
+    if ((int)blockIdx.x >= ntl) return;
+    TScale sc = {1073741824.f, 9.313225746154785e-10, 1};
+    if (WMODE != 0) {
+        sc = tile_scale(wmax_bits);
+        if ((WMODE == 1 && sc.mode == 2) || (WMODE == 2 && sc.mode != 2)) return;
+    }
+    __shared__ u64 tile[NT];
+    double *dtile = reinterpret_cast<double *>(tile);
+    const int ntz = g.nz / B, nty = g.ny / B;
+    const double s = WMODE == 0 ? (double)wscalar * sc.Sinv : sc.Sinv;
+    for (int it = blockIdx.x; it < ntl; it += gridDim.x) {
+        const int t = L.nonempty[it];
+        const int cnt = L.bcnt[t];
+        if (cnt > L.cap) continue;     // an overflowed bucket is dropped: the repair pass deposits that tile's pairs
+        const int x0 = (t / (ntz * nty)) * B, y0 = ((t / ntz) % nty) * B, z0 = (t % ntz) * B;
+        __syncthreads();
+        for (int i = threadIdx.x; i < NT; i += 256) tile[i] = 0ull;
+        __syncthreads();
+        for (int k = threadIdx.x; k < cnt; k += 256) {
+            const int gi = L.bucket[(int64_t)t * L.cap + k];
+            const P3 d = load3(disp, gi);
+            int cx, cy, cz;
+            if (!bucket_cell(g, gi, d, x0, y0, z0, cx, cy, cz)) continue;
+            const float wt = WMODE ? w[(int64_t)gi * wstride] : 1.f;
+            const float tx1 = d.x - floorf(d.x), ty1 = d.y - floorf(d.y), tz1 = d.z - floorf(d.z);
+            const float s0 = WMODE == 2 ? wt : (WMODE == 1 ? wt * sc.S : sc.S);
+            const float kx[2] = {(1.f - tx1) * s0, tx1 * s0}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int x = cx + a, y = cy + bb, z = cz + e;
+                        if ((unsigned)x < (unsigned)B && (unsigned)y < (unsigned)B && (unsigned)z < (unsigned)B) {
+                            const int q = (x * B + y) * B + z;
+                            const float v = kx[a] * ky[bb] * kz[e];
+                            if (WMODE == 2) atomicAdd(dtile + q, (double)v);
+                            else if (WMODE == 1) atomicAdd(tile + q, (u64)(long long)cvt_rpi(v));
+                            else atomicAdd(tile + q, (u64)(unsigned)cvt_rpi(v));
+                        }
+                    }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NT; i += 256) {
+            const u64 a = tile[i];
+            if (a == 0ull) continue;
+            const int lz = i % B, r = i / B, ly = r % B, lx = r / B;
+            const float v = WMODE == 2 ? (float)dtile[i] : (WMODE == 1 ? (float)((double)(long long)a * s) : (float)((double)a * s));
+            mesh[((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz] += v;   // this workgroup alone writes tile t here
+        }
+        if (threadIdx.x == 0) atomicAdd(L.cnts + C_BUCKETED, cnt);
+    }
+}
+
+// What the integer tiles could not take, with f32 global atomics (counted): (1) wild particles, all eight corners;
+// (2) repair pass, only when some bucket overflowed: every (particle, tile) pair whose tile is marked (bcnt > cap) and whose
+// window misses the particle -- the same predicate as the coverage duty, re-evaluated over all particles.
+template <int H, int NC>
+__global__ __launch_bounds__(256) void paint_leftover_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
+                                                             int64_t wstride, float wscalar, float *__restrict__ mesh, int64_t M,
+                                                             TileLists L) {
+    const int nw = min(L.cnts[C_WILD], L.listcap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) L.cnts[C_LAST] = L.cnts[C_WILD] + L.cnts[C_PAIRS];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nw; k += gridDim.x * blockDim.x) {
+        const int gi = L.list[k];
+        PIdx pi;
+        pi.i = gi;
+        pi.ipz = gi % g.nz;
+        const int r = gi / g.nz;
+        pi.ipy = r % g.ny;
+        pi.ipx = r / g.ny;
+        pi.valid = true;
+        const P3 d = load3(disp, gi);
+        float wt[3];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) wt[c] = w ? w[(int64_t)gi * wstride + c] : wscalar;
+        if (!(fabsf(d.x) < 3.0e4f && fabsf(d.y) < 3.0e4f && fabsf(d.z) < 3.0e4f)) {
+            // non-finite position, or beyond the int16 index range of the reference (nbody.py:369): no cell can be named;
+            // the first cell of every component is made non-finite so that the caller sees it
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) atomicAdd(mesh + cc * M, __int_as_float(0x7fc00000));
+            continue;
+        }
+        int c[3];
+        float f[3];
+        locate<MCPM_POS_LATTICE, 2>(g, pi, d, c, f);
+        // slab mode: a particle displaced beyond the ghost planes cannot be deposited on this rank; it is clamped to the
+        // edge and counted (mcpm_plan_slab_oob) so that the host can widen the ghost region
+        if (g.xslab && (c[0] < 0 || c[0] > g.nx - 2)) atomicAdd(L.cnts + C_OOB, 1);
+        Stencil<2> s(g, c);
+        const float kx[2] = {1.f - f[0], f[0]}, ky[2] = {1.f - f[1], f[1]}, kz[2] = {1.f - f[2], f[2]};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float k3 = kx[a] * ky[b] * kz[e];
+                    float *m = mesh + s.xo[a] + s.yo[b] + s.zo[e];
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) atomicAdd(m + cc * M, wt[cc] * k3);
+                }
+    }
+    if (L.cnts[C_PAIRS] == 0) return;
+    const int ntx = g.nx / MCPM_TILE, nty = g.ny / MCPM_TILE, ntz = g.nz / MCPM_TILE;
+    const int64_t np = (int64_t)g.px * g.py * g.pz;
+    for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < np; gi += (int64_t)gridDim.x * blockDim.x) {
+        const int qz = (int)(gi % g.nz), r = (int)(gi / g.nz), qy = r % g.ny, qx = r / g.ny + g.xoff;
+        const P3 d = load3(disp, gi);
+        const int tx = qx >> 4, ty = qy >> 4, tz = qz >> 4;
+        if (is_wild(g, d, tx * MCPM_TILE, qx & 15)) continue;
+        const float fx = floorf(d.x), fy = floorf(d.y), fz = floorf(d.z);
+        const float kx[2] = {1.f - (d.x - fx), d.x - fx}, ky[2] = {1.f - (d.y - fy), d.y - fy}, kz[2] = {1.f - (d.z - fz), d.z - fz};
+        for_uncovered<H>(g, L, tx, ty, tz, ntx, nty, ntz, L.toff ? L.toff[(tx * nty + ty) * ntz + tz] : 0, qx & 15, qy & 15, qz & 15, (int)fx, (int)fy,
+                         (int)fz, [&](int tidx, int cx, int cy, int cz) {
+                             if (L.bcnt[tidx] <= L.cap) return;      // that tile's bucket was deposited by the bucket kernel
+                             const int x0 = (tidx / (ntz * nty)) * MCPM_TILE, y0 = ((tidx / ntz) % nty) * MCPM_TILE, z0 = (tidx % ntz) * MCPM_TILE;
+                             float wt[3];
+                             for (int c = 0; c < NC; ++c) wt[c] = w ? w[gi * wstride + c] : wscalar;
+                             for (int a = 0; a < 2; ++a)
+                                 for (int b = 0; b < 2; ++b)
+                                     for (int e = 0; e < 2; ++e) {
+                                         const int x = cx + a, y = cy + b, z = cz + e;
+                                         if ((unsigned)x < (unsigned)MCPM_TILE && (unsigned)y < (unsigned)MCPM_TILE && (unsigned)z < (unsigned)MCPM_TILE) {
+                                             const float k3 = kx[a] * ky[b] * kz[e];
+                                             float *m = mesh + ((int64_t)(x0 + x) * g.ny + (y0 + y)) * g.nz + z0 + z;
+                                             for (int cc = 0; cc < NC; ++cc) atomicAdd(m + cc * M, wt[cc] * k3);
+                                         }
+                                     }
+                         });
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Three weighted paints at once (the adjoint of a three-component read: weights[N][3] -> three meshes M apart).
+//
+// Fixed-point tiles.  An LDS f64 atomic costs about twice a 64-bit integer one under the bank conflicts of real deposits
+// (tools/lds_atomic_bench.hip).  The three weighted corner contributions are rounded to 32-bit fixed point with a common
+// power-of-two scale S = 2^24 / 2^e (2^e <= max|w| < 2^(e+1), so one contribution is below 2^25 and a cell holds 64 maximal
+// ones) and travel in TWO 64-bit integer atomics per corner:
+//     word A = c0 + 2^32 c1        word B = c2 + 2^32 bound,   bound += max_c |contribution_c| / 2^11 + 1 (rounded up)
+// A signed low field added as a sign-extended 64-bit number leaves the high field exact as long as the low field's true sum
+// fits 32 bits, and modular arithmetic makes intermediate wrap-arounds harmless, so the sums are exact integers and
+// independent of the arrival order (bitwise reproducible).  `bound` proves it: a component field can only leave the int32
+// range if sum |contribution| >= 2^31, i.e. bound >= 2^20; the bound field itself cannot overflow (< 2^14 + 1 per deposit,
+// < 2^17 deposits per cell).  A tile holding a cell with bound >= 2^19 is not written: it is appended to the redo list and
+// painted by the f64 kernel.  Non-finite or tiny (< 2^-97) max|w| sends every tile there.  Rounding: half a unit per deposit
+// = max|w| 2^-25, so the mesh differs from the exact sums by ~1e-8 max|w| per cell.
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ w, int64_t stride, int64_t n, unsigned *__restrict__ out) {
+    float m = 0.f;
+    unsigned bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned b = __float_as_uint(w[i * stride]) & 0x7fffffffu;
+        bad |= b >= 0x7f800000u;
+        m = fmaxf(m, __uint_as_float(b));
+    }
+    unsigned b = bad ? 0x7fc00000u : __float_as_uint(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+    if ((threadIdx.x & 63) == 0 && b) atomicMax(out + (blockIdx.x & (MCPM_FX_SLOTS - 1)) * MCPM_FX_STRIDE, b);
+}
+
+// redo: nullptr = first (fixed-point) pass over all tiles, appending flagged tiles to `redo_out`; otherwise the f64 pass
+// over the tiles listed in redo ([0] = count, then indices).  F64: accumulators are doubles (96 KB) instead of packed fields.
+template <int H, bool F64, int THREADS, int U>
+__global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
+                                                              float *__restrict__ mesh, int64_t M, int accumulate, TileLists L,
+                                                              const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out,
+                                                              const int *__restrict__ redo_in, int duty) {
+    constexpr int B = MCPM_TILE, W = B + 2 * H + 1, NW = W * W * W, NT = B * B * B;
+    __shared__ u64 tile[(F64 ? 3 : 2) * NT];   // 64 KB (two workgroups per CU) / 96 KB
+    __shared__ int flagged;
+    __shared__ int sh27[27];
+    __shared__ int sus[MCPM_SUS + 2];
+    double *dtile = reinterpret_cast<double *>(tile);
+    const int ntx = g.nx / B, nty = g.ny / B, ntz = g.nz / B;
+    int tx, ty, tz;
+    if (redo_in) {
+        if ((int)blockIdx.x >= redo_in[0]) return;
+        const int t = redo_in[1 + blockIdx.x];
+        tz = t % ntz;
+        ty = (t / ntz) % nty;
+        tx = t / (ntz * nty);
+    } else
+        tile_of_block(ntx, nty, ntz, tx, ty, tz);
+    const int x0 = tx * B, y0 = ty * B, z0 = tz * B, tidx = (tx * nty + ty) * ntz + tz;
+    int ox = 0, oy = 0, oz = 0;
+    if (L.toff) unpack_off(L.toff[tidx], ox, oy, oz);
+    bool deposit = true;
+    float S = 1.f, Sinv = 1.f;
+    if (!F64) {
+        unsigned wb = wmax_bits[(threadIdx.x & (MCPM_FX_SLOTS - 1)) * MCPM_FX_STRIDE];   // maximum over the slots, in every wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wb = max(wb, (unsigned)__shfl_xor((int)wb, o));
+        const unsigned be = wb >> 23;
+        if (wb == 0u) {              // all weights are zero: the tile is zero (or unchanged); nothing lands anywhere
+            if (!accumulate)
+                for (int i = threadIdx.x; i < 3 * NT / 4; i += THREADS) {
+                    const int cc = i / (NT / 4), ii = i - cc * (NT / 4);
+                    const int lz = (ii % (B / 4)) * 4, r = ii / (B / 4), ly = r % B, lx = r / B;
+                    *reinterpret_cast<float4 *>(mesh + cc * M + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz) =
+                        make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            return;
+        }
+        if (be < 30u || be > 254u) {     // tiny / non-finite weights: the f64 kernel paints this tile; the duty stays here
+            deposit = false;
+            if (threadIdx.x == 0) redo_out[1 + atomicAdd(redo_out, 1)] = tidx;
+        } else {
+            S = __uint_as_float((278u - be) << 23);      // 2^(24-e)
+            Sinv = __uint_as_float((be - 24u) << 23);    // 2^(e-24)
+        }
+    }
+    if (threadIdx.x == 0) {
+        flagged = 0;
+        sus[MCPM_SUS] = 0;
+    }
+    if (deposit)
+        for (int i = threadIdx.x; i < (F64 ? 3 : 2) * NT; i += THREADS) tile[i] = 0ull;
+    float slo[3] = {(float)-H, (float)-H, (float)-H}, shi[3] = {(float)H, (float)H, (float)H};
+    if (L.toff) {
+        int omin[3], omax[3];
+        neighbour_offset_range(g, L, tx, ty, tz, ntx, nty, ntz, sh27, omin, omax);
+        sure_interval<H>(ox, omin[0], omax[0], slo[0], shi[0]);
+        sure_interval<H>(oy, omin[1], omax[1], slo[1], shi[1]);
+        sure_interval<H>(oz, omin[2], omax[2], slo[2], shi[2]);
+    }
+    __syncthreads();
+
+    for (int j0 = threadIdx.x; j0 < NW; j0 += THREADS * U) {
+        P3 d[U], wt[U];
+        int rxs[U], rys[U], rzs[U], gis[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * THREADS;
+            gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
+            if (gis[u] >= 0) {
+                d[u] = load3(disp, gis[u]);
+                wt[u] = load3(w3, gis[u]);
+            } else {
+                d[u] = P3{0.f, 0.f, 0.f};
+                wt[u] = P3{0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (gis[u] < 0) continue;
+            const int rx = rxs[u], ry = rys[u], rz = rzs[u];
+            const float fx = floorf(d[u].x), fy = floorf(d[u].y), fz = floorf(d[u].z);
+            // Coverage duty: six compares (what the round-1 outlier test cost; NaN fails them).  What they cannot clear goes
+            // to the suspect list of the home tile, for the exact test of coverage_duty_kernel (400 instructions: inlined in
+            // this unrolled loop, and entered by most waves, they doubled the kernel's time).
+            if (!(fx >= slo[0] && fx <= shi[0] && fy >= slo[1] && fy <= shi[1] && fz >= slo[2] && fz <= shi[2])) {
+                if (duty && (unsigned)rx < (unsigned)B && (unsigned)ry < (unsigned)B && (unsigned)rz < (unsigned)B) append_suspect(L, sus, gis[u]);
+                if (!(fabsf(d[u].x) < MCPM_TAME && fabsf(d[u].y) < MCPM_TAME && fabsf(d[u].z) < MCPM_TAME)) continue;   // wild
+            }
+            const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
+            if (g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2)) continue;   // beyond the ghost planes: wild (clamped + counted there)
+            if (deposit && cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
+                const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
+                const float kx[2] = {1.f - tx1, tx1}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
+                const bool vx[2] = {cx >= 0, cx < B - 1}, vy[2] = {cy >= 0, cy < B - 1}, vz[2] = {cz >= 0, cz < B - 1};
+                const int base = (cx * B + cy) * B + cz;
+                if (F64) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int bb = 0; bb < 2; ++bb) {
+                            const float kxy = kx[a] * ky[bb];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e)
+                                if (vx[a] && vy[bb] && vz[e]) {
+                                    const float k = kxy * kz[e];
+                                    double *q = dtile + base + (a * B + bb) * B + e;
+                                    atomicAdd(q, (double)(wt[u].x * k));
+                                    atomicAdd(q + NT, (double)(wt[u].y * k));
+                                    atomicAdd(q + 2 * NT, (double)(wt[u].z * k));
+                                }
+                        }
+                } else {
+                    typedef float v2f __attribute__((ext_vector_type(2)));
+                    const float sx = wt[u].x * S, sy = wt[u].y * S, sz = wt[u].z * S;
+                    const float mw = fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)) * (1.f / 2048.f);
+                    const v2f s01 = {sx, sy}, s2m = {sz, mw}, c01 = {0.f, 1.f};     // packed f32 math: two products per instruction
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int bb = 0; bb < 2; ++bb) {
+                            const float kxy = kx[a] * ky[bb];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e)
+                                if (vx[a] && vy[bb] && vz[e]) {
+                                    const float k = kxy * kz[e];
+                                    const v2f kk = {k, k};
+                                    const v2f p01 = s01 * kk, p2m = __builtin_elementwise_fma(s2m, kk, c01);
+                                    const int i0 = cvt_rpi(p01.x), i1 = cvt_rpi(p01.y), i2 = cvt_rpi(p2m.x);
+                                    const unsigned ib = (unsigned)p2m.y;
+                                    const u64 wa = ((u64)(unsigned)(i1 + (i0 >> 31)) << 32) | (unsigned)i0;
+                                    const u64 wbv = ((u64)(ib + (unsigned)(i2 >> 31)) << 32) | (unsigned)i2;
+                                    u64 *q = tile + base + (a * B + bb) * B + e;
+                                    atomicAdd(q, wa);
+                                    atomicAdd(q + NT, wbv);
+                                }
+                        }
+                }
+            }
+        }
+    }
+    if (duty && (abs(ox) > H || abs(oy) > H || abs(oz) > H)) {
+        for (int j = threadIdx.x; j < NT; j += THREADS) {
+            const int rz = j % B, rr = j / B, ry = rr % B, rx = rr / B;
+            const bool inwin = (unsigned)(rx + ox + H + 1) < (unsigned)W && (unsigned)(ry + oy + H + 1) < (unsigned)W &&
+                               (unsigned)(rz + oz + H + 1) < (unsigned)W;
+            if (inwin) continue;
+            int gx = x0 + rx;
+            if (g.xslab) {
+                gx -= g.xoff;
+                if ((unsigned)gx >= (unsigned)g.px) continue;
+            }
+            const int gi = (gx * g.ny + y0 + ry) * g.nz + z0 + rz;
+            append_suspect(L, sus, gi);
+        }
+    }
+    __syncthreads();
+    flush_suspects(L, sus);
+    if (!deposit) return;
+
+    if (!F64) {   // overflow proof: bound field of every cell
+        int over = 0;
+        for (int i = threadIdx.x; i < NT; i += THREADS) {
+            const long long bw = (long long)tile[NT + i];
+            const int c2 = (int)(unsigned)bw;
+            over |= (unsigned)((bw - (long long)c2) >> 32) >= (1u << 19);
+        }
+        if (over) flagged = 1;
+        __syncthreads();
+        if (flagged) {
+            if (threadIdx.x == 0) redo_out[1 + atomicAdd(redo_out, 1)] = tidx;
+            return;
+        }
+    }
+    for (int i = threadIdx.x; i < NT / 4; i += THREADS) {
+        const int lz = (i % (B / 4)) * 4, r = i / (B / 4), ly = r % B, lx = r / B;
+        float v[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (F64) {
+                v[0][q] = (float)dtile[4 * i + q];
+                v[1][q] = (float)dtile[NT + 4 * i + q];
+                v[2][q] = (float)dtile[2 * NT + 4 * i + q];
+            } else {
+                const long long aw = (long long)tile[4 * i + q], bw = (long long)tile[NT + 4 * i + q];
+                const int c0 = (int)(unsigned)aw, c2 = (int)(unsigned)bw;
+                const int c1 = (int)((aw - (long long)c0) >> 32);
+                v[0][q] = (float)c0 * Sinv;
+                v[1][q] = (float)c1 * Sinv;
+                v[2][q] = (float)c2 * Sinv;
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            float4 o = make_float4(v[cc][0], v[cc][1], v[cc][2], v[cc][3]);
+            float4 *dst = reinterpret_cast<float4 *>(mesh + cc * M + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz);
+            if (accumulate) {
+                const float4 old = *dst;
+                o.x += old.x;
+                o.y += old.y;
+                o.z += old.z;
+                o.w += old.w;
+            }
+            *dst = o;
+        }
+    }
+}
+
+// buckets of the three-component paint: int64 fixed point with the max|w| 2^-28 scale (F64 = false), doubles when the
+// weights are non-finite (F64 = true; each instantiation returns at once when the other one applies)
+template <bool F64>
+__global__ __launch_bounds__(256) void paint3_bucket_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
+                                                            float *__restrict__ mesh, int64_t M, TileLists L,
+                                                            const unsigned *__restrict__ wmax_bits) {
+    constexpr int B = MCPM_TILE, NT = B * B * B;
+    const int ntl = L.cnts[C_NTILES];
+    if ((int)blockIdx.x >= ntl) return;
+    const TScale sc = tile_scale(wmax_bits);
+    if (sc.mode == 0 || (F64 ? sc.mode != 2 : sc.mode == 2)) return;
+    __shared__ u64 tile[3 * NT];
+    double *dtile = reinterpret_cast<double *>(tile);
+    const int ntz = g.nz / B, nty = g.ny / B;
+    for (int it = blockIdx.x; it < ntl; it += gridDim.x) {
+        const int t = L.nonempty[it];
+        const int cnt = L.bcnt[t];
+        if (cnt > L.cap) continue;
+        const int x0 = (t / (ntz * nty)) * B, y0 = ((t / ntz) % nty) * B, z0 = (t % ntz) * B;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * NT; i += 256) tile[i] = 0ull;
+        __syncthreads();
+        for (int k = threadIdx.x; k < cnt; k += 256) {
+            const int gi = L.bucket[(int64_t)t * L.cap + k];
+            const P3 d = load3(disp, gi);
+            int cx, cy, cz;
+            if (!bucket_cell(g, gi, d, x0, y0, z0, cx, cy, cz)) continue;
+            const P3 wt = load3(w3, gi);
+            const float tx1 = d.x - floorf(d.x), ty1 = d.y - floorf(d.y), tz1 = d.z - floorf(d.z);
+            const float kx[2] = {1.f - tx1, tx1}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
+            const float s = F64 ? 1.f : sc.S;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int x = cx + a, y = cy + bb, z = cz + e;
+                        if ((unsigned)x < (unsigned)B && (unsigned)y < (unsigned)B && (unsigned)z < (unsigned)B) {
+                            const int q = (x * B + y) * B + z;
+                            const float k3 = kx[a] * ky[bb] * kz[e];
+                            if (F64) {
+                                atomicAdd(dtile + q, (double)(wt.x * k3));
+                                atomicAdd(dtile + NT + q, (double)(wt.y * k3));
+                                atomicAdd(dtile + 2 * NT + q, (double)(wt.z * k3));
+                            } else {
+                                atomicAdd(tile + q, (u64)(long long)cvt_rpi(wt.x * s * k3));
+                                atomicAdd(tile + NT + q, (u64)(long long)cvt_rpi(wt.y * s * k3));
+                                atomicAdd(tile + 2 * NT + q, (u64)(long long)cvt_rpi(wt.z * s * k3));
+                            }
+                        }
+                    }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * NT; i += 256) {
+            const u64 a = tile[i];
+            if (a == 0ull) continue;
+            const int cc = i / NT, ii = i - cc * NT;
+            const int lz = ii % B, r = ii / B, ly = r % B, lx = r / B;
+            const float v = F64 ? (float)dtile[i] : (float)((double)(long long)a * sc.Sinv);
+            mesh[cc * M + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz] += v;
+        }
+        if (threadIdx.x == 0) atomicAdd(L.cnts + C_BUCKETED, cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+static bool tiled_geometry_ok(const mcpm_plan *p, const void *mesh) {
+    const Geom &g = p->g;
+    if (!g.same_lattice) return false;
+    if (g.nx % MCPM_TILE || g.ny % MCPM_TILE || g.nz % MCPM_TILE) return false;
+    // three tiles per axis at least: a tile and the window of its neighbour must not meet around the periodic box
+    if (g.nx < 3 * MCPM_TILE || g.ny < 3 * MCPM_TILE || g.nz < 3 * MCPM_TILE) return false;
+    if (((uintptr_t)mesh) & 15) return false;
+    return p->bucket != nullptr;
+}
+
+static TileLists tile_lists(const mcpm_plan *p) {
+    return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count};
+}
+
+static void tiled_prologue(mcpm_plan *p, const float *pos) {
+    const Geom &g = p->g;
+    const int ntiles = (g.nx / MCPM_TILE) * (g.ny / MCPM_TILE) * (g.nz / MCPM_TILE);
+    (void)hipMemsetAsync(p->bucket_cnt, 0, sizeof(int) * ntiles, p->stream);
+    (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int), p->stream);                    // wild
+    (void)hipMemsetAsync(p->outlier_count + C_PAIRS, 0, sizeof(int) * 4, p->stream);      // full-bucket appends, tiles, bucketed, suspects
+    if (p->centre) tile_offset_kernel<<<(ntiles + 3) / 4, 256, 0, p->stream>>>(g, pos, p->tile_off, ntiles, 8);
+}
+
+#define DISPATCH_H(HH, CALL) \
+    switch (HH) {            \
+        case 1: CALL(1) break; \
+        case 2: CALL(2) break; \
+        case 3: CALL(3) break; \
+        case 4: CALL(4) break; \
+        default: CALL(6) break; \
+    }
+
+// Tiled density paint if the geometry allows; returns false if the caller must use the generic path.
+bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t wstride, float wscalar, float *mesh, int accumulate) {
+    if (!tiled_geometry_ok(p, mesh)) return false;
+    const Geom &g = p->g;
+    const unsigned nb = (unsigned)((g.nx / MCPM_TILE) * (g.ny / MCPM_TILE) * (g.nz / MCPM_TILE));
+    tiled_prologue(p, pos);
+    const TileLists L = tile_lists(p);
+    const unsigned nbk = nb < 1024u ? nb : 1024u;   // bucket kernels walk the list of non-empty buckets
+    if (w) {
+        (void)hipMemsetAsync(p->gx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream);
+        absmax_kernel<<<2048, 256, 0, p->stream>>>(w, wstride, p->Np, p->gx_wmax);
+#define CALLW(HH)                                                                                                                  \
+    {                                                                                                                              \
+        paint_tile_kernel<HH, 1, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+        paint_tile_kernel<HH, 2, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+    }
+        DISPATCH_H(p->halo, CALLW)
+#undef CALLW
+#define CALLD(HH) coverage_duty_kernel<HH><<<1024, 256, 0, p->stream>>>(g, pos, L);
+        DISPATCH_H(p->halo, CALLD)
+#undef CALLD
+        paint_bucket_kernel<1><<<nbk, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, L, p->gx_wmax);
+        paint_bucket_kernel<2><<<nbk, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, L, p->gx_wmax);
+    } else {
+#define CALLU(HH) paint_tile_kernel<HH, 0, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
+        DISPATCH_H(p->halo, CALLU)
+#undef CALLU
+#define CALLD(HH) coverage_duty_kernel<HH><<<1024, 256, 0, p->stream>>>(g, pos, L);
+        DISPATCH_H(p->halo, CALLD)
+#undef CALLD
+        paint_bucket_kernel<0><<<nbk, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, L, p->gx_wmax);
+    }
+#define CALLL(HH) paint_leftover_kernel<HH, 1><<<1024, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L);
+    DISPATCH_H(p->halo, CALLL)
+#undef CALLL
+    return true;
+}
+
+// Tiled three-component paint; returns false if the caller must paint the components one by one.
+bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, float *meshes3, int accumulate) {
+    if (!tiled_geometry_ok(p, meshes3) || ((p->M * 4) & 15) || p->paint3_variant < 0) return false;
+    const Geom &g = p->g;
+    const unsigned nb = (unsigned)((g.nx / MCPM_TILE) * (g.ny / MCPM_TILE) * (g.nz / MCPM_TILE));
+    if (p->fx_tiles < (int)nb) return false;
+    tiled_prologue(p, pos);
+    const TileLists L = tile_lists(p);
+    const unsigned nbk = nb < 1024u ? nb : 1024u;
+    (void)hipMemsetAsync(p->fx_redo, 0, sizeof(int), p->stream);
+    if (p->fx_src != weights3) {   // max|w| not left behind by the kernel that produced the weights
+        (void)hipMemsetAsync(p->fx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream);
+        absmax_kernel<<<2048, 256, 0, p->stream>>>(weights3, 1, 3 * p->Np, p->fx_wmax);
+    }
+    p->fx_src = nullptr;
+    if (p->paint3_variant == 4) {   // fixed-point tiles; the tiles they flag (and every tile if max|w| is unusable) in f64
+#define CALLFX(HH)                                                                                                                \
+    {                                                                                                                             \
+        paint3_tile_kernel<HH, false, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
+        paint3_tile_kernel<HH, true, 1024, 4><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, p->fx_redo, 0); \
+    }
+        DISPATCH_H(p->halo, CALLFX)
+#undef CALLFX
+    } else {   // f64 tiles everywhere (A/B and tests)
+#define CALLF64(HH) paint3_tile_kernel<HH, true, 1024, 4><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, nullptr, 1);
+        DISPATCH_H(p->halo, CALLF64)
+#undef CALLF64
+    }
+#define CALLD(HH) coverage_duty_kernel<HH><<<1024, 256, 0, p->stream>>>(g, pos, L);
+    DISPATCH_H(p->halo, CALLD)
+#undef CALLD
+    paint3_bucket_kernel<false><<<nbk, 256, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, L, p->fx_wmax);
+    paint3_bucket_kernel<true><<<nbk, 256, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, L, p->fx_wmax);
+#define CALLL(HH) paint_leftover_kernel<HH, 3><<<1024, 256, 0, p->stream>>>(g, pos, weights3, 3, 0.f, meshes3, p->M, L);
+    DISPATCH_H(p->halo, CALLL)
+#undef CALLL
+    return true;
+}

@@ -77,6 +77,11 @@ class Plan:
     def call(self, name, *args):
         check(getattr(lib, name)(self.h, *args), self.h, name)
 
+    def last_bucketed(self):
+        n = C.c_int64()
+        self.call("mcpm_plan_last_bucketed", C.byref(n))
+        return n.value
+
     def last_outliers(self):
         n = C.c_int64()
         self.call("mcpm_plan_last_outliers", C.byref(n))

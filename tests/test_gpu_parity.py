@@ -108,31 +108,115 @@ def test_paint_read_edge_cases(nb, order):
     assert np.allclose(r, o.read(pos.astype(np.float64), mesh.astype(np.float64), order), atol=2e-6 * np.abs(mesh).max() * 8)
 
 
-@pytest.mark.parametrize("n,halo,sigma", [(32, 4, 1.0), (64, 2, 1.5), (64, 4, 2.5), (16, 4, 1.0), (48, 4, 1.0)])
+def expected_bucketed(disp, n, H, centre=True):
+    """paint_tiled.hip restated in numpy: window offsets o_T = clip(rint(mean displacement of the 4x4x4 sub-grid of lattice
+    block T), +-8), and the number of (particle, tile) pairs whose lattice point lies outside the window
+    T - o_T - (H+1) ... T - o_T + 15 + H of a tile T the particle's CIC stencil touches."""
+    from itertools import product
+    nt = n // 16
+    d = disp.reshape(nt, 16, nt, 16, nt, 16, 3)[:, 2::4, :, 2::4, :, 2::4, :].astype(np.float64)
+    off = np.clip(np.rint(d.mean(axis=(1, 3, 5))), -8, 8).astype(int) if centre else np.zeros((nt, nt, nt, 3), int)
+    fl = np.floor(disp).astype(int)
+    q = np.indices((n, n, n)).reshape(3, -1).T
+    c = q + fl
+    count = 0
+    for alt in product((0, 1), repeat=3):
+        alt = np.array(alt)
+        valid = np.all((alt == 0) | (c % 16 == 15), axis=1)
+        T = (c // 16 + alt) % nt
+        rl = np.where(alt == 0, c % 16 - fl, -1 - fl)
+        k = rl + off[T[:, 0], T[:, 1], T[:, 2]] + H + 1
+        count += int((valid & ~np.all((k >= 0) & (k < 16 + 2 * H + 1), axis=1)).sum())
+    return count
+
+
+@pytest.mark.parametrize("n,halo,sigma", [(32, 4, 1.0), (64, 2, 1.5), (64, 4, 2.5), (16, 4, 1.0), (48, 2, 1.0), (80, 1, 0.8)])
 def test_paint_tiled_lattice(nb, n, halo, sigma):
-    """LDS-tiled paint (incl. its outlier path, sigma ~ halo) against the oracle; also the weighted form."""
-    import ctypes as C
+    """LDS-tiled paint (paint_tiled.hip; meshes below 48 per axis take the generic path) against the oracle, weighted form
+    included: white-noise displacements of the order of the window halo, so that many particles travel through the
+    per-tile buckets, and a few far ones wrapping several tiles."""
     shape = (n, n, n)
     N = n ** 3
     rng = np.random.default_rng(5)
     disp = (rng.standard_normal((N, 3)) * sigma).astype(np.float32)
-    disp[:100] *= 8.0   # far outliers, wrapping several tiles
+    disp[:100] *= 8.0   # far particles, wrapping several tiles
     lp = nb.LatticePos(disp, shape)
     plan = nb.get_plan(shape)
     plan.call("mcpm_plan_set_halo", halo)
-    pos64 = o.regular_pos(shape) + disp.astype(np.float64)
-    got = to_np(nb.paint(lp, shape))
-    want = o.paint(pos64, shape)
-    assert rel_l2(got, want) < 2e-6
-    assert abs(got.sum() / N - 1) < 1e-6
-    nout = plan.last_outliers()
-    expect_out = int(np.any((np.floor(disp) < -halo) | (np.floor(disp) > halo), axis=1).sum())
-    if n % 16 == 0:
-        assert nout == expect_out
-    w = rng.standard_normal(N).astype(np.float32)
-    gotw = to_np(nb.paint(lp, shape, w))
-    assert rel_l2(gotw, o.paint(pos64, shape, w.astype(np.float64))) < 2e-6
-    plan.call("mcpm_plan_set_halo", 4)
+    try:
+        pos64 = o.regular_pos(shape) + disp.astype(np.float64)
+        got = to_np(nb.paint(lp, shape))
+        want = o.paint(pos64, shape)
+        assert rel_l2(got, want) < 2e-6
+        assert abs(got.sum() / N - 1) < 1e-6
+        if n >= 48:
+            assert plan.last_outliers() == 0                  # nothing needed f32 global atomics
+            want_b = expected_bucketed(disp, n, halo)
+            assert plan.last_bucketed() == want_b > 0         # (particle, tile) pairs outside the tile's window
+            assert np.array_equal(got, to_np(nb.paint(lp, shape)))          # integer sums: bit for bit
+        w = rng.standard_normal(N).astype(np.float32)
+        gotw = to_np(nb.paint(lp, shape, w))
+        assert rel_l2(gotw, o.paint(pos64, shape, w.astype(np.float64))) < 2e-6
+        assert np.array_equal(gotw, to_np(nb.paint(lp, shape, w)))
+    finally:
+        plan.call("mcpm_plan_set_halo", 3)
+
+
+@pytest.mark.parametrize("n", [64, 96])
+def test_paint_windows_follow_the_bulk_displacement(nb, n):
+    """paint_tiled.hip: a tile's window is centred on the mean displacement of the particles around it.  A coherent flow of
+    several cells (uniform shift + a long wave) plus a small dispersion needs (almost) no bucket even at halo 2; with
+    windows centred on the tile itself (mcpm_plan_set_centre(0)) every window misses its particles, the buckets overflow
+    and the repair pass deposits them with global atomics: slower, counted, and still the same mesh (no input can lose
+    mass)."""
+    shape = (n, n, n)
+    N = n ** 3
+    rng = np.random.default_rng(9)
+    q = o.regular_pos(shape)
+    bulk = np.array([5.3, -7.1, 2.2]) + 1.5 * np.sin(2 * np.pi * q[:, [1, 2, 0]] / n)
+    disp = (bulk + 0.4 * rng.standard_normal((N, 3))).astype(np.float32)
+    lp = nb.LatticePos(disp, shape)
+    plan = nb.get_plan(shape)
+    want = o.paint(q + disp.astype(np.float64), shape)
+    plan.call("mcpm_plan_set_centre", 1)
+    plan.call("mcpm_plan_set_halo", 2)
+    try:
+        got = to_np(nb.paint(lp, shape))
+        assert rel_l2(got, want) < 2e-6
+        b_on = plan.last_bucketed()
+        assert plan.last_outliers() == 0 and b_on == expected_bucketed(disp, n, 2) and b_on < 2e-3 * N
+        # three-component form (adjoint of the force read) on the same field
+        import ctypes as C
+        import torch
+        w3 = rng.standard_normal((N, 3)).astype(np.float32)
+        out = torch.empty((3,) + shape, dtype=torch.float32, device="cuda")
+        wt = torch.from_numpy(w3).cuda()
+        plan.call("mcpm_paint3_f32", C.c_void_p(lp.disp.data_ptr()), N, 1, C.c_void_p(wt.data_ptr()), 2, C.c_void_p(out.data_ptr()), 0)
+        for c in range(3):
+            assert rel_l2(to_np(out[c]), o.paint(q + disp.astype(np.float64), shape, w3[:, c].astype(np.float64))) < 2e-6
+        plan.call("mcpm_plan_set_centre", 0)
+        got0 = to_np(nb.paint(lp, shape))
+        assert expected_bucketed(disp, n, 2, centre=False) > 0.5 * N
+        assert plan.last_outliers() > 0.25 * N            # appends that found their bucket full
+        assert rel_l2(got0, want) < 2e-6 and abs(got0.sum() / N - 1) < 1e-6
+    finally:
+        plan.call("mcpm_plan_set_centre", 1)
+        plan.call("mcpm_plan_set_halo", 3)
+
+
+def test_paint_non_finite_displacement_is_visible(nb):
+    """A NaN / absurd displacement names no cell: the particle is left to the global-atomic kernel, which makes the first
+    cell non-finite instead of indexing with garbage; every other particle is painted as usual."""
+    shape = (64, 64, 64)
+    N = 64 ** 3
+    disp = np.zeros((N, 3), np.float32)
+    disp[777, 1] = np.nan
+    disp[4242, 0] = 1e9
+    plan = nb.get_plan(shape)
+    got = to_np(nb.paint(nb.LatticePos(disp, shape), shape))
+    assert plan.last_outliers() == 2
+    assert np.isnan(got[0, 0, 0]) and np.isfinite(got.reshape(-1)[1:]).all()
+    assert abs(got.reshape(-1)[1:].sum() - (N - 3)) < 1e-3
 
 
 def test_paint_regular_grid_is_constant(nb):
