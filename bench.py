@@ -181,7 +181,7 @@ class SlabRunner:
         spec = torch.from_numpy(synth.init_mesh(n, seed=0, rms_disp=2.0)).to(device)
         f32 = dict(dtype=torch.float32, device=device)
         self.states = torch.empty((K + 1, 2, pm.Nl, 3), **f32)
-        self.f3s = torch.zeros((K, 3, pm.nxe, n, n), **f32)
+        self.f3s = torch.zeros((K, pm.nxe, n, n, 3), **f32)          # interleaved force meshes per step
         # slab-decomposed LPT start (untimed set-up) + first half drift
         pm.lpt(spec, 2, self.lpt_s[0], self.lpt_s[1], self.lpt_s[2], self.states[0, 0], self.states[0, 1])
         self.states[0, 0] += self.states[0, 1] * (self.dg / 2)

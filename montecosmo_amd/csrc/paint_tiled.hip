@@ -8,7 +8,7 @@
 //     tile are deposited (LDS integer atomics); the tile is written with plain 16-byte stores.  No global atomics, no sort.
 //   * BULK-CENTRED WINDOWS.  Particles are stored in Lagrangian order as displacements from their lattice point, and the
 //     displacement field is smooth: the particles that land in tile T come from lattice points around T - o_T, where o_T is
-//     the (rounded) mean displacement near T.  `tile_offset_kernel` samples 64 particles per tile for o_T (25 MB of reads at
+//     the (rounded) mean displacement near T.  `tile_prologue_kernel` samples 64 particles per tile for o_T (25 MB of reads at
 //     512^3), and the window of T is the (16 + 2H + 1)^3 lattice points  T - o_T - (H+1) ... T - o_T + 15 + H  with H = 2:
 //     2.3 window visits per particle instead of the 3.8 of an uncentred H = 4 window (which the 2-cell rms displacement of
 //     the benchmark needed), for the same outlier rate.
@@ -72,11 +72,15 @@ __device__ __forceinline__ void tile_of_block(int ntx, int nty, int ntz, int &tx
 }
 
 // ------------------------------------------------------------------------------------------------
-// o_T: rounded mean displacement of 64 lattice points (a 4x4x4 sub-grid) of the Lagrangian block at tile T
-__global__ __launch_bounds__(256) void tile_offset_kernel(Geom g, const float *__restrict__ disp, int *__restrict__ toff, int ntiles,
-                                                          int maxoff) {
+// Prologue of every tiled paint, one launch: resets the bucket counts and the per-paint counters, and (toff != NULL) sets
+// o_T = rounded mean displacement of 64 lattice points (a 4x4x4 sub-grid) of the Lagrangian block at tile T.
+__global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float *__restrict__ disp, int *__restrict__ toff,
+                                                            int *__restrict__ bcnt, int *__restrict__ cnts, int ntiles, int maxoff) {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x < 8 && threadIdx.x != C_LAST && threadIdx.x != C_OOB) cnts[threadIdx.x] = 0;
     if (tile >= ntiles) return;
+    if (lane == 0) bcnt[tile] = 0;
+    if (!toff) return;
     const int ntz = g.nz / MCPM_TILE, nty = g.ny / MCPM_TILE;
     const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
     int gx = tx * MCPM_TILE + 2 + 4 * (lane >> 4) - g.xoff;
@@ -449,10 +453,8 @@ __global__ __launch_bounds__(256) void paint_bucket_kernel(Geom g, const float *
     const int ntl = L.cnts[C_NTILES];
     if ((int)blockIdx.x >= ntl) return;
     TScale sc = {1073741824.f, 9.313225746154785e-10, 1};
-    if (WMODE != 0) {
-        sc = tile_scale(wmax_bits);
-        if ((WMODE == 1 && sc.mode == 2) || (WMODE == 2 && sc.mode != 2)) return;
-    }
+    if (WMODE != 0) sc = tile_scale(wmax_bits);
+    const bool f64 = WMODE != 0 && sc.mode == 2;     // non-finite weights: doubles (uniform over the launch)
     __shared__ u64 tile[NT];
     double *dtile = reinterpret_cast<double *>(tile);
     const int ntz = g.nz / B, nty = g.ny / B;
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(256) void paint_bucket_kernel(Geom g, const float *
             if (!bucket_cell(g, gi, d, x0, y0, z0, cx, cy, cz)) continue;
             const float wt = WMODE ? w[(int64_t)gi * wstride] : 1.f;
             const float tx1 = d.x - floorf(d.x), ty1 = d.y - floorf(d.y), tz1 = d.z - floorf(d.z);
-            const float s0 = WMODE == 2 ? wt : (WMODE == 1 ? wt * sc.S : sc.S);
+            const float s0 = f64 ? wt : (WMODE == 1 ? wt * sc.S : sc.S);
             const float kx[2] = {(1.f - tx1) * s0, tx1 * s0}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(256) void paint_bucket_kernel(Geom g, const float *
                         if ((unsigned)x < (unsigned)B && (unsigned)y < (unsigned)B && (unsigned)z < (unsigned)B) {
                             const int q = (x * B + y) * B + z;
                             const float v = kx[a] * ky[bb] * kz[e];
-                            if (WMODE == 2) atomicAdd(dtile + q, (double)v);
+                            if (f64) atomicAdd(dtile + q, (double)v);
                             else if (WMODE == 1) atomicAdd(tile + q, (u64)(long long)cvt_rpi(v));
                             else atomicAdd(tile + q, (u64)(unsigned)cvt_rpi(v));
                         }
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(256) void paint_bucket_kernel(Geom g, const float *
             const u64 a = tile[i];
             if (a == 0ull) continue;
             const int lz = i % B, r = i / B, ly = r % B, lx = r / B;
-            const float v = WMODE == 2 ? (float)dtile[i] : (WMODE == 1 ? (float)((double)(long long)a * s) : (float)((double)a * s));
+            const float v = f64 ? (float)dtile[i] : (WMODE == 1 ? (float)((double)(long long)a * s) : (float)((double)a * s));
             mesh[((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz] += v;   // this workgroup alone writes tile t here
         }
         if (threadIdx.x == 0) atomicAdd(L.cnts + C_BUCKETED, cnt);
@@ -823,9 +825,7 @@ __global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const floa
     }
 }
 
-// buckets of the three-component paint: int64 fixed point with the max|w| 2^-28 scale (F64 = false), doubles when the
-// weights are non-finite (F64 = true; each instantiation returns at once when the other one applies)
-template <bool F64>
+// buckets of the three-component paint: int64 fixed point with the max|w| 2^-28 scale, doubles when the weights are non-finite
 __global__ __launch_bounds__(256) void paint3_bucket_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
                                                             float *__restrict__ mesh, int64_t M, TileLists L,
                                                             const unsigned *__restrict__ wmax_bits) {
@@ -833,7 +833,8 @@ __global__ __launch_bounds__(256) void paint3_bucket_kernel(Geom g, const float 
     const int ntl = L.cnts[C_NTILES];
     if ((int)blockIdx.x >= ntl) return;
     const TScale sc = tile_scale(wmax_bits);
-    if (sc.mode == 0 || (F64 ? sc.mode != 2 : sc.mode == 2)) return;
+    if (sc.mode == 0) return;
+    const bool F64 = sc.mode == 2;      // non-finite weights: doubles (uniform over the launch)
     __shared__ u64 tile[3 * NT];
     double *dtile = reinterpret_cast<double *>(tile);
     const int ntz = g.nz / B, nty = g.ny / B;
@@ -908,10 +909,8 @@ static TileLists tile_lists(const mcpm_plan *p) {
 static void tiled_prologue(mcpm_plan *p, const float *pos) {
     const Geom &g = p->g;
     const int ntiles = (g.nx / MCPM_TILE) * (g.ny / MCPM_TILE) * (g.nz / MCPM_TILE);
-    (void)hipMemsetAsync(p->bucket_cnt, 0, sizeof(int) * ntiles, p->stream);
-    (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int), p->stream);                    // wild
-    (void)hipMemsetAsync(p->outlier_count + C_PAIRS, 0, sizeof(int) * 4, p->stream);      // full-bucket appends, tiles, bucketed, suspects
-    if (p->centre) tile_offset_kernel<<<(ntiles + 3) / 4, 256, 0, p->stream>>>(g, pos, p->tile_off, ntiles, 8);
+    tile_prologue_kernel<<<(ntiles + 3) / 4, 256, 0, p->stream>>>(g, pos, p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->outlier_count,
+                                                                  ntiles, 8);
 }
 
 #define DISPATCH_H(HH, CALL) \
@@ -945,7 +944,6 @@ bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t ws
         DISPATCH_H(p->halo, CALLD)
 #undef CALLD
         paint_bucket_kernel<1><<<nbk, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, L, p->gx_wmax);
-        paint_bucket_kernel<2><<<nbk, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, L, p->gx_wmax);
     } else {
 #define CALLU(HH) paint_tile_kernel<HH, 0, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
         DISPATCH_H(p->halo, CALLU)
@@ -992,8 +990,7 @@ bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, fl
 #define CALLD(HH) coverage_duty_kernel<HH><<<1024, 256, 0, p->stream>>>(g, pos, L);
     DISPATCH_H(p->halo, CALLD)
 #undef CALLD
-    paint3_bucket_kernel<false><<<nbk, 256, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, L, p->fx_wmax);
-    paint3_bucket_kernel<true><<<nbk, 256, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, L, p->fx_wmax);
+    paint3_bucket_kernel<<<nbk, 256, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, L, p->fx_wmax);
 #define CALLL(HH) paint_leftover_kernel<HH, 3><<<1024, 256, 0, p->stream>>>(g, pos, weights3, 3, 0.f, meshes3, p->M, L);
     DISPATCH_H(p->halo, CALLL)
 #undef CALLL

@@ -6,10 +6,12 @@ Decomposition (one process per GPU, `torch.distributed`, backend "nccl" = RCCL o
   * rank r owns mesh planes [r nx/P, (r+1) nx/P) and -- Lagrangian ownership -- the lattice particles of those
     planes.  Particles are stored as displacements from their lattice point, so they NEVER migrate; what
     crosses slab boundaries is mass, through `ghost` extra planes on each side of the local mesh.
-  * paint -> ghost planes added into the neighbours' interiors (point-to-point send/recv);
+  * paint -> ghost planes added into the neighbours' interiors (point-to-point isend / irecv of contiguous plane runs);
     FFT: local z and y passes -> ONE all-to-all (x <-> y transpose, written directly in transposed order by the
-    y pass) -> fused x pass (x FFT . k-space . inverse x FFT) -> one all-to-all back -> local y, z passes;
-    read: interior planes sent to the neighbours' ghosts (point-to-point), then the fused read+kick+drift.
+    y pass) -> fused x pass (x FFT . k-space . inverse x FFT) -> all-to-all back (two spectra) -> local y pass, ONE z pass
+    that writes the three force components interleaved [x][y][z][3];
+    read: interior planes sent straight into the neighbours' ghost planes (point-to-point, no staging copy: the three
+    components of a plane run are one contiguous block), then the fused read+kick+drift.
   The all-to-all is used for the FFT transpose only; ghost planes are point-to-point.
 The adjoint mirrors it (3 weighted paints + ghost add, 3 forward / 1 inverse transform, ghost fill, fused
 adjoint particle kernel); scalar cotangents are all-reduced once at the end.
@@ -68,8 +70,10 @@ def _pinned_slot(owner):
 
 
 class LocalComm:
-    """Single-rank communicator: every exchange is a local copy (used to validate the slab code path itself)."""
+    """Single-rank communicator: ghost exchanges are local copies (the periodic wrap of the own planes); a one-rank
+    all-to-all is the identity, so `SlabPM._a2a` hands the input buffer on instead of copying it (`alias_a2a`)."""
     world, rank = 1, 0
+    alias_a2a = True
 
     def all_to_all(self, out, inp, async_op=False):
         out.copy_(inp)
@@ -128,33 +132,12 @@ class TorchComm:
         return _Works([w]) if async_op else _Done()
 
     def neighbour_exchange(self, to_left, to_right, from_left, from_right, async_op=False):
+        """Point-to-point exchange with the two x neighbours (one batched isend / irecv group).  With RCCL the tensors are
+        used in place: callers pass contiguous plane runs of the meshes themselves, so nothing is staged or copied.  (An
+        earlier version sent both messages through one all_to_all_single with split sizes to save ~45 us of host time
+        per exchange; the all-to-all is reserved for the FFT transpose, and the host is not the bottleneck.)"""
         td, P, r = self.td, self.world, self.rank
         left, right = (r - 1) % P, (r + 1) % P
-        if not self.stage:
-            # RCCL: ONE all_to_all_single with split sizes instead of four point-to-point operations (the batched
-            # isend / irecv costs ~86 us of host time per exchange, eight exchanges per forward+adjoint step).  Chunks
-            # are ordered by peer rank; with one or two ranks both chunks travel to the same peer, [to_left, to_right].
-            n = to_left.numel()
-            first_left = left <= right
-            send = torch.cat((to_left.reshape(-1), to_right.reshape(-1)) if first_left else (to_right.reshape(-1), to_left.reshape(-1)))
-            recv = torch.empty_like(send)
-            splits = [0] * P
-            splits[left] += n
-            splits[right] += n
-            w = td.all_to_all_single(recv, send, splits, splits, group=self.group, async_op=True)
-            # the chunk from rank `left` is its to_right (my from_left); from one peer only: [its to_left, its to_right]
-            a, b = recv[:n], recv[n:]
-            fl, fr = (b, a) if left == right else ((a, b) if first_left else (b, a))
-
-            def finish():
-                from_left.copy_(fl.view_as(from_left))
-                from_right.copy_(fr.view_as(from_right))
-
-            h = _Works([w], finish)
-            if async_op:
-                return h
-            h.wait()
-            return _Done()
         sl, sr = self._h(to_left), self._h(to_right)
         rl = torch.empty(from_left.shape, dtype=from_left.dtype) if (self.stage and from_left.is_cuda) else from_left
         rr = torch.empty(from_right.shape, dtype=from_right.dtype) if (self.stage and from_right.is_cuda) else from_right
@@ -257,7 +240,34 @@ class HaloMixin:
         return _Done()
 
 
-class SlabPM(HaloMixin):
+class PlaneHalo:
+    """Ghost-plane exchanges on meshes whose LEADING axis is x: (nxl + 2G, ...).  A run of planes is then one contiguous
+    block whatever follows (ny, nz) or (ny, nz, 3): the fill receives straight into the ghost planes and sends straight from
+    the interior (no staging); the add receives into a scratch run and adds it."""
+
+    def halo_fill_x(self, ext, async_op=False):
+        G, nxl, d = self.G, self.nxl, self.depth()
+        h = self.comm.neighbour_exchange(ext[G:G + d], ext[G + nxl - d:G + nxl], ext[G - d:G], ext[G + nxl:G + nxl + d],
+                                         async_op=async_op)
+        return h if async_op else _Done()
+
+    def halo_add_x(self, ext, async_op=False):
+        G, nxl, d = self.G, self.nxl, self.depth()
+        from_l, from_r = torch.empty_like(ext[:d]), torch.empty_like(ext[:d])
+        h = self.comm.neighbour_exchange(ext[G - d:G], ext[G + nxl:G + nxl + d], from_l, from_r, async_op=async_op)
+
+        def finish():
+            h.wait()
+            ext[G:G + d] += from_l
+            ext[G + nxl - d:G + nxl] += from_r
+
+        if async_op:
+            return _Works([], finish)
+        finish()
+        return _Done()
+
+
+class SlabPM(HaloMixin, PlaneHalo):
     """Slab-decomposed PM stepper for one rank."""
 
     def __init__(self, mesh_shape, comm=None, ghost=16, device=None, adaptive_ghost=True):
@@ -283,7 +293,12 @@ class SlabPM(HaloMixin):
         f32 = dict(dtype=torch.float32, device=self.device)
         c64 = dict(dtype=torch.complex64, device=self.device)
         self.rho = torch.zeros((self.nxe, ny, nz), **f32)
-        self.f3 = torch.zeros((3, self.nxe, ny, nz), **f32)
+        self.f3 = torch.zeros((3, self.nxe, ny, nz), **f32)           # three separate meshes: lpt, cotangent paints
+        self.f3il = None                                              # (nxe, ny, nz, 3) interleaved force mesh, on first use
+        # kick_drift leaves max |d_x| of its output here (float bits in 64 slots, stride 32): the next step's ghost depth
+        self.dmax = torch.zeros(64 * 32, dtype=torch.int32, device=self.device)
+        self._dmax_ptr = None
+        check(lib.mcpm_plan_track_dmax(h, C.c_void_p(self.dmax.data_ptr())), h, "mcpm_plan_track_dmax")
         self.s1a, self.s1b = torch.empty(ss, **c64), torch.empty(ss, **c64)
         self.s6a, self.s6b = torch.empty(6 * ss, **c64), torch.empty(6 * ss, **c64)     # lpt: 6 Hessian spectra
         self.s3a, self.s3b = self.s6a[:3 * ss], self.s6b[:3 * ss]
@@ -312,6 +327,22 @@ class SlabPM(HaloMixin):
         base = ext if c is None else ext[c]
         return C.c_void_p(base.data_ptr() + 4 * self.G * self.plane)
 
+    def _interior_il(self, ext_il):
+        return C.c_void_p(ext_il.data_ptr() + 4 * 3 * self.G * self.plane)
+
+    def force_mesh_il(self):
+        """Scratch interleaved force mesh (nxe, ny, nz, 3)."""
+        if self.f3il is None:
+            self.f3il = torch.zeros((self.nxe,) + self.shape[1:] + (3,), dtype=torch.float32, device=self.device)
+        return self.f3il
+
+    def _a2a(self, out, inp, async_op=False):
+        """All-to-all of one packed spectrum; returns (handle, buffer holding the result).  A one-rank local communicator
+        hands the input on: its all-to-all is the identity (the copy cost 1.6 ms per step at 512^3)."""
+        if getattr(self.comm, "alias_a2a", False):
+            return _Done(), inp
+        return self.comm.all_to_all(out, inp, async_op=async_op), out
+
     # ---- Poisson solve on slabs ----------------------------------------------------------------------------
     # Spectra buffers are component-major ([c][rank block][x_l][y_l][nzp]), so each force component is its own
     # all-to-all; they are issued asynchronously and the per-component y / z passes (and ghost fills) of one
@@ -337,18 +368,19 @@ class SlabPM(HaloMixin):
         for w in edges:
             self._win(w)
             self.call("mcpm_slab_zinv", self._spec(spec_buf, c), self._interior(ext), self.Me, 1)
-        h = self.halo_fill(ext, async_op=True) if fill else None
+        h = self.halo_fill_x(ext, async_op=True) if fill else None
         if inner is not None:
             self._win(inner)
             self.call("mcpm_slab_zinv", self._spec(spec_buf, c), self._interior(ext), self.Me, 1)
         self._win((0, self.nxl))
         return h
 
-    def force_meshes(self, rho_ext, f3_ext, fill_ghosts=True, rho_add=None):
-        """Interior of rho_ext -> the three force meshes f3_ext (ghosts filled).  `rho_add`: handle of the ghost add of
-        rho_ext still in flight (None: ghosts already added); the inner planes' z / y passes run under it.
-        Only two spectra (A, G) cross the second all-to-all: the y pass applies the y / z force factors, and the
-        transfer of G runs under the y / z passes (and ghost fill) of the first component."""
+    def force_meshes(self, rho_ext, f3_ext, fill_ghosts=True, rho_add=None, il=False):
+        """Interior of rho_ext -> the three force meshes (ghosts filled).  il=False: f3_ext is (3, nxe, ny, nz); il=True:
+        ONE interleaved mesh (nxe, ny, nz, 3) (what the step kernels read: a CIC corner is one 12-byte gather, and a run of
+        ghost planes is one contiguous block for the three components).  `rho_add`: handle of the ghost add of rho_ext
+        still in flight (None: ghosts already added); the inner planes' z / y passes run under it.
+        Only two spectra (A, G) cross the second all-to-all: the y pass applies the y / z force factors."""
         ss = self.ss
         inner, edges = self._windows(rho_add is not None)
         for w in ([inner] if inner is not None else []) + edges:
@@ -359,36 +391,46 @@ class SlabPM(HaloMixin):
             self.call("mcpm_slab_zfwd", self._interior(rho_ext), self.Me, _p(self.s1a), 1)
             self.call("mcpm_slab_ycol", _p(self.s1a), _p(self.s1b), 1, -1, 0, 1)      # plain -> transposed order
         self._win((0, self.nxl))
-        self.comm.all_to_all(self.s1a, self.s1b)                                     # x <-> y transpose
-        self.call("mcpm_slab_xfused", _p(self.s1a), _p(self.s3a), 0)                  # -> A, G
-        hA = self.comm.all_to_all(self.s3b[:ss], self.s3a[:ss], async_op=True)
-        hG = self.comm.all_to_all(self.s3b[ss:2 * ss], self.s3a[ss:2 * ss], async_op=True)
+        _, x_in = self._a2a(self.s1a, self.s1b)                                       # x <-> y transpose
+        self.call("mcpm_slab_xfused", _p(x_in), _p(self.s3a), 0)                      # -> A, G
+        hA, bA = self._a2a(self.s3b[:ss], self.s3a[:ss], async_op=True)
+        hG, _ = self._a2a(self.s3b[ss:2 * ss], self.s3a[ss:2 * ss], async_op=True)
+        # where A, G sit now (s3a if the all-to-all was aliased, else received in s3b); the y pass writes the other buffer
+        src, dst = (self.s3a, self.s3b) if bA.data_ptr() == self.s3a.data_ptr() else (self.s3b, self.s3a)
         hA.wait()
-        self.call("mcpm_slab_ycol2", _p(self.s3b), _p(self.s3a), 1, 1, 0, 1)          # A -> force spectrum 0 (s3a[0])
-        self._zinv_fill(self.s3a, 0, f3_ext[0], False)                                # all of component 0 under G's transfer
+        self.call("mcpm_slab_ycol2", _p(src), _p(dst), 1, 1, 0, 1)                    # A -> force spectrum 0
+        if not il:
+            self._zinv_fill(dst, 0, f3_ext[0], False)                                 # all of component 0 under G's transfer
         hG.wait()
-        self.call("mcpm_slab_ycol2", _p(self.s3b), _p(self.s3a), 1, 1, 0, 2)          # G -> force spectra 1, 2
-        # ONE ghost fill for the three components: the edge planes of components 1, 2 first, the exchange (async) under
-        # their inner planes
+        self.call("mcpm_slab_ycol2", _p(src), _p(dst), 1, 1, 0, 2)                    # G -> force spectra 1, 2
         inner, edges = self._windows(fill_ghosts)
-        for c in (1, 2):
+        if il:      # ONE z pass for the three components; the edge planes first, their ghost fill (async) under the inner planes
             for w in edges:
                 self._win(w)
-                self.call("mcpm_slab_zinv", self._spec(self.s3a, c), self._interior(f3_ext[c]), self.Me, 1)
-        h = self.halo_fill(f3_ext, async_op=True) if fill_ghosts else None
-        if inner is not None:
-            self._win(inner)
+                self.call("mcpm_slab_zinv3_il", _p(dst), self._interior_il(f3_ext))
+            h = self.halo_fill_x(f3_ext, async_op=True) if fill_ghosts else None
+            if inner is not None:
+                self._win(inner)
+                self.call("mcpm_slab_zinv3_il", _p(dst), self._interior_il(f3_ext))
+        else:       # ONE ghost fill for the three components: the edge planes of components 1, 2 first
             for c in (1, 2):
-                self.call("mcpm_slab_zinv", self._spec(self.s3a, c), self._interior(f3_ext[c]), self.Me, 1)
+                for w in edges:
+                    self._win(w)
+                    self.call("mcpm_slab_zinv", self._spec(dst, c), self._interior(f3_ext[c]), self.Me, 1)
+            h = self.halo_fill(f3_ext, async_op=True) if fill_ghosts else None
+            if inner is not None:
+                self._win(inner)
+                for c in (1, 2):
+                    self.call("mcpm_slab_zinv", self._spec(dst, c), self._interior(f3_ext[c]), self.Me, 1)
         self._win((0, self.nxl))
         if h is not None:
             h.wait()
 
     def force_meshes_vjp(self, fbar3_ext, rhobar_ext, ghost_adds=None, fill_ghosts=False):
-        """fbar3_ext: three cotangent meshes (ghosts added, or `ghost_adds[c]` handles still in flight).  Writes the
-        interior of rhobar_ext (and its ghosts if fill_ghosts)."""
+        """fbar3_ext: three cotangent meshes (3, nxe, ny, nz) (ghosts added, or `ghost_adds[c]` handles still in flight).
+        Writes the interior of rhobar_ext (and its ghosts if fill_ghosts)."""
         ss = self.ss
-        handles = []
+        handles, bufs = [], []
         for c in range(3):
             add = ghost_adds[c] if ghost_adds is not None else None
             inner, edges = self._windows(add is not None)
@@ -401,15 +443,21 @@ class SlabPM(HaloMixin):
             self._win((0, self.nxl))
             if c == 0:    # a = FFTy(f_bar_x) leaves while the other two components are still being transformed
                 self.call("mcpm_slab_ycol2", _p(self.s3a), _p(self.s3b), 0, 0, 1, 1)
-                handles.append(self.comm.all_to_all(self.s3a[:ss], self.s3b[:ss], async_op=True))
+                h, b0 = self._a2a(self.s6a[3 * ss:4 * ss], self.s3b[:ss], async_op=True)
+                handles.append(h)
+                bufs.append(b0)
         self.call("mcpm_slab_ycol2", _p(self.s3a), _p(self.s3b), 0, 0, 1, 2)          # b = ky FFTy(f_bar_y) + kz FFTy(f_bar_z)
-        handles.append(self.comm.all_to_all(self.s3a[ss:2 * ss], self.s3b[ss:2 * ss], async_op=True))
+        h, _ = self._a2a(self.s6a[4 * ss:5 * ss], self.s3b[ss:2 * ss], async_op=True)
+        handles.append(h)
         for h in handles:
             h.wait()
-        self.call("mcpm_slab_xfused", _p(self.s3a), _p(self.s1a), 1)
-        self.comm.all_to_all(self.s1b, self.s1a)
-        self.call("mcpm_slab_ycol", _p(self.s1b), _p(self.s1a), 1, +1, 1, 0)
-        h = self._zinv_fill(self.s1a, 0, rhobar_ext, fill_ghosts)
+        # (a, b) received side by side in s6a[3 ss : 5 ss], or still in s3b[0 : 2 ss] when the all-to-all was aliased
+        x_in = self.s3b if bufs[0].data_ptr() == self.s3b.data_ptr() else self.s6a[3 * ss:5 * ss]
+        self.call("mcpm_slab_xfused", _p(x_in), _p(self.s1a), 1)
+        _, y_in = self._a2a(self.s1b, self.s1a)
+        y_out = self.s1a if y_in is self.s1b else self.s1b
+        self.call("mcpm_slab_ycol", _p(y_in), _p(y_out), 1, +1, 1, 0)
+        h = self._zinv_fill(y_out, 0, rhobar_ext, fill_ghosts)
         if h is not None:
             h.wait()
 
@@ -516,7 +564,11 @@ class SlabPM(HaloMixin):
         if not hasattr(self, "_dhist"):
             self.reset_depth()
         self._harvest_depth()
-        host, ev = self.comm.all_reduce_max_async(x[:, 0].abs().max())
+        if self._dmax_ptr == x.data_ptr():      # these positions came out of this plan's kick_drift: max |d_x| is already there
+            dmx = self.dmax.max().reshape(1).view(torch.float32)
+        else:
+            dmx = x[:, 0].abs().max()
+        host, ev = self.comm.all_reduce_max_async(dmx)
         self._dpending = (host, ev, paint_order)
         h = self._dhist
         if not h:
@@ -534,19 +586,18 @@ class SlabPM(HaloMixin):
             self._harvest_depth()
 
     def step(self, x, v, alpha, beta, tau, f3_out, x_out, v_out, paint_order=2):
-        """x, v: (Nl,3) local state; f3_out: (3, nxe, ny, nz) receives the ghost-filled force meshes."""
+        """x, v: (Nl,3) local state; f3_out: (nxe, ny, nz, 3) receives the ghost-filled INTERLEAVED force mesh (ghost planes
+        beyond the exchanged depth `self.ge` are left as they were: no particle of this step reads them)."""
         self.set_depth(x, paint_order)
-        if self.ge < self.G:      # ghost planes beyond the exchanged depth are never read, but keep checkpoints defined
-            f3_out[:, :self.G - self.ge].zero_()
-            f3_out[:, self.G + self.nxl + self.ge:].zero_()
         self.call("mcpm_paint_f32", _p(x), self.Nl, POS_LATTICE, None, 1, 1.0, paint_order, _p(self.rho), 0)
-        self.force_meshes(self.rho, f3_out, rho_add=self.halo_add(self.rho, async_op=True))
-        self.call("mcpm_kick_drift_f32", _p(x), _p(v), self.Nl, POS_LATTICE, _p(f3_out), paint_order, float(alpha),
+        self.force_meshes(self.rho, f3_out, rho_add=self.halo_add_x(self.rho, async_op=True), il=True)
+        self.call("mcpm_kick_drift_il_f32", _p(x), _p(v), self.Nl, POS_LATTICE, _p(f3_out), paint_order, float(alpha),
                   float(beta), float(tau), _p(x_out), _p(v_out))
+        self._dmax_ptr = x_out.data_ptr()
 
     def step_vjp(self, x, v, f3, alpha, beta, tau, xb, vb, abar_ptr, bbar_ptr, dtau_ddg=1.0, dgbar_ptr=None, paint_order=2,
                  depth=None, next_beta_tau=None):
-        """Adjoint of `step`: xb, vb (cotangents of its outputs) are updated in place.  `depth`: the ghost depth the
+        """Adjoint of `step` (f3: its interleaved force mesh): xb, vb (cotangents of its outputs) are updated in place.  `depth`: the ghost depth the
         forward step used (`self.ge` after `step`), saving its re-measurement.  `next_beta_tau`: (beta, tau) of the step
         whose adjoint comes next (the previous step of the sweep): its force cotangent is then written by this call's
         particle kernel and picked up by the next call instead of a separate pass."""
@@ -561,7 +612,7 @@ class SlabPM(HaloMixin):
         self.force_meshes_vjp(self.f3, self.rho, [add, add, add], fill_ghosts=True)
         if next_beta_tau is not None:
             self.call("mcpm_plan_hint_next_adjoint", float(next_beta_tau[0]), float(next_beta_tau[1]))
-        self.call("mcpm_step_adjoint_particles_f32", _p(x), _p(v), _p(f3), _p(self.rho), float(alpha), float(beta),
+        self.call("mcpm_step_adjoint_particles_il_f32", _p(x), _p(v), _p(f3), _p(self.rho), float(alpha), float(beta),
                   float(tau), paint_order, _p(xb), _p(vb), abar_ptr, bbar_ptr, float(dtau_ddg), dgbar_ptr)
 
 
@@ -582,14 +633,14 @@ def nbody_bf_slab(cosmo, init_mesh, a0=0., a1=1., n_steps=5, paint_order=2, lpt_
     dg, alphas, betas, lpt_s = nbody._step_scalars(cosmo, a0, a1, n_steps, integrator)
     K = n_steps
     states = torch.empty((K + 1, 2, pm.Nl, 3), dtype=torch.float32, device=spec.device)
-    f3s = torch.zeros((K, 3, pm.nxe) + shape[1:], dtype=torch.float32, device=spec.device) if return_ctx else None
+    f3s = torch.zeros((K, pm.nxe) + shape[1:] + (3,), dtype=torch.float32, device=spec.device) if return_ctx else None
     pm.lpt(spec, int(lpt_order), lpt_s[0], lpt_s[1], lpt_s[2], states[0, 0], states[0, 1])      # slab-decomposed LPT start
     states[0, 0] += states[0, 1] * (dg / 2)
     depths = []
     pm.reset_depth()
     for i in range(K):
         tau = dg / 2 if i == K - 1 else dg
-        pm.step(states[i, 0], states[i, 1], alphas[i], betas[i], tau, f3s[i] if return_ctx else pm.f3,
+        pm.step(states[i, 0], states[i, 1], alphas[i], betas[i], tau, f3s[i] if return_ctx else pm.force_mesh_il(),
                 states[i + 1, 0], states[i + 1, 1], paint_order)
         depths.append(pm.ge)
     pm.finish_depth()
