@@ -203,10 +203,25 @@ int mcpm_pm_forces_spec_f32(mcpm_plan *plan, const float *spec, const float *pos
    spec_bar = cotangent of the half-spectrum (real-pair convention, irfftn multiplicity weights included). */
 int mcpm_pm_forces_vjp_f32(mcpm_plan *plan, const float *spec, const float *pos, int64_t n, int pos_mode, int order,
                            const float *forces_bar, float *pos_bar, float *spec_bar);
+/* The painted case with the options of nbody.py:583-604: finite-difference Laplace / gradient kernels (:125-163) and
+   deconvolution of the painted density (:590-593); pos_bar carries the read and the paint dependence. */
+int mcpm_pm_forces_vjp_opts_f32(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, int order, int paint_deconv,
+                                int lap_fd, int grad_fd, const float *forces_bar, float *pos_bar);
 /* pm_forces2 (2LPT source, nbody.py:607-631). */
 int mcpm_pm_forces2_f32(mcpm_plan *plan, const float *spec, const float *pos, int64_t n, int pos_mode,
                         int order, int lap_fd, int grad_fd, float *forces);
 int mcpm_plan_force_meshes(mcpm_plan *plan, float **meshes3);
+
+/* Kaiser-Bessel assignment kernel (nbody.py:280-290, selected by kernel_type = 'kaiser_bessel' in paint :381-382 and
+   read :411-412): the same order^3 stencil, weights I0(kc sqrt(1 - (2 s / order)^2)) kc / (order sinh kc) per axis with
+   kc = kcut order / 2 and kcut = optim_kcut(oversamp) (:357-363, computed by the caller).  order 1..4.
+   mcpm_read_kb_f32: out (may be NULL) = read values; pos_bar (may be NULL) = out_bar_i d read_i / d pos (out_bar NULL:
+   the scalar obscalar) -- with mesh = mesh_bar and out_bar = weights this is the position VJP of the paint, and `out`
+   its weights VJP. */
+int mcpm_paint_kb_f32(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, const float *weights, int64_t wstride,
+                      float wscalar, int order, float kcut, float *mesh, int accumulate);
+int mcpm_read_kb_f32(mcpm_plan *plan, const float *pos, int64_t n, int pos_mode, const float *mesh, int order, float kcut,
+                     float *out, const float *out_bar, int64_t obstride, float obscalar, float *pos_bar);
 
 /* ---- BullFrog / FastPM stepping (nbody.py:902-1002) ----------------------------------------- */
 /* drift (nbody.py:942-944): pos_out = pos_in + vel * dt. */
@@ -275,6 +290,9 @@ int mcpm_lattice_dot_f32(mcpm_plan *plan, const float *meshes3, const float *a, 
    growth scalars: scalar_bars = {g_bar, g2_bar, dg2dg_bar} (host, may be NULL; forces a stream sync when given). */
 int mcpm_lpt_vjp_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, const double *lpt_scalars,
                      const float *dpos_bar, const float *vel_bar, float *init_mesh_bar, double *scalar_bars);
+/* The same with finite-difference kernels (lap_fd, grad_fd: MCPM_FD_*), as mcpm_lpt_f32 takes them. */
+int mcpm_lpt_vjp_opts_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, const double *lpt_scalars, int lap_fd,
+                          int grad_fd, const float *dpos_bar, const float *vel_bar, float *init_mesh_bar, double *scalar_bars);
 /* nbody_bf (nbody.py:967-1002), snapshots=None: LPT start at a0 then n_steps drift-kick-drift steps of size
    dg in growth-factor time.  alpha[i] and beta[i] = (1-alpha_i)/(g_i + dg/2) are host float64 arrays computed
    from the growth tables (alpha_bf nbody.py:907-919 or alpha_fpm :921-931, evaluated at the accumulated Euler

@@ -38,6 +38,8 @@ SIGNATURES = {
     "mcpm_fft_c2r": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int]),
     "mcpm_cell_index": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "mcpm_paint_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int64, C.c_float, C.c_int, _f32p, C.c_int]),
+    "mcpm_paint_kb_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int64, C.c_float, C.c_int, C.c_float, _f32p, C.c_int]),
+    "mcpm_read_kb_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_float, _f32p, _f32p, C.c_int64, C.c_float, _f32p]),
     "mcpm_paint3_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, _f32p, C.c_int]),
     "mcpm_read_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_int, _f32p]),
     "mcpm_paint_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int64, C.c_float, C.c_int, _f32p, _f32p, _f32p]),
@@ -100,6 +102,8 @@ SIGNATURES = {
     "mcpm_lpt_accum_f32": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_float, C.c_int, _f32p, _f32p]),
     "mcpm_lattice_scatter_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, _f32p]),
     "mcpm_lattice_dot_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p]),
+    "mcpm_lpt_vjp_opts_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f64p]),
+    "mcpm_pm_forces_vjp_opts_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p]),
     "mcpm_lpt_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f32p, _f32p, _f32p, _f64p]),
     "mcpm_lpt_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _f32p, _f32p]),
     "mcpm_nbody_bf_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f64p, C.c_double, _f64p, C.c_int, C.c_int, _f32p, _f32p, _f32p]),

@@ -336,38 +336,46 @@ static int ensure_pscratch(mcpm_plan *p) {
     return MCPM_OK;
 }
 
+// rho_bar = adjoint of (rho -> R2C -> k-space force kernels with FD orders / deconvolution -> 3 C2R) at f_bar (3 meshes)
+static int force_meshes_vjp_opts(mcpm_plan *p, const float *fbar3, float *rho_bar, int lap_fd, int grad_fd, int deconv) {
+    if (lap_fd == MCPM_FD_INF && grad_fd == MCPM_FD_INF && !deconv) return mcpm_force_meshes_vjp_f32(p, fbar3, rho_bar);
+    MCPM_TRY(mcpm_fft_r2c(p, fbar3, p->spec, 3));
+    MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, p->spec1, 1.f / (float)p->M, lap_fd, grad_fd, 0.f, deconv, 0, 1, 0));
+    return mcpm_fft_c2r(p, p->spec1, rho_bar, 1);
+}
+
 // Adjoint of lpt at the lattice (read_order = 1): cotangents (xb, vb) of (dpos, vel) -> init_mesh_bar (real-pair
 // convention) and three DEVICE double accumulators sb = {g_bar, -g2_bar, -dg2dg_bar} (added to, not reset).
 static int lpt_vjp_device(mcpm_plan *p, const float *init_mesh, int lpt_order, const double *lpt_scalars, const float *xb,
-                          const float *vb, float *init_mesh_bar, double *sb) {
+                          const float *vb, float *init_mesh_bar, double *sb, int lap_fd = MCPM_FD_INF, int grad_fd = MCPM_FD_INF) {
     const int64_t M = p->M;
     const float invM = 1.f / (float)M;
     dim3 grid, block;
     lattice_launch(p->g, grid, block);
     const float g = (float)lpt_scalars[0], g2 = (float)lpt_scalars[1], c2 = (float)lpt_scalars[2];
-    MCPM_TRY(spec_to_force_meshes(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, p->fmesh));
+    MCPM_TRY(spec_to_force_meshes(p, init_mesh, lap_fd, grad_fd, 0.f, 0, p->fmesh));
     MCPM_TRY(lattice_dot(p, p->fmesh, xb, nullptr, sb + 0, nullptr));
     MCPM_TRY(lattice_scatter(p, xb, vb, g, 1.f, p->fmesh));
-    const bool custom = spec_custom(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF);
+    const bool custom = spec_custom(p, init_mesh, lap_fd, grad_fd);
     if (custom) {
         MCPM_TRY(mcpm_fftpm_spec_meshes_vjp(p, p->fmesh, init_mesh_bar, 3));
     } else {
         MCPM_TRY(mcpm_fft_r2c(p, p->fmesh, p->spec, 3));
-        MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, init_mesh_bar, invM, MCPM_FD_INF, MCPM_FD_INF, 0.f, 0, 1, 0, 0));
+        MCPM_TRY(mcpm_kspace_force_vjp_f32(p, p->spec, init_mesh_bar, invM, lap_fd, grad_fd, 0.f, 0, 1, 0, 0));
     }
     if (lpt_order == 2) {
         float *h = p->fmesh, *f2 = p->fmesh + 6 * M;
-        MCPM_TRY(spec_to_delta2_real(p, init_mesh, MCPM_FD_INF, MCPM_FD_INF));        // h in fmesh[0:6], delta2 in rho
-        MCPM_TRY(delta2_to_force_meshes(p, MCPM_FD_INF, MCPM_FD_INF, f2));            // F2 meshes
+        MCPM_TRY(spec_to_delta2_real(p, init_mesh, lap_fd, grad_fd));        // h in fmesh[0:6], delta2 in rho
+        MCPM_TRY(delta2_to_force_meshes(p, lap_fd, grad_fd, f2));            // F2 meshes
         MCPM_TRY(lattice_dot(p, f2, xb, vb, sb + 1, sb + 2));  // negated on the host
         MCPM_TRY(lattice_scatter(p, xb, vb, -g2, -c2, f2));
-        MCPM_TRY(mcpm_force_meshes_vjp_f32(p, f2, p->rho));                           // delta2_bar
+        MCPM_TRY(force_meshes_vjp_opts(p, f2, p->rho, lap_fd, grad_fd, 0));          // delta2_bar
         MCPM_TRY(mcpm_hessian_combine_vjp_f32(p, h, p->rho, h));                      // in place: h -> h_bar
         if (custom) {
             MCPM_TRY(mcpm_fftpm_spec_meshes_vjp(p, h, init_mesh_bar, 6));
         } else {
             MCPM_TRY(mcpm_fft_r2c(p, h, p->spec, 6));
-            MCPM_TRY(mcpm_kspace_hessian_vjp_f32(p, p->spec, init_mesh_bar, invM, MCPM_FD_INF, MCPM_FD_INF, 1, 1));
+            MCPM_TRY(mcpm_kspace_hessian_vjp_f32(p, p->spec, init_mesh_bar, invM, lap_fd, grad_fd, 1, 1));
         }
     }
     return MCPM_OK;
@@ -654,6 +662,42 @@ int mcpm_lpt_vjp_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, const 
         scalar_bars[2] = -scalar_bars[2];
     }
     return MCPM_OK;
+}
+
+int mcpm_lpt_vjp_opts_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, const double *lpt_scalars, int lap_fd, int grad_fd,
+                          const float *dpos_bar, const float *vel_bar, float *init_mesh_bar, double *scalar_bars) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, init_mesh && lpt_scalars && dpos_bar && vel_bar && init_mesh_bar, MCPM_E_ARG, "mcpm_lpt_vjp_opts_f32: null argument");
+    MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_lpt_vjp_opts_f32: lpt_order must be 1 or 2");
+    MCPM_HIP(p, hipMemsetAsync(p->reduce, 0, sizeof(double) * 3, p->stream));
+    MCPM_TRY(lpt_vjp_device(p, init_mesh, lpt_order, lpt_scalars, dpos_bar, vel_bar, init_mesh_bar, p->reduce, lap_fd, grad_fd));
+    if (scalar_bars) {
+        MCPM_HIP(p, hipMemcpyAsync(scalar_bars, p->reduce, sizeof(double) * 3, hipMemcpyDeviceToHost, p->stream));
+        MCPM_HIP(p, hipStreamSynchronize(p->stream));
+        scalar_bars[1] = -scalar_bars[1];
+        scalar_bars[2] = -scalar_bars[2];
+    }
+    return MCPM_OK;
+}
+
+// VJP of pm_forces(pos, mesh_shape, order, paint_deconv, grad_fd, lap_fd) w.r.t. pos (painted case, nbody.py:583-604)
+int mcpm_pm_forces_vjp_opts_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, int order, int paint_deconv, int lap_fd,
+                                int grad_fd, const float *forces_bar, float *pos_bar) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, pos && forces_bar && pos_bar, MCPM_E_ARG, "mcpm_pm_forces_vjp_opts_f32: null buffer");
+    const int64_t M = p->M;
+    const int deconv = paint_deconv ? order : 0;
+    float *fm = p->fmesh, *fb = p->fmesh + 3 * M;
+    MCPM_TRY(mcpm_paint_f32(p, pos, n, mode, nullptr, 1, 1.f, order, p->rho, 0));
+    MCPM_TRY(mcpm_fft_r2c(p, p->rho, p->spec1, 1));
+    MCPM_TRY(spec_to_force_meshes(p, p->spec1, lap_fd, grad_fd, 0.f, deconv, fm));
+    MCPM_TRY(mcpm_read_vjp_pos_f32(p, pos, n, mode, fm, 3, order, forces_bar, pos_bar));
+    MCPM_TRY(mcpm_paint3_f32(p, pos, n, mode, forces_bar, order, fb, 0));
+    MCPM_TRY(force_meshes_vjp_opts(p, fb, p->rho, lap_fd, grad_fd, deconv));
+    MCPM_TRY(ensure_pscratch_n(p, 3 * n));
+    float *pb2 = p->vscratch;
+    MCPM_TRY(mcpm_paint_vjp_f32(p, pos, n, mode, nullptr, 1, 1.f, order, p->rho, pb2, nullptr));
+    return axpby(p, pos_bar, pb2, 3 * n, 1.f, 1.f, pos_bar);
 }
 
 int64_t mcpm_nbody_ckpt_floats(const mcpm_plan *p, int n_steps, int lpt_order) {

@@ -191,6 +191,120 @@ __global__ __launch_bounds__(256) void lattice_scatter_fx_kernel(Geom g, const f
 }
 
 // ------------------------------------------------------------------------------------------------
+// Kaiser-Bessel assignment (nbody.py:280-290 `kaiser_bessel`, selected by kernel_type in paint :381-382 and read :411-412):
+//     K(s) = I0(kc sqrt(1 - (2 s / order)^2)) kc / (order sinh(kc)),   kc = kcut order / 2,
+// on the same order^3 stencil and base cell (floor / round-half-even) as the rectangular kernels.  Any order 1..4 at run
+// time, absolute or lattice positions; not a hot path (the model's default is kernel_type = 'rectangular', model.py:52).
+__device__ __forceinline__ float kb_i0(float x) {          // sum_k (x^2/4)^k / (k!)^2: positive terms, no cancellation
+    const float t = 0.25f * x * x;
+    float term = 1.f, sum = 1.f;
+    for (int k = 1; k < 64; ++k) {
+        term *= t / (float)(k * k);
+        sum += term;
+        if (term < 1e-9f * sum) break;
+    }
+    return sum;
+}
+__device__ __forceinline__ float kb_i1_over_x(float x) {   // I1(x) / x = sum_k (x^2/4)^k / (2 k! (k+1)!)
+    const float t = 0.25f * x * x;
+    float term = 0.5f, sum = 0.5f;
+    for (int k = 1; k < 64; ++k) {
+        term *= t / (float)(k * (k + 1));
+        sum += term;
+        if (term < 1e-9f * sum) break;
+    }
+    return sum;
+}
+// per-axis weights w[j] = K(idx_j - pos) and dw[j] = d/dpos K(idx_j - pos) of the `order` stencil points, f = pos - id0
+__device__ __forceinline__ void kb_axis(float f, int order, float kc, float ninv, float (&w)[4], float (&dw)[4]) {
+    const int sh = -((order - 1) / 2);
+    const float so = 2.f / (float)order;
+    for (int j = 0; j < order; ++j) {
+        const float sp = ((float)(sh + j) - f) * so;
+        const float z = kc * sqrtf(fmaxf(1.f - sp * sp, 0.f));
+        w[j] = kb_i0(z) * ninv;
+        dw[j] = ninv * kc * kc * sp * so * kb_i1_over_x(z);      // -dK/ds,  I1(z) dz/ds = -kc^2 sp (2/order) I1(z)/z
+    }
+}
+struct KbStencil {
+    int64_t xo[4], yo[4];
+    int zo[4];
+};
+template <int MODE>
+__device__ __forceinline__ void kb_locate(const Geom &g, const PIdx &pi, P3 d, int order, KbStencil &s, float (&f)[3]) {
+    int c[3];
+    if (order & 1) locate<MODE, 3>(g, pi, d, c, f);      // round-half-even, f in [-1/2, 1/2]
+    else locate<MODE, 2>(g, pi, d, c, f);                 // floor, f in [0, 1)
+    const int sh = -((order - 1) / 2);
+    for (int j = 0; j < order; ++j) {
+        const int x = g.xslab ? min(max(c[0] + sh + j, 0), g.nx - 1) : wrapi(c[0] + sh + j, g.nx);
+        s.xo[j] = (int64_t)x * g.ny * g.nz;
+        s.yo[j] = (int64_t)wrapi(c[1] + sh + j, g.ny) * g.nz;
+        s.zo[j] = wrapi(c[2] + sh + j, g.nz);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void paint_kb_kernel(Geom g, const float *__restrict__ pos, int64_t n, const float *__restrict__ w,
+                                                       int64_t wstride, float *__restrict__ mesh, unsigned long long *__restrict__ acc,
+                                                       const unsigned *__restrict__ wmax_bits, int q, int order, float kc, float ninv) {
+    const FxgScale sc = fxg_scale(wmax_bits, q);
+    if (sc.S == 0. && !sc.flt) return;
+    PIdx pi = particle_index<MODE>(g, n);
+    if (!pi.valid) return;
+    KbStencil s;
+    float f[3], wx[4], wy[4], wz[4], dd[4];
+    kb_locate<MODE>(g, pi, load3(pos, pi.i), order, s, f);
+    kb_axis(f[0], order, kc, ninv, wx, dd);
+    kb_axis(f[1], order, kc, ninv, wy, dd);
+    kb_axis(f[2], order, kc, ninv, wz, dd);
+    const float wt = w ? w[pi.i * wstride] : 1.f;
+    for (int a = 0; a < order; ++a)
+        for (int b = 0; b < order; ++b)
+            for (int e = 0; e < order; ++e) {
+                const float v = wt * wx[a] * wy[b] * wz[e];
+                const int64_t cell = s.xo[a] + s.yo[b] + s.zo[e];
+                if (sc.flt) atomicAdd(mesh + cell, v);
+                else atomicAdd(acc + cell, (unsigned long long)__double2ll_rn((double)v * sc.S));
+            }
+}
+
+// out[i] = read (out != NULL); pos_bar[i] = ob_i d read_i / d pos (pos_bar != NULL; ob == NULL: obscalar); val_out as out
+template <int MODE>
+__global__ __launch_bounds__(256) void read_kb_kernel(Geom g, const float *__restrict__ pos, int64_t n, const float *__restrict__ mesh,
+                                                      int order, float kc, float ninv, float *__restrict__ out,
+                                                      const float *__restrict__ ob, int64_t obstride, float obscalar,
+                                                      float *__restrict__ pos_bar) {
+    PIdx pi = particle_index<MODE>(g, n);
+    if (!pi.valid) return;
+    KbStencil s;
+    float f[3], wx[4], wy[4], wz[4], dx[4], dy[4], dz[4];
+    kb_locate<MODE>(g, pi, load3(pos, pi.i), order, s, f);
+    kb_axis(f[0], order, kc, ninv, wx, dx);
+    kb_axis(f[1], order, kc, ninv, wy, dy);
+    kb_axis(f[2], order, kc, ninv, wz, dz);
+    float v = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int a = 0; a < order; ++a)
+        for (int b = 0; b < order; ++b) {
+            float r0 = 0.f, r1 = 0.f;
+            for (int e = 0; e < order; ++e) {
+                const float m = mesh[s.xo[a] + s.yo[b] + s.zo[e]];
+                r0 += m * wz[e];
+                r1 += m * dz[e];
+            }
+            v += wx[a] * wy[b] * r0;
+            gx += dx[a] * wy[b] * r0;
+            gy += wx[a] * dy[b] * r0;
+            gz += wx[a] * wy[b] * r1;
+        }
+    if (out) out[pi.i] = v;
+    if (pos_bar) {
+        const float o = ob ? ob[pi.i * obstride] : obscalar;
+        store3(pos_bar, pi.i, P3{o * gx, o * gy, o * gz});
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // read: gather NCOMP contiguous meshes
 template <int MODE, int ORDER, int NCOMP>
 __global__ __launch_bounds__(256) void read_kernel(Geom g, const float *__restrict__ pos, int64_t n,
@@ -467,6 +581,62 @@ int mcpm_paint_vjp_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, cons
     DISPATCH_MODE_ORDER(mode, order, CALL);
 #undef CALL
     MCPM_LAUNCH_CHECK(p, "read_vjp_pos_kernel(paint_vjp)");
+    return MCPM_OK;
+}
+
+static inline void kb_constants(int order, float kcut, float &kc, float &ninv) {
+    kc = kcut * (float)order * 0.5f;
+    ninv = (float)((double)kc / ((double)order * sinh((double)kc)));
+}
+
+int mcpm_paint_kb_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *weights, int64_t wstride, float wscalar,
+                      int order, float kcut, float *mesh, int accumulate) {
+    MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_paint_kb_f32"));
+    MCPM_REQUIRE(p, mesh != nullptr && kcut > 0.f, MCPM_E_ARG, "mcpm_paint_kb_f32: null mesh or kcut <= 0");
+    if (weights && wstride < 1) return mcpm_fail(p, MCPM_E_ARG, "mcpm_paint_kb_f32: wstride must be >= 1");
+    StageTimer st_(p, ST_PAINT, (weights ? 16.0 : 12.0) * n + (accumulate ? 8.0 : 4.0) * p->M);
+    if (!accumulate) MCPM_HIP(p, hipMemsetAsync(mesh, 0, sizeof(float) * p->M, p->stream));
+    if (n == 0) return MCPM_OK;
+    MCPM_TRY(fxg_prepare(p));
+    if (weights) {
+        MCPM_HIP(p, hipMemsetAsync(p->gx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream));
+        absmax_strided_kernel<<<2048, 256, 0, p->stream>>>(weights, wstride, n, p->gx_wmax);
+    } else {
+        fxg_set_unit_kernel<<<1, MCPM_FX_SLOTS, 0, p->stream>>>(p->gx_wmax);
+    }
+    const int q = fxg_q(n * order * order * order) - 2;     // a Kaiser-Bessel weight can exceed 1 (1.6 at order 1): two bits of headroom
+    float kc, ninv;
+    kb_constants(order, kcut, kc, ninv);
+    dim3 grid, block;
+    if (mode == MCPM_POS_LATTICE) {
+        lattice_launch(p->g, grid, block);
+        paint_kb_kernel<MCPM_POS_LATTICE><<<grid, block, 0, p->stream>>>(p->g, pos, n, weights, wstride, mesh, (unsigned long long *)p->gx_acc, p->gx_wmax, q, order, kc, ninv);
+    } else {
+        flat_launch(n, grid, block);
+        paint_kb_kernel<MCPM_POS_ABSOLUTE><<<grid, block, 0, p->stream>>>(p->g, pos, n, weights, wstride, mesh, (unsigned long long *)p->gx_acc, p->gx_wmax, q, order, kc, ninv);
+    }
+    paint_fxg_flush_kernel<<<2048, 256, 0, p->stream>>>(p->gx_acc, mesh, p->M, p->gx_wmax, q, weights ? 1.f : wscalar, (((uintptr_t)mesh) & 7) ? 0 : 1);
+    MCPM_LAUNCH_CHECK(p, "paint_kb_kernel");
+    return MCPM_OK;
+}
+
+int mcpm_read_kb_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *mesh, int order, float kcut, float *out,
+                     const float *out_bar, int64_t obstride, float obscalar, float *pos_bar) {
+    MCPM_TRY(check_particles(p, pos, n, mode, order, "mcpm_read_kb_f32"));
+    MCPM_REQUIRE(p, mesh && (out || pos_bar || n == 0) && kcut > 0.f, MCPM_E_ARG, "mcpm_read_kb_f32: null buffer or kcut <= 0");
+    StageTimer st_(p, ST_READ, 24.0 * n + 4.0 * (p->M + n));
+    if (n == 0) return MCPM_OK;
+    float kc, ninv;
+    kb_constants(order, kcut, kc, ninv);
+    dim3 grid, block;
+    if (mode == MCPM_POS_LATTICE) {
+        lattice_launch(p->g, grid, block);
+        read_kb_kernel<MCPM_POS_LATTICE><<<grid, block, 0, p->stream>>>(p->g, pos, n, mesh, order, kc, ninv, out, out_bar, obstride, obscalar, pos_bar);
+    } else {
+        flat_launch(n, grid, block);
+        read_kb_kernel<MCPM_POS_ABSOLUTE><<<grid, block, 0, p->stream>>>(p->g, pos, n, mesh, order, kc, ninv, out, out_bar, obstride, obscalar, pos_bar);
+    }
+    MCPM_LAUNCH_CHECK(p, "read_kb_kernel");
     return MCPM_OK;
 }
 

@@ -263,11 +263,40 @@ def rectangular_hat(kvec, order: int = 2):
     return out
 
 
+def kaiser_bessel(s, order, kcut):
+    """Kaiser-Bessel kernel (nbody.py:280-290), host numpy."""
+    from scipy.special import i0
+    s = np.asarray(s, dtype=np.float64) * 2 / order
+    kc = kcut * order / 2
+    return i0(kc * (1 - s ** 2) ** .5) / (order * np.sinh(kc) / kc)
+
+
+def kaiser_bessel_hat(kvec, order, kcut):
+    """Fourier transform of the Kaiser-Bessel kernel (nbody.py:293-312), host numpy."""
+    def kernel(k, kc):
+        k = np.asarray(k, dtype=np.float64) * order / 2
+        kc = kc * order / 2
+        dist = np.abs(kc ** 2 - k ** 2) ** .5
+        safe = np.where(dist == 0, 1., dist)
+        bulk = np.where(dist == 0, 1., np.sinh(safe) / safe)
+        tail = np.where(dist == 0, 1., np.sin(safe) / safe)
+        return np.where(np.abs(k) <= kc, bulk, tail) / (np.sinh(kc) / kc)
+    out = 1.
+    for ki in kvec:
+        out = out * kernel(ki, kcut)
+    return out
+
+
+def optim_kcut(oversamp, safety=0.98):
+    """Optimal wavenumber cutoff of the Kaiser-Bessel kernel (nbody.py:357-363)."""
+    return safety * np.pi * (2 - 1 / oversamp)
+
+
 # ------------------------------------------------------------------------------------------------
 # mass assignment
 def _check_kernel(kernel_type, order):
-    if kernel_type != "rectangular":
-        raise NotImplementedError("only kernel_type='rectangular' is implemented on the HIP path")
+    if kernel_type not in ("rectangular", "kaiser_bessel"):
+        raise ValueError(f"Unknown kernel type: {kernel_type}")
     if order not in (1, 2, 3, 4):
         raise ValueError("order must be 1 (NGP), 2 (CIC), 3 (TSC) or 4 (PCS)")
 
@@ -290,7 +319,10 @@ def paint(pos, shape: tuple, weights=1., order: int = 2, kernel_type='rectangula
     plan, p, n, mode = _pos_args(pos, shape)
     w, ws, wsc = _weights_args(weights, n)
     mesh = torch.empty(shape, dtype=torch.float32, device=p.device)
-    plan.call("mcpm_paint_f32", _ptr(p), n, mode, _ptr(w), ws, wsc, order, _ptr(mesh), 0)
+    if kernel_type == "kaiser_bessel":
+        plan.call("mcpm_paint_kb_f32", _ptr(p), n, mode, _ptr(w), ws, wsc, order, float(optim_kcut(oversamp)), _ptr(mesh), 0)
+    else:
+        plan.call("mcpm_paint_f32", _ptr(p), n, mode, _ptr(w), ws, wsc, order, _ptr(mesh), 0)
     return mesh
 
 
@@ -300,33 +332,45 @@ def read(pos, mesh, order: int = 2, kernel_type='rectangular', oversamp=1.):
     mesh = _f32(mesh)
     plan, p, n, mode = _pos_args(pos, mesh.shape)
     out = torch.empty((n,), dtype=torch.float32, device=p.device)
-    plan.call("mcpm_read_f32", _ptr(p), n, mode, _ptr(mesh), 1, order, _ptr(out))
+    if kernel_type == "kaiser_bessel":
+        plan.call("mcpm_read_kb_f32", _ptr(p), n, mode, _ptr(mesh), order, float(optim_kcut(oversamp)), _ptr(out), None, 1, 0.0, None)
+    else:
+        plan.call("mcpm_read_f32", _ptr(p), n, mode, _ptr(mesh), 1, order, _ptr(out))
     return out
 
 
-def paint_vjp(pos, shape, weights, mesh_bar, order: int = 2):
+def paint_vjp(pos, shape, weights, mesh_bar, order: int = 2, kernel_type='rectangular', oversamp=1.):
     """VJP of paint: -> (pos_bar (N,3), weights_bar (N,) or its sum for scalar weights)."""
-    _check_kernel('rectangular', order)
+    _check_kernel(kernel_type, order)
     shape = tuple(int(s) for s in shape)
     plan, p, n, mode = _pos_args(pos, shape)
     w, ws, wsc = _weights_args(weights, n)
     mb = _f32(mesh_bar, shape)
     pos_bar = torch.empty((n, 3), dtype=torch.float32, device=p.device)
     w_bar = torch.empty((n,), dtype=torch.float32, device=p.device)
-    plan.call("mcpm_paint_vjp_f32", _ptr(p), n, mode, _ptr(w), ws, wsc, order, _ptr(mb), _ptr(pos_bar), _ptr(w_bar))
+    if kernel_type == "kaiser_bessel":
+        plan.call("mcpm_read_kb_f32", _ptr(p), n, mode, _ptr(mb), order, float(optim_kcut(oversamp)), _ptr(w_bar), _ptr(w), ws, wsc,
+                  _ptr(pos_bar))
+    else:
+        plan.call("mcpm_paint_vjp_f32", _ptr(p), n, mode, _ptr(w), ws, wsc, order, _ptr(mb), _ptr(pos_bar), _ptr(w_bar))
     return pos_bar, (w_bar if w is not None else w_bar.double().sum())
 
 
-def read_vjp(pos, mesh, out_bar, order: int = 2):
+def read_vjp(pos, mesh, out_bar, order: int = 2, kernel_type='rectangular', oversamp=1.):
     """VJP of read: -> (pos_bar (N,3), mesh_bar)."""
-    _check_kernel('rectangular', order)
+    _check_kernel(kernel_type, order)
     mesh = _f32(mesh)
     plan, p, n, mode = _pos_args(pos, mesh.shape)
     ob = _f32(out_bar, (n,))
     pos_bar = torch.empty((n, 3), dtype=torch.float32, device=p.device)
-    plan.call("mcpm_read_vjp_pos_f32", _ptr(p), n, mode, _ptr(mesh), 1, order, _ptr(ob), _ptr(pos_bar))
     mesh_bar = torch.empty(tuple(mesh.shape), dtype=torch.float32, device=p.device)
-    plan.call("mcpm_paint_f32", _ptr(p), n, mode, _ptr(ob), 1, 0.0, order, _ptr(mesh_bar), 0)
+    if kernel_type == "kaiser_bessel":
+        kc = float(optim_kcut(oversamp))
+        plan.call("mcpm_read_kb_f32", _ptr(p), n, mode, _ptr(mesh), order, kc, None, _ptr(ob), 1, 0.0, _ptr(pos_bar))
+        plan.call("mcpm_paint_kb_f32", _ptr(p), n, mode, _ptr(ob), 1, 0.0, order, kc, _ptr(mesh_bar), 0)
+    else:
+        plan.call("mcpm_read_vjp_pos_f32", _ptr(p), n, mode, _ptr(mesh), 1, order, _ptr(ob), _ptr(pos_bar))
+        plan.call("mcpm_paint_f32", _ptr(p), n, mode, _ptr(ob), 1, 0.0, order, _ptr(mesh_bar), 0)
     return pos_bar, mesh_bar
 
 
@@ -367,10 +411,17 @@ def _shift_pos(pos, shift):
 
 
 def deconv_paint(mesh, order: int = 2, kernel_type='rectangular', oversamp=1.):
-    """Deconvolve the mesh by the paint kernel of given order (nbody.py:315-334); real or half-spectrum input."""
-    if kernel_type != 'rectangular':
-        raise NotImplementedError("only kernel_type='rectangular' is implemented on the HIP path")
+    """Deconvolve the mesh by the paint kernel of given order and type (nbody.py:315-334); real or half-spectrum input."""
+    _check_kernel(kernel_type, order)
     t = torch.as_tensor(mesh)
+    if kernel_type == 'kaiser_bessel':      # separable: three 1-D factors (host float64, nbody.py:293-312) divided out on the device
+        real = not t.is_complex()
+        spec = rfftn(t) if real else _c64(t)
+        shape = ch2rshape(spec.shape)
+        kc = optim_kcut(oversamp)
+        hx, hy, hz = (torch.from_numpy(kaiser_bessel_hat((k.reshape(-1),), order, kc).astype(np.float32)).to(spec.device) for k in rfftk(shape))
+        out = spec / (hx[:, None, None] * hy[None, :, None] * hz[None, None, :])
+        return irfftn(out) if real else out
     if not t.is_complex():
         spec = rfftn(t)
         plan = get_plan(tuple(t.shape))
@@ -393,7 +444,7 @@ def interlace(pos, shape: tuple, weights=1., paint_order: int = 2, interlace_ord
     tmp = torch.empty_like(out)
     for j in range(int(interlace_order)):
         s = j / interlace_order
-        mesh = paint(_shift_pos(pos, s), shape, weights, paint_order)
+        mesh = paint(_shift_pos(pos, s), shape, weights, paint_order, kernel_type=kernel_type, oversamp=paint_oversamp)
         plan.call("mcpm_fft_r2c", _ptr(mesh), _ptr(tmp), 1)
         plan.call("mcpm_kspace_phase_f32", _ptr(tmp), _ptr(out), 1.0 / interlace_order, float(s), 0, 0, 0, 1)
     return out
@@ -425,24 +476,36 @@ def nufft(pos, final_shape: tuple, paint_shape=None, weights=1., paint_order: in
     """Non-uniform FFT with oversampling, interlacing and kernel deconvolution (nbody.py:532-577).  `pos` in cell
     units of `final_shape`; the particles are painted on `paint_shape` (tuple, or float = oversampling factor on
     final_shape), deconvolved there and reshaped to the half-spectrum of final_shape with `chreshape`."""
+    paint_oversamp = _nufft_oversamp(final_shape, paint_shape)
     final_shape, paint_shape = _nufft_shapes(final_shape, paint_shape)
     ratio = tuple(p / f for p, f in zip(paint_shape, final_shape))
     mesh = interlace(_scale_pos(pos, ratio, paint_shape, final_shape), paint_shape, weights, paint_order, interlace_order,
-                     kernel_type=kernel_type)
+                     kernel_type=kernel_type, paint_oversamp=paint_oversamp)
     jac = float(np.prod(ratio))
     if jac != 1.0:
         mesh *= jac                       # jacobian of final units to paint units (nbody.py:570)
     if paint_deconv:
-        mesh = deconv_paint(mesh, paint_order, kernel_type=kernel_type)
+        mesh = deconv_paint(mesh, paint_order, kernel_type=kernel_type, oversamp=paint_oversamp)
     if final_shape != paint_shape:
         mesh = chreshape(mesh, r2chshape(final_shape))
     return mesh
 
 
+def _nufft_oversamp(final_shape, paint_shape):
+    """paint_oversamp as nufft derives it (nbody.py:557-566): 1, the float given, or -- for a shape -- the geometric mean of
+    final / paint (sic)."""
+    if paint_shape is None:
+        return 1.
+    if isinstance(paint_shape, float):
+        return paint_shape
+    return float(np.exp(np.log(np.divide(tuple(final_shape), tuple(paint_shape))).mean()))
+
+
 def nufft_vjp(pos, final_shape: tuple, weights, mesh_bar, paint_order: int = 2, interlace_order: int = 2, paint_deconv=True,
-              paint_shape=None):
+              paint_shape=None, kernel_type='rectangular'):
     """VJP of nufft w.r.t. (pos, weights); mesh_bar is the cotangent of the returned half-spectrum (shape
     r2chshape(final_shape)) in the real-pair convention.  Returns (pos_bar (N,3) in final_shape cell units, weights_bar)."""
+    paint_oversamp = _nufft_oversamp(final_shape, paint_shape)
     final_shape, shape = _nufft_shapes(final_shape, paint_shape)
     ratio = tuple(p / f for p, f in zip(shape, final_shape))
     mb = _c64(mesh_bar, r2chshape(final_shape))
@@ -451,15 +514,18 @@ def nufft_vjp(pos, final_shape: tuple, weights, mesh_bar, paint_order: int = 2, 
     jac = float(np.prod(ratio))
     ppos = _scale_pos(pos, ratio, shape, final_shape)
     plan = get_plan(shape, ppos.ptcl_shape if isinstance(ppos, LatticePos) else None)
+    kb = kernel_type == "kaiser_bessel"
+    if kb and paint_deconv:      # the deconvolution is a real multiplier: its adjoint is the same division
+        mb = deconv_paint(mb.clone(), paint_order, kernel_type=kernel_type, oversamp=paint_oversamp)
     tmp = torch.empty_like(mb)
     real = torch.empty(shape, dtype=torch.float32, device=mb.device)
     pos_bar, w_bar = None, None
     for j in range(int(interlace_order)):
         s = j / interlace_order
         # adjoint of (x phase / deconv / interlace_order) then of rfftn: C2R(conj(mult) * bar / multiplicity)
-        plan.call("mcpm_kspace_phase_f32", _ptr(mb), _ptr(tmp), jac / interlace_order, float(s), int(paint_order) if paint_deconv else 0, 1, 1, 0)
+        plan.call("mcpm_kspace_phase_f32", _ptr(mb), _ptr(tmp), jac / interlace_order, float(s), int(paint_order) if (paint_deconv and not kb) else 0, 1, 1, 0)
         plan.call("mcpm_fft_c2r", _ptr(tmp), _ptr(real), 1)
-        pb, wb = paint_vjp(_shift_pos(ppos, s), shape, weights, real, paint_order)
+        pb, wb = paint_vjp(_shift_pos(ppos, s), shape, weights, real, paint_order, kernel_type=kernel_type, oversamp=paint_oversamp)
         pos_bar = pb if pos_bar is None else pos_bar + pb
         w_bar = wb if w_bar is None else w_bar + wb
     if jac != 1.0 or any(r != 1.0 for r in ratio):
@@ -789,7 +855,7 @@ def _dptr(x):
 
 def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 2, lpt_order: int = 2,
              paint_deconv=False, grad_fd=np.inf, lap_fd=np.inf, snapshots=None, fn=None,
-             integrator="bullfrog", return_ctx=False, lattice_out=False):
+             integrator="bullfrog", return_ctx=False, lattice_out=False):    # fn=None is the reference's default fn=save_y
     """N-body simulation with the BullFrog solver (nbody.py:967-1002).
 
     `pos` must be the regular lattice (`bricks.regular_pos(mesh_shape, ptcl_shape)`, as at model.py:738) given
@@ -798,8 +864,6 @@ def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 
     `integrator='fastpm'` selects the alpha_fpm coefficient (nbody.py:921-931).
     `return_ctx=True` also returns the context for `nbody_bf_vjp` (checkpoints are then kept).
     """
-    if fn is not None:
-        raise NotImplementedError("only the default save function (the state itself) is implemented")
     n_steps = int(n_steps)
     spec = _c64(init_mesh)
     mesh_shape = ch2rshape(spec.shape)
@@ -812,25 +876,41 @@ def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 
     plan = get_plan(mesh_shape, ptcl_shape)
     dg, alphas, betas, lpt_s = _step_scalars(cosmo, a0, a1, n_steps, integrator)
     N = plan.N
+    want_snaps = not (snapshots is None or (isinstance(snapshots, int) and snapshots <= 1))
     if paint_deconv or grad_fd != np.inf or lap_fd != np.inf:
-        # The options the model never selects on this branch (model.py:771-773): forward only, one pm_forces call per step
-        # (paint -> rocFFT / hand-written R2C -> FD or deconvolved k-space kernel -> 3 C2R -> read) instead of the fused loop.
-        if return_ctx or not (snapshots is None or (isinstance(snapshots, int) and snapshots <= 1)):
-            raise NotImplementedError("paint_deconv / finite-difference kernels: forward final state only (no VJP, no snapshots)")
+        # The options the model never selects on this branch (model.py:771-773; nbody.py:590-593 deconvolved paint, :125-163
+        # finite-difference kernels): one pm_forces call per step (paint -> R2C -> FD / deconvolved k-space kernel -> 3 C2R ->
+        # read) instead of the fused loop; the step states are kept for the reverse sweep (`_nbody_bf_opts_vjp`) and snapshots.
         lp0 = LatticePos.regular(mesh_shape, ptcl_shape)
         dpos, v = lpt(cosmo, spec, lp0, a0, lpt_order=lpt_order, read_order=1, grad_fd=grad_fd, lap_fd=lap_fd)
+        keep = return_ctx or want_snaps
+        states = torch.empty((n_steps, 2, N, 3), dtype=torch.float32, device=spec.device) if keep else None
         x = dpos + v * (dg / 2)
         for i in range(n_steps):
+            if keep:
+                states[i, 0], states[i, 1] = x, v
             F = pm_forces(LatticePos(x, mesh_shape, ptcl_shape), mesh_shape, paint_order, paint_deconv=paint_deconv, grad_fd=grad_fd,
                           lap_fd=lap_fd)
             v = float(alphas[i]) * v + float(betas[i]) * F
             x = x + v * (dg / 2 if i == n_steps - 1 else dg)
         lp = LatticePos(x, mesh_shape, ptcl_shape)
-        return (lp, v) if lattice_out else (lp.to_absolute()[None], v[None])
+        if want_snaps:
+            if lattice_out:
+                raise NotImplementedError("snapshots are returned as absolute positions")
+            out = _snapshots(cosmo, snapshots, a0, a1, n_steps, dg, states.reshape(-1), N, lp, v)
+        else:
+            out = (lp, v) if lattice_out else (lp.to_absolute()[None], v[None])
+        if fn is not None:
+            out = _apply_fn(fn, out, lattice_out)
+        if return_ctx:
+            return out, NbodyCtx(plan=plan, init_mesh=spec, n_steps=n_steps, dg=dg, alphas=alphas, betas=betas, lpt_s=lpt_s,
+                                 lpt_order=int(lpt_order), paint_order=int(paint_order), states=states, cosmo=cosmo, a0=a0, a1=a1,
+                                 integrator=integrator, mesh_shape=mesh_shape, ptcl_shape=ptcl_shape,
+                                 opts=dict(paint_deconv=bool(paint_deconv), grad_fd=grad_fd, lap_fd=lap_fd))
+        return out
     x = torch.empty((N, 3), dtype=torch.float32, device=spec.device)
     v = torch.empty((N, 3), dtype=torch.float32, device=spec.device)
     ckpt = None
-    want_snaps = not (snapshots is None or (isinstance(snapshots, int) and snapshots <= 1))
     if return_ctx or want_snaps:
         nck = lib.mcpm_nbody_ckpt_floats(plan.h, n_steps, lpt_order)
         ckpt = torch.empty((nck,), dtype=torch.float32, device=spec.device)
@@ -843,12 +923,66 @@ def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 
         out = _snapshots(cosmo, snapshots, a0, a1, n_steps, dg, ckpt, N, lp, v)
     else:
         out = (lp, v) if lattice_out else (lp.to_absolute()[None], v[None])
+    if fn is not None:
+        out = _apply_fn(fn, out, lattice_out)
     if return_ctx:
         ctx = NbodyCtx(plan=plan, init_mesh=spec, n_steps=n_steps, dg=dg, alphas=alphas, betas=betas, lpt_s=lpt_s,
                        lpt_order=int(lpt_order), paint_order=int(paint_order), ckpt=ckpt, cosmo=cosmo, a0=a0, a1=a1,
                        integrator=integrator)
         return out, ctx
     return out
+
+
+def save_y(t, y, args=None):
+    """diffrax's default SaveAt function (nbody.py:964, `fn=save_y`): the state itself."""
+    return y
+
+
+def _apply_fn(fn, out, lattice_out):
+    """`fn(t, y, args)` of diffrax's SubSaveAt (nbody.py:968, :979-986) applied to every saved state y = (pos, vel): the
+    solver stacks what fn returns along the leading (snapshot) axis.  t is not available per snapshot here (None)."""
+    if fn is save_y:
+        return out
+    if lattice_out:
+        return fn(None, out, None)
+    pos, vel = out
+    res = [fn(None, (pos[i], vel[i]), None) for i in range(pos.shape[0])]
+    if isinstance(res[0], (tuple, list)):
+        return tuple(torch.stack([r[k] for r in res]) for k in range(len(res[0])))
+    return torch.stack(res)
+
+
+def _nbody_bf_opts_vjp(ctx, xb, vb):
+    """Reverse sweep of the options branch of nbody_bf (deconvolved paint / finite-difference kernels): the adjoint of
+    each kick through mcpm_pm_forces_vjp_opts_f32, of the LPT start through mcpm_lpt_vjp_opts_f32."""
+    plan, K, dg, o = ctx.plan, ctx.n_steps, ctx.dg, ctx.opts
+    N = plan.N
+    xb, vb = xb.clone(), vb.clone()
+    abar, bbar, dgbar = np.zeros(K), np.zeros(K), 0.0
+    for i in reversed(range(K)):
+        tau = dg / 2 if i == K - 1 else dg
+        x, v = ctx.states[i, 0], ctx.states[i, 1]
+        lp = LatticePos(x, ctx.mesh_shape, ctx.ptcl_shape)
+        F = pm_forces(lp, ctx.mesh_shape, ctx.paint_order, paint_deconv=o["paint_deconv"], grad_fd=o["grad_fd"], lap_fd=o["lap_fd"])
+        vnew = float(ctx.alphas[i]) * v + float(ctx.betas[i]) * F
+        dgbar += (0.5 if i == K - 1 else 1.0) * float((xb.double() * vnew.double()).sum())      # x' += v_new tau(dg)
+        vt = vb + tau * xb
+        abar[i] = float((vt.double() * v.double()).sum())
+        bbar[i] = float((vt.double() * F.double()).sum())
+        Fb = (float(ctx.betas[i]) * vt).contiguous()
+        pb = torch.empty((N, 3), dtype=torch.float32, device=x.device)
+        plan.call("mcpm_pm_forces_vjp_opts_f32", _ptr(x), N, POS_LATTICE, ctx.paint_order, int(o["paint_deconv"]), _fd(o["lap_fd"]),
+                  _fd(o["grad_fd"]), _ptr(Fb), _ptr(pb))
+        xb = xb + pb
+        vb = float(ctx.alphas[i]) * vt
+    v0 = ctx.states[0, 1]
+    dgbar += 0.5 * float((xb.double() * v0.double()).sum())          # initial half drift x'_0 = x_0 + v_0 dg/2
+    vb = vb + xb * (dg / 2)
+    out = torch.empty(tuple(ctx.init_mesh.shape), dtype=torch.complex64, device=xb.device)
+    sb = np.zeros(3)
+    plan.call("mcpm_lpt_vjp_opts_f32", _ptr(ctx.init_mesh), ctx.lpt_order, _dptr(np.asarray(ctx.lpt_s, dtype=np.float64)), _fd(o["lap_fd"]),
+              _fd(o["grad_fd"]), _ptr(xb.contiguous()), _ptr(vb.contiguous()), _ptr(out), _dptr(sb))
+    return out, {"alpha": abar, "beta": bbar, "g": sb[0], "g2": sb[1], "dg2dg": sb[2], "dg": dgbar}
 
 
 def _snapshots(cosmo, snapshots, a0, a1, n_steps, dg, ckpt, N, lp_final, v_final):
@@ -891,6 +1025,8 @@ def nbody_bf_vjp(ctx, pos_bar, vel_bar):
     vb = _f32(vel_bar).reshape(-1, 3)
     if xb.shape[0] != plan.N or vb.shape[0] != plan.N:
         raise ValueError("cotangent shape does not match the particle count")
+    if getattr(ctx, "opts", None) is not None:
+        return _nbody_bf_opts_vjp(ctx, xb, vb)
     out = torch.empty(tuple(ctx.init_mesh.shape), dtype=torch.complex64, device=xb.device)
     sb = np.zeros(2 * n + 4)
     plan.call("mcpm_nbody_bf_vjp_f32", _ptr(ctx.init_mesh), n, _dptr(ctx.alphas), _dptr(ctx.betas), float(ctx.dg),

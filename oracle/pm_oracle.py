@@ -222,6 +222,45 @@ def rectangular_hat(kvec, order=2):
     return out
 
 
+def kaiser_bessel(s, order, kcut):
+    """montecosmo/nbody.py:280-290"""
+    from scipy.special import i0
+    s = np.asarray(s, dtype=np.float64) * 2 / order
+    kcut = kcut * order / 2
+    return i0(kcut * np.sqrt(np.maximum(1 - s ** 2, 0.))) / (order * np.sinh(kcut) / kcut)
+
+
+def kaiser_bessel_grad(s, order, kcut):
+    """d/ds kaiser_bessel(s): -kc^2 s' (2/order) I1(z)/z / norm with s' = 2 s / order, z = kc sqrt(1 - s'^2)."""
+    from scipy.special import i1
+    sp = np.asarray(s, dtype=np.float64) * 2 / order
+    kc = kcut * order / 2
+    z = kc * np.sqrt(np.maximum(1 - sp ** 2, 0.))
+    r = np.where(z > 1e-12, i1(np.maximum(z, 1e-12)) / np.maximum(z, 1e-12), 0.5)
+    return -kc ** 2 * sp * (2 / order) * r / (order * np.sinh(kc) / kc)
+
+
+def kaiser_bessel_hat(kvec, order, kcut):
+    """montecosmo/nbody.py:293-312"""
+    def kernel(k, kc):
+        k = np.asarray(k, dtype=np.float64) * order / 2
+        kc = kc * order / 2
+        dist = np.abs(kc ** 2 - k ** 2) ** .5
+        safe = np.where(dist == 0, 1., dist)
+        bulk = np.where(dist == 0, 1., np.sinh(safe) / safe)
+        tail = np.where(dist == 0, 1., np.sin(safe) / safe)
+        return np.where(np.abs(k) <= kc, bulk, tail) / (np.sinh(kc) / kc)
+    out = 1.
+    for ki in kvec:
+        out = out * kernel(ki, kcut)
+    return out
+
+
+def optim_kcut(oversamp, safety=0.98):
+    """montecosmo/nbody.py:357-363"""
+    return safety * np.pi * (2 - 1 / oversamp)
+
+
 # --------------------------------------------------------------------------- paint / read
 def _id0_shifts(pos, ndim, order):
     """montecosmo/nbody.py:375-377: id0 = floor (even order) or round-half-even (odd order), cast to
@@ -245,49 +284,53 @@ def cell_index(pos, shape, order=2):
     return id0 % shape16
 
 
-def stencil(pos, shape, order):
+def stencil(pos, shape, order, kernel_type="rectangular", oversamp=1.):
     """Yield (flat wrapped index (N,), per-axis kernel values (N,3), per-axis kernel derivatives
-    w.r.t. pos (N,3)) for each stencil point, following nbody.py:386-389."""
+    w.r.t. pos (N,3)) for each stencil point, following nbody.py:379-389."""
     pos = np.asarray(pos, dtype=np.float64)
     shape16 = np.asarray(shape, dtype=np.int16)
     id0, ishifts = _id0_shifts(pos, len(shape), order)
     for ishift in ishifts:
         idx = id0 + ishift                      # int16, unwrapped
         s = idx - pos                           # kernel argument on the UNWRAPPED index
-        ker = rectangular(s, order)
-        dker = -rectangular_grad(s, order)      # d/dpos K(idx - pos)
+        if kernel_type == "kaiser_bessel":
+            ker, dker = kaiser_bessel(s, order, optim_kcut(oversamp)), -kaiser_bessel_grad(s, order, optim_kcut(oversamp))
+        elif kernel_type == "rectangular":
+            ker, dker = rectangular(s, order), -rectangular_grad(s, order)      # d/dpos K(idx - pos)
+        else:
+            raise ValueError(f"Unknown kernel type: {kernel_type}")
         flat = np.ravel_multi_index(tuple((idx % shape16).T.astype(np.int64)), tuple(int(v) for v in shape))
         yield flat, ker, dker
 
 
-def paint(pos, shape, weights=1., order=2):
-    """montecosmo/nbody.py:365-396 (kernel_type='rectangular')."""
+def paint(pos, shape, weights=1., order=2, kernel_type="rectangular", oversamp=1.):
+    """montecosmo/nbody.py:365-396."""
     shape = tuple(int(s) for s in shape)
     size = int(np.prod(shape))
     mesh = np.zeros(size)
     n = len(pos)
-    if _THREADS > 1 and len(shape) == 3 and 1 <= order <= 4:
+    if _THREADS > 1 and len(shape) == 3 and 1 <= order <= 4 and kernel_type == "rectangular":
         p = np.ascontiguousarray(pos, dtype=np.float64)
         w = None if np.ndim(weights) == 0 else np.ascontiguousarray(np.broadcast_to(weights, (n,)), dtype=np.float64)
         _load_clib().pmo_paint(_dptr(p), n, _dptr(w), float(weights) if w is None else 0.0, order, *shape, _dptr(mesh))
         return mesh.reshape(shape)
     weights = np.broadcast_to(np.asarray(weights, dtype=np.float64), (n,))
-    for flat, ker, _ in stencil(pos, shape, order):
+    for flat, ker, _ in stencil(pos, shape, order, kernel_type, oversamp):
         mesh += np.bincount(flat, weights=weights * ker.prod(-1), minlength=size)
     return mesh.reshape(shape)
 
 
-def read(pos, mesh, order=2):
+def read(pos, mesh, order=2, kernel_type="rectangular", oversamp=1.):
     """montecosmo/nbody.py:398-427"""
     mesh = np.asarray(mesh)
-    if _THREADS > 1 and mesh.ndim == 3 and mesh.dtype == np.float64 and 1 <= order <= 4:
+    if _THREADS > 1 and mesh.ndim == 3 and mesh.dtype == np.float64 and 1 <= order <= 4 and kernel_type == "rectangular":
         p, m = np.ascontiguousarray(pos, dtype=np.float64), np.ascontiguousarray(mesh)
         out = np.empty(len(p))
         _load_clib().pmo_read(_dptr(p), len(p), _dptr(m), order, *m.shape, _dptr(out), None, 0.0, None)
         return out
     out = np.zeros(len(pos), dtype=mesh.dtype)
     flatmesh = mesh.reshape(-1)
-    for flat, ker, _ in stencil(pos, mesh.shape, order):
+    for flat, ker, _ in stencil(pos, mesh.shape, order, kernel_type, oversamp):
         out = out + flatmesh[flat] * ker.prod(-1)
     return out
 
@@ -304,11 +347,11 @@ def _dprod(ker, dker):
     return out
 
 
-def paint_vjp(pos, shape, weights, mesh_bar, order=2):
+def paint_vjp(pos, shape, weights, mesh_bar, order=2, kernel_type="rectangular", oversamp=1.):
     """VJP of paint w.r.t. (pos, weights).  weights may be a scalar (its bar is then summed)."""
     n = len(pos)
     w = np.broadcast_to(np.asarray(weights, dtype=np.float64), (n,))
-    if _THREADS > 1 and len(shape) == 3 and 1 <= order <= 4:
+    if _THREADS > 1 and len(shape) == 3 and 1 <= order <= 4 and kernel_type == "rectangular":
         p, mb = np.ascontiguousarray(pos, dtype=np.float64), np.ascontiguousarray(mesh_bar, dtype=np.float64)
         wc = np.ascontiguousarray(w)
         pos_bar, w_bar = np.zeros((n, 3)), np.empty(n)
@@ -317,7 +360,7 @@ def paint_vjp(pos, shape, weights, mesh_bar, order=2):
     flatbar = np.asarray(mesh_bar).reshape(-1)
     pos_bar = np.zeros((n, len(shape)))
     w_bar = np.zeros(n)
-    for flat, ker, dker in stencil(pos, shape, order):
+    for flat, ker, dker in stencil(pos, shape, order, kernel_type, oversamp):
         mb = flatbar[flat]
         w_bar += mb * ker.prod(-1)
         pos_bar += (w * mb)[:, None] * _dprod(ker, dker)
@@ -326,10 +369,10 @@ def paint_vjp(pos, shape, weights, mesh_bar, order=2):
     return pos_bar, w_bar
 
 
-def read_vjp(pos, mesh, out_bar, order=2):
+def read_vjp(pos, mesh, out_bar, order=2, kernel_type="rectangular", oversamp=1.):
     """VJP of read w.r.t. (pos, mesh)."""
     mesh = np.asarray(mesh)
-    if _THREADS > 1 and mesh.ndim == 3 and mesh.dtype == np.float64 and 1 <= order <= 4:
+    if _THREADS > 1 and mesh.ndim == 3 and mesh.dtype == np.float64 and 1 <= order <= 4 and kernel_type == "rectangular":
         p, m = np.ascontiguousarray(pos, dtype=np.float64), np.ascontiguousarray(mesh)
         ob = np.ascontiguousarray(np.broadcast_to(out_bar, (len(p),)), dtype=np.float64)
         pos_bar = np.zeros((len(p), 3))
@@ -337,27 +380,29 @@ def read_vjp(pos, mesh, out_bar, order=2):
         return pos_bar, paint(pos, mesh.shape, weights=out_bar, order=order)
     flatmesh = mesh.reshape(-1)
     pos_bar = np.zeros((len(pos), mesh.ndim))
-    for flat, ker, dker in stencil(pos, mesh.shape, order):
+    for flat, ker, dker in stencil(pos, mesh.shape, order, kernel_type, oversamp):
         pos_bar += (out_bar * flatmesh[flat])[:, None] * _dprod(ker, dker)
-    mesh_bar = paint(pos, mesh.shape, weights=out_bar, order=order)
+    mesh_bar = paint(pos, mesh.shape, weights=out_bar, order=order, kernel_type=kernel_type, oversamp=oversamp)
     return pos_bar, mesh_bar
 
 
 # --------------------------------------------------------------------------- observation-side painting
-def deconv_paint(mesh, order=2):
-    """montecosmo/nbody.py:315-334 (kernel_type='rectangular')."""
+def deconv_paint(mesh, order=2, kernel_type="rectangular", oversamp=1.):
+    """montecosmo/nbody.py:315-334"""
+    hat = (lambda kv: rectangular_hat(kv, order)) if kernel_type == "rectangular" else \
+        (lambda kv: kaiser_bessel_hat(kv, order, optim_kcut(oversamp)))
     if np.isrealobj(mesh):
         kvec = rfftk(mesh.shape)
-        return _irfftn(_rfftn(mesh) / rectangular_hat(kvec, order), s=mesh.shape, axes=(0, 1, 2))
-    return mesh / rectangular_hat(rfftk(ch2rshape(mesh.shape)), order)
+        return _irfftn(_rfftn(mesh) / hat(kvec), s=mesh.shape, axes=(0, 1, 2))
+    return mesh / hat(rfftk(ch2rshape(mesh.shape)))
 
 
-def interlace(pos, shape, weights=1., paint_order=2, interlace_order=2):
+def interlace(pos, shape, weights=1., paint_order=2, interlace_order=2, kernel_type="rectangular", paint_oversamp=1.):
     """montecosmo/nbody.py:513-529"""
     kvec = rfftk(shape)
     mesh = np.zeros(r2chshape(shape), dtype=complex)
     for shift in np.arange(interlace_order) / interlace_order:
-        m = paint(pos + shift, shape, weights, paint_order)
+        m = paint(pos + shift, shape, weights, paint_order, kernel_type, paint_oversamp)
         mesh = mesh + _rfftn(m) * np.exp(1j * shift * sum(kvec)) / interlace_order
     return mesh
 
@@ -566,28 +611,41 @@ def chreshape_vjp(out_bar, in_shape):
     return back
 
 
-def nufft(pos, final_shape, paint_shape=None, weights=1., paint_order=2, interlace_order=2, paint_deconv=True):
-    """montecosmo/nbody.py:532-577 (rectangular kernels): `pos` in cell units of final_shape; the particles are
-    painted on paint_shape (tuple, or float oversampling factor), deconvolved there and reshaped to final_shape."""
+def _nufft_oversamp(final_shape, paint_shape):
+    """paint_oversamp as montecosmo/nbody.py:557-566 derives it."""
+    if paint_shape is None:
+        return 1.
+    if isinstance(paint_shape, float):
+        return paint_shape
+    return float(np.exp(np.log(np.divide(tuple(final_shape), tuple(paint_shape))).mean()))
+
+
+def nufft(pos, final_shape, paint_shape=None, weights=1., paint_order=2, interlace_order=2, paint_deconv=True,
+          kernel_type="rectangular"):
+    """montecosmo/nbody.py:532-577: `pos` in cell units of final_shape; the particles are painted on paint_shape
+    (tuple, or float oversampling factor), deconvolved there and reshaped to final_shape."""
     final_shape = tuple(int(v) for v in final_shape)
+    paint_oversamp = _nufft_oversamp(final_shape, paint_shape)
     if paint_shape is None:
         paint_shape = final_shape
     elif isinstance(paint_shape, float):
         paint_shape = scale_shape(final_shape, paint_shape)
     paint_shape = tuple(int(v) for v in paint_shape)
     ratio = np.divide(paint_shape, final_shape)
-    mesh = interlace(np.asarray(pos) * ratio, paint_shape, weights, paint_order, interlace_order)
+    mesh = interlace(np.asarray(pos) * ratio, paint_shape, weights, paint_order, interlace_order, kernel_type, paint_oversamp)
     mesh = mesh * ratio.prod()
     if paint_deconv:
-        mesh = deconv_paint(mesh, paint_order)
+        mesh = deconv_paint(mesh, paint_order, kernel_type, paint_oversamp)
     if final_shape != paint_shape:
         mesh = chreshape(mesh, r2chshape(final_shape))
     return mesh
 
 
-def nufft_vjp(pos, final_shape, weights, mesh_bar, paint_order=2, interlace_order=2, paint_deconv=True, paint_shape=None):
+def nufft_vjp(pos, final_shape, weights, mesh_bar, paint_order=2, interlace_order=2, paint_deconv=True, paint_shape=None,
+              kernel_type="rectangular"):
     """VJP of nufft w.r.t. (pos, weights); mesh_bar in the real-pair convention."""
     final_shape = tuple(int(v) for v in final_shape)
+    paint_oversamp = _nufft_oversamp(final_shape, paint_shape)
     if paint_shape is None:
         paint_shape = final_shape
     elif isinstance(paint_shape, float):
@@ -598,11 +656,12 @@ def nufft_vjp(pos, final_shape, weights, mesh_bar, paint_order=2, interlace_orde
         mesh_bar = chreshape_vjp(mesh_bar, r2chshape(shape))
     mesh_bar = mesh_bar * ratio.prod()
     kvec = rfftk(shape)
-    mult = 1.0 / rectangular_hat(kvec, paint_order) if paint_deconv else 1.0
+    hat = rectangular_hat(kvec, paint_order) if kernel_type == "rectangular" else kaiser_bessel_hat(kvec, paint_order, optim_kcut(paint_oversamp))
+    mult = 1.0 / hat if paint_deconv else 1.0
     pos_bar, w_bar = 0., 0.
     for shift in np.arange(interlace_order) / interlace_order:
         sb = mesh_bar * np.conj(mult * np.exp(1j * shift * sum(kvec)) / interlace_order)
-        pb, wb = paint_vjp(np.asarray(pos) * ratio + shift, shape, weights, rfftn_vjp(sb, shape), paint_order)
+        pb, wb = paint_vjp(np.asarray(pos) * ratio + shift, shape, weights, rfftn_vjp(sb, shape), paint_order, kernel_type, paint_oversamp)
         pos_bar, w_bar = pos_bar + pb * ratio, w_bar + wb
     return pos_bar, w_bar
 
@@ -985,30 +1044,31 @@ def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order=2, lpt_
     return (out, traj, ts, dg) if return_traj else out
 
 
-def dkd_vjp(pos, vel, pos2_bar, vel1_bar, dg, alpha, g1mid, mesh_shape, paint_order=2):
+def dkd_vjp(pos, vel, pos2_bar, vel1_bar, dg, alpha, g1mid, mesh_shape, paint_order=2, paint_deconv=False, grad_fd=np.inf,
+            lap_fd=np.inf):
     """VJP of one drift-kick-drift map (nbody.py:946-950) at fixed scalars.
     Returns (pos_bar, vel_bar, alpha_bar, beta_bar, dg_bar) with beta = (1-alpha)/g1mid."""
     beta = (1 - alpha) / g1mid
     x1 = pos + vel * (dg / 2)
-    F = pm_forces(x1, tuple(mesh_shape), paint_order)
+    F = pm_forces(x1, tuple(mesh_shape), paint_order, paint_deconv=paint_deconv, grad_fd=grad_fd, lap_fd=lap_fd)
     v1 = alpha * vel + beta * F
     dg_bar = 0.5 * float(np.sum(pos2_bar * v1))
     v1_bar = vel1_bar + pos2_bar * (dg / 2)
     x1_bar = pos2_bar.copy()
     alpha_bar = float(np.sum(v1_bar * vel))
     beta_bar = float(np.sum(v1_bar * F))
-    x1_bar += pm_forces_vjp(x1, tuple(mesh_shape), beta * v1_bar, paint_order)[0]
+    x1_bar += pm_forces_vjp(x1, tuple(mesh_shape), beta * v1_bar, paint_order, paint_deconv=paint_deconv, grad_fd=grad_fd, lap_fd=lap_fd)[0]
     vel_bar = alpha * v1_bar + x1_bar * (dg / 2)
     dg_bar += 0.5 * float(np.sum(x1_bar * vel))
     return x1_bar, vel_bar, alpha_bar, beta_bar, dg_bar
 
 
 def nbody_bf_vjp(cosmo, init_mesh, pos, pos_bar, vel_bar, a0=0., a1=1., n_steps=5, paint_order=2, lpt_order=2,
-                 alpha_fn=alpha_bf):
-    """Reverse sweep of nbody_bf (paint_deconv=False, spectral kernels) at fixed growth scalars.
+                 alpha_fn=alpha_bf, paint_deconv=False, grad_fd=np.inf, lap_fd=np.inf):
+    """Reverse sweep of nbody_bf at fixed growth scalars (options as nbody.py:967-973).
     Returns (init_mesh_bar, scalar_bars) where scalar_bars holds per-step alpha_bar/beta_bar, dg_bar and the
     LPT growth-scalar bars; `pos_bar`/`vel_bar` are cotangents of the final (pos, vel), shape (N,3)."""
-    (_, traj, ts, dg) = nbody_bf(cosmo, init_mesh, pos, a0, a1, n_steps, paint_order, lpt_order,
+    (_, traj, ts, dg) = nbody_bf(cosmo, init_mesh, pos, a0, a1, n_steps, paint_order, lpt_order, paint_deconv, grad_fd, lap_fd,
                                  alpha_fn=alpha_fn, return_traj=True)
     mesh_shape = ch2rshape(init_mesh.shape)
     xb, vb = np.array(pos_bar, dtype=np.float64), np.array(vel_bar, dtype=np.float64)
@@ -1019,11 +1079,11 @@ def nbody_bf_vjp(cosmo, init_mesh, pos, pos_bar, vel_bar, a0=0., a1=1., n_steps=
         alpha = float(alpha_fn(cosmo, ts[i], dg))
         g1mid = ts[i] + dg / 2
         # y_{i+1} = y_i + (DKD(y_i) - y_i) * r
-        xb2, vb2, ab, bb, db = dkd_vjp(x, v, r * xb, r * vb, dg, alpha, g1mid, mesh_shape, paint_order)
+        xb2, vb2, ab, bb, db = dkd_vjp(x, v, r * xb, r * vb, dg, alpha, g1mid, mesh_shape, paint_order, paint_deconv, grad_fd, lap_fd)
         xb = (1 - r) * xb + xb2
         vb = (1 - r) * vb + vb2
         abar[i], bbar[i] = ab, bb
         dgbar += db
-    mesh_bar, _, sbar = lpt_vjp(cosmo, init_mesh, pos, a0, xb, vb, lpt_order=lpt_order, read_order=1)
+    mesh_bar, _, sbar = lpt_vjp(cosmo, init_mesh, pos, a0, xb, vb, lpt_order=lpt_order, read_order=1, grad_fd=grad_fd, lap_fd=lap_fd)
     sbar.update(alpha=abar, beta=bbar, dg=dgbar)
     return mesh_bar, sbar

@@ -599,15 +599,32 @@ def test_lpt_light_cone(nb, lpt_order):
 @pytest.mark.parametrize("opts", [dict(paint_deconv=True), dict(grad_fd=4, lap_fd=2), dict(paint_deconv=True, grad_fd=2, lap_fd=4)])
 def test_nbody_bf_deconv_and_fd_kernels(nb, opts):
     """nbody.py:967-1002 with the options the model leaves at their defaults: paint_deconv (:590-593) and the
-    finite-difference Laplace / gradient kernels (:125-163), forward state against the oracle."""
+    finite-difference Laplace / gradient kernels (:125-163): forward state, reverse sweep, snapshots and a save function
+    against the oracle."""
     from montecosmo_amd import bricks, synth
     n, n_steps = 16, 4
     shape = (n, n, n)
     spec = synth.init_mesh(n, seed=2, rms_disp=1.0)
     pos = bricks.regular_pos(shape)
-    p_g, v_g = nb.nbody_bf(bricks.Planck18(), spec, pos, a0=0.1, a1=0.9, n_steps=n_steps, **opts)
+    (p_g, v_g), ctx = nb.nbody_bf(bricks.Planck18(), spec, pos, a0=0.1, a1=0.9, n_steps=n_steps, return_ctx=True, **opts)
     p_o, v_o = o.nbody_bf(obg.Planck18(), spec.astype(np.complex128), pos, a0=0.1, a1=0.9, n_steps=n_steps, **opts)
     assert rel_l2(to_np(p_g)[0] - pos, p_o[0] - pos) < 1e-5 and rel_l2(to_np(v_g)[0], v_o[0]) < 1e-5
+    # reverse sweep (the reference differentiates through both options with jax.grad, model.py:362-363)
+    rng = np.random.default_rng(8)
+    xb, vb = rng.standard_normal((n ** 3, 3)), rng.standard_normal((n ** 3, 3))
+    mb_g, sb_g = nb.nbody_bf_vjp(ctx, xb.astype(np.float32), vb.astype(np.float32))
+    mb_o, sb_o = o.nbody_bf_vjp(obg.Planck18(), spec.astype(np.complex128), pos, xb, vb, 0.1, 0.9, n_steps, **opts)
+    assert rel_l2(to_np(mb_g), mb_o) < 1e-4
+    for k in ("alpha", "beta"):
+        assert np.allclose(sb_g[k], sb_o[k], rtol=1e-3, atol=1e-3 * np.abs(sb_o[k]).max()), k
+    for k in ("g", "g2", "dg2dg", "dg"):
+        assert np.isclose(sb_g[k], sb_o[k], rtol=1e-3, atol=1e-3 * abs(sb_o["g"])), k
+    # snapshots and a save function on this branch (nbody.py:964-969: fn maps every saved state)
+    p3, v3 = nb.nbody_bf(bricks.Planck18(), spec, pos, a0=0.1, a1=0.9, n_steps=n_steps, snapshots=3, **opts)
+    p3o, v3o = o.nbody_bf(obg.Planck18(), spec.astype(np.complex128), pos, a0=0.1, a1=0.9, n_steps=n_steps, snapshots=3, **opts)
+    assert rel_l2(to_np(p3) - pos, p3o - pos) < 1e-5 and rel_l2(to_np(v3), v3o) < 1e-5
+    ke = nb.nbody_bf(bricks.Planck18(), spec, pos, a0=0.1, a1=0.9, n_steps=n_steps, snapshots=3, fn=lambda t, y, args: (y[1] ** 2).sum(), **opts)
+    assert np.allclose(to_np(ke), (v3o ** 2).sum(axis=(1, 2)), rtol=1e-4)
 
 
 @pytest.mark.parametrize("snapshots", [3, [0.3, 0.55, 1.0]])
@@ -718,3 +735,48 @@ def test_cosmology_gradient_through_growth_tables(nb):
     assert np.isclose(got, want, rtol=2e-3, atol=1e-3 * abs(want)), (got, want)
     _, sb_o = o.nbody_bf_vjp(obg.Planck18(), spec.astype(np.complex128), pos, Rx, Rv, a0, 1., n_steps)
     assert np.isclose(bars["dg"], sb_o["dg"], rtol=1e-3, atol=1e-3 * abs(sb_o["dg"]))
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
+def test_kaiser_bessel_paint_read_and_vjps(nb, order):
+    """kernel_type='kaiser_bessel' (nbody.py:280-312, :357-363, :381-382, :411-412): paint, read, both VJPs, the
+    deconvolution and the nufft (forward and VJP) against the oracle; absolute and lattice positions."""
+    shape = (16, 12, 20)
+    rng = np.random.default_rng(80 + order)
+    N = 5000
+    pos = random_pos(20, N, 81, spread=1.5)
+    w = rng.standard_normal(N).astype(np.float32)
+    p64, w64 = pos.astype(np.float64), w.astype(np.float64)
+    kb = dict(kernel_type="kaiser_bessel", oversamp=1.5)
+    okb = ("kaiser_bessel", 1.5)
+    got = to_np(nb.paint(pos, shape, w, order, **kb))
+    assert rel_l2(got, o.paint(p64, shape, w64, order, *okb)) < 3e-6
+    assert np.array_equal(got, to_np(nb.paint(pos, shape, w, order, **kb)))            # fixed-point sums: bit for bit
+    assert rel_l2(to_np(nb.paint(pos, shape, 2.0, order, **kb)), o.paint(p64, shape, 2.0, order, *okb)) < 3e-6
+    mesh = rng.standard_normal(shape).astype(np.float32)
+    assert rel_l2(to_np(nb.read(pos, mesh, order, **kb)), o.read(p64, mesh.astype(np.float64), order, *okb)) < 3e-6
+    pb, wb = nb.paint_vjp(pos, shape, w, mesh, order, **kb)
+    pb_o, wb_o = o.paint_vjp(p64, shape, w64, mesh.astype(np.float64), order, *okb)
+    assert rel_l2(to_np(pb), pb_o) < 2e-5 and rel_l2(to_np(wb), wb_o) < 3e-6
+    ob = rng.standard_normal(N).astype(np.float32)
+    pb, mb = nb.read_vjp(pos, mesh, ob, order, **kb)
+    pb_o, mb_o = o.read_vjp(p64, mesh.astype(np.float64), ob.astype(np.float64), order, *okb)
+    assert rel_l2(to_np(pb), pb_o) < 2e-5 and rel_l2(to_np(mb), mb_o) < 3e-6
+    assert rel_l2(to_np(nb.deconv_paint(mesh, order, **kb)), o.deconv_paint(mesh.astype(np.float64), order, *okb)) < 1e-5
+    # lattice displacements
+    lshape = (16, 16, 16)
+    disp = (rng.standard_normal((16 ** 3, 3)) * 1.2).astype(np.float32)
+    lp = nb.LatticePos(disp, lshape)
+    pl64 = o.regular_pos(lshape) + disp.astype(np.float64)
+    assert rel_l2(to_np(nb.paint(lp, lshape, 1., order, **kb)), o.paint(pl64, lshape, 1., order, *okb)) < 3e-6
+    # nufft with an oversampled paint mesh, and its VJP
+    fshape = (8, 8, 8)
+    posf = (p64 * 0.4) % 8
+    spec = nb.nufft(posf.astype(np.float32), fshape, 1.5, w, order, 2, kernel_type="kaiser_bessel")
+    spec_o = o.nufft(posf.astype(np.float32).astype(np.float64), fshape, 1.5, w64, order, 2, kernel_type="kaiser_bessel")
+    assert rel_l2(to_np(spec), spec_o) < 2e-5
+    sb = (rng.standard_normal(spec_o.shape) + 1j * rng.standard_normal(spec_o.shape)).astype(np.complex64)
+    pb, wb = nb.nufft_vjp(posf.astype(np.float32), fshape, w, sb, order, 2, paint_shape=1.5, kernel_type="kaiser_bessel")
+    pb_o, wb_o = o.nufft_vjp(posf.astype(np.float32).astype(np.float64), fshape, w64, sb.astype(np.complex128), order, 2, paint_shape=1.5,
+                             kernel_type="kaiser_bessel")
+    assert rel_l2(to_np(pb), pb_o) < 5e-5 and rel_l2(to_np(wb), wb_o) < 2e-5

@@ -400,3 +400,38 @@ def test_eisenstein_hu_known_answers():
     sig = np.sqrt(np.sum(0.5 * (f[1:] + f[:-1]) * np.diff(lk)) / (2 * np.pi ** 2))
     assert abs(sig - 1.0) < 2e-3
     assert 0.012 < ks[np.argmax(pows)] < 0.022                           # turnover at k_eq
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
+def test_kaiser_bessel_known_answers(order):
+    """nbody.py:280-312, :357-363: the kernel is (nearly) a partition of unity -- painted mass is conserved to the accuracy
+    Barnett et al. quote for this cutoff --, its analytic derivative matches central differences, its Fourier transform
+    `kaiser_bessel_hat` is the transform of the sampled kernel up to aliasing, and paint / read stay adjoint."""
+    rng = np.random.default_rng(70 + order)
+    kc = o.optim_kcut(1.)
+    assert np.isclose(kc, 0.98 * np.pi)
+    s = rng.uniform(-order / 2, order / 2, 200) * 0.999
+    h = 1e-6
+    assert np.allclose(o.kaiser_bessel_grad(s, order, kc), (o.kaiser_bessel(s + h, order, kc) - o.kaiser_bessel(s - h, order, kc)) / (2 * h),
+                       rtol=1e-5, atol=1e-7)
+    # continuous transform int K(s) e^{-i k s} ds by quadrature against kaiser_bessel_hat
+    x = np.linspace(-order / 2, order / 2, 40001)
+    for k in (0.0, 0.7, 2.0, kc * 0.9):
+        num = np.trapezoid(o.kaiser_bessel(x, order, kc) * np.cos(k * x), x)
+        assert np.isclose(num, o.kaiser_bessel_hat((np.array([k]),), order, kc)[0], rtol=2e-4, atol=2e-6), (order, k)
+    shape = (8, 6, 10)
+    pos = rng.uniform(-5, 15, (400, 3))
+    w, m = rng.standard_normal(400), rng.standard_normal(shape)
+    lhs = np.sum(o.paint(pos, shape, w, order, "kaiser_bessel") * m)
+    assert np.isclose(lhs, np.sum(w * o.read(pos, m, order, "kaiser_bessel")), rtol=1e-12)
+    if order >= 2:
+        assert abs(o.paint(pos, shape, 1., order, "kaiser_bessel").sum() / 400 - 1) < (0.25 if order == 2 else 0.05)
+    # VJPs against central differences
+    mb = rng.standard_normal(shape)
+    pb, wb = o.paint_vjp(pos, shape, w, mb, order, "kaiser_bessel")
+    d = rng.standard_normal(pos.shape)
+    L = lambda p_: np.sum(o.paint(p_, shape, w, order, "kaiser_bessel") * mb)
+    keep = np.all(np.abs((pos % 1.0) - 0.5) > 1e-3, axis=1) & np.all(np.abs(pos % 1.0) > 1e-3, axis=1) & np.all(np.abs(pos % 1.0) < 1 - 1e-3, axis=1)
+    dd = d * keep[:, None]
+    assert np.isclose((L(pos + h * dd) - L(pos - h * dd)) / (2 * h), np.sum(pb * dd), rtol=1e-5)
+    assert np.allclose(wb, o.read(pos, mb, order, "kaiser_bessel"))
