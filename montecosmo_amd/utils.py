@@ -64,18 +64,27 @@ def _stream_of(t):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def _norm_factor(norm, shape):
+    """rg2cgh(x, norm) / rg2cgh(x, "backward"): the norms of utils.py:826-835 differ by a constant only
+    (backward sqrt(M/2), ortho 1/sqrt(2), forward 1/sqrt(2 M))."""
+    M = float(shape[0]) * float(shape[1]) * float(shape[2])
+    if norm == "ortho":
+        return M ** -0.5
+    if norm == "forward":
+        return 1.0 / M
+    raise ValueError(f"unknown norm {norm!r}: 'backward', 'ortho', 'forward' (and 'amp' for cgh2rg)")
+
+
 def rg2cgh(mesh, norm="backward"):
     """Permute and reweight a real Gaussian tensor (3D, even sizes) into a complex Gaussian Hermitian tensor
     distributed as rfftn of a real Gaussian tensor (utils.py:892-906).  HIP kernel mcpm_rg2cgh_f32."""
     import torch
     from . import nbody
     from ._lib import lib, check
-    if norm != "backward":
-        raise NotImplementedError('only norm="backward" (the model\'s) is built')
     x = nbody._f32(mesh)
     out = torch.empty(r2chshape(x.shape), dtype=torch.complex64, device=x.device)
     check(lib.mcpm_rg2cgh_f32(_stream_of(x), nbody._ptr(x), *x.shape, nbody._ptr(out)), None, "mcpm_rg2cgh_f32")
-    return out
+    return out * _norm_factor(norm, x.shape) if norm != "backward" else out
 
 
 def rg2cgh_vjp(meshk_bar):
@@ -97,11 +106,9 @@ def cgh2rg(meshk, norm="backward"):
     import torch
     from . import nbody
     from ._lib import lib, check
-    if norm not in ("backward", "amp"):
-        raise NotImplementedError('only norm="backward" (the model\'s) and "amp" are built')
     k = nbody._c64(meshk)
     shape = ch2rshape(k.shape)
     out = torch.empty(shape, dtype=torch.float32, device=k.device)
-    fn = "mcpm_cgh2rg_f32" if norm == "backward" else "mcpm_cgh2rg_amp_f32"
+    fn = "mcpm_cgh2rg_amp_f32" if norm == "amp" else "mcpm_cgh2rg_f32"
     check(getattr(lib, fn)(_stream_of(k), nbody._ptr(k), *shape, nbody._ptr(out)), None, fn)
-    return out
+    return out / _norm_factor(norm, shape) if norm not in ("backward", "amp") else out

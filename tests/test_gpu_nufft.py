@@ -114,6 +114,13 @@ def test_rg2cgh_cgh2rg(nb, shape):
     assert rel_l2(utils.cgh2rg(Z.astype(np.complex64)).cpu().numpy(), o.cgh2rg(Z)) < 1e-6
     assert np.array_equal(utils.cgh2rg(Z.astype(np.complex64), norm="amp").cpu().numpy(),
                           o.cgh2rg(Z, "amp").astype(np.float32))             # a pure permutation of Re Z
+    for norm in ("ortho", "forward"):                                          # utils.py:826-835: a constant apart
+        Xn = utils.rg2cgh(x.astype(np.float32), norm=norm).cpu().numpy()
+        assert rel_l2(Xn, o.rg2cgh(x, norm)) < 1e-6
+        assert rel_l2(utils.cgh2rg(Xn, norm=norm).cpu().numpy(), x) < 1e-6
+        assert rel_l2(utils.cgh2rg(Z.astype(np.complex64), norm=norm).cpu().numpy(), o.cgh2rg(Z, norm)) < 1e-6
+    with pytest.raises(ValueError):
+        utils.rg2cgh(x.astype(np.float32), norm="nope")
     xb = utils.rg2cgh_vjp(Z.astype(np.complex64)).cpu().numpy()
     # transpose by linearity: <Z, rg2cgh(e)> over the stored modes
     d = rng.standard_normal(shape)
