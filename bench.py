@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mesh", type=int, default=int(os.environ.get("MCPM_BENCH_MESH", "512")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-record", action="store_true", help="skip the second (--cpu-mesh) GPU record and the CPU baseline on it: "
+                    "profiler passes want one mesh size per run, kernel names do not carry it")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent replicas instead of slabs")
     ap.add_argument("--force-slab", action="store_true", help="N = 1: run the slab code path with a local-copy communicator "
                     "(measures the slab path's own overhead: ghost planes, windowed passes, host calls)")
@@ -450,7 +452,7 @@ def main():
             out["comm_and_host_ms_per_step"] = round(dt / K * 1e3 - step_ms, 3)   # wall minus rank-0 kernel stages
             out["deposits_beyond_ghost_rank0"] = r.pm.out_of_ghost()                # must be 0
             out["ghost_planes_exchanged_per_step"] = [int(d) for d in r.depths if d is not None]   # of --ghost allocated
-        if world == 1 and not slab and not args.forward_only:
+        if world == 1 and not slab and not args.forward_only and not args.no_sub_record:
             # the metric names 256^3 as well: a second, smaller record in the same line, and the CPU baseline on ITS trajectory
             if n != args.cpu_mesh:
                 r2, out[f"mesh_{args.cpu_mesh}"] = sub_record(args.cpu_mesh, NS, K, W, device)

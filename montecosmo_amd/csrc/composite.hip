@@ -52,12 +52,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 #define MCPM_NSLOT 1024
 
-// sum the MCPM_NSLOT partial slots of the step adjoint into the two accumulators
-__global__ __launch_bounds__(MCPM_NSLOT) void reduce_slots_kernel(const double *__restrict__ slots, double *out0, double *out1,
+// sum the MCPM_NSLOT partial slots of the step adjoint into the accumulators, and leave the slots ZERO for their next
+// user (invariant of plan->reduce's slot area from mcpm_plan_create on: no memset launch per step)
+__global__ __launch_bounds__(MCPM_NSLOT) void reduce_slots_kernel(double *__restrict__ slots, double *out0, double *out1,
                                                                   double *out2) {
     __shared__ double sh[3][MCPM_NSLOT / 64];
-    double a = wave_sum(slots[threadIdx.x]), b = wave_sum(slots[MCPM_NSLOT + threadIdx.x]);
-    double c = wave_sum(slots[2 * MCPM_NSLOT + threadIdx.x]);
+    const double s0 = slots[threadIdx.x], s1 = slots[MCPM_NSLOT + threadIdx.x], s2 = slots[2 * MCPM_NSLOT + threadIdx.x];
+    slots[threadIdx.x] = slots[MCPM_NSLOT + threadIdx.x] = slots[2 * MCPM_NSLOT + threadIdx.x] = 0.;
+    double a = wave_sum(s0), b = wave_sum(s1);
+    double c = wave_sum(s2);
     int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     if (l == 0) {
         sh[0][w] = a;
@@ -260,8 +263,7 @@ static int lattice_scatter(mcpm_plan *p, const float *xb, const float *vb, float
 static int lattice_dot(mcpm_plan *p, const float *meshes3, const float *a, const float *b, double *out0, double *out1) {
     dim3 grid, block;
     lattice_launch(p->g, grid, block);
-    double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);
-    MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 3 * MCPM_NSLOT, p->stream));
+    double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);   // zero on entry, zeroed again by reduce_slots_kernel
     lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, meshes3, p->M, a, b, slots);
     MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
     reduce_slots_kernel<<<1, MCPM_NSLOT, 0, p->stream>>>(slots, a ? out0 : nullptr, b ? out1 : nullptr, nullptr);
@@ -626,8 +628,7 @@ static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float
         }
     }
     unsigned *fb_max = (fb_next && p->paint3_variant == 4) ? p->fx_wmax : nullptr;
-    double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);
-    MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 3 * MCPM_NSLOT, p->stream));
+    double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);   // zero on entry (reduce_slots_kernel leaves them so)
 #define ADJ(OR)                                                                                                                   \
     if (layout) step_adjoint_kernel<OR, true><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
                                                            slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max);  \
@@ -642,6 +643,8 @@ static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float
     if (alpha_bar || beta_bar || dg_bar) {
         reduce_slots_kernel<<<1, MCPM_NSLOT, 0, p->stream>>>(slots, alpha_bar, beta_bar, dg_bar);
         MCPM_LAUNCH_CHECK(p, "reduce_slots_kernel");
+    } else {
+        MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 3 * MCPM_NSLOT, p->stream));
     }
     return MCPM_OK;
 }

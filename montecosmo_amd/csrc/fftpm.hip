@@ -194,7 +194,22 @@ struct YLayout {
 struct XLayout {
     int NYL, iy0, XB, lgXB;  // XB is a power of two
     int64_t SBx, SC;
+    int remap;               // XCD-aware block order (col_block)
 };
+// Workgroup -> (kz block, y row) of the x passes.  Hardware hands consecutive workgroups to the 8 XCDs in turn, and each XCD
+// has its own L2: with 8 kz columns per workgroup a row segment is 64 bytes, HALF a 128-byte line, so in launch order the two
+// workgroups that share every line of their columns run on different XCDs and the line is fetched from HBM twice
+// (profiles/r01_pmc_traffic.json: 2.4 GB moved by the fused x pass for 1.6 GB of spectra).  Remapped, each XCD works a
+// contiguous run of (y row, kz block) pairs, so the neighbour's half line is an L2 hit.
+__device__ __forceinline__ void col_block(int remap, unsigned &bx, unsigned &by) {
+    bx = blockIdx.x, by = blockIdx.y;
+    if (remap) {
+        const unsigned nb = gridDim.x * gridDim.y, b = by * gridDim.x + bx;
+        const unsigned v = (b & 7u) * (nb >> 3) + (b >> 3);
+        by = v / gridDim.x;
+        bx = v - by * gridDim.x;
+    }
+}
 
 template <int N>
 __global__ __launch_bounds__(256) void zfwd_kernel(FGeom g, const float *__restrict__ real, cf *__restrict__ spec,
@@ -471,7 +486,9 @@ __global__ __launch_bounds__((ColShape<N, ML>::THREADS)) void xfused_kernel(FGeo
     typedef Tile<N, LINES, true> TL;
     __shared__ cf lds[TL::FLOATS2];
     const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
-    const int kzi = blockIdx.x * LINES + l, yl = blockIdx.y, iy = xl.iy0 + yl;
+    unsigned bx, by;
+    col_block(xl.remap, bx, by);
+    const int kzi = bx * LINES + l, yl = by, iy = xl.iy0 + yl;
     const bool ok = kzi < g.nzh;
     const uint32_t off0 = (uint32_t)yl * g.nzp + kzi, xs = (uint32_t)xl.NYL * g.nzp;
     // element offsets (complex units, < 2^31): one-spectrum side and three-spectra side (without the c*SC term)
@@ -553,7 +570,9 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xspec_kernel(FGeom g, co
     typedef Tile<N, LINES, true> TL;
     __shared__ cf lds[TL::FLOATS2];
     const int l = threadIdx.x % LINES, u = threadIdx.x / LINES;
-    const int kzi = blockIdx.x * LINES + l, yl = blockIdx.y, iy = xl.iy0 + yl;
+    unsigned bx, by;
+    col_block(xl.remap, bx, by);
+    const int kzi = bx * LINES + l, yl = by, iy = xl.iy0 + yl;
     const bool ok = kzi < g.nzh;
     const uint32_t off0 = (uint32_t)yl * g.nzp + kzi, xs = (uint32_t)xl.NYL * g.nzp;
     uint32_t os[8], o3[8];
@@ -838,6 +857,11 @@ static int y_columns2(mcpm_plan *p, const cf *in, cf *out, bool expand, bool in_
     return MCPM_OK;
 }
 
+static int xcd_remap() {   // MCPM_XCD_REMAP=0 restores launch order (A/B runs)
+    static const int v = [] { const char *e = getenv("MCPM_XCD_REMAP"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 // x pass over the y rows this rank holds after the transpose (all of them on one GPU)
 static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
     const FGeom g = fgeom(p);
@@ -845,7 +869,7 @@ static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
     const int64_t blk = (int64_t)p->nxl * nyl * g.nzp;  // one rank's block of one spectrum
     int lgxb = 0;
     while ((1 << lgxb) < p->nxl) ++lgxb;
-    const XLayout xl{nyl, p->rank * nyl, p->nxl, lgxb, blk, (int64_t)p->nranks * blk};
+    XLayout xl{nyl, p->rank * nyl, p->nxl, lgxb, blk, (int64_t)p->nranks * blk, 0};
     const float scale = 1.f / ((float)g.nx * (float)g.ny * (float)g.nz);
     // one forward + one inverse x pass of (1 + 3) spectra and the k-space multiply
     StageTimer st_(p, ST_KSPACE, (32.0 * p->nxl * g.ny * g.nzh) + 4.0 * pass_bytes(p, 1));
@@ -853,6 +877,7 @@ static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
     {                                                                                                         \
         constexpr int LINES = ColShape<NN, ML>::LINES, TH = ColShape<NN, ML>::THREADS;                        \
         dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)nyl);                                    \
+        xl.remap = xcd_remap() && (grid.x * grid.y) % 8 == 0;                                                 \
         if (mode == 0) xfused_kernel<NN, 0, ML><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]); \
         else xfused_kernel<NN, 1, ML><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]);           \
     }
@@ -873,7 +898,7 @@ static int x_spec(mcpm_plan *p, const cf *in, cf *out, int mode) {
     const int64_t blk = (int64_t)p->nxl * nyl * g.nzp;
     int lgxb = 0;
     while ((1 << lgxb) < p->nxl) ++lgxb;
-    const XLayout xl{nyl, p->rank * nyl, p->nxl, lgxb, blk, (int64_t)p->nranks * blk};
+    XLayout xl{nyl, p->rank * nyl, p->nxl, lgxb, blk, (int64_t)p->nranks * blk, 0};
     const float scale = 1.f / ((float)g.nx * (float)g.ny * (float)g.nz);
     const int nc = (mode == 2 || mode == 4) ? 3 : 6;
     StageTimer st_(p, ST_KSPACE, 8.0 * (nc + 1) * p->nxl * g.ny * g.nzh + nc * pass_bytes(p, 1));
@@ -881,6 +906,7 @@ static int x_spec(mcpm_plan *p, const cf *in, cf *out, int mode) {
     {                                                                                                         \
         constexpr int LINES = ColShape<NN>::LINES, TH = ColShape<NN>::THREADS;                                \
         dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)nyl);                                    \
+        xl.remap = xcd_remap() && (grid.x * grid.y) % 8 == 0;                                                 \
         const cf *tw = (const cf *)p->tw[0];                                                                  \
         if (mode == 2) xspec_kernel<NN, 2><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, tw);            \
         else if (mode == 3) xspec_kernel<NN, 3><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, tw);       \

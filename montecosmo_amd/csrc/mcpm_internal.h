@@ -11,7 +11,7 @@
 
 #include "../../include/mcpm.h"
 
-#define MCPM_NREDUCE 4096
+#define MCPM_NREDUCE 6144   // [0, 3072): scalar outputs and the bias / observe slot rows; [3072, 6144): the 3 x MCPM_NSLOT step-adjoint slots (kept zero between uses)
 #ifndef MCPM_NZPAD
 #define MCPM_NZPAD 16  // complex elements added to the nz/2 pitch of the internal spectra
 #endif

@@ -75,9 +75,11 @@ __device__ __forceinline__ void tile_of_block(int ntx, int nty, int ntz, int &tx
 // Prologue of every tiled paint, one launch: resets the bucket counts and the per-paint counters, and (toff != NULL) sets
 // o_T = rounded mean displacement of 64 lattice points (a 4x4x4 sub-grid) of the Lagrangian block at tile T.
 __global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float *__restrict__ disp, int *__restrict__ toff,
-                                                            int *__restrict__ bcnt, int *__restrict__ cnts, int ntiles, int maxoff) {
+                                                            int *__restrict__ bcnt, int *__restrict__ cnts, int ntiles, int maxoff,
+                                                            int *__restrict__ redo) {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x < 8 && threadIdx.x != C_LAST && threadIdx.x != C_OOB) cnts[threadIdx.x] = 0;
+    if (redo && blockIdx.x == 0 && threadIdx.x == 8) redo[0] = 0;   // empty list of tiles for the f64 repaint (paint3)
     if (tile >= ntiles) return;
     if (lane == 0) bcnt[tile] = 0;
     if (!toff) return;
@@ -906,11 +908,11 @@ static TileLists tile_lists(const mcpm_plan *p) {
     return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count};
 }
 
-static void tiled_prologue(mcpm_plan *p, const float *pos) {
+static void tiled_prologue(mcpm_plan *p, const float *pos, int *redo = nullptr) {
     const Geom &g = p->g;
     const int ntiles = (g.nx / MCPM_TILE) * (g.ny / MCPM_TILE) * (g.nz / MCPM_TILE);
     tile_prologue_kernel<<<(ntiles + 3) / 4, 256, 0, p->stream>>>(g, pos, p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->outlier_count,
-                                                                  ntiles, 8);
+                                                                  ntiles, 8, redo);
 }
 
 #define DISPATCH_H(HH, CALL) \
@@ -965,10 +967,9 @@ bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, fl
     const Geom &g = p->g;
     const unsigned nb = (unsigned)((g.nx / MCPM_TILE) * (g.ny / MCPM_TILE) * (g.nz / MCPM_TILE));
     if (p->fx_tiles < (int)nb) return false;
-    tiled_prologue(p, pos);
+    tiled_prologue(p, pos, p->fx_redo);
     const TileLists L = tile_lists(p);
     const unsigned nbk = nb < 1024u ? nb : 1024u;
-    (void)hipMemsetAsync(p->fx_redo, 0, sizeof(int), p->stream);
     if (p->fx_src != weights3) {   // max|w| not left behind by the kernel that produced the weights
         (void)hipMemsetAsync(p->fx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream);
         absmax_kernel<<<2048, 256, 0, p->stream>>>(weights3, 1, 3 * p->Np, p->fx_wmax);

@@ -156,6 +156,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     }
     (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int) * 8, p->stream);
     (void)hipMemsetAsync(p->fx_redo, 0, sizeof(int), p->stream);
+    (void)hipMemsetAsync(p->reduce, 0, sizeof(double) * MCPM_NREDUCE, p->stream);   // the slot area stays zero between uses
     *out = p;
     return MCPM_OK;
 }
