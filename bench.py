@@ -250,7 +250,7 @@ def pmc_traffic(stage, n):
     profiles/ (separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 and as calibrated here
     on axpy_kernel, whose byte count is known).  bench.py cannot collect PMC counters itself; null when the file
     has no entry for this mesh."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         d = json.load(open(path))
         return d[str(n)][stage]["bytes_per_launch"]
@@ -267,7 +267,7 @@ def host_threads():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(runner, n_sample_steps=2):
+def cpu_baseline(runner, n_sample_steps=5):
     """The reference-equivalent CPU path (the float64 oracle with its threaded back end: scipy.fft on all allowed host
     threads + the OpenMP paint / read kernels of oracle/csrc/pm_kernels.c; the JAX reference itself cannot run here), timed
     on forward+adjoint DKD steps of the SAME trajectory the GPU just ran at runner.n^3: the GPU's checkpoint of step i is
@@ -284,7 +284,7 @@ def cpu_baseline(runner, n_sample_steps=2):
         xb, vb = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
         dg = float(runner.dg)
         g0 = float(o.a2g(cos, 0.0))
-        steps = list(range(K // 2, min(K // 2 + n_sample_steps, K)))
+        steps = list(range(max(0, (K - n_sample_steps) // 2), min(max(0, (K - n_sample_steps) // 2) + n_sample_steps, K)))   # ~12 s at 256^3 on 64 threads
         states = [(runner.states[i, 0].double().cpu().numpy(), runner.states[i, 1].double().cpu().numpy()) for i in steps]
         t0 = time.perf_counter()
         for i, (xh, v) in zip(steps, states):

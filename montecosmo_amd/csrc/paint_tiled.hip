@@ -9,9 +9,10 @@
 //   * BULK-CENTRED WINDOWS.  Particles are stored in Lagrangian order as displacements from their lattice point, and the
 //     displacement field is smooth: the particles that land in tile T come from lattice points around T - o_T, where o_T is
 //     the (rounded) mean displacement near T.  `tile_prologue_kernel` samples 64 particles per tile for o_T (25 MB of reads at
-//     512^3), and the window of T is the (16 + 2H + 1)^3 lattice points  T - o_T - (H+1) ... T - o_T + 15 + H  with H = 2:
-//     2.3 window visits per particle instead of the 3.8 of an uncentred H = 4 window (which the 2-cell rms displacement of
-//     the benchmark needed), for the same outlier rate.
+//     512^3), and the window of T is the (16 + 2H + 1)^3 lattice points  T - o_T - (H+1) ... T - o_T + 15 + H  with H = 3
+//     (mcpm_plan_set_halo): 3.0 window visits per particle instead of the 3.8 of an uncentred H = 4 window (which the
+//     2-cell rms displacement of the benchmark needed), for the same outlier rate.  (H = 2, 2.3 visits, overflows the
+//     buckets on that workload: 1.54 instead of 0.92 ms at 512^3.)
 //   * BUCKETS for what the windows miss.  Every workgroup also watches the particles of its own Lagrangian block (they lie
 //     in its window whenever |o_T| <= H; a second short loop covers them otherwise): a particle whose floor(d) leaves the
 //     interval in which every neighbouring window is sure to contain it (six compares, the cost of the round-1 outlier

@@ -1,17 +1,25 @@
-"""Builds profiles/r01_pmc_traffic.json from two rocprofv3 PMC passes over bench.py (FETCH_SIZE, WRITE_SIZE).
-usage: python tools/make_traffic_json.py <fetch_dir> <write_dir> <mesh> <out.json> <per_kernel.txt>"""
-import collections, csv, glob, json, sys
+"""Builds profiles/rNN_pmc_traffic.json from two rocprofv3 PMC passes over bench.py (FETCH_SIZE, WRITE_SIZE).
+usage: python tools/make_traffic_json.py <fetch_dir> <write_dir> <mesh> <out.json> <per_kernel.txt>
+An existing <out.json> is updated (one entry per mesh), so the 512^3 and 256^3 passes share a file."""
+import collections, csv, glob, json, os, sys
 
 fetch_dir, write_dir, mesh, out_json, out_txt = sys.argv[1:6]
-stage_of = [("paint3_", "paint3"), ("absmax_kernel", "paint3"), ("paint_tile_kernel", "paint"), ("paint_outlier_kernel", "paint"), ("paint_atomic_kernel", "paint"),
+# kernel-name fragment -> stage of bench.py's stage table.  The small kernels of a tiled paint (prologue, coverage test,
+# buckets, leftovers) serve both the density paint and the three-component paint: they are attributed in dispatch order to
+# the paint whose tile kernel they surround (a prologue belongs to the tile kernel that follows it, the others to the one
+# before them).
+stage_of = [("paint3_tile_kernel", "paint3"), ("paint3_bucket_kernel", "paint3"), ("paint_tile_kernel", "paint"), ("paint_bucket_kernel", "paint"),
+            ("paint_atomic_kernel", "paint"), ("paint_fxg_flush_kernel", "paint"),
             ("zfwd_kernel", "fft_r2c"), ("ycol2_kernel<512, false", "fft_r2c"), ("ycol2_kernel<256, false", "fft_r2c"),
             ("ycol2_kernel<512, true", "fft_c2r"), ("ycol2_kernel<256, true", "fft_c2r"), ("ycol_kernel<512, -1>", "fft_r2c"), ("ycol_kernel<256, -1>", "fft_r2c"),
             ("ycol_kernel<512, 1>", "fft_c2r"), ("ycol_kernel<256, 1>", "fft_c2r"), ("zinv_kernel", "fft_c2r"), ("zinv3_il_kernel", "fft_c2r"),
             ("xfused_kernel", "kspace"), ("kick_drift_kernel", "kick_drift"), ("step_adjoint_kernel", "step_adjoint"),
             ("axpby_kernel", "axpy"), ("axpy_kernel", "axpy")]
-# auxiliary kernels of a stage: their bytes count, their launches do not (the f64 repaint of the tiles the fixed-point
-# three-component paint flags is a separate, normally empty, launch)
-outlier_kernels = ("paint_outlier_kernel", "paint3_outlier_kernel", "paint3_tile_kernel", "absmax_kernel")
+shared_before = ("tile_prologue_kernel",)                                    # belongs to the NEXT tile kernel
+shared_after = ("coverage_duty_kernel", "paint_leftover_kernel", "absmax_kernel")   # belong to the PREVIOUS tile kernel
+# the kernels that count as "one launch of the stage" (its main kernel); the others only add their bytes
+main_kernels = ("paint_tile_kernel", "paint3_tile_kernel<3, false", "paint3_tile_kernel<4, false", "paint_atomic_kernel", "zfwd_kernel", "ycol2_kernel", "ycol_kernel",
+                "zinv_kernel", "zinv3_il_kernel", "xfused_kernel", "kick_drift_kernel", "step_adjoint_kernel", "axpby_kernel", "axpy_kernel")
 
 
 def stage(name):
@@ -24,21 +32,41 @@ def stage(name):
 tot = collections.defaultdict(lambda: {"fetch_kb": 0.0, "write_kb": 0.0, "launches": 0})
 per_kernel = collections.defaultdict(lambda: {"fetch_kb": [], "write_kb": []})
 for d, key in ((fetch_dir, "fetch_kb"), (write_dir, "write_kb")):
-    import os
-    f = max(glob.glob(f"{d}/*/*counter_collection.csv"), key=os.path.getmtime)      # the latest pass
-    for r in csv.DictReader(open(f)):
+    f = max(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)      # the latest pass
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
+    current, pending = None, 0.0
+    for r in rows:
         nm, v = r["Kernel_Name"], float(r["Counter_Value"])
         per_kernel[nm.split("(")[0]][key].append(v)
+        if any(s in nm for s in shared_before):
+            pending += v
+            continue
+        if any(s in nm for s in shared_after):
+            if current:
+                tot[current][key] += v
+            continue
         st = stage(nm)
+        if st in ("paint", "paint3") and "tile_kernel" in nm:
+            if "paint3_tile_kernel" not in nm or ", false" in nm:    # the f64 repaint launch follows its fixed-point pass
+                tot[st][key] += pending
+                pending = 0.0
+            current = st
         if st:
             tot[st][key] += v
-            if key == "fetch_kb" and not any(o in nm for o in outlier_kernels):
+            if key == "fetch_kb" and any(m in nm for m in main_kernels):
                 tot[st]["launches"] += 1
-out = {str(mesh): {}, "_method": (
-    "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu-baseline --warmup 0`; "
-    "counters are KB; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
+method = (
+    "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --no-sub-record --no-cpu-baseline --warmup 0 "
+    "[--mesh 256]`; counters are KB; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
     "128-B requests as 64 B), calibrated here on axpy_kernel / lpt_accum_kernel whose byte counts are known; the counters sit "
-    "on the L2 fabric side, so Infinity-Cache hits are included. Per stage = sum over the stage's kernels / stage launches.")}
+    "on the L2 fabric side, so Infinity-Cache hits are included. Per stage = sum over the stage's kernels (incl. the small "
+    "prologue / coverage / bucket / leftover kernels of a tiled paint) / launches of the stage's main kernel.")
+try:
+    out = json.load(open(out_json))
+except Exception:
+    out = {}
+out["_method"] = method
+out[str(mesh)] = {}
 for st, v in tot.items():
     n = max(v["launches"], 1)
     out[str(mesh)][st] = {"bytes_per_launch": round((2 * v["fetch_kb"] + v["write_kb"]) * 1024 / n),

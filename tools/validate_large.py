@@ -14,7 +14,8 @@ shape = (n, n, n)
 spec = synth.init_mesh(n, seed=0, rms_disp=2.0)
 pos = bricks.regular_pos(shape)
 rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.complex128) - b) / np.linalg.norm(b))
-(lp, vel), ctx = nbody.nbody_bf(bricks.Planck18(), spec, pos, a0=0., a1=1., n_steps=n_steps, lattice_out=True, return_ctx=bool(grad))
+res = nbody.nbody_bf(bricks.Planck18(), spec, pos, a0=0., a1=1., n_steps=n_steps, lattice_out=True, return_ctx=bool(grad))
+(lp, vel), ctx = res if grad else (res, None)
 t0 = time.time()
 (p_o, v_o) = o.nbody_bf(obg.Planck18(), spec.astype(np.complex128), pos, 0., 1., n_steps)
 print(f"oracle forward {time.time()-t0:.0f} s", flush=True)
