@@ -50,6 +50,9 @@ def parse():
                     "(measures the slab path's own overhead: ghost planes, windowed passes, host calls)")
     ap.add_argument("--forward-only", action="store_true", help="time forward steps only (BASELINE config 2)")
     ap.add_argument("--ghost", type=int, default=8)
+    ap.add_argument("--chains", type=int, default=0, help="slab path: ALSO time this many independent trajectories issued alternately "
+                    "on their own streams / process groups (extra `interleaved_chains` record; `value` stays the single trajectory). "
+                    "0 = 2 when N > 1, else off")
     ap.add_argument("--fixed-ghost", action="store_true", help="slabs: always exchange all ghost planes (default: only the "
                     "planes each step's displacements can reach)")
     ap.add_argument("--cpu-mesh", type=int, default=256, help="mesh of the second GPU record and of the CPU baseline (unscaled)")
@@ -170,17 +173,20 @@ class Runner:
 class SlabRunner:
     """The same K forward + K adjoint steps on an x-slab of the mesh (one rank of N)."""
 
-    def __init__(self, n, K, device, ghost, adaptive_ghost=True):
+    def __init__(self, n, K, device, ghost, adaptive_ghost=True, seed=0, group=None):
+        """Everything (plan, buffers, kernels, collectives) lives on the torch stream that is current at construction
+        (`self.stream`), so that a second, independent trajectory built under another stream can run concurrently."""
         from montecosmo_amd import nbody, bricks, synth, dist
         self.n, self.K = n, K
         shape = (n, n, n)
         import torch.distributed as td
-        self.comm = dist.TorchComm() if (td.is_available() and td.is_initialized()) else dist.LocalComm()
+        self.stream = torch.cuda.current_stream(device)
+        self.comm = dist.TorchComm(group) if (td.is_available() and td.is_initialized()) else dist.LocalComm()
         self.pm = dist.SlabPM(shape, self.comm, ghost, device, adaptive_ghost=adaptive_ghost)
         pm = self.pm
         cosmo = bricks.Planck18()
         self.dg, self.alphas, self.betas, self.lpt_s = nbody._step_scalars(cosmo, 0.0, 1.0, K, "bullfrog")
-        spec = torch.from_numpy(synth.init_mesh(n, seed=0, rms_disp=2.0)).to(device)
+        spec = torch.from_numpy(synth.init_mesh(n, seed=seed, rms_disp=2.0)).to(device)
         f32 = dict(dtype=torch.float32, device=device)
         self.states = torch.empty((K + 1, 2, pm.Nl, 3), **f32)
         self.f3s = torch.zeros((K, pm.nxe, n, n, 3), **f32)          # interleaved force meshes per step
@@ -189,34 +195,70 @@ class SlabRunner:
         self.states[0, 0] += self.states[0, 1] * (self.dg / 2)
         del spec
         torch.cuda.empty_cache()
-        rng = np.random.default_rng(1 + pm.rank)
+        rng = np.random.default_rng(1 + pm.rank + 1000 * seed)
         self.pos_bar = torch.from_numpy(rng.standard_normal((pm.Nl, 3), dtype=np.float32)).to(device)
         self.vel_bar = torch.from_numpy(rng.standard_normal((pm.Nl, 3), dtype=np.float32)).to(device)
         self.xb, self.vb = torch.empty((pm.Nl, 3), **f32), torch.empty((pm.Nl, 3), **f32)
         self.sbar = torch.zeros((2 * K + 1,), dtype=torch.float64, device=device)
         self.depths = [None] * K
 
-    def forward(self, steps):
-        K = self.K
+    # one trajectory = fwd_begin, fwd_step(0..s-1), fwd_end, bwd_begin, bwd_step(s-1..0): split so that two trajectories can
+    # be issued alternately (run_interleaved)
+    def fwd_begin(self):
         self.pm.reset_depth()           # a new trajectory: first step at full ghost depth, then predicted depths
-        for i in range(steps):
-            tau = self.dg / 2 if i == K - 1 else self.dg
-            self.pm.step(self.states[i, 0], self.states[i, 1], self.alphas[i], self.betas[i], tau, self.f3s[i],
-                         self.states[i + 1, 0], self.states[i + 1, 1])
-            self.depths[i] = self.pm.ge
+
+    def fwd_step(self, i):
+        K = self.K
+        tau = self.dg / 2 if i == K - 1 else self.dg
+        self.pm.step(self.states[i, 0], self.states[i, 1], self.alphas[i], self.betas[i], tau, self.f3s[i],
+                     self.states[i + 1, 0], self.states[i + 1, 1])
+        self.depths[i] = self.pm.ge
+
+    def fwd_end(self):
         self.pm.finish_depth()          # verifies the last prediction (the only host stop of the trajectory)
 
-    def backward(self, steps):
-        K = self.K
+    def bwd_begin(self):
         self.xb.copy_(self.pos_bar)
         self.vb.copy_(self.vel_bar)
-        for i in reversed(range(steps)):
+
+    def bwd_step(self, i):
+        K = self.K
+        tau = self.dg / 2 if i == K - 1 else self.dg
+        self.pm.step_vjp(self.states[i, 0], self.states[i, 1], self.f3s[i], self.alphas[i], self.betas[i], tau,
+                         self.xb, self.vb, C.c_void_p(self.sbar.data_ptr() + 8 * i),
+                         C.c_void_p(self.sbar.data_ptr() + 8 * (K + i)), 0.5 if i == K - 1 else 1.0,
+                         C.c_void_p(self.sbar.data_ptr() + 8 * 2 * K), depth=self.depths[i],
+                         next_beta_tau=(self.betas[i - 1], self.dg) if i > 0 else None)
+
+    def traj_gen(self, s):
+        """One trajectory of s forward + s adjoint steps as a generator of compute segments (see run_interleaved)."""
+        K = self.K
+        self.fwd_begin()
+        for i in range(s):
             tau = self.dg / 2 if i == K - 1 else self.dg
-            self.pm.step_vjp(self.states[i, 0], self.states[i, 1], self.f3s[i], self.alphas[i], self.betas[i], tau,
-                             self.xb, self.vb, C.c_void_p(self.sbar.data_ptr() + 8 * i),
-                             C.c_void_p(self.sbar.data_ptr() + 8 * (K + i)), 0.5 if i == K - 1 else 1.0,
-                             C.c_void_p(self.sbar.data_ptr() + 8 * 2 * K), depth=self.depths[i],
-                             next_beta_tau=(self.betas[i - 1], self.dg) if i > 0 else None)
+            yield from self.pm.step_gen(self.states[i, 0], self.states[i, 1], self.alphas[i], self.betas[i], tau, self.f3s[i],
+                                        self.states[i + 1, 0], self.states[i + 1, 1])
+            self.depths[i] = self.pm.ge
+        self.fwd_end()
+        self.bwd_begin()
+        for i in reversed(range(s)):
+            tau = self.dg / 2 if i == K - 1 else self.dg
+            yield from self.pm.step_vjp_gen(self.states[i, 0], self.states[i, 1], self.f3s[i], self.alphas[i], self.betas[i], tau,
+                                            self.xb, self.vb, C.c_void_p(self.sbar.data_ptr() + 8 * i),
+                                            C.c_void_p(self.sbar.data_ptr() + 8 * (K + i)), 0.5 if i == K - 1 else 1.0,
+                                            C.c_void_p(self.sbar.data_ptr() + 8 * 2 * K), depth=self.depths[i],
+                                            next_beta_tau=(self.betas[i - 1], self.dg) if i > 0 else None)
+
+    def forward(self, steps):
+        self.fwd_begin()
+        for i in range(steps):
+            self.fwd_step(i)
+        self.fwd_end()
+
+    def backward(self, steps):
+        self.bwd_begin()
+        for i in reversed(range(steps)):
+            self.bwd_step(i)
 
     def run(self, steps):
         while steps > 0:
@@ -243,6 +285,44 @@ class SlabRunner:
         ns = lib.mcpm_plan_profile_read(self.pm.h, nmax, ms, by, calls)
         assert ns > 0
         return list(ms)[:ns], list(by)[:ns], list(calls)[:ns]
+
+
+def run_interleaved(runners, steps, offset=None, token=None):
+    """`steps` forward+adjoint steps of EACH of the independent trajectories in `runners` (SlabRunner s built under their own
+    torch streams and process groups) as a software pipeline: a trajectory is a generator that yields whenever it has just
+    launched a collective and would next wait for it (dist.SlabPM.step_gen); the driver then issues the next compute
+    segment of ANOTHER trajectory, so that one's all-to-alls / ghost exchanges run under the other's kernels -- the
+    multi-chain form in which a sampler uses the slab path (the reference's multi-device mode is independent chains,
+    script.py:13-20).
+      offset: trajectory c runs `offset` segments behind trajectory c-1, so that the communication-heavy Poisson section of
+              one meets the particle kernels of the other (segments per forward step: kick-drift + paint + inner z/y passes |
+              edge z/y | fused x | y of A | y of G + z | ...);
+      token : compute segments of different trajectories are chained by events (never concurrent): what overlaps a
+              collective is then exactly what was issued between its launch and its wait.  Off by default: it also makes a
+              trajectory wait for the other's collectives (measured slower on the one-rank RCCL proxy, tools/chain_sweep.sh)."""
+    offset = int(os.environ.get("MCPM_CHAIN_OFFSET", "2")) if offset is None else offset
+    token = (os.environ.get("MCPM_CHAIN_TOKEN", "0") == "1") if token is None else token
+    K, n = runners[0].K, len(runners)
+    while steps > 0:
+        s = min(steps, K)
+        gens = [r.traj_gen(s) for r in runners]
+        live, adv, tok = [True] * n, [0] * n, None
+        while any(live):
+            for c, r in enumerate(runners):
+                if not live[c] or (c > 0 and live[c - 1] and adv[c - 1] - adv[c] < offset):
+                    continue
+                with torch.cuda.stream(r.stream):
+                    if token and tok is not None:
+                        r.stream.wait_event(tok)
+                    try:
+                        next(gens[c])
+                    except StopIteration:
+                        live[c] = False
+                    if token:
+                        tok = torch.cuda.Event()
+                        tok.record(r.stream)
+                adv[c] += 1
+        steps -= s
 
 
 def pmc_traffic(stage, n):
@@ -363,6 +443,13 @@ def main():
     # MCPM_BENCH_DIST=1 with one rank initialises the process group anyway: on a one-GPU box it drives the slab path
     # through the real RCCL calls (self send/recv, one-rank all-to-all) instead of the local-copy communicator
     dist = world > 1 or os.environ.get("MCPM_BENCH_DIST") == "1"
+    if dist:
+        # The slab path overlaps collectives (RCCL's stream) with kernels (the plan's stream, and a second trajectory's).  HIP
+        # multiplexes streams onto 4 hardware queues by default, and streams that share a queue run in submission order:
+        # the trace of the one-rank RCCL run showed the plan's stream, the second trajectory's and a communicator's on ONE
+        # queue (16.15 -> 15.45 ms per step with 8 queues, profiles/r02_chain_pipeline.txt).  Read at HIP initialisation,
+        # which has not happened yet (importing torch does not initialise the GPU).
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     ndev = max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank % ndev)
     device = torch.device("cuda", local_rank % ndev)
@@ -404,6 +491,32 @@ def main():
     out = None
     prof = r.profile() if (slab or rank == 0) else None     # slabbed: collective, every rank takes part
     pmf_ms = r.force_cycle_ms() if (rank == 0 and not slab) else None
+    # independent trajectories issued alternately (collective: every rank takes part)
+    chains_rec = None
+    nch = args.chains if args.chains > 0 else (2 if (slab and world > 1) else 1)
+    if slab and nch > 1:
+        runners = [r]
+        for c in range(1, nch):
+            grp = td.new_group(backend=td.get_backend()) if dist else None      # own communicator: no head-of-line blocking
+            with torch.cuda.stream(torch.cuda.Stream(device)):
+                runners.append(SlabRunner(n, NS, device, args.ghost, not args.fixed_ghost, seed=c, group=grp))
+        torch.cuda.synchronize()
+        run_interleaved(runners, min(max(W, 1), NS))
+        barrier()
+        t0 = time.perf_counter()
+        run_interleaved(runners, K)
+        barrier()
+        dtc = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([dtc], dtype=torch.float64, device=device if td.get_backend() == "nccl" else "cpu")
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            dtc = float(t.item())
+        chains_rec = {"chains": nch, "offset": int(os.environ.get("MCPM_CHAIN_OFFSET", "2")), "value": round(nch * K / dtc, 3), "unit": "steps/s (all chains)", "ms_per_step": round(dtc / (nch * K) * 1e3, 3),
+                      "vs_single_trajectory": round(nch * K / dtc / (K / dt), 3),
+                      "note": f"{nch} independent {n}^3 trajectories (seeds 0..{nch - 1}) on their own streams and process groups, issued "
+                              "as a software pipeline of compute segments (run_interleaved), so that one's all-to-all / ghost exchanges "
+                              "run under the other's kernels; `value` above stays the single trajectory"}
+        del runners
     if rank == 0:
         M = float(n) ** 3          # whole mesh: stage times below are rank 0's, which holds 1/world of it when slabbed
         steps_per_s = (1 if slab else world) * K / dt
@@ -452,6 +565,8 @@ def main():
             out["comm_and_host_ms_per_step"] = round(dt / K * 1e3 - step_ms, 3)   # wall minus rank-0 kernel stages
             out["deposits_beyond_ghost_rank0"] = r.pm.out_of_ghost()                # must be 0
             out["ghost_planes_exchanged_per_step"] = [int(d) for d in r.depths if d is not None]   # of --ghost allocated
+            if chains_rec is not None:
+                out["interleaved_chains"] = chains_rec
         if world == 1 and not slab and not args.forward_only and not args.no_sub_record:
             # the metric names 256^3 as well: a second, smaller record in the same line, and the CPU baseline on ITS trajectory
             if n != args.cpu_mesh:

@@ -36,8 +36,14 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def _exhaust(gen):
+    for _ in gen:
+        pass
+
+
 class _Done:
     """Handle of an exchange that has already completed."""
+    done = True
 
     def wait(self):
         pass
@@ -375,8 +381,14 @@ class SlabPM(HaloMixin, PlaneHalo):
         self._win((0, self.nxl))
         return h
 
-    def force_meshes(self, rho_ext, f3_ext, fill_ghosts=True, rho_add=None, il=False):
-        """Interior of rho_ext -> the three force meshes (ghosts filled).  il=False: f3_ext is (3, nxe, ny, nz); il=True:
+    def force_meshes(self, *args, **kw):
+        """See force_meshes_gen (this runs it to the end)."""
+        _exhaust(self.force_meshes_gen(*args, **kw))
+
+    def force_meshes_gen(self, rho_ext, f3_ext, fill_ghosts=True, rho_add=None, il=False):
+        """GENERATOR: yields each time a collective has been launched and the next thing this trajectory would do is wait
+        for it, so that a driver holding several independent trajectories can issue another one's kernels in between
+        (bench.run_interleaved).  Interior of rho_ext -> the three force meshes (ghosts filled).  il=False: f3_ext is (3, nxe, ny, nz); il=True:
         ONE interleaved mesh (nxe, ny, nz, 3) (what the step kernels read: a CIC corner is one 12-byte gather, and a run of
         ghost planes is one contiguous block for the three components).  `rho_add`: handle of the ghost add of rho_ext
         still in flight (None: ghosts already added); the inner planes' z / y passes run under it.
@@ -385,22 +397,27 @@ class SlabPM(HaloMixin, PlaneHalo):
         inner, edges = self._windows(rho_add is not None)
         for w in ([inner] if inner is not None else []) + edges:
             if rho_add is not None and w is not inner:
+                yield
                 rho_add.wait()
                 rho_add = None
             self._win(w)
             self.call("mcpm_slab_zfwd", self._interior(rho_ext), self.Me, _p(self.s1a), 1)
             self.call("mcpm_slab_ycol", _p(self.s1a), _p(self.s1b), 1, -1, 0, 1)      # plain -> transposed order
         self._win((0, self.nxl))
-        _, x_in = self._a2a(self.s1a, self.s1b)                                       # x <-> y transpose
+        h1, x_in = self._a2a(self.s1a, self.s1b, async_op=True)                       # x <-> y transpose
+        yield
+        h1.wait()
         self.call("mcpm_slab_xfused", _p(x_in), _p(self.s3a), 0)                      # -> A, G
         hA, bA = self._a2a(self.s3b[:ss], self.s3a[:ss], async_op=True)
         hG, _ = self._a2a(self.s3b[ss:2 * ss], self.s3a[ss:2 * ss], async_op=True)
         # where A, G sit now (s3a if the all-to-all was aliased, else received in s3b); the y pass writes the other buffer
         src, dst = (self.s3a, self.s3b) if bA.data_ptr() == self.s3a.data_ptr() else (self.s3b, self.s3a)
+        yield
         hA.wait()
         self.call("mcpm_slab_ycol2", _p(src), _p(dst), 1, 1, 0, 1)                    # A -> force spectrum 0
         if not il:
             self._zinv_fill(dst, 0, f3_ext[0], False)                                 # all of component 0 under G's transfer
+        yield
         hG.wait()
         self.call("mcpm_slab_ycol2", _p(src), _p(dst), 1, 1, 0, 2)                    # G -> force spectra 1, 2
         inner, edges = self._windows(fill_ghosts)
@@ -424,10 +441,14 @@ class SlabPM(HaloMixin, PlaneHalo):
                     self.call("mcpm_slab_zinv", self._spec(dst, c), self._interior(f3_ext[c]), self.Me, 1)
         self._win((0, self.nxl))
         if h is not None:
+            yield
             h.wait()
 
-    def force_meshes_vjp(self, fbar3_ext, rhobar_ext, ghost_adds=None, fill_ghosts=False):
-        """fbar3_ext: three cotangent meshes (3, nxe, ny, nz) (ghosts added, or `ghost_adds[c]` handles still in flight).
+    def force_meshes_vjp(self, *args, **kw):
+        _exhaust(self.force_meshes_vjp_gen(*args, **kw))
+
+    def force_meshes_vjp_gen(self, fbar3_ext, rhobar_ext, ghost_adds=None, fill_ghosts=False):
+        """GENERATOR (see force_meshes_gen).  fbar3_ext: three cotangent meshes (3, nxe, ny, nz) (ghosts added, or `ghost_adds[c]` handles still in flight).
         Writes the interior of rhobar_ext (and its ghosts if fill_ghosts)."""
         ss = self.ss
         handles, bufs = [], []
@@ -436,6 +457,8 @@ class SlabPM(HaloMixin, PlaneHalo):
             inner, edges = self._windows(add is not None)
             for w in ([inner] if inner is not None else []) + edges:
                 if add is not None and w is not inner:
+                    if not getattr(add, "done", False):
+                        yield
                     add.wait()
                     add = None
                 self._win(w)
@@ -449,16 +472,20 @@ class SlabPM(HaloMixin, PlaneHalo):
         self.call("mcpm_slab_ycol2", _p(self.s3a), _p(self.s3b), 0, 0, 1, 2)          # b = ky FFTy(f_bar_y) + kz FFTy(f_bar_z)
         h, _ = self._a2a(self.s6a[4 * ss:5 * ss], self.s3b[ss:2 * ss], async_op=True)
         handles.append(h)
+        yield
         for h in handles:
             h.wait()
         # (a, b) received side by side in s6a[3 ss : 5 ss], or still in s3b[0 : 2 ss] when the all-to-all was aliased
         x_in = self.s3b if bufs[0].data_ptr() == self.s3b.data_ptr() else self.s6a[3 * ss:5 * ss]
         self.call("mcpm_slab_xfused", _p(x_in), _p(self.s1a), 1)
-        _, y_in = self._a2a(self.s1b, self.s1a)
+        h1, y_in = self._a2a(self.s1b, self.s1a, async_op=True)
+        yield
+        h1.wait()
         y_out = self.s1a if y_in is self.s1b else self.s1b
         self.call("mcpm_slab_ycol", _p(y_in), _p(y_out), 1, +1, 1, 0)
         h = self._zinv_fill(y_out, 0, rhobar_ext, fill_ghosts)
         if h is not None:
+            yield
             h.wait()
 
     # ---- lpt on slabs (nbody.py:634-667 at the lattice, read_order = 1) -------------------------------------
@@ -585,19 +612,25 @@ class SlabPM(HaloMixin, PlaneHalo):
         if self.adaptive_ghost:
             self._harvest_depth()
 
-    def step(self, x, v, alpha, beta, tau, f3_out, x_out, v_out, paint_order=2):
-        """x, v: (Nl,3) local state; f3_out: (nxe, ny, nz, 3) receives the ghost-filled INTERLEAVED force mesh (ghost planes
+    def step(self, *args, **kw):
+        _exhaust(self.step_gen(*args, **kw))
+
+    def step_vjp(self, *args, **kw):
+        _exhaust(self.step_vjp_gen(*args, **kw))
+
+    def step_gen(self, x, v, alpha, beta, tau, f3_out, x_out, v_out, paint_order=2):
+        """GENERATOR (see force_meshes_gen; `step` runs it to the end).  x, v: (Nl,3) local state; f3_out: (nxe, ny, nz, 3) receives the ghost-filled INTERLEAVED force mesh (ghost planes
         beyond the exchanged depth `self.ge` are left as they were: no particle of this step reads them)."""
         self.set_depth(x, paint_order)
         self.call("mcpm_paint_f32", _p(x), self.Nl, POS_LATTICE, None, 1, 1.0, paint_order, _p(self.rho), 0)
-        self.force_meshes(self.rho, f3_out, rho_add=self.halo_add_x(self.rho, async_op=True), il=True)
+        yield from self.force_meshes_gen(self.rho, f3_out, rho_add=self.halo_add_x(self.rho, async_op=True), il=True)
         self.call("mcpm_kick_drift_il_f32", _p(x), _p(v), self.Nl, POS_LATTICE, _p(f3_out), paint_order, float(alpha),
                   float(beta), float(tau), _p(x_out), _p(v_out))
         self._dmax_ptr = x_out.data_ptr()
 
-    def step_vjp(self, x, v, f3, alpha, beta, tau, xb, vb, abar_ptr, bbar_ptr, dtau_ddg=1.0, dgbar_ptr=None, paint_order=2,
-                 depth=None, next_beta_tau=None):
-        """Adjoint of `step` (f3: its interleaved force mesh): xb, vb (cotangents of its outputs) are updated in place.  `depth`: the ghost depth the
+    def step_vjp_gen(self, x, v, f3, alpha, beta, tau, xb, vb, abar_ptr, bbar_ptr, dtau_ddg=1.0, dgbar_ptr=None, paint_order=2,
+                     depth=None, next_beta_tau=None):
+        """GENERATOR (`step_vjp` runs it to the end).  Adjoint of `step` (f3: its interleaved force mesh): xb, vb (cotangents of its outputs) are updated in place.  `depth`: the ghost depth the
         forward step used (`self.ge` after `step`), saving its re-measurement.  `next_beta_tau`: (beta, tau) of the step
         whose adjoint comes next (the previous step of the sweep): its force cotangent is then written by this call's
         particle kernel and picked up by the next call instead of a separate pass."""
@@ -609,7 +642,7 @@ class SlabPM(HaloMixin, PlaneHalo):
             fb = _p(self.Fb)
         self.call("mcpm_paint3_f32", _p(x), self.Nl, POS_LATTICE, fb, paint_order, _p(self.f3), 0)
         add = self.halo_add(self.f3, async_op=True)      # ONE exchange for the three components, under the inner planes' passes
-        self.force_meshes_vjp(self.f3, self.rho, [add, add, add], fill_ghosts=True)
+        yield from self.force_meshes_vjp_gen(self.f3, self.rho, [add, add, add], fill_ghosts=True)
         if next_beta_tau is not None:
             self.call("mcpm_plan_hint_next_adjoint", float(next_beta_tau[0]), float(next_beta_tau[1]))
         self.call("mcpm_step_adjoint_particles_il_f32", _p(x), _p(v), _p(f3), _p(self.rho), float(alpha), float(beta),

@@ -163,3 +163,46 @@ def gpu_slab_golden_worker(rank, world, port, out_dir, name, backend="gloo"):
         json.dump(res, open(os.path.join(out_dir, "result.json"), "w"))
     td.barrier()
     td.destroy_process_group()
+
+
+def gpu_interleaved_worker(rank, world, port, out_dir, n, n_steps, backend="gloo"):
+    """bench.run_interleaved: two independent trajectories (own streams, own process groups) issued alternately must give,
+    bit for bit, what each gives when it runs alone (every kernel of the path is order-independent)."""
+    import json
+    import torch
+    td = _init(rank, world, port, backend) if world > 1 or backend == "nccl" else None
+    import bench
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    a = bench.SlabRunner(n, n_steps, dev, 8, True, seed=0)
+    grp = td.new_group(backend=td.get_backend()) if td is not None else None
+    with torch.cuda.stream(torch.cuda.Stream(dev)):
+        b = bench.SlabRunner(n, n_steps, dev, 8, True, seed=1, group=grp)
+    torch.cuda.synchronize()
+    solo = []
+    for r in (a, b):
+        with torch.cuda.stream(r.stream):
+            r.run(n_steps)
+        torch.cuda.synchronize()
+        solo.append((r.states[n_steps].clone(), r.xb.clone(), r.vb.clone(), r.sbar.clone()))
+        r.states[1:].zero_()
+        r.sbar.zero_()
+    bench.run_interleaved([a, b], n_steps)
+    torch.cuda.synchronize()
+    ok = True
+    for r, (st, xb, vb, sb) in zip((a, b), solo):
+        ok = ok and torch.equal(r.states[n_steps], st) and torch.equal(r.xb, xb) and torch.equal(r.vb, vb)
+        ok = ok and bool(torch.isfinite(xb).all()) and float(xb.abs().max()) > 0
+        # the scalar cotangents accumulate over calls (+=): after zeroing they must come back the same
+        ok = ok and torch.allclose(r.sbar, sb, rtol=1e-12, atol=0)
+    differ = not torch.equal(a.states[n_steps], b.states[n_steps])       # two different trajectories, really
+    if td is not None:
+        t = torch.tensor([float(ok and differ)])
+        td.all_reduce(t, op=td.ReduceOp.MIN)
+        ok_all = bool(t.item() > 0)
+        td.barrier()
+        td.destroy_process_group()
+    else:
+        ok_all = ok and differ
+    if rank == 0:
+        json.dump({"ok": ok_all}, open(os.path.join(out_dir, "result.json"), "w"))

@@ -68,6 +68,18 @@ def test_bench_gpus_2_gloo_shared_gpu(gpu):
     assert line["n_gpus"] == 2 and line["rccl_world"] == 2 and line["comm_backend"] == "gloo"
     assert line["scaling"] == "strong" and line["value"] > 0 and line["deposits_beyond_ghost_rank0"] == 0
     assert line["config"]["parallelism"] == "slab2"
+    ic = line["interleaved_chains"]                      # N > 1: two independent trajectories issued alternately, timed too
+    assert ic["chains"] == 2 and ic["value"] > 0 and ic["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_interleaved_chains_equal_solo_runs(gpu, world):
+    """Two independent trajectories on their own streams / process groups, issued alternately (`bench.run_interleaved`, the
+    multi-chain form that hides one chain's all-to-alls under the other's kernels), reproduce their solo runs bit for bit."""
+    from _dist_worker import gpu_interleaved_worker
+    out = _spawn(gpu_interleaved_worker, world, 64, 3)
+    assert json.load(open(os.path.join(out, "result.json")))["ok"]
 
 
 @pytest.mark.gpu
