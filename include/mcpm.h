@@ -80,7 +80,6 @@ int mcpm_plan_last_bucketed(mcpm_plan *plan, int64_t *count);
    displacement (default 1; 0 = on the tile itself, which needs halo 4 at the benchmark's 2-cell rms displacement). */
 int mcpm_plan_set_halo(mcpm_plan *plan, int halo);
 int mcpm_plan_set_centre(mcpm_plan *plan, int centre);
-int mcpm_plan_set_tile_order(mcpm_plan *plan, int order);
 /* Accumulator of the tiled three-component paint (mcpm_paint3_f32, the adjoint of the force read): 1 = fixed point
    (default: 32-bit fields in 64-bit integer LDS atomics, exact order-independent sums, overflow proven per tile by a
    bound field, flagged tiles repainted in f64; particles.hip), 0 = f64 tiles.  mcpm_plan_last_redo returns how many

@@ -45,7 +45,6 @@ struct Geom {
     int same_lattice; // px==nx && py==ny && pz==nz (unit lattice spacing)
     int xoff;         // slab mode: mesh plane of lattice plane 0 (= ghost width); 0 otherwise
     int xslab;        // slab mode: x is NOT periodic on this (ghost-extended) mesh
-    int tile_order;   // tiled paints: 0 = a contiguous run (pencil) of tiles per XCD, 1 = compact bricks of tiles per XCD
 };
 
 #define MCPM_FX_SLOTS 64

@@ -83,7 +83,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     if ((int64_t)px * py * pz >= (int64_t)1 << 31) return mcpm_fail(nullptr, MCPM_E_SHAPE, "more than 2^31 particles per plan");
     mcpm_plan *p = new (std::nothrow) mcpm_plan();
     if (!p) return mcpm_fail(nullptr, MCPM_E_NOMEM, "host allocation");
-    p->g = Geom{nx, ny, nz, px, py, pz, nz / 2 + 1, ((slab || px == nx) && py == ny && pz == nz) ? 1 : 0, slab ? ghost : 0, slab ? 1 : 0, 0};
+    p->g = Geom{nx, ny, nz, px, py, pz, nz / 2 + 1, ((slab || px == nx) && py == ny && pz == nz) ? 1 : 0, slab ? ghost : 0, slab ? 1 : 0};
     p->nranks = nranks;
     p->rank = rank;
     p->ghost = ghost;
@@ -220,12 +220,6 @@ int mcpm_plan_last_bucketed(mcpm_plan *p, int64_t *count) {
     return MCPM_OK;
 }
 
-int mcpm_plan_set_tile_order(mcpm_plan *p, int order) {
-    if (!p) return MCPM_E_ARG;
-    MCPM_REQUIRE(p, order == 0 || order == 1, MCPM_E_ARG, "tile order must be 0 (pencils) or 1 (bricks)");
-    p->g.tile_order = order;
-    return MCPM_OK;
-}
 
 int mcpm_plan_set_paint3_fixed(mcpm_plan *p, int fixed) {
     if (!p) return MCPM_E_ARG;
