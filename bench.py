@@ -491,32 +491,6 @@ def main():
     out = None
     prof = r.profile() if (slab or rank == 0) else None     # slabbed: collective, every rank takes part
     pmf_ms = r.force_cycle_ms() if (rank == 0 and not slab) else None
-    # independent trajectories issued alternately (collective: every rank takes part)
-    chains_rec = None
-    nch = args.chains if args.chains > 0 else (2 if (slab and world > 1) else 1)
-    if slab and nch > 1:
-        runners = [r]
-        for c in range(1, nch):
-            grp = td.new_group(backend=td.get_backend()) if dist else None      # own communicator: no head-of-line blocking
-            with torch.cuda.stream(torch.cuda.Stream(device)):
-                runners.append(SlabRunner(n, NS, device, args.ghost, not args.fixed_ghost, seed=c, group=grp))
-        torch.cuda.synchronize()
-        run_interleaved(runners, min(max(W, 1), NS))
-        barrier()
-        t0 = time.perf_counter()
-        run_interleaved(runners, K)
-        barrier()
-        dtc = time.perf_counter() - t0
-        if dist:
-            t = torch.tensor([dtc], dtype=torch.float64, device=device if td.get_backend() == "nccl" else "cpu")
-            td.all_reduce(t, op=td.ReduceOp.MAX)
-            dtc = float(t.item())
-        chains_rec = {"chains": nch, "offset": int(os.environ.get("MCPM_CHAIN_OFFSET", "2")), "value": round(nch * K / dtc, 3), "unit": "steps/s (all chains)", "ms_per_step": round(dtc / (nch * K) * 1e3, 3),
-                      "vs_single_trajectory": round(nch * K / dtc / (K / dt), 3),
-                      "note": f"{nch} independent {n}^3 trajectories (seeds 0..{nch - 1}) on their own streams and process groups, issued "
-                              "as a software pipeline of compute segments (run_interleaved), so that one's all-to-all / ghost exchanges "
-                              "run under the other's kernels; `value` above stays the single trajectory"}
-        del runners
     if rank == 0:
         M = float(n) ** 3          # whole mesh: stage times below are rank 0's, which holds 1/world of it when slabbed
         steps_per_s = (1 if slab else world) * K / dt
@@ -565,8 +539,6 @@ def main():
             out["comm_and_host_ms_per_step"] = round(dt / K * 1e3 - step_ms, 3)   # wall minus rank-0 kernel stages
             out["deposits_beyond_ghost_rank0"] = r.pm.out_of_ghost()                # must be 0
             out["ghost_planes_exchanged_per_step"] = [int(d) for d in r.depths if d is not None]   # of --ghost allocated
-            if chains_rec is not None:
-                out["interleaved_chains"] = chains_rec
         if world == 1 and not slab and not args.forward_only and not args.no_sub_record:
             # the metric names 256^3 as well: a second, smaller record in the same line, and the CPU baseline on ITS trajectory
             if n != args.cpu_mesh:
@@ -575,6 +547,54 @@ def main():
                 r2 = r
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(r2)
+    # ---- independent trajectories as a software pipeline (collective: every rank takes part).  Measured AFTER the line
+    # above is complete, under a watchdog: whatever happens here (a second communicator that cannot be created, a hang), the
+    # single-trajectory result is printed.
+    nch = args.chains if args.chains > 0 else (2 if (slab and world > 1) else 1)
+    if slab and nch > 1:
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["interleaved_chains"] = {"chains": nch, "error": "timed out"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(float(os.environ.get("MCPM_CHAINS_TIMEOUT", "300")), bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            runners = [r]
+            for c in range(1, nch):
+                grp = td.new_group(backend=td.get_backend()) if dist else None      # own communicator: no head-of-line blocking
+                with torch.cuda.stream(torch.cuda.Stream(device)):
+                    runners.append(SlabRunner(n, NS, device, args.ghost, not args.fixed_ghost, seed=c, group=grp))
+            torch.cuda.synchronize()
+            run_interleaved(runners, min(max(W, 1), NS))
+            barrier()
+            t0 = time.perf_counter()
+            run_interleaved(runners, K)
+            barrier()
+            dtc = time.perf_counter() - t0
+            if dist:
+                t = torch.tensor([dtc], dtype=torch.float64, device=device if td.get_backend() == "nccl" else "cpu")
+                td.all_reduce(t, op=td.ReduceOp.MAX)
+                dtc = float(t.item())
+            if rank == 0:
+                out["interleaved_chains"] = {
+                    "chains": nch, "offset": int(os.environ.get("MCPM_CHAIN_OFFSET", "2")), "value": round(nch * K / dtc, 3), "unit": "steps/s (all chains)",
+                    "ms_per_step": round(dtc / (nch * K) * 1e3, 3), "vs_single_trajectory": round(nch * K / dtc / (K / dt), 3),
+                    "note": f"{nch} independent {n}^3 trajectories (seeds 0..{nch - 1}) on their own streams and process groups, issued "
+                            "as a software pipeline of compute segments (run_interleaved), so that one's all-to-all / ghost exchanges "
+                            "run under the other's kernels; `value` above stays the single trajectory"}
+            del runners
+        except Exception as e:      # the other ranks may be stuck in a collective: their watchdogs end them
+            if rank == 0:
+                out["interleaved_chains"] = {"chains": nch, "error": repr(e)[:300]}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        finally:
+            timer.cancel()
     if dist:
         td.barrier()
         td.destroy_process_group()
