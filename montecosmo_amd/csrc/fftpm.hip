@@ -857,6 +857,11 @@ static int y_columns2(mcpm_plan *p, const cf *in, cf *out, bool expand, bool in_
     return MCPM_OK;
 }
 
+static size_t xf_lds_pad() {   // experiment: unused dynamic LDS (bytes) to lower the x pass's occupancy (MCPM_XF_LDS_PAD)
+    static const size_t v = [] { const char *e = getenv("MCPM_XF_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+    return v;
+}
+
 static int xcd_remap() {   // MCPM_XCD_REMAP=0 restores launch order (A/B runs)
     static const int v = [] { const char *e = getenv("MCPM_XCD_REMAP"); return e ? atoi(e) : 1; }();
     return v;
@@ -878,8 +883,8 @@ static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
         constexpr int LINES = ColShape<NN, ML>::LINES, TH = ColShape<NN, ML>::THREADS;                        \
         dim3 grid((unsigned)((g.nzh + LINES - 1) / LINES), (unsigned)nyl);                                    \
         xl.remap = xcd_remap() && (grid.x * grid.y) % 8 == 0;                                                 \
-        if (mode == 0) xfused_kernel<NN, 0, ML><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]); \
-        else xfused_kernel<NN, 1, ML><<<grid, TH, 0, p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]);           \
+        if (mode == 0) xfused_kernel<NN, 0, ML><<<grid, TH, xf_lds_pad(), p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]); \
+        else xfused_kernel<NN, 1, ML><<<grid, TH, xf_lds_pad(), p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]);           \
     }
 #define CALL(NN)                                                                                              \
     if (col_lines_x() == 8 && NN >= 512) CALLL(NN, 8) else CALLL(NN, 16)
