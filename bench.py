@@ -539,6 +539,7 @@ def main():
             out["comm_and_host_ms_per_step"] = round(dt / K * 1e3 - step_ms, 3)   # wall minus rank-0 kernel stages
             out["deposits_beyond_ghost_rank0"] = r.pm.out_of_ghost()                # must be 0
             out["ghost_planes_exchanged_per_step"] = [int(d) for d in r.depths if d is not None]   # of --ghost allocated
+            out["a2a_chunks"] = r.pm.chunks      # all-to-alls per transposed spectrum (dist.SlabPM chunks; MCPM_SLAB_CHUNKS)
         if world == 1 and not slab and not args.forward_only and not args.no_sub_record:
             # the metric names 256^3 as well: a second, smaller record in the same line, and the CPU baseline on ITS trajectory
             if n != args.cpu_mesh:

@@ -184,6 +184,12 @@ int mcpm_slab_ycol2(mcpm_plan *plan, const float *in, float *out, int expand, in
    still address plane 0).  Planes are independent in those passes, so a caller can transform the planes a halo
    exchange does not touch while the exchange is in flight.  (0, nx_local) restores the default. */
 int mcpm_slab_set_window(mcpm_plan *plan, int x0, int count);
+/* Splits every all-to-all (transposed-order) layout into `chunks` chunks of nx_local / chunks planes:
+   [c][chunk][rank][x in chunk][y_local][nzp] instead of [c][rank][x_local][y_local][nzp], so that a transpose becomes
+   `chunks` all-to-alls of contiguous regions (each 1/chunks of a spectrum) that the caller overlaps with the z / y passes
+   of the other chunks (planes of a chunk: mcpm_slab_set_window).  chunks: a power of two dividing nx_local; 1 = default.
+   Applies to the buffers of the following mcpm_slab_* calls; set it once after mcpm_plan_create_slab. */
+int mcpm_slab_set_chunks(mcpm_plan *plan, int chunks);
 int mcpm_slab_xfused(mcpm_plan *plan, const float *in, float *out, int mode);
 int mcpm_slab_zinv(mcpm_plan *plan, const float *spec, float *real, int64_t real_bstride, int batch);
 /* z C2R of three spectra (spec_elems apart) into ONE interleaved real mesh [x][y][z][3] (window of local planes as above). */

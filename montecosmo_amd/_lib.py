@@ -77,6 +77,7 @@ SIGNATURES = {
     "mcpm_slab_ycol": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mcpm_slab_ycol2": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mcpm_slab_set_window": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mcpm_slab_set_chunks": (C.c_int, [C.c_void_p, C.c_int]),
     "mcpm_slab_xfused": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int]),
     "mcpm_slab_zinv": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_int]),
     "mcpm_pm_forces_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f32p]),

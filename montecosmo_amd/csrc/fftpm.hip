@@ -184,17 +184,32 @@ struct ZBatch {
 // y-line addressing of a column pass: point y of x-plane xl of spectrum c sits at
 // c*BS + xl*PS + (y / YB)*SB + (y % YB)*nzp (complex).  Plain layout [c][xl][y][nzp]: YB = ny, SB = 0.
 // All-to-all (transposed-order) layout [c][dest rank][xl][y_local][nzp]: YB = ny/ranks, SB = one rank block.
+// Chunked all-to-all layout (mcpm_slab_set_chunks, C chunks of CW = nxl / C planes, so that a transpose is C all-to-alls
+// that overlap the passes of the other chunks): [c][chunk w][dest rank][xlw][y_local][nzp]; plane xl then sits at
+// (xl / CW) * WS + (xl % CW) * PS with WS = ranks * SB and SB = CW * YB * nzp.  C = 1 is the layout above.
 struct YLayout {
     int64_t BS, PS, SB;
     int YB, NXL, lgYB;  // YB is a power of two
     int X0, NXW;        // the pass covers local planes [X0, X0 + NXW)
+    int64_t WS;         // chunk stride (0 when not chunked)
+    int lgCW, CW;       // planes per chunk (power of two); CW = NXL when not chunked
+    __device__ __forceinline__ int64_t plane(int xl) const { return (int64_t)(xl >> lgCW) * WS + (int64_t)(xl & (CW - 1)) * PS; }
 };
 // x-line addressing of the fused pass.  One-spectrum side: [x][yl][nzp] (NYL rows per x).  Three-spectra side:
 // c*SC + (x / XB)*SBx + ((x % XB)*NYL + yl)*nzp  (single GPU: XB = nx; slabs: [c][src/dest rank][xl][yl][nzp]).
+// With C chunks (see YLayout) the multi-rank side is [c][chunk w][rank][xlw][yl][nzp]:
+// c*SC + ((x % XB) / CW) * WS + (x / XB) * SBx + (((x % XB) % CW) * NYL + yl) * nzp, SBx = CW * NYL * nzp, WS = ranks * SBx.
 struct XLayout {
     int NYL, iy0, XB, lgXB;  // XB is a power of two
     int64_t SBx, SC;
     int remap;               // XCD-aware block order (col_block)
+    int lgCW, CW;            // planes per chunk (CW = XB when not chunked)
+    uint32_t WS;
+    // element offset of (x, yl) of one spectrum in the rank-blocked layout, without the kz term
+    __device__ __forceinline__ uint32_t off(int x, uint32_t xs) const {
+        const int xloc = x & (XB - 1);
+        return (uint32_t)(xloc >> lgCW) * WS + (uint32_t)((x >> lgXB) * SBx) + (uint32_t)(xloc & (CW - 1)) * xs;
+    }
 };
 // Workgroup -> (kz block, y row) of the x passes.  Hardware hands consecutive workgroups to the 8 XCDs in turn, and each XCD
 // has its own L2: with 8 kz columns per workgroup a row segment is 64 bytes, HALF a 128-byte line, so in launch order the two
@@ -359,8 +374,8 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void ycol_kernel(FGeom g, con
     const int kz = blockIdx.x * LINES + l;
     const bool ok = kz < g.nzh;
     const int pc = blockIdx.y / li.NXW, pxl = li.X0 + (blockIdx.y - pc * li.NXW);
-    const cf *ib = in + pc * li.BS + pxl * li.PS + kz;
-    cf *ob = out + pc * lo.BS + pxl * lo.PS + kz;
+    const cf *ib = in + pc * li.BS + li.plane(pxl) + kz;
+    cf *ob = out + pc * lo.BS + lo.plane(pxl) + kz;
     cf v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -395,8 +410,8 @@ __global__ __launch_bounds__((ColShape<N, ML>::THREADS)) void ycol2_kernel(
     const int kzi = blockIdx.x * LINES + l;
     const bool ok = kzi < g.nzh;
     const int plane = li.X0 + blockIdx.y;                    // local x plane; component c adds c * BS
-    const cf *ib = in + (int64_t)plane * li.PS + kzi;
-    cf *ob = out + (int64_t)plane * lo.PS + kzi;
+    const cf *ib = in + li.plane(plane) + kzi;
+    cf *ob = out + lo.plane(plane) + kzi;
     const bool special = (kzi == 0) || (kzi == g.nz / 2);
     const float fz = (kzi == g.nz / 2) ? 0.f : MCPM_TWO_PI * (float)kzi / (float)g.nz;
     // one transform at a time (load, FFT, store) keeps the kernel at two workgroups per CU; offsets are recomputed
@@ -500,8 +515,8 @@ __global__ __launch_bounds__((ColShape<N, ML>::THREADS)) void xfused_kernel(FGeo
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int x = u + T * m;
-        o1[m] = off0 + (uint32_t)x * xs;
-        o3[m] = (uint32_t)((x >> xl.lgXB) * xl.SBx) + (uint32_t)(x & (xl.XB - 1)) * xs + off0;
+        o1[m] = xl.off(x, xs) + off0;      // the one-spectrum side is in the same rank-blocked (and chunked) layout
+        o3[m] = o1[m];
         const float kx = dkx * (float)(x < N / 2 ? x : x - N);
         const float kk = kx * kx + ky * ky + kz * kz;
         L[m] = kk == 0.f ? 0.f : -scale * __frcp_rn(kk);
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(ColShape<N>::THREADS) void xspec_kernel(FGeom g, co
     for (int m = 0; m < 8; ++m) {
         const int x = u + T * m;
         os[m] = ((uint32_t)x * g.ny + iy) * g.nzh + kzi;  // caller's plain layout
-        o3[m] = (uint32_t)((x >> xl.lgXB) * xl.SBx) + (uint32_t)(x & (xl.XB - 1)) * xs + off0;
+        o3[m] = xl.off(x, xs) + off0;
         kx[m] = dkx * (float)(x < N / 2 ? x : x - N);
         const float kk = kx[m] * kx[m] + ky * ky + kz * kz;
         L[m] = kk == 0.f ? 0.f : -scale * __frcp_rn(kk);
@@ -791,12 +806,27 @@ static int z_inverse3_il(mcpm_plan *p, const cf *spec3, float *real_il) {
 }
 
 // packed = all-to-all layout [c][dest rank][xl][y_local][nzp]; every spectrum is spec_elems() complex
+static int lg2i(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+// planes per chunk of the all-to-all layouts (mcpm_slab_set_chunks; nxl when not chunked)
+static int chunk_planes(const mcpm_plan *p) { return p->nxl / (p->chunks > 0 ? p->chunks : 1); }
+
 static YLayout ylayout(const mcpm_plan *p, bool packed) {
     const int64_t nzp = p->g.nz / 2 + MCPM_NZPAD;
-    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
-    if (!packed) return YLayout{spec_elems(p), (int64_t)p->g.ny * nzp, 0, p->g.ny, p->nxl, lg(p->g.ny), p->xw0, p->xwn};
-    const int nyl = p->g.ny / p->nranks;
-    return YLayout{spec_elems(p), (int64_t)nyl * nzp, (int64_t)p->nxl * nyl * nzp, nyl, p->nxl, lg(nyl), p->xw0, p->xwn};
+    if (!packed) return YLayout{spec_elems(p), (int64_t)p->g.ny * nzp, 0, p->g.ny, p->nxl, lg2i(p->g.ny), p->xw0, p->xwn, 0, lg2i(p->nxl), p->nxl};
+    const int nyl = p->g.ny / p->nranks, cw = chunk_planes(p);
+    const int64_t sb = (int64_t)cw * nyl * nzp;
+    return YLayout{spec_elems(p), (int64_t)nyl * nzp, sb, nyl, p->nxl, lg2i(nyl), p->xw0, p->xwn, (int64_t)p->nranks * sb, lg2i(cw), cw};
+}
+
+static XLayout xlayout(const mcpm_plan *p) {
+    const FGeom g = fgeom(p);
+    const int nyl = g.ny / p->nranks, cw = chunk_planes(p);
+    const int64_t sbx = (int64_t)cw * nyl * g.nzp;
+    return XLayout{nyl, p->rank * nyl, p->nxl, lg2i(p->nxl), sbx, spec_elems(p), 0, lg2i(cw), cw, (uint32_t)(p->nranks * sbx)};
 }
 
 // kz columns per workgroup of the register-heavy passes (ycol2, xfused; 75-118 VGPRs, so a 1024-thread workgroup is
@@ -871,10 +901,7 @@ static int xcd_remap() {   // MCPM_XCD_REMAP=0 restores launch order (A/B runs)
 static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
     const FGeom g = fgeom(p);
     const int nyl = g.ny / p->nranks;
-    const int64_t blk = (int64_t)p->nxl * nyl * g.nzp;  // one rank's block of one spectrum
-    int lgxb = 0;
-    while ((1 << lgxb) < p->nxl) ++lgxb;
-    XLayout xl{nyl, p->rank * nyl, p->nxl, lgxb, blk, (int64_t)p->nranks * blk, 0};
+    XLayout xl = xlayout(p);
     const float scale = 1.f / ((float)g.nx * (float)g.ny * (float)g.nz);
     // one forward + one inverse x pass of (1 + 3) spectra and the k-space multiply
     StageTimer st_(p, ST_KSPACE, (32.0 * p->nxl * g.ny * g.nzh) + 4.0 * pass_bytes(p, 1));
@@ -900,10 +927,7 @@ static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
 static int x_spec(mcpm_plan *p, const cf *in, cf *out, int mode) {
     const FGeom g = fgeom(p);
     const int nyl = g.ny / p->nranks;
-    const int64_t blk = (int64_t)p->nxl * nyl * g.nzp;
-    int lgxb = 0;
-    while ((1 << lgxb) < p->nxl) ++lgxb;
-    XLayout xl{nyl, p->rank * nyl, p->nxl, lgxb, blk, (int64_t)p->nranks * blk, 0};
+    XLayout xl = xlayout(p);
     const float scale = 1.f / ((float)g.nx * (float)g.ny * (float)g.nz);
     const int nc = (mode == 2 || mode == 4) ? 3 : 6;
     StageTimer st_(p, ST_KSPACE, 8.0 * (nc + 1) * p->nxl * g.ny * g.nzh + nc * pass_bytes(p, 1));
@@ -1058,6 +1082,14 @@ int mcpm_slab_ycol(mcpm_plan *p, const float *in, float *out, int batch, int sig
     MCPM_REQUIRE(p, mcpm_fftpm_supported(p), MCPM_E_UNSUPPORTED, "slab FFT needs power-of-two axes in [64, 1024]");
     MCPM_TRY(ensure_twiddles(p));
     return y_columns(p, (const cf *)in, (cf *)out, batch, sign, in_packed != 0, out_packed != 0);
+}
+
+int mcpm_slab_set_chunks(mcpm_plan *p, int chunks) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, chunks >= 1 && (chunks & (chunks - 1)) == 0 && p->nxl % chunks == 0 && p->nxl / chunks >= 1, MCPM_E_ARG,
+                 "mcpm_slab_set_chunks: the chunk count must be a power of two dividing the local planes");
+    p->chunks = chunks;
+    return MCPM_OK;
 }
 
 int mcpm_slab_set_window(mcpm_plan *p, int x0, int count) {

@@ -80,6 +80,7 @@ struct mcpm_plan {
     int nranks, rank, ghost, nx_global, nxl;
     unsigned *dmax; // caller's MCPM_FX_SLOTS x MCPM_FX_STRIDE slots: kick_drift leaves max |d_x| (as float bits) there; NULL = off
     int xw0, xwn;  // window of local planes the slab z / y passes work on (mcpm_slab_set_window; default all nxl)
+    int chunks;    // chunks of the all-to-all layouts (mcpm_slab_set_chunks; 1 = one all-to-all per spectrum)
 
     // rocFFT plans keyed by batch
     std::map<int, rocfft_plan> r2c, c2r;

@@ -92,6 +92,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->dmax = nullptr;
     p->xw0 = 0;
     p->xwn = p->nxl;
+    p->chunks = 1;
     p->stream = (hipStream_t)stream;
     p->M = (int64_t)nx * ny * nz;
     p->Mh = (int64_t)nx * ny * p->g.nzh;

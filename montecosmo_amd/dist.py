@@ -49,6 +49,16 @@ class _Done:
         pass
 
 
+class _HandleOf:
+    """Adapts anything with .wait() (a _Works, a _Done) to the torch Work interface _Works expects."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def wait(self):
+        self.h.wait()
+
+
 class _Works:
     def __init__(self, works, after=None):
         self.works, self.after, self.done = works, after, False
@@ -276,7 +286,12 @@ class PlaneHalo:
 class SlabPM(HaloMixin, PlaneHalo):
     """Slab-decomposed PM stepper for one rank."""
 
-    def __init__(self, mesh_shape, comm=None, ghost=16, device=None, adaptive_ghost=True):
+    def __init__(self, mesh_shape, comm=None, ghost=16, device=None, adaptive_ghost=True, chunks=None):
+        """chunks: every FFT transpose is split into this many all-to-alls of 1 / chunks of a spectrum each (chunks of
+        nx_local / chunks planes, `mcpm_slab_set_chunks`), issued as soon as the chunk's z / y passes are done and consumed
+        chunk by chunk on the other side, so that the transfers run under the passes of the other chunks.  Default
+        (None): MCPM_SLAB_CHUNKS, else 1 on one rank, 4 with at least 128 local planes and 2 below (each chunk costs a
+        launch of every z / y pass: +0.12 / +0.24 / +0.77 ms per step at 512^3 for 2 / 4 / 8 chunks, tools/chunk_sweep.sh)."""
         self.adaptive_ghost = bool(adaptive_ghost)
         self.comm = comm if comm is not None else LocalComm()
         P, r = self.comm.world, self.comm.rank
@@ -292,6 +307,13 @@ class SlabPM(HaloMixin, PlaneHalo):
         check(lib.mcpm_plan_create_slab(nx, ny, nz, P, r, self.G, C.c_void_p(self.stream.cuda_stream), C.byref(h)), None,
               "mcpm_plan_create_slab")
         self.h = h
+        if chunks is None:
+            import os
+            chunks = int(os.environ.get("MCPM_SLAB_CHUNKS", "1" if P == 1 else ("4" if self.nxl >= 128 else "2")))
+        while chunks > 1 and (self.nxl % chunks or self.nxl // chunks < 2 * self.G):    # a chunk holds at most one edge
+            chunks //= 2
+        self.chunks = max(1, int(chunks))
+        check(lib.mcpm_slab_set_chunks(h, self.chunks), h, "mcpm_slab_set_chunks")
         self.Nl = self.nxl * ny * nz                   # local particles
         self.Me = self.nxe * ny * nz                   # ghost-extended local mesh
         self.plane = ny * nz
@@ -342,13 +364,6 @@ class SlabPM(HaloMixin, PlaneHalo):
             self.f3il = torch.zeros((self.nxe,) + self.shape[1:] + (3,), dtype=torch.float32, device=self.device)
         return self.f3il
 
-    def _a2a(self, out, inp, async_op=False):
-        """All-to-all of one packed spectrum; returns (handle, buffer holding the result).  A one-rank local communicator
-        hands the input on: its all-to-all is the identity (the copy cost 1.6 ms per step at 512^3)."""
-        if getattr(self.comm, "alias_a2a", False):
-            return _Done(), inp
-        return self.comm.all_to_all(out, inp, async_op=async_op), out
-
     # ---- Poisson solve on slabs ----------------------------------------------------------------------------
     # Spectra buffers are component-major ([c][rank block][x_l][y_l][nzp]), so each force component is its own
     # all-to-all; they are issued asynchronously and the per-component y / z passes (and ghost fills) of one
@@ -356,30 +371,49 @@ class SlabPM(HaloMixin, PlaneHalo):
     def _spec(self, buf, c):
         return C.c_void_p(buf.data_ptr() + 8 * c * self.ss)
 
-    def _windows(self, pending):
-        """Plane windows in issue order.  With a halo exchange pending (or about to start) the passes are split into
-        the G edge planes on each side, which the exchange touches, and the inner planes, which it does not."""
-        d, nxl = self.depth(), self.nxl
-        if not pending or nxl <= 2 * d:
-            return None, [(0, nxl)]
-        return (d, nxl - 2 * d), [(0, d), (nxl - d, d)]
-
     def _win(self, w):
         self.call("mcpm_slab_set_window", int(w[0]), int(w[1]))
 
-    def _zinv_fill(self, spec_buf, c, ext, fill):
-        """z C2R of spectrum c into the interior of ext; the edge planes go first so that their ghost fill (async) runs
-        under the inner planes' transform."""
-        inner, edges = self._windows(fill)
-        for w in edges:
-            self._win(w)
-            self.call("mcpm_slab_zinv", self._spec(spec_buf, c), self._interior(ext), self.Me, 1)
-        h = self.halo_fill_x(ext, async_op=True) if fill else None
-        if inner is not None:
-            self._win(inner)
-            self.call("mcpm_slab_zinv", self._spec(spec_buf, c), self._interior(ext), self.Me, 1)
-        self._win((0, self.nxl))
-        return h
+    # ---- chunked transposes ---------------------------------------------------------------------------------
+    def _region(self, buf, w):
+        """Chunk w of one spectrum buffer (ss complex): the contiguous [rank][x in chunk][y_local][nzp] region."""
+        n = self.ss // self.chunks
+        return buf[w * n:(w + 1) * n]
+
+    def _a2a_chunk(self, out, inp, w, async_op=True):
+        """All-to-all of chunk w of one spectrum; returns (handle, True if the result stayed in `inp`)."""
+        if getattr(self.comm, "alias_a2a", False):
+            return _Done(), True
+        return self.comm.all_to_all(self._region(out, w), self._region(inp, w), async_op=async_op), False
+
+    def _a2a_all(self, out, inp):
+        """All chunks of one spectrum, asynchronously (the LPT transposes: not on the per-step path, no overlap scheduling).
+        Unlike _a2a_chunk the result is always in `out` (a local communicator copies)."""
+        n = self.ss // self.chunks
+        return _Works([_HandleOf(self.comm.all_to_all(out[w * n:(w + 1) * n], inp[w * n:(w + 1) * n], async_op=True))
+                       for w in range(self.chunks)])
+
+    def _chunk_parts(self, pending):
+        """Per chunk w: (interior planes (x0, n) or None, [edge plane runs]).  The first / last `depth` local planes are
+        what a ghost exchange touches; with one pending they are transformed after it, the interior before."""
+        d, nxl, cw = self.depth(), self.nxl, self.nxl // self.chunks
+        out = []
+        for w in range(self.chunks):
+            lo, hi = w * cw, (w + 1) * cw
+            if pending and nxl <= 2 * d:                 # every plane is within reach of the exchange
+                out.append((None, [(lo, hi - lo)]))
+                continue
+            a = max(lo, d) if pending else lo
+            b = min(hi, nxl - d) if pending else hi
+            edges = ([(lo, a - lo)] if a > lo else []) + ([(b, hi - b)] if hi > b else [])
+            out.append(((a, b - a) if b > a else None, edges))
+        return out
+
+    def _edge_first(self):
+        """Chunk order of the return transposes: the chunks holding the edge planes first (their ghost fill then runs under
+        the others)."""
+        C = self.chunks
+        return [0] + ([C - 1] if C > 1 else []) + list(range(1, C - 1))
 
     def force_meshes(self, *args, **kw):
         """See force_meshes_gen (this runs it to the end)."""
@@ -388,113 +422,166 @@ class SlabPM(HaloMixin, PlaneHalo):
     def force_meshes_gen(self, rho_ext, f3_ext, fill_ghosts=True, rho_add=None, il=False):
         """GENERATOR: yields each time a collective has been launched and the next thing this trajectory would do is wait
         for it, so that a driver holding several independent trajectories can issue another one's kernels in between
-        (bench.run_interleaved).  Interior of rho_ext -> the three force meshes (ghosts filled).  il=False: f3_ext is (3, nxe, ny, nz); il=True:
-        ONE interleaved mesh (nxe, ny, nz, 3) (what the step kernels read: a CIC corner is one 12-byte gather, and a run of
-        ghost planes is one contiguous block for the three components).  `rho_add`: handle of the ghost add of rho_ext
-        still in flight (None: ghosts already added); the inner planes' z / y passes run under it.
-        Only two spectra (A, G) cross the second all-to-all: the y pass applies the y / z force factors."""
-        ss = self.ss
-        inner, edges = self._windows(rho_add is not None)
-        for w in ([inner] if inner is not None else []) + edges:
-            if rho_add is not None and w is not inner:
-                yield
-                rho_add.wait()
-                rho_add = None
-            self._win(w)
+        (bench.run_interleaved).  Interior of rho_ext -> the three force meshes (ghosts filled).  il=False: f3_ext is
+        (3, nxe, ny, nz); il=True: ONE interleaved mesh (nxe, ny, nz, 3) (what the step kernels read: a CIC corner is one
+        12-byte gather, and a run of ghost planes is one contiguous block for the three components).  `rho_add`: handle of
+        the ghost add of rho_ext still in flight (None: ghosts already added).
+        Transposes are chunked (`self.chunks`): a chunk's all-to-all leaves as soon as its z / y passes are done, and on the
+        way back a chunk's inverse y / z passes run while the next chunks are still in flight.  Only two spectra (A, G)
+        cross the second transpose: the y pass applies the y / z force factors."""
+        ss, C = self.ss, self.chunks
+        # ---- forward z / y passes chunk by chunk, each chunk's all-to-all right behind them
+        parts = self._chunk_parts(rho_add is not None)
+        h1, aliased = [None] * C, False
+
+        def zy(win):
+            self._win(win)
             self.call("mcpm_slab_zfwd", self._interior(rho_ext), self.Me, _p(self.s1a), 1)
             self.call("mcpm_slab_ycol", _p(self.s1a), _p(self.s1b), 1, -1, 0, 1)      # plain -> transposed order
-        self._win((0, self.nxl))
-        h1, x_in = self._a2a(self.s1a, self.s1b, async_op=True)                       # x <-> y transpose
-        yield
-        h1.wait()
-        self.call("mcpm_slab_xfused", _p(x_in), _p(self.s3a), 0)                      # -> A, G
-        hA, bA = self._a2a(self.s3b[:ss], self.s3a[:ss], async_op=True)
-        hG, _ = self._a2a(self.s3b[ss:2 * ss], self.s3a[ss:2 * ss], async_op=True)
-        # where A, G sit now (s3a if the all-to-all was aliased, else received in s3b); the y pass writes the other buffer
-        src, dst = (self.s3a, self.s3b) if bA.data_ptr() == self.s3a.data_ptr() else (self.s3b, self.s3a)
-        yield
-        hA.wait()
-        self.call("mcpm_slab_ycol2", _p(src), _p(dst), 1, 1, 0, 1)                    # A -> force spectrum 0
-        if not il:
-            self._zinv_fill(dst, 0, f3_ext[0], False)                                 # all of component 0 under G's transfer
-        yield
-        hG.wait()
-        self.call("mcpm_slab_ycol2", _p(src), _p(dst), 1, 1, 0, 2)                    # G -> force spectra 1, 2
-        inner, edges = self._windows(fill_ghosts)
-        if il:      # ONE z pass for the three components; the edge planes first, their ghost fill (async) under the inner planes
-            for w in edges:
-                self._win(w)
-                self.call("mcpm_slab_zinv3_il", _p(dst), self._interior_il(f3_ext))
-            h = self.halo_fill_x(f3_ext, async_op=True) if fill_ghosts else None
+
+        for w, (inner, edges) in enumerate(parts):
             if inner is not None:
-                self._win(inner)
-                self.call("mcpm_slab_zinv3_il", _p(dst), self._interior_il(f3_ext))
-        else:       # ONE ghost fill for the three components: the edge planes of components 1, 2 first
-            for c in (1, 2):
-                for w in edges:
-                    self._win(w)
-                    self.call("mcpm_slab_zinv", self._spec(dst, c), self._interior(f3_ext[c]), self.Me, 1)
-            h = self.halo_fill(f3_ext, async_op=True) if fill_ghosts else None
-            if inner is not None:
-                self._win(inner)
-                for c in (1, 2):
-                    self.call("mcpm_slab_zinv", self._spec(dst, c), self._interior(f3_ext[c]), self.Me, 1)
-        self._win((0, self.nxl))
-        if h is not None:
+                zy(inner)
+            if not edges:
+                h1[w], aliased = self._a2a_chunk(self.s1a, self.s1b, w)
+        if rho_add is not None:
             yield
+            rho_add.wait()
+        for w, (inner, edges) in enumerate(parts):
+            for e in edges:
+                zy(e)
+            if edges:
+                h1[w], aliased = self._a2a_chunk(self.s1a, self.s1b, w)
+        self._win((0, self.nxl))
+        x_in = self.s1b if aliased else self.s1a
+        yield
+        for h in h1:
             h.wait()
+        self.call("mcpm_slab_xfused", _p(x_in), _p(self.s3a), 0)                      # -> A, G
+        # ---- back: A and G chunk by chunk, the edge chunks first
+        order = self._edge_first()
+        hA, hG = {}, {}
+        for w in order:
+            hA[w], aliased = self._a2a_chunk(self.s3b[:ss], self.s3a[:ss], w)
+            hG[w], _ = self._a2a_chunk(self.s3b[ss:2 * ss], self.s3a[ss:2 * ss], w)
+        src, dst = (self.s3a, self.s3b) if aliased else (self.s3b, self.s3a)
+        parts = dict(enumerate(self._chunk_parts(fill_ghosts)))
+        n_edge_chunks = sum(1 for w in order if parts[w][1])
+        fill = None
+
+        def zinv(win):
+            self._win(win)
+            if il:
+                self.call("mcpm_slab_zinv3_il", _p(dst), self._interior_il(f3_ext))
+            else:
+                for c in range(3):
+                    self.call("mcpm_slab_zinv", self._spec(dst, c), self._interior(f3_ext[c]), self.Me, 1)
+
+        cw = self.nxl // C
+        for k, w in enumerate(order):
+            yield
+            hA[w].wait()
+            self._win((w * cw, cw))
+            self.call("mcpm_slab_ycol2", _p(src), _p(dst), 1, 1, 0, 1)                # A -> force spectrum 0
+            hG[w].wait()
+            self.call("mcpm_slab_ycol2", _p(src), _p(dst), 1, 1, 0, 2)                # G -> force spectra 1, 2
+            inner, edges = parts[w]
+            for e in edges:                                                          # the edge planes first ...
+                zinv(e)
+            if edges:
+                n_edge_chunks -= 1
+                if n_edge_chunks == 0 and fill_ghosts:                               # ... so that the ghost fill runs under the rest
+                    fill = self.halo_fill_x(f3_ext, async_op=True) if il else self.halo_fill(f3_ext, async_op=True)
+            if inner is not None:
+                zinv(inner)
+        self._win((0, self.nxl))
+        if fill is not None:
+            yield
+            fill.wait()
 
     def force_meshes_vjp(self, *args, **kw):
         _exhaust(self.force_meshes_vjp_gen(*args, **kw))
 
     def force_meshes_vjp_gen(self, fbar3_ext, rhobar_ext, ghost_adds=None, fill_ghosts=False):
-        """GENERATOR (see force_meshes_gen).  fbar3_ext: three cotangent meshes (3, nxe, ny, nz) (ghosts added, or `ghost_adds[c]` handles still in flight).
-        Writes the interior of rhobar_ext (and its ghosts if fill_ghosts)."""
-        ss = self.ss
-        handles, bufs = [], []
-        for c in range(3):
-            add = ghost_adds[c] if ghost_adds is not None else None
-            inner, edges = self._windows(add is not None)
-            for w in ([inner] if inner is not None else []) + edges:
-                if add is not None and w is not inner:
-                    if not getattr(add, "done", False):
-                        yield
-                    add.wait()
-                    add = None
-                self._win(w)
+        """GENERATOR (see force_meshes_gen).  fbar3_ext: three cotangent meshes (3, nxe, ny, nz) (ghosts added, or
+        `ghost_adds[c]` handles still in flight).  Writes the interior of rhobar_ext (and its ghosts if fill_ghosts)."""
+        ss, C = self.ss, self.chunks
+        adds = [a for a in (ghost_adds or []) if a is not None]
+        parts = self._chunk_parts(bool(adds))
+        ha, hb, aliased = [None] * C, [None] * C, False
+
+        def zy(win):      # three z transforms, then a = FFTy(f_bar_x) and b = ky FFTy(f_bar_y) + kz FFTy(f_bar_z)
+            self._win(win)
+            for c in range(3):
                 self.call("mcpm_slab_zfwd", self._interior(fbar3_ext, c), self.Me, self._spec(self.s3a, c), 1)
-            self._win((0, self.nxl))
-            if c == 0:    # a = FFTy(f_bar_x) leaves while the other two components are still being transformed
-                self.call("mcpm_slab_ycol2", _p(self.s3a), _p(self.s3b), 0, 0, 1, 1)
-                h, b0 = self._a2a(self.s6a[3 * ss:4 * ss], self.s3b[:ss], async_op=True)
-                handles.append(h)
-                bufs.append(b0)
-        self.call("mcpm_slab_ycol2", _p(self.s3a), _p(self.s3b), 0, 0, 1, 2)          # b = ky FFTy(f_bar_y) + kz FFTy(f_bar_z)
-        h, _ = self._a2a(self.s6a[4 * ss:5 * ss], self.s3b[ss:2 * ss], async_op=True)
-        handles.append(h)
+            self.call("mcpm_slab_ycol2", _p(self.s3a), _p(self.s3b), 0, 0, 1, 3)
+
+        def send(w):
+            nonlocal aliased
+            ha[w], aliased = self._a2a_chunk(self.s6a[3 * ss:4 * ss], self.s3b[:ss], w)
+            hb[w], _ = self._a2a_chunk(self.s6a[4 * ss:5 * ss], self.s3b[ss:2 * ss], w)
+
+        for w, (inner, edges) in enumerate(parts):
+            if inner is not None:
+                zy(inner)
+            if not edges:
+                send(w)
+        if adds:
+            if not all(getattr(a, "done", False) for a in adds):
+                yield
+            for a in adds:
+                a.wait()
+        for w, (inner, edges) in enumerate(parts):
+            for e in edges:
+                zy(e)
+            if edges:
+                send(w)
+        self._win((0, self.nxl))
         yield
-        for h in handles:
+        for h in ha + hb:
             h.wait()
         # (a, b) received side by side in s6a[3 ss : 5 ss], or still in s3b[0 : 2 ss] when the all-to-all was aliased
-        x_in = self.s3b if bufs[0].data_ptr() == self.s3b.data_ptr() else self.s6a[3 * ss:5 * ss]
+        x_in = self.s3b if aliased else self.s6a[3 * ss:5 * ss]
         self.call("mcpm_slab_xfused", _p(x_in), _p(self.s1a), 1)
-        h1, y_in = self._a2a(self.s1b, self.s1a, async_op=True)
-        yield
-        h1.wait()
-        y_out = self.s1a if y_in is self.s1b else self.s1b
-        self.call("mcpm_slab_ycol", _p(y_in), _p(y_out), 1, +1, 1, 0)
-        h = self._zinv_fill(y_out, 0, rhobar_ext, fill_ghosts)
-        if h is not None:
+        order = self._edge_first()
+        h1 = {}
+        for w in order:
+            h1[w], aliased = self._a2a_chunk(self.s1b, self.s1a, w)
+        y_in, y_out = (self.s1a, self.s1b) if aliased else (self.s1b, self.s1a)
+        parts = dict(enumerate(self._chunk_parts(fill_ghosts)))
+        n_edge_chunks = sum(1 for w in order if parts[w][1])
+        fill = None
+        cw = self.nxl // C
+
+        def zinv(win):
+            self._win(win)
+            self.call("mcpm_slab_zinv", _p(y_out), self._interior(rhobar_ext), self.Me, 1)
+
+        for w in order:
             yield
-            h.wait()
+            h1[w].wait()
+            self._win((w * cw, cw))
+            self.call("mcpm_slab_ycol", _p(y_in), _p(y_out), 1, +1, 1, 0)
+            inner, edges = parts[w]
+            for e in edges:
+                zinv(e)
+            if edges:
+                n_edge_chunks -= 1
+                if n_edge_chunks == 0 and fill_ghosts:
+                    fill = self.halo_fill_x(rhobar_ext, async_op=True)
+            if inner is not None:
+                zinv(inner)
+        self._win((0, self.nxl))
+        if fill is not None:
+            yield
+            fill.wait()
 
     # ---- lpt on slabs (nbody.py:634-667 at the lattice, read_order = 1) -------------------------------------
     def spec_to_meshes(self, spec_full, out_ext, nc):
         """Replicated plain half-spectrum -> nc = 3 force meshes or nc = 6 Hessian meshes (interiors of out_ext[c])."""
         ss = self.ss
         self.call("mcpm_slab_xfused", _p(spec_full), _p(self.s6a), 2 if nc == 3 else 3)
-        a2a = [self.comm.all_to_all(self.s6b[c * ss:(c + 1) * ss], self.s6a[c * ss:(c + 1) * ss], async_op=True)
-               for c in range(nc)]
+        a2a = [self._a2a_all(self.s6b[c * ss:(c + 1) * ss], self.s6a[c * ss:(c + 1) * ss]) for c in range(nc)]
         for c in range(nc):
             a2a[c].wait()
             self.call("mcpm_slab_ycol", self._spec(self.s6b, c), self._spec(self.s6a, c), 1, +1, 1, 0)
@@ -507,7 +594,7 @@ class SlabPM(HaloMixin, PlaneHalo):
         for c in range(nc):
             self.call("mcpm_slab_zfwd", self._interior(meshes_ext, c), self.Me, self._spec(self.s6a, c), 1)
             self.call("mcpm_slab_ycol", self._spec(self.s6a, c), self._spec(self.s6b, c), 1, -1, 0, 1)
-            a2a.append(self.comm.all_to_all(self.s6a[c * ss:(c + 1) * ss], self.s6b[c * ss:(c + 1) * ss], async_op=True))
+            a2a.append(self._a2a_all(self.s6a[c * ss:(c + 1) * ss], self.s6b[c * ss:(c + 1) * ss]))
         for h in a2a:
             h.wait()
         self.call("mcpm_slab_xfused", _p(self.s6a), _p(spec_bar_full), 4 if nc == 3 else 5)

@@ -114,15 +114,18 @@ def test_slab_path_against_oracle(gpu, world):
 
 
 @pytest.mark.gpu
-def test_slab_path_single_rank(gpu):
-    """One rank, local-copy communicator: exercises ghost-extended paint/read, the packed FFT layouts and the
-    slab adjoint against the plain single-GPU path."""
+@pytest.mark.parametrize("chunks", [1, 2, 4])
+def test_slab_path_single_rank(gpu, chunks):
+    """One rank, local-copy communicator: exercises ghost-extended paint/read, the packed (and chunked: every transpose as
+    `chunks` all-to-alls of contiguous chunk regions) FFT layouts and the slab adjoint against the plain single-GPU path."""
     from montecosmo_amd import nbody, bricks, synth, dist
     n, n_steps = 64, 3
     shape = (n, n, n)
     spec = synth.init_mesh(n, seed=3, rms_disp=1.5)
     cosmo = bricks.Planck18()
-    (d, v), ctx = dist.nbody_bf_slab(cosmo, spec, a0=0.1, a1=1.0, n_steps=n_steps, ghost=16, return_ctx=True)
+    pm = dist.SlabPM(shape, None, 8, chunks=chunks)
+    assert pm.chunks == chunks
+    (d, v), ctx = dist.nbody_bf_slab(cosmo, spec, a0=0.1, a1=1.0, n_steps=n_steps, slab=pm, return_ctx=True)
     (lp, v1), c1 = nbody.nbody_bf(cosmo, spec, nbody.LatticePos.regular(shape), a0=0.1, a1=1.0, n_steps=n_steps,
                                   return_ctx=True, lattice_out=True)
     rel = lambda a, b: float((a - b).norm() / b.norm())
