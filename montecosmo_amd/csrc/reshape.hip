@@ -55,10 +55,48 @@ __device__ __forceinline__ void sources(const RS &r, int ix, int iy, int k, floa
     }
 }
 
+// Scale of the fixed-point accumulators of the adjoint scatter: S = 2^(40 - e) with 2^e <= max|cotangent| < 2^(e+1), from the
+// float bits of the maximum (fxmax[0]); mode 0: all zero, 1: fixed point, 2: non-finite input (plain float atomics, the result
+// is non-finite either way).  One contribution is below 2^41 r.scale, a destination takes at most 8: no overflow for any
+// mesh ratio below 2^18.
+struct FxS {
+    float S;
+    double Sinv;
+    int mode;
+};
+__device__ __forceinline__ FxS fx_scale(const unsigned *__restrict__ fxmax) {
+    const unsigned wb = fxmax[0];
+    int be = (int)(wb >> 23);
+    FxS r;
+    r.mode = wb == 0u ? 0 : (be >= 255 ? 2 : 1);
+    be = min(max(be, 42), 254);
+    const int e = be - 127;
+    r.S = __uint_as_float((unsigned)(127 + 40 - e) << 23);
+    r.Sinv = __longlong_as_double((long long)(1023 - 40 + e) << 52);
+    return r;
+}
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float *__restrict__ v, int64_t n, unsigned *__restrict__ out) {
+    unsigned m = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = max(m, __float_as_uint(v[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__global__ __launch_bounds__(256) void fx_flush_kernel(const long long *__restrict__ acc, float *__restrict__ out, int64_t n,
+                                                       const unsigned *__restrict__ fxmax) {
+    const FxS sc = fx_scale(fxmax);
+    if (sc.mode == 2) return;       // the float path wrote `out` directly
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (float)((double)acc[i] * sc.Sinv);
+}
+
 template <bool ADJOINT>
-__global__ __launch_bounds__(256) void chreshape_kernel(RS r, const float2 *__restrict__ in, float2 *__restrict__ out) {
+__global__ __launch_bounds__(256) void chreshape_kernel(RS r, const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                        long long *__restrict__ acc = nullptr, const unsigned *__restrict__ fxmax = nullptr) {
     // forward: in = input spectrum, out = reshaped.  adjoint: in = cotangent of the reshaped spectrum, out = cotangent
-    // of the input (zeroed by the caller; contributions are scattered with atomics)
+    // of the input.  Up to 8 outputs share an input (Nyquist planes), so the adjoint is a scatter; its sums are taken in
+    // 64-bit FIXED POINT (integer atomics into `acc`, zeroed by the caller, flushed by fx_flush_kernel): float atomics would
+    // add the contributions in arrival order and change the last bit of a few elements from call to call, which a
+    // sampler then amplifies into different chains from the same seed.
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n = (int64_t)r.sx * r.sy * r.szc;
     if (idx >= n) return;
@@ -84,10 +122,19 @@ __global__ __launch_bounds__(256) void chreshape_kernel(RS r, const float2 *__re
     } else {
         if (!valid) return;
         const float2 ob = in[idx];
+        const FxS sc = fx_scale(fxmax);
+        if (sc.mode == 0) return;
         sources(r, ix, iy, ok, r.scale * fx * fy * fz, [&](int jx, int jy, int k, float w, bool cj) {
-            float *dst = reinterpret_cast<float *>(out + ((int64_t)jx * r.my + jy) * r.mzc + k);
-            atomicAdd(dst, w * ob.x);
-            atomicAdd(dst + 1, cj ? -w * ob.y : w * ob.y);
+            const int64_t e = 2 * (((int64_t)jx * r.my + jy) * r.mzc + k);
+            const float vx = w * ob.x, vy = cj ? -w * ob.y : w * ob.y;
+            if (sc.mode == 2) {
+                float *dst = reinterpret_cast<float *>(out) + e;
+                atomicAdd(dst, vx);
+                atomicAdd(dst + 1, vy);
+            } else {
+                atomicAdd(reinterpret_cast<unsigned long long *>(acc) + e, (unsigned long long)__float2ll_rn(vx * sc.S));
+                atomicAdd(reinterpret_cast<unsigned long long *>(acc) + e + 1, (unsigned long long)__float2ll_rn(vy * sc.S));
+            }
         });
     }
 }
@@ -220,9 +267,23 @@ int mcpm_chreshape_vjp_c64(void *stream, const float *out_bar, int out_nx, int o
     const RS r{in_nx, in_ny, in_nz / 2 + 1, out_nx, out_ny, out_nz / 2 + 1,
                (float)(((double)out_nx * out_ny * out_nz) / ((double)in_nx * in_ny * in_nz))};
     const int64_t n = (int64_t)r.sx * r.sy * r.szc, ni = (int64_t)r.mx * r.my * r.mzc;
-    if (hipMemsetAsync(in_bar, 0, sizeof(float2) * ni, (hipStream_t)stream) != hipSuccess) return MCPM_E_HIP;
-    chreshape_kernel<true><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(r, (const float2 *)out_bar, (float2 *)in_bar);
-    return hipGetLastError() == hipSuccess ? MCPM_OK : MCPM_E_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    // scratch of the call: 2 ni 64-bit accumulators + the maximum (stream-ordered allocation, freed behind the flush)
+    char *scratch = nullptr;
+    const size_t acc_bytes = sizeof(long long) * 2 * (size_t)ni;
+    if (hipMallocAsync((void **)&scratch, acc_bytes + 256, st) != hipSuccess) return MCPM_E_NOMEM;
+    long long *acc = (long long *)scratch;
+    unsigned *fxmax = (unsigned *)(scratch + acc_bytes);
+    bool ok = hipMemsetAsync(scratch, 0, acc_bytes + 256, st) == hipSuccess &&
+              hipMemsetAsync(in_bar, 0, sizeof(float2) * ni, st) == hipSuccess;
+    if (ok) {
+        absmax_bits_kernel<<<1024, 256, 0, st>>>(out_bar, 2 * n, fxmax);
+        chreshape_kernel<true><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(r, (const float2 *)out_bar, (float2 *)in_bar, acc, fxmax);
+        fx_flush_kernel<<<1024, 256, 0, st>>>(acc, in_bar, 2 * ni, fxmax);
+        ok = hipGetLastError() == hipSuccess;
+    }
+    (void)hipFreeAsync(scratch, st);
+    return ok ? MCPM_OK : MCPM_E_HIP;
 }
 
 int mcpm_rg2cgh_f32(void *stream, const float *real, int nx, int ny, int nz, float *spec) {

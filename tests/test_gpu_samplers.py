@@ -42,6 +42,23 @@ def _cos(c, s8):
     return c
 
 
+def test_log_density_and_gradient_are_bitwise_reproducible(gpu):
+    """The same state gives the same log density and the same gradient, bit for bit, call after call: every sum on the path
+    is order-independent (integer accumulators in the paints and in the scatter adjoint of chreshape, whose float atomics
+    once changed the last bit of a few Nyquist-plane elements from call to call -- enough for a seeded NUTS chain to end
+    1 % away from its twin)."""
+    import torch
+    samplers, flat, q0, ref = _setup()
+    rng = np.random.default_rng(0)
+    for trial in range(3):
+        q = q0 + 0.2 * trial * torch.from_numpy(rng.standard_normal(tuple(q0.shape)).astype(np.float32)).to(q0.device)
+        lp0, g0 = flat(q)
+        g0 = g0.clone()
+        for _ in range(60):
+            lp, g = flat(q)
+            assert lp == lp0 and torch.equal(g, g0)
+
+
 def test_nuts_chain_over_the_hip_log_density(gpu):
     samplers, flat, q0, ref = _setup()
     run = lambda: samplers.nuts_sample(flat, q0, n_warmup=12, n_samples=8, max_tree_depth=4, seed=3)
@@ -59,8 +76,8 @@ def test_nuts_chain_over_the_hip_log_density(gpu):
     # a seeded chain is reproducible: same decisions, same states
     r2 = run()
     assert [i["n_leapfrog"] for i in r2["infos"]] == [i["n_leapfrog"] for i in infos]
-    assert np.allclose(r2["samples"][-1].cpu().numpy(), r1["samples"][-1].cpu().numpy(), rtol=1e-4, atol=1e-5)
-    assert abs(r2["step_size"] - r1["step_size"]) < 1e-6 * r1["step_size"]
+    assert np.array_equal(r2["samples"][-1].cpu().numpy(), r1["samples"][-1].cpu().numpy())      # bit for bit
+    assert r2["step_size"] == r1["step_size"]
 
 
 def test_mclmc_chain_over_the_hip_log_density(gpu):
@@ -76,5 +93,5 @@ def test_mclmc_chain_over_the_hip_log_density(gpu):
     lp, lp_o = flat(r1["samples"][-1])[0], ref(r1["samples"][-1])
     assert abs(lp - lp_o) < 2e-4 * abs(lp_o) + 0.05, (lp, lp_o)
     r2 = run()
-    assert np.allclose(r2["samples"][-1].cpu().numpy(), r1["samples"][-1].cpu().numpy(), rtol=1e-4, atol=1e-5)
-    assert abs(r2["step_size"] - r1["step_size"]) < 1e-5 * r1["step_size"]
+    assert np.array_equal(r2["samples"][-1].cpu().numpy(), r1["samples"][-1].cpu().numpy())      # bit for bit
+    assert r2["step_size"] == r1["step_size"]
