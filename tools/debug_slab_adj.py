@@ -1,4 +1,6 @@
-"""Bisect a slab-vs-plain adjoint discrepancy: one adjoint step composed from public calls on both plans. usage: n"""
+"""Where does a slab-vs-plain gradient difference come from?  One adjoint step composed from public calls on both plans, the
+whole reverse sweep both ways, four implementations of the first adjoint step, and the particles whose cotangent differs
+(at 128^3: ONE particle sitting 5.6e-8 from a cell face, in different cells on the two trajectories).  usage: debug_slab_adj.py n"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -78,9 +80,6 @@ for j in reversed(range(K)):
               C.c_void_p(sbp.data_ptr() + 8 * 2 * K))
     print("after adjoint of step", j, ": xb", rel(xs, xp), "vb", rel(vs, vp))
 print("scalars slab", sbs.cpu().numpy(), "\nscalars plain", sbp.cpu().numpy())
-# ---- LPT adjoint on identical inputs
-out_s, ls = pm.lpt_vjp(ctx.spec, 2, ctx.lpt_s[0], ctx.lpt_s[1], ctx.lpt_s[2], xp.clone(), vp.clone())
-out_p, lp_ = nbody.lpt_vjp(cosmo, ctx.spec, nbody.LatticePos.regular(shape), 0.1, xp.clone(), vp.clone(), lpt_order=2) if False else (None, None)
 print("---- variants of the first adjoint step (slab) against the plain step without hint")
 j = K - 1
 tj = ctx.dg / 2
@@ -124,13 +123,6 @@ def slab_fused():
     return xs, vs
 A, B, Cc = plain_fused(), plain_composed(), slab_fused()
 print("plain fused vs plain composed", rel(A[0], B[0]), " slab fused vs plain composed", rel(Cc[0], B[0]), " plain fused vs slab fused", rel(A[0], Cc[0]))
-# the oracle's one-step VJP in float64 on the same state
-from oracle import pm_oracle as o, background as obg
-o.set_threads(16)
-pos = o.regular_pos(shape)
-xh = states_p[j, 0].double().cpu().numpy(); vh = states_p[j, 1].double().cpu().numpy()
-dg = float(ctx.dg)
-res = o.dkd_vjp(pos + xh - vh * (dg / 2), vh, xb0.double().cpu().numpy(), vb0.double().cpu().numpy(), dg, float(ctx.alphas[j]), 0.0, shape) if False else None
 dx = (Cc[0] - B[0]).abs()
 bad = (dx > 1e-3 * B[0].abs().mean()).any(dim=1)
 idx = bad.nonzero().flatten()
