@@ -329,13 +329,17 @@ def pmc_traffic(stage, n):
     """HBM-side bytes per launch of `stage`, from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under
     profiles/ (separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 and as calibrated here
     on axpy_kernel, whose byte count is known).  bench.py cannot collect PMC counters itself; null when the file
-    has no entry for this mesh."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-        return d[str(n)][stage]["bytes_per_launch"]
-    except Exception:
-        return None
+    has no entry for this mesh.  Returns (bytes, file used): the newest profiles/r*_pmc_traffic.json
+    that holds the stage; the line names the file (`traffic_source`) so that a stale table is visible."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))      # rNN_...: the newest round sorts last
+    for path in reversed(files):
+        try:
+            d = json.load(open(path))
+            return d[str(n)][stage]["bytes_per_launch"], os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
 
 
 def host_threads():
@@ -400,17 +404,40 @@ def spawn_ranks(nproc):
     and never will), one per GPU, rendezvous on 127.0.0.1, and relay their output.  Returns the worst exit code."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    # the rendezvous port stays bound (SO_REUSEADDR) until the ranks have been started, so that no other process is handed it
+    sk = socket.socket()
+    sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
     procs = []
     for r in range(nproc):
         env = dict(os.environ, WORLD_SIZE=str(nproc), RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(nproc),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
+    sk.close()
+    # poll all ranks: the first failure ends the others (they would sit in a collective for ever), and so does the deadline
+    deadline = time.time() + float(os.environ.get("MCPM_BENCH_DEADLINE", "1500"))
+    rc, live = 0, list(procs)
+    while live:
+        for pr in list(live):
+            r = pr.poll()
+            if r is not None:
+                live.remove(pr)
+                rc = max(rc, abs(r))
+        if live and (rc != 0 or time.time() > deadline):
+            if rc == 0:
+                rc = 5
+                print("bench.py: ranks still running at the deadline; ending them", file=sys.stderr, flush=True)
+            for pr in live:
+                pr.terminate()
+            t_end = time.time() + 10
+            for pr in live:
+                try:
+                    pr.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+            break
+        time.sleep(0.05)
     return rc
 
 
@@ -522,7 +549,8 @@ def main():
                        "mesh": n, "n_steps": NS, "parallelism": (("slab1 (RCCL, one rank)" if dist else "slab1 (local-copy communicator)") if slab else "single") if world == 1 else (f"slab{world}" if slab else f"replicas{world}")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(stages[dom]["algorithmic_GBps"] / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(dom, n) if world == 1 else None},
+                         "traffic": pmc_traffic(dom, n)[0] if world == 1 else None,
+                         "traffic_source": pmc_traffic(dom, n)[1] if world == 1 else None},
             # "ms": the stages of the cycle inside a step, where the read also kicks and drifts (60 B/particle instead of
             # the 36 the 100 B/cell figure counts); "pm_forces_*": the function pm_forces itself, which is what 100 B/cell describes
             "force_cycle": {"ms": round(cyc_ms, 4), "algorithmic_GBps": round(B_PER_CELL_CYCLE * Mloc / (cyc_ms * 1e-3) / 1e9, 1),
@@ -548,6 +576,16 @@ def main():
                 r2 = r
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(r2)
+                # SURVEY 8(d) lists 64^3 and 128^3 as well: the same measurement on their own trajectories (a second or two each)
+                del r2
+                small = {}
+                for m in (128, 64):
+                    if m in (n, args.cpu_mesh):
+                        continue
+                    rs, rec = sub_record(m, NS, K, W, device)
+                    small[str(m)] = dict(cpu_baseline(rs, n_sample_steps=NS), gpu_steps_per_s=rec["value"])
+                    del rs
+                out["cpu_baseline_small_meshes"] = small
     # ---- independent trajectories as a software pipeline (collective: every rank takes part).  Measured AFTER the line
     # above is complete, under a watchdog: whatever happens here (a second communicator that cannot be created, a hang), the
     # single-trajectory result is printed.
@@ -556,10 +594,12 @@ def main():
         import threading
 
         def bail():
+            # a stuck collective cannot be left from Python: print what is finished and end THIS process with a failure code
+            # (every rank runs its own watchdog), so that the launcher and spawn_ranks see the hang instead of rc 0
             if rank == 0:
                 out["interleaved_chains"] = {"chains": nch, "error": "timed out"}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)
 
         timer = threading.Timer(float(os.environ.get("MCPM_CHAINS_TIMEOUT", "300")), bail)
         timer.daemon = True
@@ -593,7 +633,9 @@ def main():
             if rank == 0:
                 out["interleaved_chains"] = {"chains": nch, "error": repr(e)[:300]}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            else:
+                print(f"bench.py rank {rank}: interleaved chains failed: {e!r}", file=sys.stderr, flush=True)
+            os._exit(4)
         finally:
             timer.cancel()
     if dist:

@@ -93,7 +93,7 @@ struct mcpm_plan {
     float *fmesh;    // 9 real meshes scratch (force meshes / hessians)
     float *spec1;    // 1 half-spectrum scratch
     float *fft_pad;  // 1 padded spectrum: scratch of the generic hand-written R2C / C2R (allocated on first use)
-    int *outliers;   // outlier particle list of the tiled paint (Np ints)
+    int *outliers;   // lists of the tiled paint: suspects (Np ints), then wild particles (Np ints)
     int *outlier_count;  // device counters (8 ints, see paint_tiled.hip: wild, last, slab oob, overflow pairs, dropped, bucketed)
     double *reduce;  // device accumulators for scalar cotangents (MCPM_NREDUCE doubles)
     float *pscratch; // 9*Np floats, allocated on first VJP (adjoint state + force cotangent)

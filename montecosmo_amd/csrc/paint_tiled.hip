@@ -134,14 +134,16 @@ struct TileLists {
     int *bucket;       // [tile][cap] particle indices
     int cap;
     int *nonempty;     // tiles whose bucket received something (cnts[C_NTILES] of them): what the bucket kernels walk
-    int *list;         // wild particles from the front, suspects from the back (a particle is one or the other: capacity Np)
+    int *list;         // suspects, from the back (capacity Np: at most one entry per particle)
+    int *wild;         // wild particles (own Np ints: every wild particle found by the coverage kernel is also a suspect, so a
+                       // shared list could be overrun while other threads still read suspects from it -- ADVICE r2)
     int listcap;
     int *cnts;
 };
 
 __device__ __forceinline__ void append_wild(const TileLists &L, int gi) {
     const int k = atomicAdd(L.cnts + C_WILD, 1);
-    if (k < L.listcap) L.list[k] = gi;      // at most one entry per particle: cannot overflow
+    if (k < L.listcap) L.wild[k] = gi;      // at most one entry per particle: cannot overflow
 }
 
 // Suspects are staged in LDS (one global atomic per workgroup instead of one per suspect: a single global counter serialised
@@ -365,12 +367,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
             // Coverage duty: six compares (what the round-1 outlier test cost; NaN fails them).  What they cannot clear goes
             // to the suspect list of the home tile, for the exact test of coverage_duty_kernel (400 instructions: inlined in
             // this unrolled loop, and entered by most waves, they doubled the kernel's time).
-            if (!(fx >= slo[0] && fx <= shi[0] && fy >= slo[1] && fy <= shi[1] && fz >= slo[2] && fz <= shi[2])) {
-                if (duty && (unsigned)rx < (unsigned)B && (unsigned)ry < (unsigned)B && (unsigned)rz < (unsigned)B) append_suspect(L, sus, gis[u]);
-                if (!(fabsf(d[u].x) < MCPM_TAME && fabsf(d[u].y) < MCPM_TAME && fabsf(d[u].z) < MCPM_TAME)) continue;   // wild
+            // Slab plans: a base cell beyond the ghost planes is nobody's to deposit; its HOME tile must hand it to the exact
+            // test too (is_wild() sends it to the clamping, counting leftover kernel) -- with bulk-centred windows the sure
+            // interval alone reaches |floor(d_x)| = 8 + H, past a ghost region of 8 planes, and such a particle used to vanish
+            // uncounted.
+            const bool unsure = !(fx >= slo[0] && fx <= shi[0] && fy >= slo[1] && fy <= shi[1] && fz >= slo[2] && fz <= shi[2]);
+            const bool home = (unsigned)rx < (unsigned)B && (unsigned)ry < (unsigned)B && (unsigned)rz < (unsigned)B;
+            if (unsure && !(fabsf(d[u].x) < MCPM_TAME && fabsf(d[u].y) < MCPM_TAME && fabsf(d[u].z) < MCPM_TAME)) {   // wild
+                if (duty && home) append_suspect(L, sus, gis[u]);
+                continue;
             }
             const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
-            if (g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2)) continue;   // beyond the ghost planes: wild (clamped + counted there)
+            const bool beyond = g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
+            if ((unsure || beyond) && duty && home) append_suspect(L, sus, gis[u]);
+            if (beyond) continue;   // clamped + counted by paint_leftover_kernel
             if (cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
                 const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
                 const float s0 = WMODE == 2 ? wt[u] : (WMODE == 1 ? wt[u] * sc.S : sc.S);   // exact power-of-two scaling
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(256) void paint_leftover_kernel(Geom g, const float
     const int nw = min(L.cnts[C_WILD], L.listcap);
     if (blockIdx.x == 0 && threadIdx.x == 0) L.cnts[C_LAST] = L.cnts[C_WILD] + L.cnts[C_PAIRS];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nw; k += gridDim.x * blockDim.x) {
-        const int gi = L.list[k];
+        const int gi = L.wild[k];
         PIdx pi;
         pi.i = gi;
         pi.ipz = gi % g.nz;
@@ -705,12 +715,20 @@ __global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const floa
             // Coverage duty: six compares (what the round-1 outlier test cost; NaN fails them).  What they cannot clear goes
             // to the suspect list of the home tile, for the exact test of coverage_duty_kernel (400 instructions: inlined in
             // this unrolled loop, and entered by most waves, they doubled the kernel's time).
-            if (!(fx >= slo[0] && fx <= shi[0] && fy >= slo[1] && fy <= shi[1] && fz >= slo[2] && fz <= shi[2])) {
-                if (duty && (unsigned)rx < (unsigned)B && (unsigned)ry < (unsigned)B && (unsigned)rz < (unsigned)B) append_suspect(L, sus, gis[u]);
-                if (!(fabsf(d[u].x) < MCPM_TAME && fabsf(d[u].y) < MCPM_TAME && fabsf(d[u].z) < MCPM_TAME)) continue;   // wild
+            // Slab plans: a base cell beyond the ghost planes is nobody's to deposit; its HOME tile must hand it to the exact
+            // test too (is_wild() sends it to the clamping, counting leftover kernel) -- with bulk-centred windows the sure
+            // interval alone reaches |floor(d_x)| = 8 + H, past a ghost region of 8 planes, and such a particle used to vanish
+            // uncounted.
+            const bool unsure = !(fx >= slo[0] && fx <= shi[0] && fy >= slo[1] && fy <= shi[1] && fz >= slo[2] && fz <= shi[2]);
+            const bool home = (unsigned)rx < (unsigned)B && (unsigned)ry < (unsigned)B && (unsigned)rz < (unsigned)B;
+            if (unsure && !(fabsf(d[u].x) < MCPM_TAME && fabsf(d[u].y) < MCPM_TAME && fabsf(d[u].z) < MCPM_TAME)) {   // wild
+                if (duty && home) append_suspect(L, sus, gis[u]);
+                continue;
             }
             const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
-            if (g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2)) continue;   // beyond the ghost planes: wild (clamped + counted there)
+            const bool beyond = g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
+            if ((unsure || beyond) && duty && home) append_suspect(L, sus, gis[u]);
+            if (beyond) continue;   // clamped + counted by paint_leftover_kernel
             if (deposit && cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
                 const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
                 const float kx[2] = {1.f - tx1, tx1}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
@@ -906,7 +924,7 @@ static bool tiled_geometry_ok(const mcpm_plan *p, const void *mesh) {
 }
 
 static TileLists tile_lists(const mcpm_plan *p) {
-    return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count};
+    return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, p->outliers + p->Np, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count};
 }
 
 static void tiled_prologue(mcpm_plan *p, const float *pos, int *redo = nullptr) {

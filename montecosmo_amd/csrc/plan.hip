@@ -135,7 +135,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     }
     alloc((void **)&p->fmesh, sizeof(float) * p->M * 9);
     alloc((void **)&p->spec1, sizeof(float) * 2 * p->Mh);
-    alloc((void **)&p->outliers, sizeof(int) * p->Np);
+    alloc((void **)&p->outliers, sizeof(int) * 2 * p->Np);   // suspects | wild particles
     alloc((void **)&p->outlier_count, sizeof(int) * 8);
     if (p->g.same_lattice && nx % 16 == 0 && ny % 16 == 0 && nz % 16 == 0 && nx >= 48 && ny >= 48 && nz >= 48) {
         const size_t ntiles = (size_t)(nx / 16) * (ny / 16) * (nz / 16);

@@ -325,7 +325,10 @@ class SlabPM(HaloMixin, PlaneHalo):
         self.f3il = None                                              # (nxe, ny, nz, 3) interleaved force mesh, on first use
         # kick_drift leaves max |d_x| of its output here (float bits in 64 slots, stride 32): the next step's ghost depth
         self.dmax = torch.zeros(64 * 32, dtype=torch.int32, device=self.device)
-        self._dmax_ptr = None
+        # token of the positions whose max |d_x| the slots hold: (tensor kept alive, so its address cannot be reused;
+        # torch version counter; kick-drift generation of this plan).  Anything else falls back to a reduction pass.
+        self._dmax_token = None
+        self._kd_gen = 0
         check(lib.mcpm_plan_track_dmax(h, C.c_void_p(self.dmax.data_ptr())), h, "mcpm_plan_track_dmax")
         self.s1a, self.s1b = torch.empty(ss, **c64), torch.empty(ss, **c64)
         self.s6a, self.s6b = torch.empty(6 * ss, **c64), torch.empty(6 * ss, **c64)     # lpt: 6 Hessian spectra
@@ -343,6 +346,9 @@ class SlabPM(HaloMixin, PlaneHalo):
             pass
 
     def call(self, name, *args):
+        if name.startswith("mcpm_kick_drift"):     # every such call re-zeroes and refills the plan's dmax slots
+            self._kd_gen += 1
+            self._dmax_token = None
         check(getattr(lib, name)(self.h, *args), self.h, name)
 
     def out_of_ghost(self):
@@ -678,7 +684,12 @@ class SlabPM(HaloMixin, PlaneHalo):
         if not hasattr(self, "_dhist"):
             self.reset_depth()
         self._harvest_depth()
-        if self._dmax_ptr == x.data_ptr():      # these positions came out of this plan's kick_drift: max |d_x| is already there
+        tok, self._dmax_token = self._dmax_token, None
+        if (tok is not None and tok[0].data_ptr() == x.data_ptr() and tok[0].shape == x.shape and tok[1] == x._version
+                and tok[2] == self._kd_gen):
+            # these positions came out of this plan's latest kick_drift and torch has not written to them since (an in-place
+            # update bumps the version counter; the token keeps the tensor alive, so the address cannot belong to another one;
+            # any other kick_drift on this plan drops the token): max |d_x| is already in the slots
             dmx = self.dmax.max().reshape(1).view(torch.float32)
         else:
             dmx = x[:, 0].abs().max()
@@ -713,7 +724,7 @@ class SlabPM(HaloMixin, PlaneHalo):
         yield from self.force_meshes_gen(self.rho, f3_out, rho_add=self.halo_add_x(self.rho, async_op=True), il=True)
         self.call("mcpm_kick_drift_il_f32", _p(x), _p(v), self.Nl, POS_LATTICE, _p(f3_out), paint_order, float(alpha),
                   float(beta), float(tau), _p(x_out), _p(v_out))
-        self._dmax_ptr = x_out.data_ptr()
+        self._dmax_token = (x_out, x_out._version, self._kd_gen)
 
     def step_vjp_gen(self, x, v, f3, alpha, beta, tau, xb, vb, abar_ptr, bbar_ptr, dtau_ddg=1.0, dgbar_ptr=None, paint_order=2,
                      depth=None, next_beta_tau=None):

@@ -43,15 +43,15 @@ def cpu_comm_worker(rank, world, port, out_dir):
     h.halo_fill(ext)
     idx = np.arange(rank * nxl - G, (rank + 1) * nxl + G) % nx
     assert np.array_equal(ext.numpy(), glob[:, idx]), "halo_fill"
-    # the same through the un-staged branch (what RCCL runs: one all_to_all_single with split sizes per exchange),
-    # synchronous and asynchronous
+    # the same through the un-staged branch (what RCCL runs: point-to-point batch_isend_irecv of the contiguous plane runs,
+    # dist.TorchComm.exchange), synchronous and asynchronous
     h2 = Halo()
     h2.comm, h2.G, h2.nxl = TorchComm(stage=False), G, nxl
     for async_op in (False, True):
         ext2 = torch.zeros((2, nxl + 2 * G, ny, nz))
         ext2[:, G:G + nxl] = torch.from_numpy(glob[:, rank * nxl:(rank + 1) * nxl])
         h2.halo_fill(ext2, async_op=async_op).wait()
-        assert np.array_equal(ext2.numpy(), glob[:, idx]), "halo_fill, split all-to-all"
+        assert np.array_equal(ext2.numpy(), glob[:, idx]), "halo_fill, un-staged point-to-point"
     # halo_add: every rank paints an extended slab; the sum over ranks of the unfolded slabs is the global mesh
     ext_all = rng.standard_normal((world, nxl + 2 * G, ny, nz)).astype(np.float32)
     want = np.zeros((nx, ny, nz), np.float64)

@@ -207,3 +207,28 @@ def test_too_small_ghost_is_detected(gpu):
     pm.call("mcpm_paint_f32", C.c_void_p(disp.data_ptr()), pm.Nl, POS_LATTICE, None, 1, 1.0, 2, C.c_void_p(pm.rho.data_ptr()), 0)
     assert pm.out_of_ghost() == 20
     assert abs(float(pm.rho.double().sum()) - pm.Nl) < 1e-3 * pm.Nl     # mass is clamped, not lost
+
+
+@pytest.mark.gpu
+def test_coherent_flow_beyond_the_ghost_planes_is_counted(gpu):
+    """with bulk-centred windows the tile kernels' sure interval reaches |floor(d_x)| = 8 + H, so a COHERENT x flow of
+    more than `ghost` cells used to pass the six compares, and its particles beyond the ghost planes were neither listed,
+    deposited nor counted.  They must be clamped to the edge plane (mass conserved) and counted."""
+    import ctypes as C
+    import torch
+    from montecosmo_amd import dist
+    from montecosmo_amd._lib import POS_LATTICE
+    n, G = 64, 8
+    pm = dist.SlabPM((n, n, n), ghost=G)
+    for flow in (9.3, -9.6):
+        before = pm.out_of_ghost()
+        disp = torch.zeros((pm.Nl, 3), dtype=torch.float32, device="cuda")
+        disp[:, 0] = flow                                  # every particle moves by the same 9+ cells: tile offsets follow it
+        disp[:, 1:] = 0.25
+        pm.call("mcpm_paint_f32", C.c_void_p(disp.data_ptr()), pm.Nl, POS_LATTICE, None, 1, 1.0, 2, C.c_void_p(pm.rho.data_ptr()), 0)
+        oob = pm.out_of_ghost() - before
+        # lattice planes whose base cell floor(x + flow) leaves [0, n + 2G - 2] on the ghost-extended mesh
+        import math
+        planes = sum(1 for x in range(n) if not (0 <= G + x + math.floor(flow) <= n + 2 * G - 2))
+        assert planes > 0 and oob == planes * n * n, (flow, oob, planes)
+        assert abs(float(pm.rho.double().sum()) - pm.Nl) < 1e-4 * pm.Nl           # clamped, not lost

@@ -39,6 +39,17 @@ def test_index_semantics():
     assert o.cell_index(pos, (8, 8, 8), 2).dtype == np.int16
 
 
+def test_assignment_kernel_at_zero_matches_valid_nbody_notebook():
+    """tests_old/valid_nbody.ipynb:3046-3048 (the cell at :3066-3067 prints `paint_kernels[i](0)` for i = 2, 3, 4):
+    1, 0.75, 0.6666666666666666 -- a reference-held datum for `rectangular` (nbody.py:220-246)."""
+    assert float(o.rectangular(0., 2)) == 1.0
+    assert float(o.rectangular(0., 3)) == 0.75
+    assert float(o.rectangular(0., 4)) == 0.6666666666666666
+    # the product's host-side kernel is held to the same numbers
+    from montecosmo_amd import nbody
+    assert [float(np.asarray(nbody.rectangular(np.zeros(1), i))[0]) for i in (2, 3, 4)] == [1.0, 0.75, 0.6666666666666666]
+
+
 def test_plane_wave_force():
     """Item 3: density eps cos(k.x) on the mesh -> force eps (k/k^2) sin(k.x), read at lattice points (NGP)."""
     n, eps = 16, 1e-3
