@@ -154,6 +154,20 @@ def test_slab_path_multi_rank_shared_gpu(gpu, world):
 
 
 @pytest.mark.gpu
+def test_slab_path_at_the_8_gpu_slab_shape(gpu):
+    """256^3 over 4 ranks = local slabs of 64 planes, the per-rank shape of BASELINE config 4 (512^3 over
+    8 GPUs), against the single-GPU path (tools/check_slab_large.py as a test; ranks share cuda:0 through gloo).  Forward:
+    round-off (measured 8e-8 / 1.5e-7).  Gradient: the two forward states differ by ~1e-7, a few particles sit within that
+    distance of a cell face and end in different cells on the two trajectories, and each changes its own gradient row by
+    O(1) (profiles/r02_slab_gradient_bisection_128.txt; measured 1.8e-4 here): the bound is DESIGN section 5's."""
+    from _dist_worker import gpu_slab_worker
+    out = _spawn(gpu_slab_worker, 4, 256, 2)
+    res = json.load(open(os.path.join(out, "result.json")))
+    assert res["disp"] < 2e-7 and res["vel"] < 4e-7, res
+    assert res["grad"] < 1e-3 and res["alpha"] < 2e-3 and res["beta"] < 2e-3 and res["lpt_scalars"] < 2e-3, res
+
+
+@pytest.mark.gpu
 def test_predicted_ghost_depth_is_verified(gpu):
     """The exchanged ghost depth of a step is predicted from the previous steps' displacement maxima (no host stop per
     step) and verified one step later: smooth growth stays within the prediction with a spare plane, a jump beyond it is

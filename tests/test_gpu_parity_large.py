@@ -32,7 +32,11 @@ def rel_l2(a, b):
 @pytest.fixture(scope="module")
 def nb(gpu):
     from montecosmo_amd import nbody
-    prev = o.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        nthr = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nthr = os.cpu_count() or 1
+    prev = o.set_threads(max(1, min(nthr, 64)))
     yield nbody
     o.set_threads(prev)
 
@@ -57,11 +61,11 @@ def _check_forward(nb, shape, pos, lp, vel, out):
     assert mism < 5e-5, mism
 
 
-def test_config2_128_forward_and_gradient_anatomy(nb):
-    n, K = 128, 10
+def _gradient_anatomy(nb, n, K, shape, spec, pos, ctx, cos, traj, ts, dg):
+    """fp32 VJP (GPU) against (1) the float64 reverse sweep evaluated on the GPU's own fp32 trajectory -- the error of the
+    hand-written kernels -- and (2) the pure float64 run, whose distance from (1) is the float64 VJP's sensitivity to the
+    linearisation point.  Returns (e_kernels, e_traj, e_total, flips, sb_g, sb_o)."""
     N = n ** 3
-    shape, spec, pos, lp, vel, ctx, cos, out, traj, ts, dg = _run(nb, n, K)
-    _check_forward(nb, shape, pos, lp, vel, out)
     rng = np.random.default_rng(1)
     xb, vb = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
     mb_g, sb_g = nb.nbody_bf_vjp(ctx, xb.astype(np.float32), vb.astype(np.float32))
@@ -80,7 +84,14 @@ def test_config2_128_forward_and_gradient_anatomy(nb):
         xo = traj[i][0] + traj[i][1] * (dg / 2)
         flips += float(np.any(o.cell_index(pos + xh, shape) != o.cell_index(xo, shape), axis=1).mean())
     mb_mixed, _, _ = o.lpt_vjp(cos, spec.astype(np.complex128), pos, 0., xbb, vbb, lpt_order=2, read_order=1)
-    e_kernels, e_traj, e_total = rel_l2(mb_g, mb_mixed), rel_l2(mb_mixed, mb_o), rel_l2(mb_g, mb_o)
+    return rel_l2(mb_g, mb_mixed), rel_l2(mb_mixed, mb_o), rel_l2(mb_g, mb_o), flips, sb_g, sb_o
+
+
+def test_config2_128_forward_and_gradient_anatomy(nb):
+    n, K = 128, 10
+    shape, spec, pos, lp, vel, ctx, cos, out, traj, ts, dg = _run(nb, n, K)
+    _check_forward(nb, shape, pos, lp, vel, out)
+    e_kernels, e_traj, e_total, flips, sb_g, sb_o = _gradient_anatomy(nb, n, K, shape, spec, pos, ctx, cos, traj, ts, dg)
     assert e_kernels < 1e-5, e_kernels            # the hand-written VJP itself (measured 1.1e-6)
     assert e_total < 6e-4, e_total                # documented bound (measured 1.8e-4) ...
     assert abs(e_total - e_traj) < 0.1 * e_traj   # ... all of it the float64 VJP's sensitivity to the linearisation point
@@ -90,15 +101,47 @@ def test_config2_128_forward_and_gradient_anatomy(nb):
 
 
 def test_config3_256_forward_and_vjp(nb):
+    """256^3 with the same decomposition as at 128^3: the kernels' own error stays at the 1e-6 level, and
+    the whole distance to the pure float64 gradient is the float64 VJP's sensitivity to the linearisation point."""
     n, K = 256, 10
-    N = n ** 3
     shape, spec, pos, lp, vel, ctx, cos, out, traj, ts, dg = _run(nb, n, K)
     _check_forward(nb, shape, pos, lp, vel, out)
-    del traj
-    rng = np.random.default_rng(1)
-    xb, vb = rng.standard_normal((N, 3)), rng.standard_normal((N, 3))
-    mb_g, sb_g = nb.nbody_bf_vjp(ctx, xb.astype(np.float32), vb.astype(np.float32))
-    mb_o, sb_o = o.nbody_bf_vjp(cos, spec.astype(np.complex128), pos, xb, vb, 0., 1., K)
-    assert rel_l2(mb_g.cpu().numpy(), mb_o) < 1e-3          # measured 3.1e-4 (trajectory sensitivity, see the 128^3 test)
+    e_kernels, e_traj, e_total, flips, sb_g, sb_o = _gradient_anatomy(nb, n, K, shape, spec, pos, ctx, cos, traj, ts, dg)
+    assert e_kernels < 1e-5, e_kernels            # the hand-written VJP itself
+    assert e_total < 1e-3, e_total                # measured 3.1e-4 ...
+    assert abs(e_total - e_traj) < 0.1 * e_traj   # ... trajectory sensitivity, not kernel arithmetic
+    assert 0 < flips < 2e-4, flips
     assert np.allclose(sb_g["alpha"], sb_o["alpha"], rtol=1e-3, atol=1e-3 * np.abs(sb_o["alpha"]).max())
     assert np.allclose(sb_g["beta"], sb_o["beta"], rtol=1e-3, atol=1e-3 * np.abs(sb_o["beta"]).max())
+
+
+def test_config4_512_forward_parity_and_properties(nb):
+    """The bench size itself: 512^3, 10 steps, forward state against the threaded float64 oracle at the
+    north-star tolerances, plus properties that do not need an oracle: mass conservation, paint / read adjointness, zero
+    net force (same assignment order for paint and read), bitwise repeatability of the force cycle."""
+    import torch
+    from montecosmo_amd import bricks, synth
+    n, K = 512, 10
+    N = n ** 3
+    shape = (n, n, n)
+    spec = synth.init_mesh(n, seed=0, rms_disp=2.0)
+    pos = bricks.regular_pos(shape)
+    lp, vel = nb.nbody_bf(bricks.Planck18(), spec, pos, a0=0., a1=1., n_steps=K, lattice_out=True)
+    out = o.nbody_bf(obg.Planck18(), spec.astype(np.complex128), pos, 0., 1., K)
+    _check_forward(nb, shape, pos, lp, vel, out)
+    del out, pos
+    # properties at full size
+    rho = nb.paint(lp, shape)
+    assert abs(float(rho.double().sum()) / N - 1.0) < 1e-6                                  # paint conserves mass
+    g = torch.Generator(device="cuda").manual_seed(3)
+    m = torch.randn(shape, device="cuda", generator=g)
+    w = torch.randn(N, device="cuda", generator=g)
+    lhs = float((nb.paint(lp, shape, weights=w).double() * m.double()).sum())
+    rhs = float((w.double() * nb.read(lp, m).double()).sum())
+    # both sides are sums of 8 N products of unit normals (magnitude ~ sqrt(8 N) = 3e4); fp32 terms: error ~ 1e-7 of that
+    assert abs(lhs - rhs) < 2e-5 * (8 * N) ** 0.5, (lhs, rhs)                               # paint and read are adjoint
+    F1 = nb.pm_forces(lp, shape)
+    F2 = nb.pm_forces(lp, shape)
+    assert torch.equal(F1, F2)                                                              # order-independent sums
+    net = F1.double().sum(0).abs().max().item()
+    assert net < 1e-6 * float(F1.double().abs().sum(0).max()), net                          # momentum conservation
