@@ -195,6 +195,61 @@ int mcpm_slab_zinv(mcpm_plan *plan, const float *spec, float *real, int64_t real
 /* z C2R of three spectra (spec_elems apart) into ONE interleaved real mesh [x][y][z][3] (window of local planes as above). */
 int mcpm_slab_zinv3_il(mcpm_plan *plan, const float *spec3, float *real_il);
 
+/* ---- One slab-decomposed BullFrog step and its adjoint behind the ABI ("the library
+   owns ... the RCCL communicator").  The library issues the FFT transposes (all-to-all) and the ghost-plane exchanges
+   (point-to-point with the two x neighbours) on its own communication stream, ordered against the plan's stream with
+   events: one host call per step.  No reference counterpart (montecosmo/script.py:13-20 runs independent chains); the
+   kernels, windows and their order are those of montecosmo_amd/dist.py SlabPM.step_gen / step_vjp_gen, so both paths give
+   bitwise equal results (tests/test_dist.py).
+
+   Transport, chosen once per plan:
+     mcpm_slab_comm_init_local  one rank: ghost exchanges are device copies, the transpose is the identity;
+     mcpm_slab_comm_init_rccl   RCCL communicator owned by the plan.  `id128`: the 128-byte ncclUniqueId that rank 0 obtained
+                                from mcpm_slab_rccl_unique_id and the host distributed to every rank.  librccl is opened
+                                at run time (the copy already mapped into the process, else ROCm's); MCPM_E_RCCL on failure;
+     mcpm_slab_comm_init_ops    host-provided callbacks (tests drive the multi-rank algebra through gloo with them).
+   mcpm_slab_bind_workspace: device scratch the steps work in (caller-allocated, as everywhere in this ABI):
+     rho (nxe ny nz), f3 (3 nxe ny nz), s1a, s1b (mcpm_slab_spec_elems() complex each), s6a, s6b (6 spectra each),
+     Fb (3 N_local), halo (6 ghost ny nz floats), nxe = nx/nranks + 2 ghost. */
+typedef struct mcpm_comm_ops {
+    void *ctx;
+    /* Start n_send sends and n_recv receives (device pointers, byte counts, peer ranks), ordered after the work already
+       enqueued on `stream`; between one pair of ranks the k-th send meets the k-th receive.  *ticket identifies the batch. */
+    int (*p2p_begin)(void *ctx, int n_send, const void *const *send_ptrs, const int64_t *send_bytes, const int *send_peers,
+                     int n_recv, void *const *recv_ptrs, const int64_t *recv_bytes, const int *recv_peers, void *stream,
+                     int *ticket);
+    /* Order `stream` after the batch `ticket`. */
+    int (*wait)(void *ctx, int ticket, void *stream);
+    /* Replace the device float by its maximum over ranks, in stream order. */
+    int (*allreduce_max_f32)(void *ctx, float *dev_value, void *stream);
+} mcpm_comm_ops;
+int mcpm_slab_rccl_unique_id(void *id128);
+int mcpm_slab_comm_init_local(mcpm_plan *plan);
+int mcpm_slab_comm_init_rccl(mcpm_plan *plan, const void *id128);
+int mcpm_slab_comm_init_ops(mcpm_plan *plan, const mcpm_comm_ops *ops);
+int mcpm_slab_bind_workspace(mcpm_plan *plan, float *rho, float *f3, float *s1a, float *s1b, float *s6a, float *s6b, float *Fb,
+                             float *halo);
+/* One DKD step on this rank's slab (nbody.py:933-951 as merged in DESIGN.md "Stepping form"): paint -> ghost add -> slab
+   Poisson solve -> ghost fill -> read+kick+drift.  depth: ghost planes this step's displacements can reach (1..ghost).
+   f3_out (nxe, ny, nz, 3) receives the interleaved force mesh (the adjoint's checkpoint).  Also enqueues the measurement of
+   max |d_x| over ranks of x_out (mcpm_plan_track_dmax slots; mcpm_slab_dmax_read). */
+int mcpm_slab_step_f32(mcpm_plan *plan, const float *x, const float *v, double alpha, double beta, double tau, int paint_order,
+                       int depth, float *f3_out, float *x_out, float *v_out);
+/* Adjoint of mcpm_slab_step_f32 (f3: its force mesh): xb, vb updated in place; scalar cotangents accumulated as in
+   mcpm_step_adjoint_particles_f32.  has_next: the adjoint of the step with (next_beta, next_tau) follows (its force
+   cotangent is then written by this call's particle kernel, mcpm_plan_hint_next_adjoint). */
+int mcpm_slab_step_vjp_f32(mcpm_plan *plan, const float *x, const float *v, const float *f3, double alpha, double beta,
+                           double tau, int paint_order, int depth, float *xb, float *vb, double *alpha_bar, double *beta_bar,
+                           double dtau_ddg, double *dg_bar, int has_next, double next_beta, double next_tau);
+/* Ghost-depth measurements: every mcpm_slab_step_f32 enqueues max |d_x| over ranks of its x_out into a ring of four pinned
+   floats; mcpm_slab_dmax_seq = measurements enqueued so far (the next step's measurement gets that number);
+   mcpm_slab_dmax_read waits for measurement `seq` and returns it (*valid = 0: never taken or already overwritten).  Read one
+   step late (montecosmo_amd/dist.py) the wait is free and the host never stops for the depth. */
+int64_t mcpm_slab_dmax_seq(const mcpm_plan *plan);
+int mcpm_slab_dmax_read(mcpm_plan *plan, int64_t seq, float *value, int *valid);
+/* out = a x + b y over n floats (the ghost-plane additions of the slab steps; also the drift / kick building block). */
+int mcpm_axpby_f32(mcpm_plan *plan, const float *x, const float *y, int64_t n, float a, float b, float *out);
+
 /* ---- forces (nbody.py:583-631) -------------------------------------------------------------- */
 /* pm_forces with mesh = shape tuple: paint -> R2C -> k-space -> 3 C2R -> read; forces[N][3].
    Leaves the three force meshes in the plan (mcpm_plan_force_meshes). */

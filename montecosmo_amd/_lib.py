@@ -109,6 +109,17 @@ SIGNATURES = {
     "mcpm_nbody_bf_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f64p, C.c_double, _f64p, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
     "mcpm_nbody_ckpt_floats": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
     "mcpm_nbody_bf_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f64p, C.c_double, _f64p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _f64p]),
+    "mcpm_slab_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "mcpm_slab_comm_init_local": (C.c_int, [C.c_void_p]),
+    "mcpm_slab_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mcpm_slab_comm_init_ops": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mcpm_slab_bind_workspace": (C.c_int, [C.c_void_p] + [_f32p] * 8),
+    "mcpm_slab_step_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
+    "mcpm_slab_step_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _f32p, _f32p,
+                                        C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_double, C.c_double]),
+    "mcpm_slab_dmax_seq": (C.c_int64, [C.c_void_p]),
+    "mcpm_slab_dmax_read": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mcpm_axpby_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_float, C.c_float, _f32p]),
     "mcpm_growth_table": (C.c_int, [C.c_double] * 6 + [C.c_int] + [_f64p] * 7),
     "mcpm_distance_table": (C.c_int, [C.c_double] * 6 + [C.c_int] + [_f64p] * 2),
 }

@@ -571,6 +571,13 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *v
 // mcpm_step_adjoint_particles_f32 call was hinted (mcpm_plan_hint_next_adjoint) with exactly these (beta, tau) and
 // cotangent arrays: *fb then points at plan-owned memory (Np x 3 floats, valid until the next hinted call) and the caller
 // can skip forming it.  *fb = NULL otherwise.  Used by callers that compose the adjoint step themselves (slabs).
+int mcpm_axpby_f32(mcpm_plan *p, const float *x, const float *y, int64_t n, float a, float b, float *out) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, x && y && out && n >= 0, MCPM_E_ARG, "mcpm_axpby_f32: bad argument");
+    if (n == 0) return MCPM_OK;
+    return axpby(p, x, y, n, a, b, out);
+}
+
 int mcpm_plan_chained_fb(mcpm_plan *p, double beta, double tau, const float *pos_bar, const float *vel_bar, float **fb) {
     if (!p || !fb) return MCPM_E_ARG;
     *fb = nullptr;

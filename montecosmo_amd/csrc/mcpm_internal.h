@@ -81,6 +81,7 @@ struct mcpm_plan {
     unsigned *dmax; // caller's MCPM_FX_SLOTS x MCPM_FX_STRIDE slots: kick_drift leaves max |d_x| (as float bits) there; NULL = off
     int xw0, xwn;  // window of local planes the slab z / y passes work on (mcpm_slab_set_window; default all nxl)
     int chunks;    // chunks of the all-to-all layouts (mcpm_slab_set_chunks; 1 = one all-to-all per spectrum)
+    void *slab_state;  // transport + workspace of the native slab steps (slab.hip); NULL until mcpm_slab_comm_init_*
 
     // rocFFT plans keyed by batch
     std::map<int, rocfft_plan> r2c, c2r;
@@ -142,6 +143,7 @@ struct StageTimer {
 extern thread_local std::string g_mcpm_create_error;
 
 int mcpm_fail(mcpm_plan *plan, int code, const std::string &msg);
+void mcpm_slab_state_free(mcpm_plan *p);   // slab.hip
 
 // hand-written FFT Poisson solve (fftpm.hip); power-of-two axes only
 bool mcpm_fftpm_supported(const mcpm_plan *p);

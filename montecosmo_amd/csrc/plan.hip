@@ -93,6 +93,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->xw0 = 0;
     p->xwn = p->nxl;
     p->chunks = 1;
+    p->slab_state = nullptr;
     p->stream = (hipStream_t)stream;
     p->M = (int64_t)nx * ny * nz;
     p->Mh = (int64_t)nx * ny * p->g.nzh;
@@ -181,6 +182,7 @@ int mcpm_plan_destroy(mcpm_plan *p) {
     (void)hipFree(p->fmesh);
     (void)hipFree(p->spec1);
     (void)hipFree(p->fft_pad);
+    mcpm_slab_state_free(p);
     (void)hipFree(p->outliers);
     (void)hipFree(p->outlier_count);
     (void)hipFree(p->tile_off);

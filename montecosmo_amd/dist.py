@@ -209,6 +209,91 @@ class TorchComm:
         return torch.cat(outs, dim=0).to(t.device)
 
 
+class _CommOps(C.Structure):
+    """include/mcpm.h `mcpm_comm_ops`."""
+    P2P = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int,
+                      C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int))
+    WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+    AMAX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+    _fields_ = [("ctx", C.c_void_p), ("p2p_begin", P2P), ("wait", WAIT), ("allreduce_max_f32", AMAX)]
+
+
+class HostStagedOps:
+    """Transport callbacks for the native slab steps (`mcpm_slab_comm_init_ops`) over a STAGED torch.distributed communicator
+    (gloo): every batch is completed synchronously through host memory.  Test infrastructure: it lets several ranks sharing one
+    GPU (or CPU-only gloo runs of the algebra) drive the multi-rank code of csrc/slab.hip; production uses the plan-owned RCCL
+    communicator."""
+
+    def __init__(self, comm):
+        import torch.distributed as td
+        self.td, self.comm = td, comm
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipMemcpy.restype = C.c_int
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.error = None
+        self.struct = _CommOps(None, _CommOps.P2P(self._p2p), _CommOps.WAIT(self._wait), _CommOps.AMAX(self._amax))
+
+    def _guard(self, fn, *a):
+        try:
+            return fn(*a)
+        except Exception as e:      # an exception must not cross the C frame: reported as a failed callback
+            self.error = e
+            return 1
+
+    def _copy(self, dst, src, n, kind):
+        if self.hip.hipMemcpy(dst, src, n, kind) != 0:
+            raise RuntimeError("hipMemcpy failed in the staged transport")
+
+    def _p2p(self, ctx, ns, sp, sb, speer, nr, rp, rb, rpeer, stream, ticket):
+        return self._guard(self._p2p_impl, ns, sp, sb, speer, nr, rp, rb, rpeer, stream, ticket)
+
+    def _p2p_impl(self, ns, sp, sb, speer, nr, rp, rb, rpeer, stream, ticket):
+        td, me, grp = self.td, self.comm.rank, self.comm.group
+        self.hip.hipStreamSynchronize(stream)
+        ops, recvs, self_s, self_r = [], [], [], []
+        for i in range(ns):
+            if speer[i] == me:
+                self_s.append((sp[i], sb[i]))
+                continue
+            t = torch.empty(sb[i], dtype=torch.uint8)
+            self._copy(t.data_ptr(), sp[i], sb[i], 2)                 # device -> host
+            ops.append(td.P2POp(td.isend, t, speer[i], grp))
+        for i in range(nr):
+            if rpeer[i] == me:
+                self_r.append((rp[i], rb[i]))
+                continue
+            t = torch.empty(rb[i], dtype=torch.uint8)
+            recvs.append((rp[i], t))
+            ops.append(td.P2POp(td.irecv, t, rpeer[i], grp))
+        assert len(self_s) == len(self_r)
+        for (s_, n_), (r_, m_) in zip(self_s, self_r):                # own block of an all-to-all: k-th send meets k-th receive
+            assert n_ == m_
+            if s_ != r_:
+                self._copy(r_, s_, n_, 3)                             # device -> device
+        if ops:
+            for w in td.batch_isend_irecv(ops):
+                w.wait()
+        for dst, t in recvs:
+            self._copy(dst, t.data_ptr(), t.numel(), 1)               # host -> device
+        ticket[0] = 0
+        return 0
+
+    def _wait(self, ctx, ticket, stream):
+        return 0
+
+    def _amax(self, ctx, dev, stream):
+        return self._guard(self._amax_impl, dev, stream)
+
+    def _amax_impl(self, dev, stream):
+        self.hip.hipStreamSynchronize(stream)
+        t = torch.empty(1, dtype=torch.float32)
+        self._copy(t.data_ptr(), dev, 4, 2)
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX, group=self.comm.group)
+        self._copy(dev, t.data_ptr(), 4, 1)
+        return 0
+
+
 class HaloMixin:
     """Ghost-plane algebra of an x-slab (needs self.comm, self.G, self.nxl); meshes are (..., nxl + 2G, ny, nz)."""
 
@@ -286,7 +371,7 @@ class PlaneHalo:
 class SlabPM(HaloMixin, PlaneHalo):
     """Slab-decomposed PM stepper for one rank."""
 
-    def __init__(self, mesh_shape, comm=None, ghost=16, device=None, adaptive_ghost=True, chunks=None):
+    def __init__(self, mesh_shape, comm=None, ghost=16, device=None, adaptive_ghost=True, chunks=None, native=None):
         """chunks: every FFT transpose is split into this many all-to-alls of 1 / chunks of a spectrum each (chunks of
         nx_local / chunks planes, `mcpm_slab_set_chunks`), issued as soon as the chunk's z / y passes are done and consumed
         chunk by chunk on the other side, so that the transfers run under the passes of the other chunks.  Default
@@ -336,6 +421,38 @@ class SlabPM(HaloMixin, PlaneHalo):
         self.h6 = None                                                                # (6, nxe, ny, nz), allocated by lpt
         self.Fb = torch.empty((self.Nl, 3), **f32)
         self.sbar = None
+        # `native` (default: MCPM_SLAB_NATIVE, else on): step / step_vjp are ONE library call each (csrc/slab.hip issues the
+        # kernels AND the exchanges, on a plan-owned RCCL communicator when the torch communicator is RCCL); off: the
+        # exchanges are issued from here through torch.distributed, kernel by kernel (the reference both are tested against).
+        if native is None:
+            import os
+            native = os.environ.get("MCPM_SLAB_NATIVE", "1") != "0"
+        self.native = bool(native)
+        self._mq = []                      # sequence numbers of the library's pending ghost-depth measurements
+        if self.native:
+            self._init_native_transport()
+
+    def _init_native_transport(self):
+        h, comm = self.h, self.comm
+        self._halo = torch.empty(6 * self.G * self.plane, dtype=torch.float32, device=self.device)
+        self._host_ops = None
+        if isinstance(comm, LocalComm):
+            check(lib.mcpm_slab_comm_init_local(h), h, "mcpm_slab_comm_init_local")
+        elif getattr(comm, "stage", False):                    # gloo: the host carries the bytes (tests)
+            self._host_ops = HostStagedOps(comm)
+            check(lib.mcpm_slab_comm_init_ops(h, C.byref(self._host_ops.struct)), h, "mcpm_slab_comm_init_ops")
+        else:                                                   # RCCL: the plan gets its own communicator
+            td = comm.td
+            idt = torch.zeros(128, dtype=torch.uint8)
+            if comm.rank == 0:
+                check(lib.mcpm_slab_rccl_unique_id(C.c_void_p(idt.data_ptr())), None, "mcpm_slab_rccl_unique_id")
+            dev_id = idt.to(self.device)                        # the group's backend moves device tensors
+            src = td.get_global_rank(comm.group, 0) if comm.group is not None else 0
+            td.broadcast(dev_id, src=src, group=comm.group)
+            idt = dev_id.cpu()
+            check(lib.mcpm_slab_comm_init_rccl(h, C.c_void_p(idt.data_ptr())), h, "mcpm_slab_comm_init_rccl")
+        check(lib.mcpm_slab_bind_workspace(h, _p(self.rho), _p(self.f3), _p(self.s1a), _p(self.s1b), _p(self.s6a), _p(self.s6b),
+                                           _p(self.Fb), _p(self._halo)), h, "mcpm_slab_bind_workspace")
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -350,6 +467,13 @@ class SlabPM(HaloMixin, PlaneHalo):
             self._kd_gen += 1
             self._dmax_token = None
         check(getattr(lib, name)(self.h, *args), self.h, name)
+
+    def _native_call(self, name, *args):
+        rc = getattr(lib, name)(self.h, *args)
+        if rc != 0 and self._host_ops is not None and self._host_ops.error is not None:
+            err, self._host_ops.error = self._host_ops.error, None
+            raise err
+        check(rc, self.h, name)
 
     def out_of_ghost(self):
         """Cumulative count of deposits that fell beyond this rank's ghost planes (must stay 0)."""
@@ -648,6 +772,7 @@ class SlabPM(HaloMixin, PlaneHalo):
     def reset_depth(self):
         """Forget the displacement history (call before the first step of a new trajectory: its depth is then the full G)."""
         self._dhist, self._dpending, self._dused = [], None, []
+        self._mq = []
 
     def _harvest_depth(self):
         """Collects the measurement enqueued by the previous `set_depth` (its device work was enqueued a whole step ago, so
@@ -656,9 +781,16 @@ class SlabPM(HaloMixin, PlaneHalo):
             return
         host, ev, order = self._dpending
         self._dpending = None
-        if ev is not None:
-            ev.synchronize()
-        dmax = float(host[0])
+        if host == "native":            # taken by the library at the end of the step before last (ev = its sequence number)
+            val, ok = C.c_float(), C.c_int()
+            self.call("mcpm_slab_dmax_read", int(ev), C.byref(val), C.byref(ok))
+            if not ok.value:
+                raise RuntimeError("ghost-depth measurement lost (more than four native steps without set_depth)")
+            dmax = float(val.value)
+        else:
+            if ev is not None:
+                ev.synchronize()
+            dmax = float(host[0])
         self._dhist.append(dmax)
         need = min(self.G, int(math.floor(dmax)) + 1 + (1 if order > 2 else 0))
         if self._dused and self._dused[-1] < need:
@@ -685,6 +817,14 @@ class SlabPM(HaloMixin, PlaneHalo):
             self.reset_depth()
         self._harvest_depth()
         tok, self._dmax_token = self._dmax_token, None
+        if (self.native and tok is not None and isinstance(tok[0], str) and tok[1] == x.data_ptr() and tok[2] == self._kd_gen
+                and self._mq):
+            # x came out of the latest native step, which enqueued max |d_x| over ranks itself (no collective from here)
+            self._dpending = ("native", self._mq.pop(0), paint_order)
+            self._predict_depth(paint_order)
+            return
+        if tok is not None and not isinstance(tok[0], torch.Tensor):
+            tok = None
         if (tok is not None and tok[0].data_ptr() == x.data_ptr() and tok[0].shape == x.shape and tok[1] == x._version
                 and tok[2] == self._kd_gen):
             # these positions came out of this plan's latest kick_drift and torch has not written to them since (an in-place
@@ -695,6 +835,9 @@ class SlabPM(HaloMixin, PlaneHalo):
             dmx = x[:, 0].abs().max()
         host, ev = self.comm.all_reduce_max_async(dmx)
         self._dpending = (host, ev, paint_order)
+        self._predict_depth(paint_order)
+
+    def _predict_depth(self, paint_order):
         h = self._dhist
         if not h:
             self.ge = self.G
@@ -720,6 +863,15 @@ class SlabPM(HaloMixin, PlaneHalo):
         """GENERATOR (see force_meshes_gen; `step` runs it to the end).  x, v: (Nl,3) local state; f3_out: (nxe, ny, nz, 3) receives the ghost-filled INTERLEAVED force mesh (ghost planes
         beyond the exchanged depth `self.ge` are left as they were: no particle of this step reads them)."""
         self.set_depth(x, paint_order)
+        if self.native:
+            seq = int(lib.mcpm_slab_dmax_seq(self.h))
+            self._kd_gen += 1
+            self._dmax_token = None
+            self._native_call("mcpm_slab_step_f32", _p(x), _p(v), float(alpha), float(beta), float(tau), int(paint_order), int(self.ge),
+                              _p(f3_out), _p(x_out), _p(v_out))
+            self._mq = (self._mq + [seq])[-2:]          # this step's measurement (of x_out); at most one older one is still unread
+            self._dmax_token = ("native", x_out.data_ptr(), self._kd_gen)
+            return
         self.call("mcpm_paint_f32", _p(x), self.Nl, POS_LATTICE, None, 1, 1.0, paint_order, _p(self.rho), 0)
         yield from self.force_meshes_gen(self.rho, f3_out, rho_add=self.halo_add_x(self.rho, async_op=True), il=True)
         self.call("mcpm_kick_drift_il_f32", _p(x), _p(v), self.Nl, POS_LATTICE, _p(f3_out), paint_order, float(alpha),
@@ -733,6 +885,12 @@ class SlabPM(HaloMixin, PlaneHalo):
         whose adjoint comes next (the previous step of the sweep): its force cotangent is then written by this call's
         particle kernel and picked up by the next call instead of a separate pass."""
         self.set_depth(x, paint_order, depth)
+        if self.native:
+            nb, nt = next_beta_tau if next_beta_tau is not None else (0.0, 0.0)
+            self._native_call("mcpm_slab_step_vjp_f32", _p(x), _p(v), _p(f3), float(alpha), float(beta), float(tau), int(paint_order),
+                              int(self.ge), _p(xb), _p(vb), abar_ptr, bbar_ptr, float(dtau_ddg), dgbar_ptr,
+                              1 if next_beta_tau is not None else 0, float(nb), float(nt))
+            return
         fb = C.c_void_p()
         self.call("mcpm_plan_chained_fb", float(beta), float(tau), _p(xb), _p(vb), C.byref(fb))
         if not fb.value:
@@ -753,13 +911,13 @@ class SlabCtx:
 
 
 def nbody_bf_slab(cosmo, init_mesh, a0=0., a1=1., n_steps=5, paint_order=2, lpt_order=2, comm=None, ghost=16,
-                  integrator="bullfrog", return_ctx=False, slab=None):
+                  integrator="bullfrog", return_ctx=False, slab=None, native=None, chunks=None):
     """Slab-decomposed `nbody_bf` (nbody.py:967-1002).  `init_mesh` is the full half-spectrum, replicated on every
     rank.  Returns this rank's (disp, vel), each (N/P, 3): displacement from the lattice and velocity of the
     particles whose lattice plane lies in the rank's slab (rows [r N/P, (r+1) N/P) of the global arrays)."""
     spec = nbody._c64(init_mesh)
     shape = nbody.ch2rshape(spec.shape)
-    pm = slab if slab is not None else SlabPM(shape, comm, ghost)
+    pm = slab if slab is not None else SlabPM(shape, comm, ghost, native=native, chunks=chunks)
     n_steps = int(n_steps)
     dg, alphas, betas, lpt_s = nbody._step_scalars(cosmo, a0, a1, n_steps, integrator)
     K = n_steps

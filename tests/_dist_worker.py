@@ -206,3 +206,45 @@ def gpu_interleaved_worker(rank, world, port, out_dir, n, n_steps, backend="gloo
         ok_all = ok and differ
     if rank == 0:
         json.dump({"ok": ok_all}, open(os.path.join(out_dir, "result.json"), "w"))
+
+
+def gpu_native_equal_worker(rank, world, port, out_dir, n, n_steps, backend="gloo", chunks=None):
+    """csrc/slab.hip (one library call per step, the library issues the exchanges) against the Python-issued path of
+    dist.SlabPM: same kernels, same windows, same order -> every output must be BITWISE equal.  world > 1: gloo ranks sharing
+    cuda:0, the library's exchanges go through the host-callback transport (dist.HostStagedOps); backend "nccl" with one rank:
+    the plan-owned RCCL communicator against torch's."""
+    import json
+    import torch
+    torch.cuda.set_device(0)
+    td = _init(rank, world, port, backend) if (world > 1 or backend == "nccl") else None
+    from montecosmo_amd import bricks, dist, synth
+    shape = (n, n, n)
+    spec = synth.init_mesh(n, seed=3, rms_disp=2.0)
+    rng = np.random.default_rng(5)
+    Nl = n ** 3 // world
+    xb = rng.standard_normal((n ** 3, 3)).astype(np.float32)[rank * Nl:(rank + 1) * Nl]
+    vb = rng.standard_normal((n ** 3, 3)).astype(np.float32)[rank * Nl:(rank + 1) * Nl]
+    outs = []
+    for native in (False, True):
+        comm = dist.TorchComm() if td is not None else dist.LocalComm()
+        (d, v), ctx = dist.nbody_bf_slab(bricks.Planck18(), spec, a0=0.1, a1=1.0, n_steps=n_steps, comm=comm, ghost=8,
+                                         return_ctx=True, native=native, chunks=chunks)
+        assert ctx.pm.native == native
+        mb, sb = dist.nbody_bf_slab_vjp(ctx, xb, vb)
+        outs.append((d.clone(), v.clone(), mb.clone(), sb, list(ctx.depths), ctx.pm.out_of_ghost()))
+        del ctx
+    a, b = outs
+    ok = torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    ok = ok and all(np.array_equal(np.asarray(a[3][k]), np.asarray(b[3][k])) for k in a[3])
+    ok = ok and a[4] == b[4] and a[5] == b[5] == 0
+    ok = ok and bool(torch.isfinite(a[2].real).all()) and float(a[0].abs().max()) > 0.5
+    if td is not None:
+        t = torch.tensor([float(ok)])
+        if backend == "nccl":
+            t = t.cuda()
+        td.all_reduce(t, op=td.ReduceOp.MIN)
+        ok = bool(t.item() > 0)
+        td.barrier()
+        td.destroy_process_group()
+    if rank == 0:
+        json.dump({"ok": ok, "depths": a[4], "depths_native": b[4]}, open(os.path.join(out_dir, "result.json"), "w"))

@@ -246,3 +246,16 @@ def test_coherent_flow_beyond_the_ghost_planes_is_counted(gpu):
         planes = sum(1 for x in range(n) if not (0 <= G + x + math.floor(flow) <= n + 2 * G - 2))
         assert planes > 0 and oob == planes * n * n, (flow, oob, planes)
         assert abs(float(pm.rho.double().sum()) - pm.Nl) < 1e-4 * pm.Nl           # clamped, not lost
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,backend,chunks", [(1, "gloo", 1), (1, "gloo", 2), (1, "gloo", 4), (2, "gloo", None), (4, "gloo", 2),
+                                                  (1, "nccl", 2)])
+def test_native_slab_steps_equal_the_python_issued_path(gpu, world, backend, chunks):
+    """the slab step behind the C ABI (`mcpm_slab_step_f32` / `_vjp_f32`, exchanges issued by the library)
+    is bitwise the Python-issued path: one rank with the local transport (1 / 2 / 4 chunks), 2 and 4 gloo ranks through the
+    host-callback transport, one RCCL rank on the plan-owned communicator."""
+    from _dist_worker import gpu_native_equal_worker
+    out = _spawn(gpu_native_equal_worker, world, 64, 3, backend, chunks)
+    res = json.load(open(os.path.join(out, "result.json")))
+    assert res["ok"], res
