@@ -33,6 +33,7 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllToAll) AllToAll = nullptr;     // RCCL extension (optional): the equal-split transposes
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string why;
 };
@@ -62,6 +63,7 @@ RcclApi *rccl_api() {
         SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(Send) SYM(Recv) SYM(GroupStart) SYM(GroupEnd) SYM(AllReduce)
         SYM(GetErrorString)
 #undef SYM
+        a.AllToAll = (decltype(a.AllToAll))dlsym(a.lib, "ncclAllToAll");
         return a;
     }();
     return &api;
@@ -116,6 +118,11 @@ struct Batch {
     std::vector<void *> rp;
     std::vector<int64_t> sb, rb;
     std::vector<int> speer, rpeer;
+    // an equal-split all-to-all (block q of `a2a_in` to rank q, block q of `a2a_out` from rank q): transports with a native
+    // all-to-all take it whole instead of the sends / receives above, which describe the same transfer
+    const void *a2a_in = nullptr;
+    void *a2a_out = nullptr;
+    int64_t a2a_bytes = 0;
     void send(const void *ptr, int64_t bytes, int peer) { sp.push_back(ptr); sb.push_back(bytes); speer.push_back(peer); }
     void recv(void *ptr, int64_t bytes, int peer) { rp.push_back(ptr); rb.push_back(bytes); rpeer.push_back(peer); }
 };
@@ -146,10 +153,14 @@ int xfer_begin(mcpm_plan *p, const Batch &b, int *ticket) {
     s->next_ticket = (t + 1) % NTICKETS;
     MCPM_HIP(p, hipEventRecord(s->ready[t], p->stream));
     MCPM_HIP(p, hipStreamWaitEvent(s->cs, s->ready[t], 0));
-    RCCL_TRY(p, a->GroupStart());
-    for (size_t i = 0; i < b.sp.size(); ++i) RCCL_TRY(p, a->Send(b.sp[i], (size_t)b.sb[i], ncclInt8, b.speer[i], s->comm, s->cs));
-    for (size_t i = 0; i < b.rp.size(); ++i) RCCL_TRY(p, a->Recv(b.rp[i], (size_t)b.rb[i], ncclInt8, b.rpeer[i], s->comm, s->cs));
-    RCCL_TRY(p, a->GroupEnd());
+    if (b.a2a_in && a->AllToAll) {
+        RCCL_TRY(p, a->AllToAll(b.a2a_in, b.a2a_out, (size_t)b.a2a_bytes, ncclInt8, s->comm, s->cs));
+    } else {
+        RCCL_TRY(p, a->GroupStart());
+        for (size_t i = 0; i < b.sp.size(); ++i) RCCL_TRY(p, a->Send(b.sp[i], (size_t)b.sb[i], ncclInt8, b.speer[i], s->comm, s->cs));
+        for (size_t i = 0; i < b.rp.size(); ++i) RCCL_TRY(p, a->Recv(b.rp[i], (size_t)b.rb[i], ncclInt8, b.rpeer[i], s->comm, s->cs));
+        RCCL_TRY(p, a->GroupEnd());
+    }
     MCPM_HIP(p, hipEventRecord(s->done[t], s->cs));
     *ticket = t;
     return MCPM_OK;
@@ -231,6 +242,9 @@ int a2a_chunk(const Ctx &c, float *out, const float *in, int w, int *ticket, boo
     Batch b;
     for (int q = 0; q < c.P; ++q) b.send(in + 2 * (w * n + q * blk), 8 * blk, q);
     for (int q = 0; q < c.P; ++q) b.recv(out + 2 * (w * n + q * blk), 8 * blk, q);
+    b.a2a_in = in + 2 * w * n;
+    b.a2a_out = out + 2 * w * n;
+    b.a2a_bytes = 8 * blk;
     return xfer_begin(c.p, b, ticket);
 }
 
@@ -523,7 +537,14 @@ int mcpm_slab_comm_init_rccl(mcpm_plan *p, const void *id128) {
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
     RCCL_TRY(p, a->CommInitRank(&s->comm, p->nranks, id, p->rank));
-    MCPM_HIP(p, hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking));
+    // A high-priority stream: HIP multiplexes streams onto a few hardware queues, and streams that share a queue run in
+    // submission order -- on the compute stream's queue the transfers would never overlap a kernel.
+    // Priority streams get queues of their own, and the copy kernels of an exchange are short.  MCPM_SLAB_COMM_PRIORITY=0: default.
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const char *pe = getenv("MCPM_SLAB_COMM_PRIORITY");
+    if (pe && atoi(pe) == 0) MCPM_HIP(p, hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking));
+    else MCPM_HIP(p, hipStreamCreateWithPriority(&s->cs, hipStreamNonBlocking, hi));
     MCPM_TRY(ensure_events(p, s));
     s->mode = MODE_RCCL;
     return MCPM_OK;

@@ -20,7 +20,40 @@ fm = C.POINTER(C.c_float)()
 addr = {"states": r.states.data_ptr(), "fmesh": r.fmesh.data_ptr(), "xb": r.xb.data_ptr(), "vb": r.vb.data_ptr(),
         "pos_bar": r.pos_bar.data_ptr(), "spec": r.spec.data_ptr()}
 free, total = torch.cuda.mem_get_info()
+import subprocess, threading
+
+
+def read_smi():
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=20).stdout
+        card = json.loads(out)
+        card = card[sorted(card)[0]]
+        return {k.replace(" clock speed:", "").replace("Temperature (Sensor ", "T(").replace("Current Socket Graphics Package Power (W)", "W"): v
+                for k, v in card.items() if any(t in k.lower() for t in ("sclk clock speed", "mclk clock speed", "fclk clock speed", "socclk clock speed", "power", "sensor junction", "sensor memory"))}
+    except Exception as e:
+        return {"error": repr(e)[:100]}
+
+
+# clocks WHILE the workload runs: a sampler thread beside ~3 s of steps
+samples, stop = [], threading.Event()
+
+
+def sampler():
+    while not stop.is_set():
+        samples.append(read_smi())
+
+
+th = threading.Thread(target=sampler)
+th.start()
+import time
+t_end = time.time() + 3.0
+while time.time() < t_end:
+    r.run(10)
+    torch.cuda.synchronize()
+stop.set()
+th.join()
+smi = {"during": samples[:4], "after": read_smi()}
 print(json.dumps({"pad": pad, "ms": {k: round(v, 4) for k, v in ms.items()},
                   "addr": {k: hex(v) for k, v in addr.items()},
                   "addr_mod_1G": {k: hex(v % (1 << 30)) for k, v in addr.items()},
-                  "free_GiB": round(free / 2 ** 30, 2)}), flush=True)
+                  "free_GiB": round(free / 2 ** 30, 2), "smi_after": smi}), flush=True)
