@@ -116,6 +116,10 @@ def detrunc_truncnorm_log_prob_and_grad(x, c):
     y, d1, d2 = std2trunc_and_derivs(x, c["loc_fid"], c["scale_fid"], c["low"], c["high"])
     z = (y - c["loc"]) / c["scale"]
     logZ = math.log(ndtr((c["high"] - c["loc"]) / c["scale"]) - ndtr((c["low"] - c["loc"]) / c["scale"]))
+    if not (math.isfinite(d1) and abs(d1) > 0.0 and math.isfinite(y)):
+        # far in a tail the map has saturated in double precision (d std2trunc / dx underflows): the density there is zero for
+        # every purpose -- jax would return -inf / nan and the sampler would reject; a math domain error would end the chain
+        return -math.inf, 0.0, y, 0.0
     lp = -0.5 * LOG2PI - math.log(c["scale"]) - 0.5 * z * z - logZ + math.log(abs(d1))
     return lp, -z / c["scale"] * d1 + d2 / d1, y, d1
 
@@ -124,6 +128,8 @@ def detrunc_unif_log_prob_and_grad(x, c):
     """DetruncUnif.log_prob (utils.py:314-353): Uniform(low, high).log_prob(std2trunc(x; fid)) + log |d std2trunc / dx|, its
     d/dx, the base value and d base / dx."""
     y, d1, d2 = std2trunc_and_derivs(x, c["loc_fid"], c["scale_fid"], c["low"], c["high"])
+    if not (math.isfinite(d1) and abs(d1) > 0.0 and math.isfinite(y)):
+        return -math.inf, 0.0, y, 0.0          # saturated tail (see detrunc_truncnorm_log_prob_and_grad)
     return -math.log(c["high"] - c["low"]) + math.log(abs(d1)), d2 / d1, y, d1
 
 
@@ -358,6 +364,8 @@ class FieldLevelLogDensity:
                     l, gl, d1 = -0.5 * LOG2PI - math.log(sd) - 0.5 * ((x - mu) / sd) ** 2, -(x - mu) / sd ** 2, c["scale_fid"]
                 lp += l
                 ngb_prior_grad[i], ngb_dbase[i] = gl, d1
+        if lp == -math.inf:      # a latent sits in a saturated tail: zero density whatever the field (no forward model needed)
+            return -math.inf, {}
         w = nbody._f32(sample["white_mesh_"], fwd.init_shape)
         if self.scale is None:
             lp += float(-0.5 * LOG2PI * w.numel() - 0.5 * (w.double() ** 2).sum())

@@ -95,3 +95,57 @@ def test_mclmc_chain_over_the_hip_log_density(gpu):
     r2 = run()
     assert np.array_equal(r2["samples"][-1].cpu().numpy(), r1["samples"][-1].cpu().numpy())      # bit for bit
     assert r2["step_size"] == r1["step_size"]
+
+
+def _mock_posterior(nf=16, seed=0):
+    """A 16^3 field-level inference problem whose truth is known: the truth is a prior draw (sigma8_ = b1_ = 0 in sample
+    space), the observation the model's own mean at the truth plus its Gaussian noise (model.py:893-908)."""
+    import torch
+    from montecosmo_amd import model, logdensity, samplers, bricks, utils, nbody
+    ks = np.logspace(-3, 1, 128)
+    kpow = (ks, 3.0e4 * (ks / 0.02) / (1 + (ks / 0.02) ** 2.6))
+    fwd = model.FieldLevelForward(final_shape=(nf,) * 3, cell_length=40., box_center=(0., 0., 2500.), evolution="lpt",
+                                  lpt_order=2, a_obs=0.65, lin_kpow=kpow)
+    lat = {"sigma8": dict(loc=0.8102, scale=0.1, loc_fid=0.8102, scale_fid=1e-2, low=0., high=np.inf),
+           "b1": dict(loc=1., scale=1e2, loc_fid=1., scale_fid=1e-2)}
+    fixed = dict(Omega_m=0.3111, b2=0., bs2=0., bn2=0., b3=0., bds2=0., bs3=0., bnpar=0., ngbars=1e-3, s_e=1.0, s_ed=0., s_e2=0.)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    truth = {k + "_": 0.0 for k in lat}
+    ld0 = logdensity.FieldLevelLogDensity(fwd, torch.zeros(fwd.final_shape), lat, fixed, precond="kaiser")
+    prior_std = 1.0 if ld0.scale is None else ld0.scale
+    truth["white_mesh_"] = torch.randn(fwd.init_shape, device="cuda", generator=g) * prior_std
+    base = ld0.base_params(truth)
+    white = utils.rg2cgh(truth["white_mesh_"]) * ld0.transfer
+    gxy = fwd.evolve(ld0.make_cosmo(base), {k: base[k] for k in bricks.BIAS_KEYS}, white)
+    rc = fixed["ngbars"] * fwd.cell_length ** 3
+    cm = rc * nbody.irfftn(utils.chreshape(nbody.rfftn(gxy), utils.r2chshape(fwd.final_shape)))
+    obs = cm + rc ** .5 * torch.randn(fwd.final_shape, device="cuda", generator=g)
+    ld = logdensity.FieldLevelLogDensity(fwd, obs, lat, fixed, precond="kaiser")
+    flat = samplers.FlatLogDensity(ld)
+    start = dict(truth)
+    start["white_mesh_"] = 0.1 * torch.randn(fwd.init_shape, device="cuda", generator=g) * prior_std
+    return samplers, ld, flat, flat.pack(start), truth
+
+
+def test_posterior_of_sigma8_covers_the_truth(gpu):
+    """adapted chains over the HIP log density of a 16^3 mock land on a posterior that covers the truth:
+    the posterior mean of sigma8_ (and b1_) is within 3 posterior standard deviations of the true value.  MCLMC with the step
+    size and L tuned as the reference does (samplers.py:322-331), NUTS with the windowed diagonal mass matrix (samplers.py:44)."""
+    samplers, ld, flat, q0, truth = _mock_posterior()
+    ns = len(flat.scalars)
+    assert flat.scalars == ["sigma8_", "b1_"]
+    lp_truth = ld(truth)
+    r = samplers.mclmc_sample(flat, q0, n_warmup=600, n_samples=600, seed=1, keep=lambda q: q[:ns].tolist())
+    d = np.array(r["samples"])
+    mean, std = d.mean(0), d.std(0)
+    assert np.all(np.abs(mean) < 3 * std), (mean, std)              # truth = 0 in sample space
+    assert 0.5 < std[0] < 30 and std[1] > 0.5, std                   # a posterior, not a stuck chain; sigma8 to a few 1e-2
+    assert r["L"] != math.sqrt(q0.numel()) and 0.2 * math.sqrt(q0.numel()) < r["L"] < 20 * math.sqrt(q0.numel())     # L was tuned
+    assert abs(r["infos"][-1]["logdensity"] - lp_truth) < 0.02 * abs(lp_truth)   # the chain sits at the truth's level
+    # NUTS with window adaptation (short: each transition is up to 63 gradients)
+    n = samplers.nuts_sample(flat, q0, n_warmup=80, n_samples=80, max_tree_depth=6, seed=1, keep=lambda q: q[:ns].tolist())
+    dn = np.array(n["samples"])
+    assert np.all(np.abs(dn.mean(0)) < 3 * dn.std(0) + 3 * std), (dn.mean(0), dn.std(0))
+    minv = n["inverse_mass"]
+    assert minv is not None and float(minv[0]) > 1.5 and float(minv[1]) > 1.5     # the scalar latents are wider than unit scale
+    assert np.mean([i["accept_stat"] for i in n["infos"][80:]]) > 0.5

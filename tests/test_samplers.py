@@ -119,3 +119,55 @@ def test_flat_log_density_packs_per_shell_latents():
     lp, g = flat(q)
     assert np.isclose(lp, -0.5 * float((q ** 2).sum())) and torch.allclose(g, -q)
     assert flat.unpack(q)["ngbars_"] == [2.0, 3.0, 4.0]
+
+
+def test_warmup_windows_follow_stans_schedule():
+    """`blackjax.window_adaptation` (reference samplers.py:44) builds Stan's schedule: 75 fast, slow windows 25, 50, 100, ...
+    (the last one stretched to the terminal buffer), 50 fast."""
+    assert samplers.warmup_windows(1000) == [(75, 100), (100, 150), (150, 250), (250, 450), (450, 950)]
+    assert samplers.warmup_windows(200) == [(75, 100), (100, 150)]
+    assert samplers.warmup_windows(100) == [(15, 90)]              # short warm-up: 15 % / 75 % / 10 %
+    assert samplers.warmup_windows(10) == []
+
+
+def test_nuts_window_adaptation_learns_the_scales():
+    """A Gaussian whose standard deviations span 1e-2 .. 1e1: the adapted diagonal metric recovers the variances, the draws have
+    the right moments, and trajectories are an order of magnitude shorter than with the identity metric."""
+    d = 30
+    sd = torch.logspace(-2, 1, d, dtype=torch.float64)
+
+    def fn(q):
+        z = q / sd
+        return float(-0.5 * (z * z).sum()), -(z / sd)
+
+    q0 = 0.5 * sd
+    out = samplers.nuts_sample(fn, q0, n_warmup=400, n_samples=600, seed=2)
+    ratio = (out["inverse_mass"] / sd ** 2).numpy()
+    assert np.all(ratio > 0.4) and np.all(ratio < 2.5), ratio
+    x = torch.stack(out["samples"]).numpy()
+    assert np.all(np.abs(x.std(0) / sd.numpy() - 1) < 0.2)
+    assert np.all(np.abs(x.mean(0)) < 0.3 * sd.numpy())
+    plain = samplers.nuts_sample(fn, q0, n_warmup=400, n_samples=100, seed=2, adapt_mass=False)
+    leap = lambda o, a: np.mean([i["n_leapfrog"] for i in o["infos"][a:]])
+    assert leap(out, 400) < 16 and leap(plain, 400) > 8 * leap(out, 400), (leap(out, 400), leap(plain, 400))
+    # a resumed chain keeps the metric
+    st = out["last_state"]
+    more = samplers.nuts_sample(fn, None, n_warmup=0, n_samples=5, state=st)
+    assert torch.equal(more["inverse_mass"], out["inverse_mass"])
+
+
+def test_mclmc_tunes_L_to_the_size_of_the_typical_set():
+    """Second warm-up stage of mclmc_find_L_and_step_size (reference samplers.py:322-331): L = sqrt(sum of position variances)."""
+    d = 100
+    sd = torch.linspace(0.5, 2.0, d, dtype=torch.float64)
+
+    def fn(q):
+        z = q / sd
+        return float(-0.5 * (z * z).sum()), -(z / sd)
+
+    out = samplers.mclmc_sample(fn, torch.ones(d, dtype=torch.float64), n_warmup=6000, n_samples=10, seed=5)
+    want = float(torch.sqrt((sd ** 2).sum()))
+    assert 0.6 * want < out["L"] < 1.5 * want, (out["L"], want)
+    assert out["infos"][0]["L"] == math.sqrt(d) and out["infos"][-1]["L"] == out["L"]
+    fixed = samplers.mclmc_sample(fn, torch.ones(d, dtype=torch.float64), n_warmup=200, n_samples=10, seed=5, L=7.0)
+    assert fixed["L"] == 7.0
