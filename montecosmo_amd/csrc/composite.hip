@@ -278,7 +278,8 @@ static int axpby(mcpm_plan *p, const float *x, const float *y, int64_t n, float 
     with_max = with_max && p->paint3_variant == 4;
     if (with_max && nb > 16384) nb = 16384;      // grid-stride: few workgroups commit the maximum
     if (with_max) {
-        MCPM_HIP(p, hipMemsetAsync(p->fx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream));
+        if (!p->fx_clean) MCPM_HIP(p, hipMemsetAsync(p->fx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream));
+        p->fx_clean = 0;
         p->fx_src = out;
     }
     axpby_kernel<<<nb, 256, 0, p->stream>>>(x, y, n, a, b, out, with_max ? p->fx_wmax : nullptr);
@@ -416,7 +417,8 @@ int mcpm_pm_forces_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, int 
     MCPM_TRY(mcpm_paint_f32(p, pos, n, mode, nullptr, 1, 1.f, order, p->rho, 0));
     if (!paint_deconv && lap_fd == MCPM_FD_INF && grad_fd == MCPM_FD_INF && kcut <= 0.f) {
         if (step_layout(p)) {   // interleaved force mesh: one 12-byte gather per stencil corner
-            MCPM_TRY(mcpm_fftpm_force_meshes(p, p->rho, p->fmesh, 1));
+            static const int nt = [] { const char *e = getenv("MCPM_NT3"); return e ? atoi(e) : 1; }();
+            MCPM_TRY(mcpm_fftpm_force_meshes(p, p->rho, p->fmesh, 1, nt));
             return mcpm_read3_il(p, pos, n, mode, p->fmesh, order, forces);
         }
         MCPM_TRY(mcpm_force_meshes_f32(p, p->rho, p->fmesh));
@@ -629,8 +631,9 @@ static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float
         p->fb_xb = pos_bar;
         p->fb_vb = vel_bar;
         p->hint_set = 0;
-        if (p->paint3_variant == 4) {   // the fixed-point paint of fb_next needs max|fb_next|
-            MCPM_HIP(p, hipMemsetAsync(p->fx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream));
+        if (p->paint3_variant == 4) {   // the fixed-point paint of fb_next needs max|fb_next| (slots zero after a tiled paint3)
+            if (!p->fx_clean) MCPM_HIP(p, hipMemsetAsync(p->fx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream));
+            p->fx_clean = 0;
             p->fx_src = fb_next;
         }
     }

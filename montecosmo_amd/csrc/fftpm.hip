@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void zinv_kernel(FGeom g, const cf *__restrict
 
 // z C2R of the three force spectra of one line pair, written interleaved [x][y][z][3] (one 12-byte store per cell):
 // the layout the step kernels gather from (particles_dev.h interp3)
-template <int N>
+// NTOUT: streaming 12-byte stores, for callers whose consumer comes after the mesh has left the caches anyway (pm_forces: the
+// gathers of the read start at the other end of a 1.6 GB mesh); the steppers keep plain stores (measured: no gain there)
+template <int N, bool NTOUT = false>
 __global__ __launch_bounds__(256) void zinv3_il_kernel(FGeom g, const cf *__restrict__ spec, float *__restrict__ real,
                                                       const cf *__restrict__ W, int64_t npairs, int64_t spec_cstride) {
     constexpr int T = FftShape<N>::T, PAIRS = 256 / T;
@@ -197,8 +199,15 @@ __global__ __launch_bounds__(256) void zinv3_il_kernel(FGeom g, const cf *__rest
     F3 *a = reinterpret_cast<F3 *>(real) + line * N, *b = a + N;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        a[u + T * m] = F3{r[0][m].x, r[1][m].x, r[2][m].x};
-        b[u + T * m] = F3{r[0][m].y, r[1][m].y, r[2][m].y};
+        if (NTOUT) {
+            typedef float f3v __attribute__((ext_vector_type(3)));
+            const f3v va = {r[0][m].x, r[1][m].x, r[2][m].x}, vb = {r[0][m].y, r[1][m].y, r[2][m].y};
+            asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(&a[u + T * m]), "v"(va) : "memory");
+            asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(&b[u + T * m]), "v"(vb) : "memory");
+        } else {
+            a[u + T * m] = F3{r[0][m].x, r[1][m].x, r[2][m].x};
+            b[u + T * m] = F3{r[0][m].y, r[1][m].y, r[2][m].y};
+        }
     }
 }
 
@@ -636,7 +645,7 @@ static int z_inverse(mcpm_plan *p, const cf *spec, float *real, int64_t real_bst
     return MCPM_OK;
 }
 
-static int z_inverse3_il(mcpm_plan *p, const cf *spec3, float *real_il) {
+static int z_inverse3_il(mcpm_plan *p, const cf *spec3, float *real_il, bool nt_out = false) {
     const FGeom g = fgeom(p);
     const int64_t npairs = (int64_t)p->xwn * g.ny / 2;
     real_il += (int64_t)p->xw0 * g.ny * g.nz * 3;
@@ -645,7 +654,8 @@ static int z_inverse3_il(mcpm_plan *p, const cf *spec3, float *real_il) {
 #define CALL(NN)                                                                                                   \
     {                                                                                                              \
         constexpr int PAIRS = 256 / (NN / 8);                                                                      \
-        zinv3_il_kernel<NN><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, spec3, real_il, (const cf *)p->tw[2], npairs, spec_elems(p)); \
+        if (nt_out) zinv3_il_kernel<NN, true><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, spec3, real_il, (const cf *)p->tw[2], npairs, spec_elems(p)); \
+        else zinv3_il_kernel<NN><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, spec3, real_il, (const cf *)p->tw[2], npairs, spec_elems(p)); \
     }
     DISPATCH_N(g.nz, CALL)
 #undef CALL
@@ -816,7 +826,7 @@ int mcpm_fftpm_spec_meshes_vjp(mcpm_plan *p, const float *meshes_bar, float *spe
 }
 
 // rho (real mesh) -> three force meshes irfftn(-(i k_c)(-1/k^2) rfftn(rho)); single-GPU plans
-int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3, int interleaved) {
+int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3, int interleaved, int nt_out) {
     MCPM_TRY(ensure_twiddles(p));
     const int64_t ss = spec_elems(p);
     cf *s0 = (cf *)p->spec, *s123 = s0 + ss;
@@ -825,7 +835,7 @@ int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3, int inte
     MCPM_TRY(y_columns(p, s0, s0, 1, -1, false, false));
     MCPM_TRY(x_fused(p, s0, s45, 0));
     MCPM_TRY(y_columns2(p, s45, s123, true, false, false));
-    if (interleaved) return z_inverse3_il(p, s123, fm3);   // [cell][3] for the step kernels
+    if (interleaved) return z_inverse3_il(p, s123, fm3, nt_out != 0);   // [cell][3] for the step kernels
     MCPM_TRY(z_inverse(p, s123, fm3, p->M, 3));
     return MCPM_OK;
 }

@@ -69,6 +69,7 @@ struct mcpm_plan {
     int *fx_redo;       // fixed-point paint: [0] = number of flagged tiles, then their indices (device)
     int fx_tiles;       // capacity of fx_redo
     const float *fx_src; // weights whose max|w| a producer kernel already left in fx_wmax (else NULL)
+    int fx_clean;        // fx_wmax is all zero (the last three-component paint's epilogue cleared it): producers skip their memset
     long long *gx_acc;  // generic (order-independent) paint: int64 fixed-point accumulator mesh, all-zero between calls; allocated on first use
     unsigned *gx_wmax;  // generic paint: bits of max|w| (MCPM_FX_SLOTS slots)
     // chaining of adjoint steps (mcpm_plan_hint_next_adjoint): the adjoint particle kernel of step i also writes the
@@ -147,7 +148,7 @@ void mcpm_slab_state_free(mcpm_plan *p);   // slab.hip
 
 // hand-written FFT Poisson solve (fftpm.hip); power-of-two axes only
 bool mcpm_fftpm_supported(const mcpm_plan *p);
-int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3, int interleaved = 0);
+int mcpm_fftpm_force_meshes(mcpm_plan *p, const float *rho, float *fm3, int interleaved = 0, int nt_out = 0);
 int mcpm_kick_drift_layout(mcpm_plan *p, const float *pos_in, const float *vel_in, int64_t n, int mode, const float *meshes3,
                                       int layout, int order, float alpha, float beta, float dt, float *pos_out, float *vel_out);
 int mcpm_read3_il(mcpm_plan *p, const float *pos, int64_t n, int mode, const float *fm_il, int order, float *out);

@@ -305,12 +305,48 @@ __device__ __forceinline__ int window_point(const Geom &g, int j, int x0, int y0
     return (gx * g.ny + gy) * g.nz + gz;
 }
 
+// Window points of one thread, visited in the order j = tid, tid + THREADS, tid + 2 THREADS, ...: (jx, jy, jz) are carried
+// along with add-and-carry (7 instructions) instead of two divisions by W per visit, and -- FAST: power-of-two periodic
+// meshes, every single-GPU bench configuration -- the periodic wrap is one AND per axis.  The generic window_point() spends
+// ~45 vector and ~10 scalar-branch instructions per visit on the runtime choice between the slab, power-of-two and general
+// wraps; that was a quarter of the tile kernels' instruction stream.
+template <int H, int THREADS>
+struct WinIter {
+    static constexpr int W = MCPM_TILE + 2 * H + 1;
+    static constexpr int DX = THREADS / (W * W), DY = (THREADS % (W * W)) / W, DZ = (THREADS % (W * W)) % W;
+    int jx, jy, jz;
+    __device__ __forceinline__ WinIter(int tid) {
+        jz = tid % W;
+        const int r = tid / W;
+        jy = r % W;
+        jx = r / W;
+    }
+    __device__ __forceinline__ bool valid() const { return jx < W; }
+    __device__ __forceinline__ void next() {
+        jz += DZ;
+        const int cz = jz >= W ? 1 : 0;
+        jz -= cz ? W : 0;
+        jy += DY + cz;
+        const int cy = jy >= W ? 1 : 0;
+        jy -= cy ? W : 0;
+        jx += DX + cy;
+    }
+    // lattice point relative to the tile (r) and flat lattice index of the current point; power-of-two periodic mesh
+    __device__ __forceinline__ int point_fast(const Geom &g, int x0, int y0, int z0, int ox, int oy, int oz, int &rx, int &ry, int &rz) const {
+        rx = jx - (H + 1) - ox;
+        ry = jy - (H + 1) - oy;
+        rz = jz - (H + 1) - oz;
+        const int gx = (x0 + rx) & (g.nx - 1), gy = (y0 + ry) & (g.ny - 1), gz = (z0 + rz) & (g.nz - 1);
+        return (gx * g.ny + gy) * g.nz + gz;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // density paint.  WMODE 0: unweighted (2^-30 fixed point, scalar weight applied at the flush); 1: weighted, fixed point with
 // the max|w| scale; 2: weighted, f64 accumulators (non-finite weights only: runs when tile_scale().mode == 2, WMODE 1 otherwise)
 // (amdgpu_num_sgpr: with more than 80 scalar registers a CU admits 7 waves per SIMD instead of 8, i.e. three of these
 // 512-thread workgroups instead of four -- measured +45 % on the kernel; MI355X_MICROARCH.md "Residency")
-template <int H, int WMODE, int THREADS, int U>
+template <int H, int WMODE, int THREADS, int U, bool FAST = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void paint_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
                                                              int64_t wstride, float wscalar, float *__restrict__ mesh,
                                                              int accumulate, TileLists L, const unsigned *__restrict__ wmax_bits,
@@ -343,6 +379,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
     }
     __syncthreads();
 
+    WinIter<H, THREADS> wi(threadIdx.x);
     for (int j0 = threadIdx.x; j0 < NW; j0 += THREADS * U) {
         P3 d[U];
         float wt[U];
@@ -350,7 +387,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u * THREADS;
-            gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
+            if (FAST) {
+                gis[u] = wi.valid() ? wi.point_fast(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
+                wi.next();
+            } else
+                gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
             if (gis[u] >= 0) {
                 d[u] = load3(disp, gis[u]);
                 wt[u] = WMODE ? w[(int64_t)gis[u] * wstride] : 1.f;
@@ -378,7 +419,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
                 continue;
             }
             const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
-            const bool beyond = g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
+            const bool beyond = !FAST && g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
             if ((unsure || beyond) && duty && home) append_suspect(L, sus, gis[u]);
             if (beyond) continue;   // clamped + counted by paint_leftover_kernel
             if (cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
@@ -395,6 +436,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
                         const float wxy = kx[a] * ky[bb];
 #pragma unroll
                         for (int e = 0; e < 2; ++e)
+                            // (depositing an outside corner into a per-lane trash cell instead, 8 unconditional atomics and no
+                            // per-corner exec mask, is SLOWER: 0.956 vs 0.902 ms at 512^3 -- +90 vector instructions per 4 visits)
                             if (vx[a] && vy[bb] && vz[e]) {
                                 const int q = base + (a * B + bb) * B + e;
                                 if (WMODE == 2) atomicAdd(dtile + q, (double)(wxy * kz[e]));
@@ -443,7 +486,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
             v.z += o.z;
             v.w += o.w;
         }
-        *dst = v;
+        *dst = v;      // (a streaming store here is slower: 0.915 vs 0.902 ms at 512^3)
     }
 }
 
@@ -459,20 +502,19 @@ __device__ __forceinline__ bool bucket_cell(const Geom &g, int gi, const P3 &d, 
 
 // deposits the bucket of every tile through an LDS integer tile and adds the touched cells to the mesh
 template <int WMODE>
-__global__ __launch_bounds__(256) void paint_bucket_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
-                                                           int64_t wstride, float wscalar, float *__restrict__ mesh, TileLists L,
-                                                           const unsigned *__restrict__ wmax_bits) {
+__device__ __forceinline__ void paint_bucket_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w,
+                                                  int64_t wstride, float wscalar, float *__restrict__ mesh, const TileLists &L,
+                                                  const unsigned *__restrict__ wmax_bits, u64 *tile, const int bid, const int nblk) {
     constexpr int B = MCPM_TILE, NT = B * B * B;
     const int ntl = L.cnts[C_NTILES];
-    if ((int)blockIdx.x >= ntl) return;
+    if (bid >= ntl) return;
     TScale sc = {1073741824.f, 9.313225746154785e-10, 1};
     if (WMODE != 0) sc = tile_scale(wmax_bits);
     const bool f64 = WMODE != 0 && sc.mode == 2;     // non-finite weights: doubles (uniform over the launch)
-    __shared__ u64 tile[NT];
     double *dtile = reinterpret_cast<double *>(tile);
     const int ntz = g.nz / B, nty = g.ny / B;
     const double s = WMODE == 0 ? (double)wscalar * sc.Sinv : sc.Sinv;
-    for (int it = blockIdx.x; it < ntl; it += gridDim.x) {
+    for (int it = bid; it < ntl; it += nblk) {
         const int t = L.nonempty[it];
         const int cnt = L.bcnt[t];
         if (cnt > L.cap) continue;     // an overflowed bucket is dropped: the repair pass deposits that tile's pairs
@@ -521,12 +563,12 @@ __global__ __launch_bounds__(256) void paint_bucket_kernel(Geom g, const float *
 // (2) repair pass, only when some bucket overflowed: every (particle, tile) pair whose tile is marked (bcnt > cap) and whose
 // window misses the particle -- the same predicate as the coverage duty, re-evaluated over all particles.
 template <int H, int NC>
-__global__ __launch_bounds__(256) void paint_leftover_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
-                                                             int64_t wstride, float wscalar, float *__restrict__ mesh, int64_t M,
-                                                             TileLists L) {
+__device__ __forceinline__ void paint_leftover_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w,
+                                                    int64_t wstride, float wscalar, float *__restrict__ mesh, int64_t M,
+                                                    const TileLists &L, const int bid, const int nblk) {
     const int nw = min(L.cnts[C_WILD], L.listcap);
-    if (blockIdx.x == 0 && threadIdx.x == 0) L.cnts[C_LAST] = L.cnts[C_WILD] + L.cnts[C_PAIRS];
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nw; k += gridDim.x * blockDim.x) {
+    if (bid == 0 && threadIdx.x == 0) L.cnts[C_LAST] = L.cnts[C_WILD] + L.cnts[C_PAIRS];
+    for (int k = bid * blockDim.x + threadIdx.x; k < nw; k += nblk * blockDim.x) {
         const int gi = L.wild[k];
         PIdx pi;
         pi.i = gi;
@@ -569,7 +611,7 @@ __global__ __launch_bounds__(256) void paint_leftover_kernel(Geom g, const float
     if (L.cnts[C_PAIRS] == 0) return;
     const int ntx = g.nx / MCPM_TILE, nty = g.ny / MCPM_TILE, ntz = g.nz / MCPM_TILE;
     const int64_t np = (int64_t)g.px * g.py * g.pz;
-    for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < np; gi += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t gi = (int64_t)bid * blockDim.x + threadIdx.x; gi < np; gi += (int64_t)nblk * blockDim.x) {
         const int qz = (int)(gi % g.nz), r = (int)(gi / g.nz), qy = r % g.ny, qx = r / g.ny + g.xoff;
         const P3 d = load3(disp, gi);
         const int tx = qx >> 4, ty = qy >> 4, tz = qz >> 4;
@@ -594,6 +636,19 @@ __global__ __launch_bounds__(256) void paint_leftover_kernel(Geom g, const float
                                      }
                          });
     }
+}
+
+// Epilogue of a tiled density paint, ONE launch (it used to be two: at 128^3, where a kernel lasts a few microseconds, every
+// launch costs about as much as the kernel): blocks [0, nbk) deposit the buckets, blocks [nbk, nbk + nlo) run the
+// global-atomic leftovers (wild particles, overflowed buckets).  The two touch disjoint (particle, tile) pairs and both only
+// read what the coverage kernel left, so they need no order between them.
+template <int H, int WMODE>
+__global__ __launch_bounds__(256) void paint_epilogue_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
+                                                             int64_t wstride, float wscalar, float *__restrict__ mesh, int64_t M,
+                                                             TileLists L, const unsigned *__restrict__ wmax_bits, int nbk) {
+    __shared__ u64 tile[MCPM_TILE * MCPM_TILE * MCPM_TILE];
+    if ((int)blockIdx.x < nbk) paint_bucket_body<WMODE>(g, disp, w, wstride, wscalar, mesh, L, wmax_bits, tile, (int)blockIdx.x, nbk);
+    else paint_leftover_body<H, 1>(g, disp, w, wstride, wscalar, mesh, M, L, (int)blockIdx.x - nbk, (int)gridDim.x - nbk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -627,7 +682,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ w
 
 // redo: nullptr = first (fixed-point) pass over all tiles, appending flagged tiles to `redo_out`; otherwise the f64 pass
 // over the tiles listed in redo ([0] = count, then indices).  F64: accumulators are doubles (96 KB) instead of packed fields.
-template <int H, bool F64, int THREADS, int U>
+template <int H, bool F64, int THREADS, int U, bool FAST = false>
 __global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
                                                               float *__restrict__ mesh, int64_t M, int accumulate, TileLists L,
                                                               const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out,
@@ -692,13 +747,18 @@ __global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const floa
     }
     __syncthreads();
 
+    WinIter<H, THREADS> wi(threadIdx.x);
     for (int j0 = threadIdx.x; j0 < NW; j0 += THREADS * U) {
         P3 d[U], wt[U];
         int rxs[U], rys[U], rzs[U], gis[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u * THREADS;
-            gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
+            if (FAST) {
+                gis[u] = wi.valid() ? wi.point_fast(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
+                wi.next();
+            } else
+                gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
             if (gis[u] >= 0) {
                 d[u] = load3(disp, gis[u]);
                 wt[u] = load3(w3, gis[u]);
@@ -726,7 +786,7 @@ __global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const floa
                 continue;
             }
             const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
-            const bool beyond = g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
+            const bool beyond = !FAST && g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
             if ((unsure || beyond) && duty && home) append_suspect(L, sus, gis[u]);
             if (beyond) continue;   // clamped + counted by paint_leftover_kernel
             if (deposit && cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
@@ -847,19 +907,18 @@ __global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const floa
 }
 
 // buckets of the three-component paint: int64 fixed point with the max|w| 2^-28 scale, doubles when the weights are non-finite
-__global__ __launch_bounds__(256) void paint3_bucket_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
-                                                            float *__restrict__ mesh, int64_t M, TileLists L,
-                                                            const unsigned *__restrict__ wmax_bits) {
+__device__ __forceinline__ void paint3_bucket_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w3,
+                                                   float *__restrict__ mesh, int64_t M, const TileLists &L,
+                                                   const unsigned *__restrict__ wmax_bits, u64 *tile, const int bid, const int nblk) {
     constexpr int B = MCPM_TILE, NT = B * B * B;
     const int ntl = L.cnts[C_NTILES];
-    if ((int)blockIdx.x >= ntl) return;
+    if (bid >= ntl) return;
     const TScale sc = tile_scale(wmax_bits);
     if (sc.mode == 0) return;
     const bool F64 = sc.mode == 2;      // non-finite weights: doubles (uniform over the launch)
-    __shared__ u64 tile[3 * NT];
     double *dtile = reinterpret_cast<double *>(tile);
     const int ntz = g.nz / B, nty = g.ny / B;
-    for (int it = blockIdx.x; it < ntl; it += gridDim.x) {
+    for (int it = bid; it < ntl; it += nblk) {
         const int t = L.nonempty[it];
         const int cnt = L.bcnt[t];
         if (cnt > L.cap) continue;
@@ -911,6 +970,38 @@ __global__ __launch_bounds__(256) void paint3_bucket_kernel(Geom g, const float 
     }
 }
 
+// Epilogue of the three-component paint, one launch: buckets | leftovers (see paint_epilogue_kernel).  The last block to
+// finish also clears the max|w| slots: they are zero between paints, so the kernel that produces the next weights (the
+// adjoint particle kernel, axpby) commits its maximum without a memset launch in front of it.
+__global__ __launch_bounds__(256) void paint3_epilogue_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
+                                                              float *__restrict__ mesh, int64_t M, TileLists L,
+                                                              unsigned *__restrict__ wmax_bits, int nbk, int H, unsigned *__restrict__ done) {
+    __shared__ u64 tile[3 * MCPM_TILE * MCPM_TILE * MCPM_TILE];
+    __shared__ int last;
+    if ((int)blockIdx.x < nbk) paint3_bucket_body(g, disp, w3, mesh, M, L, wmax_bits, tile, (int)blockIdx.x, nbk);
+    else {
+        const int bid = (int)blockIdx.x - nbk, nblk = (int)gridDim.x - nbk;
+        switch (H) {
+            case 1: paint_leftover_body<1, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
+            case 2: paint_leftover_body<2, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
+            case 3: paint_leftover_body<3, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
+            case 4: paint_leftover_body<4, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
+            default: paint_leftover_body<6, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
+        }
+    }
+    // every block has read the slots by now (tile_scale at its top, or it never needs them): the last one out clears them
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last) {
+        for (int i = threadIdx.x; i < MCPM_FX_SLOTS; i += 256) wmax_bits[i * MCPM_FX_STRIDE] = 0u;
+        if (threadIdx.x == 0) *done = 0u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 static bool tiled_geometry_ok(const mcpm_plan *p, const void *mesh) {
@@ -921,6 +1012,14 @@ static bool tiled_geometry_ok(const mcpm_plan *p, const void *mesh) {
     if (g.nx < 3 * MCPM_TILE || g.ny < 3 * MCPM_TILE || g.nz < 3 * MCPM_TILE) return false;
     if (((uintptr_t)mesh) & 15) return false;
     return p->bucket != nullptr;
+}
+
+// the FAST instantiations of the tile kernels: periodic power-of-two meshes (MCPM_PAINT_FAST=0: the generic ones, A/B runs)
+static bool tiled_fast(const mcpm_plan *p) {
+    static const int on = [] { const char *e = getenv("MCPM_PAINT_FAST"); return e ? atoi(e) : 1; }();
+    const Geom &g = p->g;
+    auto pow2 = [](int n) { return (n & (n - 1)) == 0; };
+    return on && !g.xslab && pow2(g.nx) && pow2(g.ny) && pow2(g.nz);
 }
 
 static TileLists tile_lists(const mcpm_plan *p) {
@@ -950,7 +1049,13 @@ bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t ws
     const unsigned nb = (unsigned)((g.nx / MCPM_TILE) * (g.ny / MCPM_TILE) * (g.nz / MCPM_TILE));
     tiled_prologue(p, pos);
     const TileLists L = tile_lists(p);
-    const unsigned nbk = nb < 1024u ? nb : 1024u;   // bucket kernels walk the list of non-empty buckets
+    const bool fast = tiled_fast(p);
+    // bucket blocks walk the list of non-empty buckets (grid-stride); every block of the epilogue launch is scheduled with the
+    // bucket tile's LDS whether it finds work or not, so small meshes (few non-empty buckets) get few of them
+    const unsigned nbk = nb <= 4096u ? (nb < 256u ? nb : 256u) : 1024u;
+    // leftover blocks: grid-stride over the wild list (normally empty) and, only after a bucket overflow, over the particles.
+    // Few: every block of the launch carries the bucket blocks' LDS tile, so 1024 of them cost more than the launch they save
+    const unsigned nlo = 64u;
     if (w) {
         (void)hipMemsetAsync(p->gx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream);
         absmax_kernel<<<2048, 256, 0, p->stream>>>(w, wstride, p->Np, p->gx_wmax);
@@ -961,22 +1066,21 @@ bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t ws
     }
         DISPATCH_H(p->halo, CALLW)
 #undef CALLW
-#define CALLD(HH) coverage_duty_kernel<HH><<<1024, 256, 0, p->stream>>>(g, pos, L);
-        DISPATCH_H(p->halo, CALLD)
-#undef CALLD
-        paint_bucket_kernel<1><<<nbk, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, L, p->gx_wmax);
     } else {
-#define CALLU(HH) paint_tile_kernel<HH, 0, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
+#define CALLU(HH)                                                                                                                    \
+    if (fast) paint_tile_kernel<HH, 0, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+    else paint_tile_kernel<HH, 0, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
         DISPATCH_H(p->halo, CALLU)
 #undef CALLU
-#define CALLD(HH) coverage_duty_kernel<HH><<<1024, 256, 0, p->stream>>>(g, pos, L);
-        DISPATCH_H(p->halo, CALLD)
-#undef CALLD
-        paint_bucket_kernel<0><<<nbk, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, L, p->gx_wmax);
     }
-#define CALLL(HH) paint_leftover_kernel<HH, 1><<<1024, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L);
-    DISPATCH_H(p->halo, CALLL)
-#undef CALLL
+#define CALLD(HH) coverage_duty_kernel<HH><<<1024, 256, 0, p->stream>>>(g, pos, L);
+    DISPATCH_H(p->halo, CALLD)
+#undef CALLD
+#define CALLE(HH)                                                                                                                          \
+    if (w) paint_epilogue_kernel<HH, 1><<<nbk + nlo, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L, p->gx_wmax, (int)nbk); \
+    else paint_epilogue_kernel<HH, 0><<<nbk + nlo, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L, p->gx_wmax, (int)nbk);
+    DISPATCH_H(p->halo, CALLE)
+#undef CALLE
     return true;
 }
 
@@ -988,16 +1092,18 @@ bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, fl
     if (p->fx_tiles < (int)nb) return false;
     tiled_prologue(p, pos, p->fx_redo);
     const TileLists L = tile_lists(p);
-    const unsigned nbk = nb < 1024u ? nb : 1024u;
+    const bool fast = tiled_fast(p);
+    const unsigned nbk = nb <= 4096u ? (nb < 256u ? nb : 256u) : 1024u;   // see mcpm_paint_tiled
     if (p->fx_src != weights3) {   // max|w| not left behind by the kernel that produced the weights
-        (void)hipMemsetAsync(p->fx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream);
+        if (!p->fx_clean) (void)hipMemsetAsync(p->fx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream);
         absmax_kernel<<<2048, 256, 0, p->stream>>>(weights3, 1, 3 * p->Np, p->fx_wmax);
     }
     p->fx_src = nullptr;
     if (p->paint3_variant == 4) {   // fixed-point tiles; the tiles they flag (and every tile if max|w| is unusable) in f64
 #define CALLFX(HH)                                                                                                                \
     {                                                                                                                             \
-        paint3_tile_kernel<HH, false, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
+        if (fast) paint3_tile_kernel<HH, false, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
+        else paint3_tile_kernel<HH, false, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
         paint3_tile_kernel<HH, true, 1024, 4><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, p->fx_redo, 0); \
     }
         DISPATCH_H(p->halo, CALLFX)
@@ -1010,9 +1116,10 @@ bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, fl
 #define CALLD(HH) coverage_duty_kernel<HH><<<1024, 256, 0, p->stream>>>(g, pos, L);
     DISPATCH_H(p->halo, CALLD)
 #undef CALLD
-    paint3_bucket_kernel<<<nbk, 256, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, L, p->fx_wmax);
-#define CALLL(HH) paint_leftover_kernel<HH, 3><<<1024, 256, 0, p->stream>>>(g, pos, weights3, 3, 0.f, meshes3, p->M, L);
-    DISPATCH_H(p->halo, CALLL)
-#undef CALLL
+    const unsigned nlo = 64u;     // see mcpm_paint_tiled
+    // buckets | leftovers in one launch; its last block leaves the max|w| slots zero for the next producer
+    paint3_epilogue_kernel<<<nbk + nlo, 256, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, L, p->fx_wmax, (int)nbk, p->halo,
+                                                             (unsigned *)(p->outlier_count + 7));
+    p->fx_clean = 1;
     return true;
 }

@@ -325,19 +325,20 @@ __global__ __launch_bounds__(256) void read_kernel(Geom g, const float *__restri
 }
 
 // three components from one interleaved [cell][3] mesh
-template <int MODE, int ORDER>
+template <int MODE, int ORDER, bool NT = false, bool NTIN = false>
 __global__ __launch_bounds__(256) void read3_il_kernel(Geom g, const float *__restrict__ pos, int64_t n,
                                                        const float *__restrict__ fm, float *__restrict__ out) {
     PIdx pi = particle_index<MODE>(g, n);
     if (!pi.valid) return;
-    P3 d = load3(pos, pi.i);
+    P3 d = NTIN ? load3_nt(pos, pi.i) : load3(pos, pi.i);
     int c[3];
     float f[3];
     locate<MODE, ORDER>(g, pi, d, c, f);
     Stencil<ORDER> s(g, c);
     float F[3], G[3][3];
     interp3<ORDER, false, true>(fm, 0, s, f, F, G);
-    store3(out, pi.i, P3{F[0], F[1], F[2]});
+    if (NT) store3_nt(out, pi.i, F[0], F[1], F[2]);
+    else store3(out, pi.i, P3{F[0], F[1], F[2]});
 }
 
 // VJP of read w.r.t. pos (also the pos-VJP of paint with NCOMP = 1 and out_bar = weights).
@@ -723,7 +724,12 @@ int mcpm_read3_il(mcpm_plan *p, const float *pos, int64_t n, int mode, const flo
     if (n == 0) return MCPM_OK;
     dim3 grid, block;
     if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
-#define CALL(MO, OR) read3_il_kernel<MO, OR><<<grid, block, 0, p->stream>>>(p->g, pos, n, fm_il, out)
+    static const bool nt = [] { const char *e = getenv("MCPM_NT3"); return e ? atoi(e) != 0 : true; }();   // streaming output (A/B knob)
+    static const bool ntin = [] { const char *e = getenv("MCPM_NT_POS"); return e ? atoi(e) != 0 : true; }();    // streaming position loads
+#define CALL(MO, OR)                                                                                  \
+    if (nt && ntin) read3_il_kernel<MO, OR, true, true><<<grid, block, 0, p->stream>>>(p->g, pos, n, fm_il, out);  \
+    else if (nt) read3_il_kernel<MO, OR, true><<<grid, block, 0, p->stream>>>(p->g, pos, n, fm_il, out);  \
+    else read3_il_kernel<MO, OR><<<grid, block, 0, p->stream>>>(p->g, pos, n, fm_il, out)
     DISPATCH_MODE_ORDER(mode, order, CALL);
 #undef CALL
     MCPM_LAUNCH_CHECK(p, "read3_il_kernel");

@@ -12,6 +12,22 @@ __device__ __forceinline__ P3 load3(const float *__restrict__ p, int64_t i) {
     return reinterpret_cast<const P3 *>(p)[i];
 }
 __device__ __forceinline__ void store3(float *__restrict__ p, int64_t i, P3 v) { reinterpret_cast<P3 *>(p)[i] = v; }
+// 12-byte streaming store (`nt`): for outputs nothing reads again before they have left every cache (pm_forces' force array,
+// the force mesh it gathers from once): they then do not evict the lines the gathers are re-using.  The builtin nontemporal
+// store has no 96-bit form, hence the instruction itself.
+typedef float mcpm_f3v __attribute__((ext_vector_type(3)));
+// 12-byte streaming load: for a kernel's FIRST load of a particle (nothing else of the wave is in flight: the wait is exact)
+__device__ __forceinline__ P3 load3_nt(const float *p, int64_t i) {
+    mcpm_f3v v;
+    const float *q = p + 3 * i;
+    asm volatile("global_load_dwordx3 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(q) : "memory");
+    return P3{v.x, v.y, v.z};
+}
+__device__ __forceinline__ void store3_nt(float *p, int64_t i, float a, float b, float c) {
+    const mcpm_f3v v = {a, b, c};
+    float *q = p + 3 * i;
+    asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(q), "v"(v) : "memory");
+}
 
 // Python-style modulo for |c| < 2^16, n < 2^15.
 __device__ __forceinline__ int wrapi(int c, int n) {

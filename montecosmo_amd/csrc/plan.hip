@@ -116,6 +116,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->fx_redo = nullptr;
     p->fx_tiles = 0;
     p->fx_src = nullptr;
+    p->fx_clean = 0;
     p->gx_acc = nullptr;
     p->gx_wmax = nullptr;
     p->reduce = nullptr;
@@ -141,6 +142,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     if (p->g.same_lattice && nx % 16 == 0 && ny % 16 == 0 && nz % 16 == 0 && nx >= 48 && ny >= 48 && nz >= 48) {
         const size_t ntiles = (size_t)(nx / 16) * (ny / 16) * (nz / 16);
         p->bucket_cap = 1024;
+        if (const char *e = getenv("MCPM_BUCKET_CAP")) { const int c = atoi(e); if (c >= 64 && c <= 65536) p->bucket_cap = c; }
         alloc((void **)&p->tile_off, sizeof(int) * ntiles);
         alloc((void **)&p->bucket_cnt, sizeof(int) * ntiles);
         alloc((void **)&p->bucket_tiles, sizeof(int) * ntiles);

@@ -3,7 +3,7 @@
 #   bench lines (512^3 default with the 256^3 sub-record and the CPU baseline; 256^3; 128^3; forward-only; slab code path),
 #   rocprofv3 --kernel-trace --stats of the default workload and of 256^3, PMC FETCH_SIZE / WRITE_SIZE passes (separate runs,
 #   as MI355X_MICROARCH.md prescribes) for both meshes.  Outputs under gpurun_out/<tag>/; copy what is to be judged to profiles/.
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/$tag && O=gpurun_out/$tag && \
 python3 bench.py > $O/bench512.json 2> $O/bench512.err && echo "bench512 done" && \
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats512 -o k -- python3 bench.py --no-sub-record --no-cpu-baseline > $O/bench512_prof.json 2>> $O/prof.err && \

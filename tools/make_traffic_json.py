@@ -8,7 +8,8 @@ fetch_dir, write_dir, mesh, out_json, out_txt = sys.argv[1:6]
 # buckets, leftovers) serve both the density paint and the three-component paint: they are attributed in dispatch order to
 # the paint whose tile kernel they surround (a prologue belongs to the tile kernel that follows it, the others to the one
 # before them).
-stage_of = [("paint3_tile_kernel", "paint3"), ("paint3_bucket_kernel", "paint3"), ("paint_tile_kernel", "paint"), ("paint_bucket_kernel", "paint"),
+stage_of = [("paint3_tile_kernel", "paint3"), ("paint3_bucket_kernel", "paint3"), ("paint3_epilogue_kernel", "paint3"), ("paint_tile_kernel", "paint"),
+            ("paint_bucket_kernel", "paint"), ("paint_epilogue_kernel", "paint"),
             ("paint_atomic_kernel", "paint"), ("paint_fxg_flush_kernel", "paint"),
             ("zfwd_kernel", "fft_r2c"), ("ycol2_kernel<512, false", "fft_r2c"), ("ycol2_kernel<256, false", "fft_r2c"),
             ("ycol2_kernel<512, true", "fft_c2r"), ("ycol2_kernel<256, true", "fft_c2r"), ("ycol_kernel<512, -1>", "fft_r2c"), ("ycol_kernel<256, -1>", "fft_r2c"),
