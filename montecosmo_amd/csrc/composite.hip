@@ -155,13 +155,20 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
                                                            const float *__restrict__ fm, const float *__restrict__ rho_bar,
                                                            int64_t M, float alpha, float beta, float tau,
                                                            double *slots, float *__restrict__ fb_next, float beta_next,
-                                                           float tau_next, float dtau_ddg, unsigned *__restrict__ fb_max) {
+                                                           float tau_next, float dtau_ddg, unsigned *__restrict__ fb_max, int nt) {
     PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
     double ra = 0., rb = 0., rc = 0.;
     P3 fbn = {0.f, 0.f, 0.f};
     if (pi.valid) {
-        const P3 d = load3(x, pi.i), vi = load3(v, pi.i);
-        P3 xbi = load3(xb, pi.i), vbi = load3(vb, pi.i);
+        P3 d, vi, xbi, vbi;
+        if (nt & 1) load3_nt4(x, v, xb, vb, pi.i, d, vi, xbi, vbi);      // streaming: each is read once by this kernel
+        else {
+            d = load3(x, pi.i);
+            vi = load3(v, pi.i);
+            xbi = load3(xb, pi.i);
+            vbi = load3(vb, pi.i);
+        }
+        const P3 xin = xbi;
         int c[3];
         float f[3];
         locate<MCPM_POS_LATTICE, ORDER>(g, pi, d, c, f);
@@ -186,17 +193,22 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
         ra = (double)(vt.x * vi.x + vt.y * vi.y + vt.z * vi.z);
         rb = (double)(vt.x * F[0] + vt.y * F[1] + vt.z * F[2]);
         {   // explicit dependence of the drift x' += v_new tau on the step size: <x_bar_in, v_new> dtau/ddg
-            const P3 xin = load3(xb, pi.i);
             const float vnx = alpha * vi.x + beta * F[0], vny = alpha * vi.y + beta * F[1], vnz = alpha * vi.z + beta * F[2];
             rc = (double)(dtau_ddg * (xin.x * vnx + xin.y * vny + xin.z * vnz));
         }
         const P3 vnew = {alpha * vt.x, alpha * vt.y, alpha * vt.z};
-        store3(xb, pi.i, xbi);
-        store3(vb, pi.i, vnew);
+        if (nt & 2) {
+            store3_nt(xb, pi.i, xbi.x, xbi.y, xbi.z);
+            store3_nt(vb, pi.i, vnew.x, vnew.y, vnew.z);
+        } else {
+            store3(xb, pi.i, xbi);
+            store3(vb, pi.i, vnew);
+        }
         if (fb_next) {  // force cotangent of the PREVIOUS step, F_bar = beta' (v_bar + tau' x_bar)
             fbn = P3{beta_next * (vnew.x + tau_next * xbi.x), beta_next * (vnew.y + tau_next * xbi.y),
                      beta_next * (vnew.z + tau_next * xbi.z)};
-            store3(fb_next, pi.i, fbn);
+            if (nt & 2) store3_nt(fb_next, pi.i, fbn.x, fbn.y, fbn.z);
+            else store3(fb_next, pi.i, fbn);
         }
     }
     if (fb_max) absmax_commit(fbn.x, fbn.y, fbn.z, fb_max);
@@ -418,7 +430,7 @@ int mcpm_pm_forces_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, int 
     if (!paint_deconv && lap_fd == MCPM_FD_INF && grad_fd == MCPM_FD_INF && kcut <= 0.f) {
         if (step_layout(p)) {   // interleaved force mesh: one 12-byte gather per stencil corner
             static const int nt = [] { const char *e = getenv("MCPM_NT3"); return e ? atoi(e) : 1; }();
-            MCPM_TRY(mcpm_fftpm_force_meshes(p, p->rho, p->fmesh, 1, nt));
+            MCPM_TRY(mcpm_fftpm_force_meshes(p, p->rho, p->fmesh, 1, nt == 1 || nt == 2));
             return mcpm_read3_il(p, pos, n, mode, p->fmesh, order, forces);
         }
         MCPM_TRY(mcpm_force_meshes_f32(p, p->rho, p->fmesh));
@@ -638,12 +650,13 @@ static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float
         }
     }
     unsigned *fb_max = (fb_next && p->paint3_variant == 4) ? p->fx_wmax : nullptr;
+    static const int ntp = [] { const char *e = getenv("MCPM_NT_PART"); return e ? atoi(e) : 3; }();     // streaming loads / stores: 2.80 -> 2.62 ms at 512^3
     double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);   // zero on entry (reduce_slots_kernel leaves them so)
 #define ADJ(OR)                                                                                                                   \
     if (layout) step_adjoint_kernel<OR, true><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
-                                                           slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max);  \
+                                                           slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max, ntp);  \
     else step_adjoint_kernel<OR, false><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
-                                                           slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max)
+                                                           slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max, ntp)
     if (paint_order == 2) ADJ(2);
     else if (paint_order == 1) ADJ(1);
     else if (paint_order == 3) ADJ(3);

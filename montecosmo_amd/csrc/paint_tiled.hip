@@ -74,7 +74,7 @@ __device__ __forceinline__ void tile_of_block(int ntx, int nty, int ntz, int &tx
 
 // ------------------------------------------------------------------------------------------------
 // Prologue of every tiled paint, one launch: resets the bucket counts and the per-paint counters, and (toff != NULL) sets
-// o_T = rounded mean displacement of 64 lattice points (a 4x4x4 sub-grid) of the Lagrangian block at tile T.
+// o_T = rounded mean displacement of 64 lattice points (four z rows) of the Lagrangian block at tile T.
 __global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float *__restrict__ disp, int *__restrict__ toff,
                                                             int *__restrict__ bcnt, int *__restrict__ cnts, int ntiles, int maxoff,
                                                             int *__restrict__ redo) {
@@ -86,8 +86,10 @@ __global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float 
     if (!toff) return;
     const int ntz = g.nz / MCPM_TILE, nty = g.ny / MCPM_TILE;
     const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
-    int gx = tx * MCPM_TILE + 2 + 4 * (lane >> 4) - g.xoff;
-    const int gy = ty * MCPM_TILE + 2 + 4 * ((lane >> 2) & 3), gz = tz * MCPM_TILE + 2 + 4 * (lane & 3);
+    // four whole z rows of the tile ((x, y) = (4, 4), (4, 12), (12, 4), (12, 12); 16 consecutive particles = 192 bytes each):
+    // 8 cache lines per tile instead of the 32 a 4 x 4 x 4 sub-grid touches (the kernel is bound by the lines it pulls)
+    int gx = tx * MCPM_TILE + 4 + 8 * (lane >> 5) - g.xoff;
+    const int gy = ty * MCPM_TILE + 4 + 8 * ((lane >> 4) & 1), gz = tz * MCPM_TILE + (lane & 15);
     if (g.xslab) gx = min(max(gx, 0), g.px - 1);   // ghost tiles: the nearest lattice plane
     const P3 d = load3(disp, ((int64_t)gx * g.ny + gy) * g.nz + gz);
     float sx = d.x, sy = d.y, sz = d.z;
@@ -682,25 +684,20 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ w
 
 // redo: nullptr = first (fixed-point) pass over all tiles, appending flagged tiles to `redo_out`; otherwise the f64 pass
 // over the tiles listed in redo ([0] = count, then indices).  F64: accumulators are doubles (96 KB) instead of packed fields.
-template <int H, bool F64, int THREADS, int U, bool FAST = false>
-__global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
-                                                              float *__restrict__ mesh, int64_t M, int accumulate, TileLists L,
-                                                              const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out,
-                                                              const int *__restrict__ redo_in, int duty) {
+// One tile of the three-component paint (redo_tile < 0: the tile of this block; else the given tile, for the f64 repaint).
+template <int H, bool F64, int THREADS, int U, bool FAST>
+__device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w3,
+                                                 float *__restrict__ mesh, int64_t M, int accumulate, const TileLists &L,
+                                                 const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out, int redo_tile, int duty,
+                                                 u64 *tile, int &flagged, int *sh27, int *sus) {
     constexpr int B = MCPM_TILE, W = B + 2 * H + 1, NW = W * W * W, NT = B * B * B;
-    __shared__ u64 tile[(F64 ? 3 : 2) * NT];   // 64 KB (two workgroups per CU) / 96 KB
-    __shared__ int flagged;
-    __shared__ int sh27[27];
-    __shared__ int sus[MCPM_SUS + 2];
     double *dtile = reinterpret_cast<double *>(tile);
     const int ntx = g.nx / B, nty = g.ny / B, ntz = g.nz / B;
     int tx, ty, tz;
-    if (redo_in) {
-        if ((int)blockIdx.x >= redo_in[0]) return;
-        const int t = redo_in[1 + blockIdx.x];
-        tz = t % ntz;
-        ty = (t / ntz) % nty;
-        tx = t / (ntz * nty);
+    if (redo_tile >= 0) {
+        tz = redo_tile % ntz;
+        ty = (redo_tile / ntz) % nty;
+        tx = redo_tile / (ntz * nty);
     } else
         tile_of_block(ntx, nty, ntz, tx, ty, tz);
     const int x0 = tx * B, y0 = ty * B, z0 = tz * B, tidx = (tx * nty + ty) * ntz + tz;
@@ -906,6 +903,31 @@ __global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const floa
     }
 }
 
+// redo_in == nullptr: the first pass, one workgroup per tile.  Otherwise the f64 repaint of the tiles listed in redo_in
+// ([0] = count, then indices): a small grid that walks the list (it is empty on every PM workload: a whole-mesh launch of
+// workgroups that return at once cost 30 us per adjoint step at 512^3).
+template <int H, bool F64, int THREADS, int U, bool FAST = false>
+__global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
+                                                              float *__restrict__ mesh, int64_t M, int accumulate, TileLists L,
+                                                              const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out,
+                                                              const int *__restrict__ redo_in, int duty) {
+    constexpr int NT = MCPM_TILE * MCPM_TILE * MCPM_TILE;
+    __shared__ u64 tile[(F64 ? 3 : 2) * NT];   // 64 KB (two workgroups per CU) / 96 KB
+    __shared__ int flagged;
+    __shared__ int sh27[27];
+    __shared__ int sus[MCPM_SUS + 2];
+    if (!redo_in) {
+        paint3_tile_body<H, F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, -1, duty, tile, flagged, sh27, sus);
+        return;
+    }
+    const int n = redo_in[0];
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        paint3_tile_body<H, F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, redo_in[1 + k], duty, tile, flagged,
+                                                   sh27, sus);
+        __syncthreads();
+    }
+}
+
 // buckets of the three-component paint: int64 fixed point with the max|w| 2^-28 scale, doubles when the weights are non-finite
 __device__ __forceinline__ void paint3_bucket_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w3,
                                                    float *__restrict__ mesh, int64_t M, const TileLists &L,
@@ -989,11 +1011,16 @@ __global__ __launch_bounds__(256) void paint3_epilogue_kernel(Geom g, const floa
             default: paint_leftover_body<6, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
         }
     }
-    // every block has read the slots by now (tile_scale at its top, or it never needs them): the last one out clears them
+    // The bucket blocks that found work are the only readers of the max|w| slots in this launch (tile_scale at their top): the
+    // last of THEM clears the slots (every block counting on one address cost 30 us: 1088 serialised atomics); with no reader
+    // at all the first leftover block does it.
+    const int nread = min(L.cnts[C_NTILES], nbk);
+    const bool reader = (int)blockIdx.x < nread, lone = nread == 0 && (int)blockIdx.x == nbk;
+    if (!reader && !lone) return;
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        last = atomicAdd(done, 1u) == gridDim.x - 1;
+        last = lone || atomicAdd(done, 1u) == (unsigned)nread - 1u;
     }
     __syncthreads();
     if (last) {
@@ -1104,7 +1131,7 @@ bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, fl
     {                                                                                                                             \
         if (fast) paint3_tile_kernel<HH, false, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
         else paint3_tile_kernel<HH, false, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
-        paint3_tile_kernel<HH, true, 1024, 4><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, p->fx_redo, 0); \
+        paint3_tile_kernel<HH, true, 1024, 4><<<nb < 256u ? nb : 256u, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, p->fx_redo, 0); \
     }
         DISPATCH_H(p->halo, CALLFX)
 #undef CALLFX

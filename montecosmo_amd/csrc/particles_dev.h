@@ -16,6 +16,27 @@ __device__ __forceinline__ void store3(float *__restrict__ p, int64_t i, P3 v) {
 // the force mesh it gathers from once): they then do not evict the lines the gathers are re-using.  The builtin nontemporal
 // store has no 96-bit form, hence the instruction itself.
 typedef float mcpm_f3v __attribute__((ext_vector_type(3)));
+// two / four 12-byte streaming loads issued together (one wait): a particle kernel's first loads
+__device__ __forceinline__ void load3_nt2(const float *a, const float *b, int64_t i, P3 &A, P3 &B) {
+    mcpm_f3v va, vb;
+    const float *qa = a + 3 * i, *qb = b + 3 * i;
+    asm volatile("global_load_dwordx3 %0, %2, off nt\n\tglobal_load_dwordx3 %1, %3, off nt\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(va), "=&v"(vb) : "v"(qa), "v"(qb) : "memory");
+    A = P3{va.x, va.y, va.z};
+    B = P3{vb.x, vb.y, vb.z};
+}
+__device__ __forceinline__ void load3_nt4(const float *a, const float *b, const float *c, const float *d, int64_t i, P3 &A, P3 &B, P3 &Cc,
+                                          P3 &D) {
+    mcpm_f3v va, vb, vc, vd;
+    const float *qa = a + 3 * i, *qb = b + 3 * i, *qc = c + 3 * i, *qd = d + 3 * i;
+    asm volatile("global_load_dwordx3 %0, %4, off nt\n\tglobal_load_dwordx3 %1, %5, off nt\n\tglobal_load_dwordx3 %2, %6, off nt\n\t"
+                 "global_load_dwordx3 %3, %7, off nt\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(va), "=&v"(vb), "=&v"(vc), "=&v"(vd) : "v"(qa), "v"(qb), "v"(qc), "v"(qd) : "memory");
+    A = P3{va.x, va.y, va.z};
+    B = P3{vb.x, vb.y, vb.z};
+    Cc = P3{vc.x, vc.y, vc.z};
+    D = P3{vd.x, vd.y, vd.z};
+}
 // 12-byte streaming load: for a kernel's FIRST load of a particle (nothing else of the wave is in flight: the wait is exact)
 __device__ __forceinline__ P3 load3_nt(const float *p, int64_t i) {
     mcpm_f3v v;
@@ -26,7 +47,10 @@ __device__ __forceinline__ P3 load3_nt(const float *p, int64_t i) {
 __device__ __forceinline__ void store3_nt(float *p, int64_t i, float a, float b, float c) {
     const mcpm_f3v v = {a, b, c};
     float *q = p + 3 * i;
-    asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(q), "v"(v) : "memory");
+    // s_nop: a store of more than 8 bytes reads its data registers a cycle or two after issue, and the compiler's hazard
+    // recognizer, which keeps VALU writes away from them, cannot see into inline asm (without it a few cells in ten thousand
+    // received whatever the next instructions had put into those registers)
+    asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 2" : : "v"(q), "v"(v) : "memory");
 }
 
 // Python-style modulo for |c| < 2^16, n < 2^15.

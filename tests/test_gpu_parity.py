@@ -109,12 +109,12 @@ def test_paint_read_edge_cases(nb, order):
 
 
 def expected_bucketed(disp, n, H, centre=True):
-    """paint_tiled.hip restated in numpy: window offsets o_T = clip(rint(mean displacement of the 4x4x4 sub-grid of lattice
-    block T), +-8), and the number of (particle, tile) pairs whose lattice point lies outside the window
+    """paint_tiled.hip restated in numpy: window offsets o_T = clip(rint(mean displacement of four z rows -- (x, y) = (4, 4), (4, 12),
+    (12, 4), (12, 12) -- of lattice block T), +-8), and the number of (particle, tile) pairs whose lattice point lies outside the window
     T - o_T - (H+1) ... T - o_T + 15 + H of a tile T the particle's CIC stencil touches."""
     from itertools import product
     nt = n // 16
-    d = disp.reshape(nt, 16, nt, 16, nt, 16, 3)[:, 2::4, :, 2::4, :, 2::4, :].astype(np.float64)
+    d = disp.reshape(nt, 16, nt, 16, nt, 16, 3)[:, 4::8, :, 4::8, :, :, :].astype(np.float64)
     off = np.clip(np.rint(d.mean(axis=(1, 3, 5))), -8, 8).astype(int) if centre else np.zeros((nt, nt, nt, 3), int)
     fl = np.floor(disp).astype(int)
     q = np.indices((n, n, n)).reshape(3, -1).T
