@@ -430,7 +430,7 @@ int mcpm_pm_forces_f32(mcpm_plan *p, const float *pos, int64_t n, int mode, int 
     if (!paint_deconv && lap_fd == MCPM_FD_INF && grad_fd == MCPM_FD_INF && kcut <= 0.f) {
         if (step_layout(p)) {   // interleaved force mesh: one 12-byte gather per stencil corner
             static const int nt = [] { const char *e = getenv("MCPM_NT3"); return e ? atoi(e) : 1; }();
-            MCPM_TRY(mcpm_fftpm_force_meshes(p, p->rho, p->fmesh, 1, nt == 1 || nt == 2));
+            MCPM_TRY(mcpm_fftpm_force_meshes(p, p->rho, p->fmesh, 1, (nt == 1 || nt == 2) && p->M >= ((int64_t)1 << 23)));
             return mcpm_read3_il(p, pos, n, mode, p->fmesh, order, forces);
         }
         MCPM_TRY(mcpm_force_meshes_f32(p, p->rho, p->fmesh));
@@ -650,7 +650,8 @@ static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float
         }
     }
     unsigned *fb_max = (fb_next && p->paint3_variant == 4) ? p->fx_wmax : nullptr;
-    static const int ntp = [] { const char *e = getenv("MCPM_NT_PART"); return e ? atoi(e) : 3; }();     // streaming loads / stores: 2.80 -> 2.62 ms at 512^3
+    static const int ntp_env = [] { const char *e = getenv("MCPM_NT_PART"); return e ? atoi(e) : 3; }();     // streaming loads / stores: 2.80 -> 2.62 ms at 512^3
+    const int ntp = N < ((int64_t)1 << 23) ? 0 : ntp_env;      // not for problems that live in the caches
     double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);   // zero on entry (reduce_slots_kernel leaves them so)
 #define ADJ(OR)                                                                                                                   \
     if (layout) step_adjoint_kernel<OR, true><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \

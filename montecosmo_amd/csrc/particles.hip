@@ -735,9 +735,10 @@ int mcpm_read3_il(mcpm_plan *p, const float *pos, int64_t n, int mode, const flo
     if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
     static const bool nt = [] { const char *e = getenv("MCPM_NT3"); const int v = e ? atoi(e) : 1; return v == 1 || v == 3; }();   // streaming output (A/B knob)
     static const bool ntin = [] { const char *e = getenv("MCPM_NT_POS"); return e ? atoi(e) != 0 : true; }();    // streaming position loads
+    const bool big = n >= ((int64_t)1 << 23);      // streaming hints only when the arrays do not fit the caches anyway
 #define CALL(MO, OR)                                                                                  \
-    if (nt && ntin) read3_il_kernel<MO, OR, true, true><<<grid, block, 0, p->stream>>>(p->g, pos, n, fm_il, out);  \
-    else if (nt) read3_il_kernel<MO, OR, true><<<grid, block, 0, p->stream>>>(p->g, pos, n, fm_il, out);  \
+    if (nt && ntin && big) read3_il_kernel<MO, OR, true, true><<<grid, block, 0, p->stream>>>(p->g, pos, n, fm_il, out);  \
+    else if (nt && big) read3_il_kernel<MO, OR, true><<<grid, block, 0, p->stream>>>(p->g, pos, n, fm_il, out);  \
     else read3_il_kernel<MO, OR><<<grid, block, 0, p->stream>>>(p->g, pos, n, fm_il, out)
     DISPATCH_MODE_ORDER(mode, order, CALL);
 #undef CALL
@@ -756,7 +757,8 @@ int mcpm_kick_drift_layout(mcpm_plan *p, const float *pos_in, const float *vel_i
     dim3 grid, block;
     if (mode == MCPM_POS_LATTICE) lattice_launch(p->g, grid, block); else flat_launch(n, grid, block);
     static const int ntp_env = [] { const char *e = getenv("MCPM_NT_PART"); return e ? atoi(e) : 3; }();   // streaming loads (1) and stores (2): step 11.95 -> 11.6 ms at 512^3
-    const int ntp = (pos_in == pos_out || vel_in == vel_out) ? 0 : ntp_env;     // in-place updates keep ordinary accesses
+    // in-place updates keep ordinary accesses; so do small problems, whose arrays live in the caches (128^3: hints cost 1-10 %)
+    const int ntp = (pos_in == pos_out || vel_in == vel_out || n < ((int64_t)1 << 23)) ? 0 : ntp_env;
 #define CALL(MO, OR)                                                                                                             \
     if (layout) kick_drift_kernel<MO, OR, true><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, n, meshes3, p->M, alpha, beta, dt, pos_out, vel_out, p->dmax, ntp); \
     else kick_drift_kernel<MO, OR, false><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, n, meshes3, p->M, alpha, beta, dt, pos_out, vel_out, p->dmax, ntp)
