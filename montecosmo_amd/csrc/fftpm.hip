@@ -695,7 +695,7 @@ static XLayout xlayout(const mcpm_plan *p) {
 // ms).  Knobs: MCPM_XCOL_LINES, MCPM_YCOL_LINES = 8 | 16 (MCPM_COL_LINES sets both).
 static int col_lines(const char *name, int dflt) {
     const char *e = getenv(name);
-    if (!e) e = getenv("MCPM_COL_LINES");
+    if (!e && dflt) e = getenv("MCPM_COL_LINES");
     const int v = e ? atoi(e) : dflt;
     return (v == 8 || v == 16) ? v : dflt;
 }
@@ -772,8 +772,13 @@ static int x_fused(mcpm_plan *p, const cf *in, cf *out, int mode) {
         if (mode == 0) xfused_kernel<NN, 0, ML><<<grid, TH, xf_lds_pad(), p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]); \
         else xfused_kernel<NN, 1, ML><<<grid, TH, xf_lds_pad(), p->stream>>>(g, in, out, xl, scale, (const cf *)p->tw[0]);           \
     }
+    // columns per workgroup: 8 at N >= 512 (above) and below it too -- with 16 the 2 -> 1 (adjoint) form takes 146 VGPRs at
+    // N = 256 (three waves per SIMD: 89 us at 256^3 against 61-67 us with 8) and the 1 -> 2 form 128 (56-60 vs 51 us).
+    // MCPM_XCOL_LINES_SMALL=16: round 2's choice.
+    static const int small_lines = col_lines("MCPM_XCOL_LINES_SMALL", 0);
+    const int lines_small = small_lines ? small_lines : 8;
 #define CALL(NN)                                                                                              \
-    if (col_lines_x() == 8 && NN >= 512) CALLL(NN, 8) else CALLL(NN, 16)
+    if ((NN >= 512 ? col_lines_x() : lines_small) == 8) CALLL(NN, 8) else CALLL(NN, 16)
     DISPATCH_N(g.nx, CALL)
 #undef CALL
 #undef CALLL

@@ -853,9 +853,14 @@ def _dptr(x):
     return x.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def save_y(t, y, args=None):
+    """diffrax's default SaveAt function (nbody.py:964, `fn=save_y`): the state itself."""
+    return y
+
+
 def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 2, lpt_order: int = 2,
-             paint_deconv=False, grad_fd=np.inf, lap_fd=np.inf, snapshots=None, fn=None,
-             integrator="bullfrog", return_ctx=False, lattice_out=False):    # fn=None is the reference's default fn=save_y
+             paint_deconv=False, grad_fd=np.inf, lap_fd=np.inf, snapshots=None, fn=save_y,
+             integrator="bullfrog", return_ctx=False, lattice_out=False):    # signature and defaults of nbody.py:967-969 (+ three keyword extras)
     """N-body simulation with the BullFrog solver (nbody.py:967-1002).
 
     `pos` must be the regular lattice (`bricks.regular_pos(mesh_shape, ptcl_shape)`, as at model.py:738) given
@@ -931,11 +936,6 @@ def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 
                        integrator=integrator)
         return out, ctx
     return out
-
-
-def save_y(t, y, args=None):
-    """diffrax's default SaveAt function (nbody.py:964, `fn=save_y`): the state itself."""
-    return y
 
 
 def _apply_fn(fn, out, lattice_out):
