@@ -737,8 +737,10 @@ static int y_columns2(mcpm_plan *p, const cf *in, cf *out, bool expand, bool in_
         if (expand) ycol2_kernel<NN, true, ML><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1], parts);  \
         else ycol2_kernel<NN, false, ML><<<grid, TH, 0, p->stream>>>(g, in, out, li, lo, (const cf *)p->tw[1], parts);        \
     }
+    static const int ysmall = col_lines("MCPM_YCOL_LINES_SMALL", 0);
+    const int ylines_small = ysmall ? ysmall : 16;
 #define CALL(NN)                                                                                       \
-    if (col_lines_y() == 8 && NN >= 512) CALLL(NN, 8) else CALLL(NN, 16)
+    if ((NN >= 512 ? col_lines_y() : ylines_small) == 8) CALLL(NN, 8) else CALLL(NN, 16)
     DISPATCH_N(g.ny, CALL)
 #undef CALL
 #undef CALLL
