@@ -127,6 +127,38 @@ __global__ __launch_bounds__(256) void lattice_dot_kernel(Geom g, const float *_
     block_add2(ra, rb, a ? slots + slot : nullptr, b ? slots + MCPM_NSLOT + slot : nullptr);
 }
 
+// Sums of three per-lane values over the 256-thread workgroup (waves in f32 -- the lane values are f32 products already --,
+// the four waves and everything beyond in f64), added to three spread slots; optionally the workgroup maximum of |a|, |b|, |c|
+// (see absmax_commit).  One barrier.
+__device__ __forceinline__ void block_add3_max(float a, float b, float c, double *s0, double *s1, double *s2, float ma, float mb, float mc,
+                                               unsigned *__restrict__ out_max) {
+    __shared__ double sh[3][4];
+    __shared__ unsigned shm[4];
+    const float ta = wave_sum_dpp(a), tb = wave_sum_dpp(b), tc = wave_sum_dpp(c);
+    unsigned m = 0u;
+    if (out_max) m = wave_umax_dpp(max(max(__float_as_uint(ma) & 0x7fffffffu, __float_as_uint(mb) & 0x7fffffffu), __float_as_uint(mc) & 0x7fffffffu));
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) {
+        sh[0][w] = (double)ta;
+        sh[1][w] = (double)tb;
+        sh[2][w] = (double)tc;
+        shm[w] = m;
+    }
+    __syncthreads();
+    const int nw = (blockDim.x + 63) >> 6;      // 1 .. 4 waves (lattice rows shorter than 256 run smaller workgroups)
+    if (threadIdx.x < 3) {
+        double t = 0.;
+        for (int i = 0; i < nw; ++i) t += sh[threadIdx.x][i];
+        double *dst = threadIdx.x == 0 ? s0 : (threadIdx.x == 1 ? s1 : s2);
+        if (t != 0.) atomicAdd(dst, t);
+    } else if (threadIdx.x == 3 && out_max) {
+        unsigned mm = 0u;
+        for (int i = 0; i < nw; ++i) mm = max(mm, shm[i]);
+        unsigned *slot = out_max + (blockIdx.x & (MCPM_FX_SLOTS - 1)) * MCPM_FX_STRIDE;
+        if (mm > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mm);
+    }
+}
+
 // Adjoint of one fused step (see file header).  Inputs: x'_i, v_i (checkpoint), cotangents xb, vb of
 // (x'_{i+1}, v_{i+1}) (updated in place to those of (x'_i, v_i)), the step's three force meshes and
 // rho_bar = cotangent of the painted density.
@@ -157,7 +189,7 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
                                                            double *slots, float *__restrict__ fb_next, float beta_next,
                                                            float tau_next, float dtau_ddg, unsigned *__restrict__ fb_max, int nt) {
     PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
-    double ra = 0., rb = 0., rc = 0.;
+    float ra = 0.f, rb = 0.f, rc = 0.f;
     P3 fbn = {0.f, 0.f, 0.f};
     if (pi.valid) {
         P3 d, vi, xbi, vbi;
@@ -190,11 +222,11 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
             xbi.y += gy;
             xbi.z += gz;
         }
-        ra = (double)(vt.x * vi.x + vt.y * vi.y + vt.z * vi.z);
-        rb = (double)(vt.x * F[0] + vt.y * F[1] + vt.z * F[2]);
+        ra = vt.x * vi.x + vt.y * vi.y + vt.z * vi.z;
+        rb = vt.x * F[0] + vt.y * F[1] + vt.z * F[2];
         {   // explicit dependence of the drift x' += v_new tau on the step size: <x_bar_in, v_new> dtau/ddg
             const float vnx = alpha * vi.x + beta * F[0], vny = alpha * vi.y + beta * F[1], vnz = alpha * vi.z + beta * F[2];
-            rc = (double)(dtau_ddg * (xin.x * vnx + xin.y * vny + xin.z * vnz));
+            rc = dtau_ddg * (xin.x * vnx + xin.y * vny + xin.z * vnz);
         }
         const P3 vnew = {alpha * vt.x, alpha * vt.y, alpha * vt.z};
         if (nt & 2) {
@@ -211,11 +243,8 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
             else store3(fb_next, pi.i, fbn);
         }
     }
-    if (fb_max) absmax_commit(fbn.x, fbn.y, fbn.z, fb_max);
     const int slot = blockIdx.x % MCPM_NSLOT;
-    block_add2(ra, rb, slots + slot, slots + MCPM_NSLOT + slot);
-    __syncthreads();
-    block_add2(rc, 0., slots + 2 * MCPM_NSLOT + slot, nullptr);
+    block_add3_max(ra, rb, rc, slots + slot, slots + MCPM_NSLOT + slot, slots + 2 * MCPM_NSLOT + slot, fbn.x, fbn.y, fbn.z, fb_max);
 }
 
 // *out += scale * sum_i a[i] b[i]  (a few thousand blocks: spread atomics are not needed)

@@ -378,12 +378,8 @@ __global__ __launch_bounds__(256) void axpy_kernel(const float *__restrict__ x, 
     if (i < n) out[i] = a * x[i] + b * y[i];
 }
 
-// maximum over the wave (call with every lane active)
-__device__ __forceinline__ unsigned wave_umax(unsigned m) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    return m;
-}
+// maximum over the wave, valid in lane 63 (call with every lane active)
+__device__ __forceinline__ unsigned wave_umax(unsigned m) { return wave_umax_dpp(m); }
 
 template <int MODE, int ORDER, bool IL>
 __global__ __launch_bounds__(256) void kick_drift_kernel(Geom g, const float *__restrict__ pos_in,
@@ -420,7 +416,7 @@ __global__ __launch_bounds__(256) void kick_drift_kernel(Geom g, const float *__
     if (dmax) {   // max |x displacement| of the new positions (slab plans: the ghost depth the next step needs); every lane
                   // of the wave is active again here; one L2-coherent read per wave, an atomic only while the slot is smaller
         const unsigned m = wave_umax(mbits);
-        if ((threadIdx.x & 63) == 0) {
+        if ((threadIdx.x & 63) == 63) {
             unsigned *slot = dmax + (blockIdx.x & (MCPM_FX_SLOTS - 1)) * MCPM_FX_STRIDE;
             if (m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
         }

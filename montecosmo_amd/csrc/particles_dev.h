@@ -389,3 +389,28 @@ __device__ __forceinline__ void interp3(const float *__restrict__ m, int64_t M, 
             }
         }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Wave reductions by DPP (row shifts within 16-lane rows, then row_bcast:15 / :31): 6 VALU instructions per value where the
+// __shfl-based versions are 12 ds_bpermute (doubles) through the LDS crossbar -- the adjoint particle kernel issued 42 of them
+// per wave next to its 30 vector-memory instructions.  Every lane of the wave must be active; the result is in lane 63.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xf, true); }
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __int_as_float(dpp_i<0x111, 0xf>(__float_as_int(v)));   // row_shr:1
+    v += __int_as_float(dpp_i<0x112, 0xf>(__float_as_int(v)));   // row_shr:2
+    v += __int_as_float(dpp_i<0x114, 0xf>(__float_as_int(v)));   // row_shr:4
+    v += __int_as_float(dpp_i<0x118, 0xf>(__float_as_int(v)));   // row_shr:8   -> lane 15 of every row holds the row's sum
+    v += __int_as_float(dpp_i<0x142, 0xa>(__float_as_int(v)));   // row_bcast:15 into rows 1 and 3
+    v += __int_as_float(dpp_i<0x143, 0xc>(__float_as_int(v)));   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return v;
+}
+__device__ __forceinline__ unsigned wave_umax_dpp(unsigned m) {
+    m = max(m, (unsigned)dpp_i<0x111, 0xf>((int)m));
+    m = max(m, (unsigned)dpp_i<0x112, 0xf>((int)m));
+    m = max(m, (unsigned)dpp_i<0x114, 0xf>((int)m));
+    m = max(m, (unsigned)dpp_i<0x118, 0xf>((int)m));
+    m = max(m, (unsigned)dpp_i<0x142, 0xa>((int)m));
+    m = max(m, (unsigned)dpp_i<0x143, 0xc>((int)m));
+    return m;
+}
