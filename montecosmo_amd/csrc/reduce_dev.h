@@ -7,9 +7,22 @@
 
 namespace {
 
+// Sum over the 64 lanes, valid in LANE 63, by DPP (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31 on the two halves of the double:
+// 18 VALU instructions) instead of __shfl_down, which is two ds_bpermute_b32 per step through the LDS crossbar (DESIGN finding
+// 27).  Every lane of the wave must be active.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_shift_d(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
+    return __hiloint2double(hi, lo);       // lanes without a source read +0.0
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    v += dpp_shift_d<0x111, 0xf>(v);
+    v += dpp_shift_d<0x112, 0xf>(v);
+    v += dpp_shift_d<0x114, 0xf>(v);
+    v += dpp_shift_d<0x118, 0xf>(v);
+    v += dpp_shift_d<0x142, 0xa>(v);
+    v += dpp_shift_d<0x143, 0xc>(v);
     return v;
 }
 
@@ -20,7 +33,7 @@ __device__ __forceinline__ void block_add(const double (&v)[K], double *slots) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const double s = wave_sum(v[k]);
-        if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = s;
+        if ((threadIdx.x & 63) == 63) sh[k][threadIdx.x >> 6] = s;
     }
     __syncthreads();
     if (threadIdx.x < K) {
@@ -34,7 +47,7 @@ __global__ __launch_bounds__(NSLOT) void fold_kernel(const double *__restrict__ 
     __shared__ double sh[NSLOT / 64];
     for (int k = 0; k < K; ++k) {
         const double s = wave_sum(slots[k * NSLOT + threadIdx.x]);
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+        if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = s;
         __syncthreads();
         if (threadIdx.x == 0) {
             double t = 0.;
