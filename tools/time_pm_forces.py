@@ -24,4 +24,12 @@ r.plan.call("mcpm_plan_profile", 0)
 st = {lib.mcpm_stage_name(i).decode(): round(ms[i] / 10, 4) for i in range(ns) if calls[i]}    # 10 calls profiled (5 x (1 warm + 1))
 M = float(n) ** 3
 med = statistics.median(ts)
+import hashlib
+r.force_cycle_ms(reps=1)
+torch.cuda.synchronize()
+digest = hashlib.sha1(r.xb.cpu().numpy().tobytes()).hexdigest()[:16]      # the forces of the last call: A/B runs of a knob must agree bit for bit
+print(f"forces sha1 {digest}")
+if os.environ.get("MCPM_DUMP"):
+    import numpy as np
+    np.save(os.environ["MCPM_DUMP"], r.xb.cpu().numpy())
 print(f"pm_forces {n}^3: batches {[round(t, 4) for t in ts]} ms, median {med:.4f} ms = {100 * M / (med * 1e-3) / 1e9 / 8000:.4f} of 8 TB/s; stages per call {st}", flush=True)
