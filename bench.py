@@ -567,6 +567,9 @@ def main():
             out["comm_and_host_ms_per_step"] = round(dt / K * 1e3 - step_ms, 3)   # wall minus rank-0 kernel stages
             out["deposits_beyond_ghost_rank0"] = r.pm.out_of_ghost()                # must be 0
             out["ghost_planes_exchanged_per_step"] = [int(d) for d in r.depths if d is not None]   # of --ghost allocated
+            pm = r.pm       # who issues the exchanges: the library (csrc/slab.hip) unless its transport failed its self-test
+            out["slab_transport"] = (("library, local copies" if world == 1 and not dist else "library, plan-owned RCCL communicator (self-test passed)")
+                                     if pm.native else f"torch.distributed ({pm.native_fallback or 'MCPM_SLAB_NATIVE=0'})")
             out["a2a_chunks"] = r.pm.chunks      # all-to-alls per transposed spectrum (dist.SlabPM chunks; MCPM_SLAB_CHUNKS)
         if world == 1 and not slab and not args.forward_only and not args.no_sub_record:
             # the metric names 256^3 as well: a second, smaller record in the same line, and the CPU baseline on ITS trajectory

@@ -113,6 +113,8 @@ SIGNATURES = {
     "mcpm_slab_comm_init_local": (C.c_int, [C.c_void_p]),
     "mcpm_slab_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mcpm_slab_comm_init_ops": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mcpm_slab_comm_selftest": (C.c_int, [C.c_void_p]),
+    "mcpm_slab_comm_shutdown": (C.c_int, [C.c_void_p]),
     "mcpm_slab_bind_workspace": (C.c_int, [C.c_void_p] + [_f32p] * 8),
     "mcpm_slab_step_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
     "mcpm_slab_step_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _f32p, _f32p,

@@ -512,6 +512,13 @@ int mcpm_slab_rccl_unique_id(void *id128) {
     return MCPM_OK;
 }
 
+int mcpm_slab_comm_shutdown(mcpm_plan *p) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_HIP(p, hipStreamSynchronize(p->stream));
+    mcpm_slab_state_free(p);
+    return MCPM_OK;
+}
+
 static SlabState *fresh_state(mcpm_plan *p) {
     if (p->slab_state) mcpm_slab_state_free(p);
     SlabState *s = new (std::nothrow) SlabState();
@@ -558,6 +565,90 @@ int mcpm_slab_comm_init_ops(mcpm_plan *p, const mcpm_comm_ops *ops) {
     s->ops = *ops;
     s->mode = MODE_OPS;
     return MCPM_OK;
+}
+
+// One small round of every exchange pattern a slab step uses, checked on the host: an equal-split all-to-all (the FFT transposes),
+// a send / receive with both x neighbours (the ghost planes) and the max all-reduce (the ghost depth).  A communicator that came up
+// but cannot move data between its peers -- the first contact of this code with a multi-GPU node is the driver's scaling run --
+// fails HERE, with a message, and the host can still choose the torch.distributed transport (dist.SlabPM); a failure inside the
+// first step could only abort the run.  Collective: every rank of the plan's communicator calls it.  Synchronises the stream.
+int mcpm_slab_comm_selftest(mcpm_plan *p) {
+    if (!p) return MCPM_E_ARG;
+    SlabState *s = state(p);
+    MCPM_REQUIRE(p, s && s->mode != MODE_NONE, MCPM_E_ARG, "mcpm_slab_comm_selftest: no transport (mcpm_slab_comm_init_*)");
+    const int P = p->nranks, r = p->rank, left = (r - 1 + P) % P, right = (r + 1) % P;
+    constexpr int W = 16;                                  // floats per block
+    const size_t nblk = (size_t)P + 2, bytes = nblk * W * sizeof(float);
+    std::vector<float> h(nblk * W), back(nblk * W, -1.f);
+    for (int q = 0; q < P; ++q)
+        for (int i = 0; i < W; ++i) h[(size_t)q * W + i] = (float)(1000 * r + 10 * q) + 0.25f * i;      // block q: from r to q
+    for (int i = 0; i < W; ++i) h[(size_t)P * W + i] = (float)(-1000 * r - 1) - 0.25f * i;              // to the left neighbour
+    for (int i = 0; i < W; ++i) h[(size_t)(P + 1) * W + i] = (float)(-1000 * r - 2) - 0.25f * i;        // to the right neighbour
+    float *src = nullptr, *dst = nullptr, *mx = nullptr;
+    MCPM_HIP(p, hipMalloc((void **)&src, bytes));
+    MCPM_HIP(p, hipMalloc((void **)&dst, bytes));
+    MCPM_HIP(p, hipMalloc((void **)&mx, sizeof(float)));
+    int rc = MCPM_OK;
+    auto run = [&]() -> int {
+        MCPM_HIP(p, hipMemcpyAsync(src, h.data(), bytes, hipMemcpyHostToDevice, p->stream));
+        MCPM_HIP(p, hipMemsetAsync(dst, 0xff, bytes, p->stream));
+        const float mine = (float)(r + 1);
+        MCPM_HIP(p, hipMemcpyAsync(mx, &mine, sizeof(float), hipMemcpyHostToDevice, p->stream));
+        int t0 = -1, t1 = -1;
+        {
+            Batch b;
+            for (int q = 0; q < P; ++q) b.send(src + (size_t)q * W, W * sizeof(float), q);
+            for (int q = 0; q < P; ++q) b.recv(dst + (size_t)q * W, W * sizeof(float), q);
+            b.a2a_in = src, b.a2a_out = dst, b.a2a_bytes = W * sizeof(float);
+            MCPM_TRY(xfer_begin(p, b, &t0));
+        }
+        {   // the order of halo_fill_begin: to left, to right; from right, from left
+            Batch b;
+            b.send(src + (size_t)P * W, W * sizeof(float), left);
+            b.send(src + (size_t)(P + 1) * W, W * sizeof(float), right);
+            b.recv(dst + (size_t)(P + 1) * W, W * sizeof(float), right);
+            b.recv(dst + (size_t)P * W, W * sizeof(float), left);
+            MCPM_TRY(xfer_begin(p, b, &t1));
+        }
+        MCPM_TRY(xfer_wait(p, t0));
+        MCPM_TRY(xfer_wait(p, t1));
+        if (s->mode == MODE_RCCL && P > 1) {
+            RcclApi *a = rccl_api();
+            const int t = s->next_ticket;
+            s->next_ticket = (t + 1) % NTICKETS;
+            MCPM_HIP(p, hipEventRecord(s->ready[t], p->stream));
+            MCPM_HIP(p, hipStreamWaitEvent(s->cs, s->ready[t], 0));
+            RCCL_TRY(p, a->AllReduce(mx, mx, 1, ncclFloat32, ncclMax, s->comm, s->cs));
+            MCPM_HIP(p, hipEventRecord(s->done[t], s->cs));
+            MCPM_HIP(p, hipStreamWaitEvent(p->stream, s->done[t], 0));
+        } else if (s->mode == MODE_OPS) {
+            if (s->ops.allreduce_max_f32(s->ops.ctx, mx, (void *)p->stream) != 0)
+                return mcpm_fail(p, MCPM_E_RCCL, "transport callback allreduce_max_f32 failed");
+        }
+        float got = 0.f;
+        MCPM_HIP(p, hipMemcpyAsync(back.data(), dst, bytes, hipMemcpyDeviceToHost, p->stream));
+        MCPM_HIP(p, hipMemcpyAsync(&got, mx, sizeof(float), hipMemcpyDeviceToHost, p->stream));
+        MCPM_HIP(p, hipStreamSynchronize(p->stream));
+        for (int q = 0; q < P; ++q)
+            for (int i = 0; i < W; ++i)
+                if (back[(size_t)q * W + i] != (float)(1000 * q + 10 * r) + 0.25f * i)
+                    return mcpm_fail(p, MCPM_E_RCCL, "transport self-test: all-to-all block from rank " + std::to_string(q) + " is wrong");
+        // what the left neighbour sent to ITS right (block P+1 of rank `left`) lands in my from-left block P, and vice versa
+        for (int i = 0; i < W; ++i) {
+            if (back[(size_t)P * W + i] != (float)(-1000 * left - 2) - 0.25f * i)
+                return mcpm_fail(p, MCPM_E_RCCL, "transport self-test: the block from the left neighbour is wrong");
+            if (back[(size_t)(P + 1) * W + i] != (float)(-1000 * right - 1) - 0.25f * i)
+                return mcpm_fail(p, MCPM_E_RCCL, "transport self-test: the block from the right neighbour is wrong");
+        }
+        if (got != (float)P) return mcpm_fail(p, MCPM_E_RCCL, "transport self-test: max all-reduce gave " + std::to_string(got));
+        return MCPM_OK;
+    };
+    rc = run();
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    (void)hipFree(mx);
+    return rc;
 }
 
 int mcpm_slab_bind_workspace(mcpm_plan *p, float *rho, float *f3, float *s1a, float *s1b, float *s6a, float *s6b, float *Fb,

@@ -424,13 +424,38 @@ class SlabPM(HaloMixin, PlaneHalo):
         # `native` (default: MCPM_SLAB_NATIVE, else on): step / step_vjp are ONE library call each (csrc/slab.hip issues the
         # kernels AND the exchanges, on a plan-owned RCCL communicator when the torch communicator is RCCL); off: the
         # exchanges are issued from here through torch.distributed, kernel by kernel (the reference both are tested against).
+        import os
+        asked = native is not None or "MCPM_SLAB_NATIVE" in os.environ
         if native is None:
-            import os
             native = os.environ.get("MCPM_SLAB_NATIVE", "1") != "0"
         self.native = bool(native)
+        self.native_fallback = None        # why the library's transport was given up for torch.distributed, if it was
         self._mq = []                      # sequence numbers of the library's pending ghost-depth measurements
         if self.native:
+            self._bring_up_native(strict=asked)
+
+    def _bring_up_native(self, strict):
+        """Communicator + one verified round of every exchange pattern (mcpm_slab_comm_selftest).  The ranks AGREE on the outcome:
+        if any of them could not bring the library's transport up, all keep the torch.distributed path (native=False) -- unless
+        the caller asked for the native path explicitly, in which case the error is raised."""
+        err = None
+        try:
             self._init_native_transport()
+            check(lib.mcpm_slab_comm_selftest(self.h), self.h, "mcpm_slab_comm_selftest")
+        except Exception as e:              # MCPM_E_RCCL, a missing librccl, a failing callback
+            if self._host_ops is not None and self._host_ops.error is not None:
+                e, self._host_ops.error = self._host_ops.error, None
+            err = e
+        bad = 0 if err is None else 1
+        if self.comm.world > 1:
+            bad = int(self.comm.all_reduce_max_float(float(bad)))
+        if not bad:
+            return
+        if strict:
+            raise err if err is not None else RuntimeError("another rank could not bring up the library's slab transport")
+        lib.mcpm_slab_comm_shutdown(self.h)
+        self.native = False
+        self.native_fallback = repr(err) if err is not None else "another rank's transport failed"
 
     def _init_native_transport(self):
         h, comm = self.h, self.comm
@@ -443,13 +468,15 @@ class SlabPM(HaloMixin, PlaneHalo):
             check(lib.mcpm_slab_comm_init_ops(h, C.byref(self._host_ops.struct)), h, "mcpm_slab_comm_init_ops")
         else:                                                   # RCCL: the plan gets its own communicator
             td = comm.td
-            idt = torch.zeros(128, dtype=torch.uint8)
-            if comm.rank == 0:
-                check(lib.mcpm_slab_rccl_unique_id(C.c_void_p(idt.data_ptr())), None, "mcpm_slab_rccl_unique_id")
+            idt = torch.zeros(129, dtype=torch.uint8)           # ncclUniqueId + "rank 0 has one" (a rank that raised before the
+            if comm.rank == 0:                                  # broadcast would leave the others waiting in it)
+                idt[128] = 1 if lib.mcpm_slab_rccl_unique_id(C.c_void_p(idt.data_ptr())) == 0 else 0
             dev_id = idt.to(self.device)                        # the group's backend moves device tensors
             src = td.get_global_rank(comm.group, 0) if comm.group is not None else 0
             td.broadcast(dev_id, src=src, group=comm.group)
             idt = dev_id.cpu()
+            if int(idt[128]) != 1:
+                raise RuntimeError("mcpm_slab_rccl_unique_id failed on rank 0 (librccl missing or unusable: MCPM_E_RCCL)")
             check(lib.mcpm_slab_comm_init_rccl(h, C.c_void_p(idt.data_ptr())), h, "mcpm_slab_comm_init_rccl")
         check(lib.mcpm_slab_bind_workspace(h, _p(self.rho), _p(self.f3), _p(self.s1a), _p(self.s1b), _p(self.s6a), _p(self.s6b),
                                            _p(self.Fb), _p(self._halo)), h, "mcpm_slab_bind_workspace")

@@ -248,3 +248,52 @@ def gpu_native_equal_worker(rank, world, port, out_dir, n, n_steps, backend="glo
         td.destroy_process_group()
     if rank == 0:
         json.dump({"ok": ok, "depths": a[4], "depths_native": b[4]}, open(os.path.join(out_dir, "result.json"), "w"))
+
+
+def gpu_native_fallback_worker(rank, world, port, out_dir, n, n_steps):
+    """The library's transport fails its self-test on ONE rank (mcpm_slab_comm_selftest patched to return MCPM_E_RCCL there):
+    every rank must give it up together and keep issuing the exchanges through torch.distributed, with results bitwise those
+    of a run that asked for that path; asking for the native path explicitly must raise instead."""
+    import json
+    import torch
+    torch.cuda.set_device(0)
+    td = _init(rank, world, port, "gloo")
+    from montecosmo_amd import bricks, dist, synth
+    real = dist.lib.mcpm_slab_comm_selftest
+    calls = []
+
+    class Patched:
+        def __getattr__(self, name):
+            if name == "mcpm_slab_comm_selftest":
+                def selftest(h):
+                    calls.append(1)
+                    rc = real(h)                       # the real one runs (it is collective) and passes ...
+                    return -5 if rank == world - 1 else rc     # ... but the last rank reports MCPM_E_RCCL
+                return selftest
+            return getattr(real_lib, name)
+
+    real_lib, dist.lib = dist.lib, Patched()
+    spec = synth.init_mesh(n, seed=3, rms_disp=2.0)
+    outs = []
+    try:
+        for native in (False, None):
+            (d, v), ctx = dist.nbody_bf_slab(bricks.Planck18(), spec, a0=0.1, a1=1.0, n_steps=n_steps, comm=dist.TorchComm(), ghost=8,
+                                             return_ctx=True, native=native)
+            outs.append((d.clone(), v.clone(), ctx.pm.native, ctx.pm.native_fallback))
+            del ctx
+        raised = False
+        try:
+            dist.SlabPM((n, n, n), dist.TorchComm(), 8, native=True)
+        except Exception:
+            raised = True
+    finally:
+        dist.lib = real_lib
+    a, b = outs
+    ok = torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] is False and b[2] is False and a[3] is None and b[3] is not None
+    ok = ok and raised and len(calls) == 2 and float(a[0].abs().max()) > 0.5
+    t = torch.tensor([float(ok)])
+    td.all_reduce(t, op=td.ReduceOp.MIN)
+    td.barrier()
+    td.destroy_process_group()
+    if rank == 0:
+        json.dump({"ok": bool(t.item() > 0), "reason": b[3]}, open(os.path.join(out_dir, "result.json"), "w"))

@@ -259,3 +259,16 @@ def test_native_slab_steps_equal_the_python_issued_path(gpu, world, backend, chu
     out = _spawn(gpu_native_equal_worker, world, 64, 3, backend, chunks)
     res = json.load(open(os.path.join(out, "result.json")))
     assert res["ok"], res
+
+
+@pytest.mark.gpu
+def test_failed_transport_self_test_falls_back_on_every_rank(gpu):
+    """`mcpm_slab_comm_selftest` runs once after the communicator comes up (an all-to-all, both neighbour exchanges, the max
+    all-reduce, verified on the host).  If ONE rank reports a failure, ALL ranks keep the torch.distributed path and the run goes
+    on, bitwise equal to a run that asked for that path; `native=True` raises instead.  (What the driver's first multi-GPU run
+    would otherwise meet inside its first step.)"""
+    from _dist_worker import gpu_native_fallback_worker
+    out = _spawn(gpu_native_fallback_worker, 2, 64, 2)
+    res = json.load(open(os.path.join(out, "result.json")))
+    assert res["ok"], res
+    assert "MCPM" in res["reason"] or "rank" in res["reason"], res
