@@ -61,11 +61,26 @@ __device__ __forceinline__ int cvt_rpi(float x) {   // floor(x + 0.5)
 }
 
 // Tile of this workgroup.  Blocks b, b+8, ... run on the same XCD (and share its 4 MB L2): each XCD works through one
-// contiguous run of tiles, z fastest (a pencil of tiles whose flushes and particle reads are contiguous in memory; compact
-// bricks of tiles per XCD measured 4-15 % slower).
-__device__ __forceinline__ void tile_of_block(int ntx, int nty, int ntz, int &tx, int &ty, int &tz) {
+// contiguous run of tiles -- a slab of ntx / 8 tile planes -- in pencils along z (flushes and particle reads contiguous in
+// memory; compact bricks of tiles per XCD measured 4-15 % slower).  ORDER of the pencils within the slab (MCPM_TILE_ORDER):
+// 0 = y fastest, then x: the ~128 tiles an XCD has in flight are four y-neighbouring pencils of ONE x plane, and the x halo
+// of every window (7 of 23 planes) is fetched again from HBM when the next plane's turn comes, 1024 tiles later;
+// 1 (default) = x fastest over the slab's planes, then y: the pencils in flight are x neighbours and share that halo in L2.
+// Counters at 512^3 (profiles/r03_tile_order.txt): the three-component paint fetches 5.27 instead of 6.75 GB per launch, the
+// density paint 2.97 / 2.89 GB (no change); neither kernel's time moves (they are bound by their LDS atomics).  Bricks of
+// 4 x 4 x 8 tiles in flight fetch MORE (7.44 / 3.43 GB).
+__device__ __forceinline__ void tile_of_block(int ntx, int nty, int ntz, int &tx, int &ty, int &tz, int order = 0) {
     const int nb = gridDim.x, b = blockIdx.x;
-    const int t = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+    const bool x8 = nb % 8 == 0;
+    const int t = x8 ? (b % 8) * (nb / 8) + b / 8 : b;
+    if (order == 1 && x8 && ntx % 8 == 0 && nb == ntx * nty * ntz) {
+        const int nxp = ntx / 8, k = b % 8, l = b / 8;       // planes per XCD slab, XCD, index within the run
+        tz = l % ntz;
+        const int r = l / ntz;
+        tx = k * nxp + r % nxp;
+        ty = r / nxp;
+        return;
+    }
     tz = t % ntz;
     const int tt = t / ntz;
     ty = tt % nty;
@@ -141,6 +156,7 @@ struct TileLists {
                        // shared list could be overrun while other threads still read suspects from it -- ADVICE r2)
     int listcap;
     int *cnts;
+    int order;         // order of the tile pencils within an XCD's slab (tile_of_block)
 };
 
 __device__ __forceinline__ void append_wild(const TileLists &L, int gi) {
@@ -365,7 +381,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
     }
     const int ntx = g.nx / B, nty = g.ny / B, ntz = g.nz / B;
     int tx, ty, tz;
-    tile_of_block(ntx, nty, ntz, tx, ty, tz);
+    tile_of_block(ntx, nty, ntz, tx, ty, tz, L.order);
     const int x0 = tx * B, y0 = ty * B, z0 = tz * B;
     for (int i = threadIdx.x; i < NT; i += THREADS) tile[i] = 0ull;
     if (threadIdx.x == 0) sus[MCPM_SUS] = 0;
@@ -699,7 +715,7 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
         ty = (redo_tile / ntz) % nty;
         tx = redo_tile / (ntz * nty);
     } else
-        tile_of_block(ntx, nty, ntz, tx, ty, tz);
+        tile_of_block(ntx, nty, ntz, tx, ty, tz, L.order);
     const int x0 = tx * B, y0 = ty * B, z0 = tz * B, tidx = (tx * nty + ty) * ntz + tz;
     int ox = 0, oy = 0, oz = 0;
     if (L.toff) unpack_off(L.toff[tidx], ox, oy, oz);
@@ -1049,8 +1065,13 @@ static bool tiled_fast(const mcpm_plan *p) {
     return on && !g.xslab && pow2(g.nx) && pow2(g.ny) && pow2(g.nz);
 }
 
+static int tile_order() {
+    static const int o = [] { const char *e = getenv("MCPM_TILE_ORDER"); return e ? atoi(e) : 1; }();
+    return o;
+}
+
 static TileLists tile_lists(const mcpm_plan *p) {
-    return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, p->outliers + p->Np, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count};
+    return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, p->outliers + p->Np, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count, tile_order()};
 }
 
 static void tiled_prologue(mcpm_plan *p, const float *pos, int *redo = nullptr) {
