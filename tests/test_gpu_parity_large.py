@@ -145,3 +145,47 @@ def test_config4_512_forward_parity_and_properties(nb):
     assert torch.equal(F1, F2)                                                              # order-independent sums
     net = F1.double().sum(0).abs().max().item()
     assert net < 1e-6 * float(F1.double().abs().sum(0).max()), net                          # momentum conservation
+
+
+def test_config4_512_adjoint_against_finite_differences(gpu):
+    """A gradient check AT the bench size (nothing checked one at 512^3): the hand-written reverse sweep's
+    cotangents of the step scalars alpha_i, beta_i (nbody.py:933-944 kick coefficients) against central finite differences of
+    the loss <x_bar, x'_K> + <v_bar, v_K> over the same 10-step trajectory, which bench.py times.  A scalar perturbation moves
+    every particle coherently, so the difference quotient stands far above the fp32 noise of a 1.3e8-particle sum; the
+    cotangent itself is a sum over all particles and all later steps of the chain paint3 -> FFT -> read, so a wrong adjoint of
+    any kernel at this size shows here.  Size-independent property; no oracle involved.  The loss is piecewise smooth (CIC cell
+    crossings), so the difference quotient approaches the cotangent linearly in the step: beta_1 2.1e-2, 1.3e-2, 8e-3, 3.4e-3,
+    1.6e-3 at relative steps 4e-3 ... 2e-4, then fp32 noise (1e-2 at 1e-4); late steps agree to 1e-4 .. 1e-3.  Step 5e-4."""
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n, K = 512, 10
+    dev = torch.device("cuda", 0)
+    r = bench.Runner(n, K, dev)
+
+    def loss():
+        r.forward(K)
+        return float((r.pos_bar.double() * r.states[K, 0].double()).sum() + (r.vel_bar.double() * r.states[K, 1].double()).sum())
+
+    l0 = loss()
+    r.backward(K)
+    torch.cuda.synchronize()
+    sb = r.sbar.cpu().numpy().copy()
+    abar, bbar = sb[:K], sb[K:2 * K]
+    assert np.all(np.isfinite(sb)) and np.abs(bbar).max() > 0
+    worst = 0.0
+    for name, arr, bar, idx in (("beta", r.betas, bbar, (1, 5, 8)), ("alpha", r.alphas, abar, (2, 7))):
+        for i in idx:
+            keep = float(arr[i])
+            eps = 5e-4 * abs(keep)
+            arr[i] = keep + eps
+            lp = loss()
+            arr[i] = keep - eps
+            lm = loss()
+            arr[i] = keep
+            fd = (lp - lm) / (2 * eps)
+            rel = abs(fd - bar[i]) / max(abs(bar[i]), 1e-30)
+            print(f"{name}[{i}] = {keep:.5f}: cotangent {bar[i]:.6e}, finite difference {fd:.6e}, rel {rel:.2e} (loss {l0:.6e})")
+            worst = max(worst, rel)
+    assert worst < 8e-3, worst
