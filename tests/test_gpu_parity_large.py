@@ -169,6 +169,7 @@ def test_config4_512_adjoint_against_finite_differences(gpu):
         return float((r.pos_bar.double() * r.states[K, 0].double()).sum() + (r.vel_bar.double() * r.states[K, 1].double()).sum())
 
     l0 = loss()
+    r.sbar.zero_()          # the adjoint steps add into their scalar cotangents
     r.backward(K)
     torch.cuda.synchronize()
     sb = r.sbar.cpu().numpy().copy()

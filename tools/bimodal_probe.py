@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 names, fwd, bwd = r.profile()
 ms = {nm: (fwd[0][i] + bwd[0][i]) / max(fwd[2][i] + bwd[2][i], 1) for i, nm in enumerate(names) if fwd[2][i] + bwd[2][i]}
 fm = C.POINTER(C.c_float)()
-addr = {"states": r.states.data_ptr(), "fmesh": r.fmesh.data_ptr(), "xb": r.xb.data_ptr(), "vb": r.vb.data_ptr(),
+addr = {"states": r._flat.data_ptr(), "fmesh": r.fmesh.data_ptr(), "xb": r.xb.data_ptr(), "vb": r.vb.data_ptr(),
         "pos_bar": r.pos_bar.data_ptr(), "spec": r.spec.data_ptr()}
 free, total = torch.cuda.mem_get_info()
 import subprocess, threading
