@@ -71,6 +71,15 @@ class _States:
         i, c = key
         return self.views[i][c]
 
+    def pair(self, i):
+        """(2, N, 3) copy of checkpoint i."""
+        return torch.stack([self.views[i][0], self.views[i][1]])
+
+    def zero_from(self, i0):
+        for x, v in self.views[i0:]:
+            x.zero_()
+            v.zero_()
+
 
 class Runner:
     """K forward steps + K adjoint steps through the step-level C ABI, on pre-allocated HBM buffers.
@@ -259,17 +268,27 @@ class SlabRunner:
         self.dg, self.alphas, self.betas, self.lpt_s = nbody._step_scalars(cosmo, 0.0, 1.0, K, "bullfrog")
         spec = torch.from_numpy(synth.init_mesh(n, seed=seed, rms_disp=2.0)).to(device)
         f32 = dict(dtype=torch.float32, device=device)
-        self.states = torch.empty((K + 1, 2, pm.Nl, 3), **f32)
+        # particle arrays: one flat buffer, array j shifted by j * 4352 bytes, so that the streams of a step kernel are not in
+        # phase in every low address bit (Runner's doc string; no per-process probe here: the ranks would have to agree on it)
+        stagger = int(os.environ.get("MCPM_BENCH_STAGGER", "4352"))
+        assert stagger % 16 == 0
+        pitch = 3 * pm.Nl + stagger // 4
+        self._flat = torch.empty((2 * (K + 1) + 4) * pitch, **f32)
+        arr = lambda j: self._flat[j * pitch: j * pitch + 3 * pm.Nl].view(pm.Nl, 3)
+        self.states = _States([(arr(2 * i), arr(2 * i + 1)) for i in range(K + 1)])
+        self.layout = {"stagger_bytes": stagger, "probed_ms_per_step": None}
         self.f3s = torch.zeros((K, pm.nxe, n, n, 3), **f32)          # interleaved force meshes per step
         # slab-decomposed LPT start (untimed set-up) + first half drift
         pm.lpt(spec, 2, self.lpt_s[0], self.lpt_s[1], self.lpt_s[2], self.states[0, 0], self.states[0, 1])
-        self.states[0, 0] += self.states[0, 1] * (self.dg / 2)
+        x0 = self.states[0, 0]
+        x0 += self.states[0, 1] * (self.dg / 2)
         del spec
         torch.cuda.empty_cache()
         rng = np.random.default_rng(1 + pm.rank + 1000 * seed)
-        self.pos_bar = torch.from_numpy(rng.standard_normal((pm.Nl, 3), dtype=np.float32)).to(device)
-        self.vel_bar = torch.from_numpy(rng.standard_normal((pm.Nl, 3), dtype=np.float32)).to(device)
-        self.xb, self.vb = torch.empty((pm.Nl, 3), **f32), torch.empty((pm.Nl, 3), **f32)
+        j = 2 * (K + 1)
+        self.pos_bar, self.vel_bar, self.xb, self.vb = arr(j), arr(j + 1), arr(j + 2), arr(j + 3)
+        self.pos_bar.copy_(torch.from_numpy(rng.standard_normal((pm.Nl, 3), dtype=np.float32)))
+        self.vel_bar.copy_(torch.from_numpy(rng.standard_normal((pm.Nl, 3), dtype=np.float32)))
         self.sbar = torch.zeros((2 * K + 1,), dtype=torch.float64, device=device)
         self.depths = [None] * K
 
@@ -632,7 +651,7 @@ def main():
             out["force_cycle"].update({"pm_forces_ms": round(pmf_ms, 4),
                                        "pm_forces_GBps": round(B_PER_CELL_CYCLE * M / (pmf_ms * 1e-3) / 1e9, 1),
                                        "pm_forces_frac_of_hbm_peak": round(B_PER_CELL_CYCLE * M / (pmf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
-        if not slab:
+        if True:
             out["layout"] = dict(r.layout, note="particle arrays in one flat buffer, array j shifted by j * stagger_bytes; None probed = fixed "
                                              "(MCPM_BENCH_STAGGER, a small mesh or forward only); probed: one untimed forward+adjoint block per candidate during set-up")
         if slab:

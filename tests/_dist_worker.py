@@ -184,18 +184,18 @@ def gpu_interleaved_worker(rank, world, port, out_dir, n, n_steps, backend="gloo
         with torch.cuda.stream(r.stream):
             r.run(n_steps)
         torch.cuda.synchronize()
-        solo.append((r.states[n_steps].clone(), r.xb.clone(), r.vb.clone(), r.sbar.clone()))
-        r.states[1:].zero_()
+        solo.append((r.states.pair(n_steps), r.xb.clone(), r.vb.clone(), r.sbar.clone()))
+        r.states.zero_from(1)
         r.sbar.zero_()
     bench.run_interleaved([a, b], n_steps)
     torch.cuda.synchronize()
     ok = True
     for r, (st, xb, vb, sb) in zip((a, b), solo):
-        ok = ok and torch.equal(r.states[n_steps], st) and torch.equal(r.xb, xb) and torch.equal(r.vb, vb)
+        ok = ok and torch.equal(r.states.pair(n_steps), st) and torch.equal(r.xb, xb) and torch.equal(r.vb, vb)
         ok = ok and bool(torch.isfinite(xb).all()) and float(xb.abs().max()) > 0
         # the scalar cotangents accumulate over calls (+=): after zeroing they must come back the same
         ok = ok and torch.allclose(r.sbar, sb, rtol=1e-12, atol=0)
-    differ = not torch.equal(a.states[n_steps], b.states[n_steps])       # two different trajectories, really
+    differ = not torch.equal(a.states.pair(n_steps), b.states.pair(n_steps))       # two different trajectories, really
     if td is not None:
         t = torch.tensor([float(ok and differ)])
         td.all_reduce(t, op=td.ReduceOp.MIN)
