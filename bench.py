@@ -189,14 +189,16 @@ class Runner:
 
     def backward(self, steps):
         K = self.K
-        self.xb.copy_(self.pos_bar)
-        self.vb.copy_(self.vel_bar)
         for i in reversed(range(steps)):
             tau = self.dg / 2 if i == K - 1 else self.dg
             if i > 0:   # chain: this step's particle kernel also writes the force cotangent of step i-1
                 self.plan.call("mcpm_plan_hint_next_adjoint", float(self.betas[i - 1]), float(self.dg))
-            self.plan.call("mcpm_bullfrog_step_vjp_f32", self.p(self.states[i, 0]), self.p(self.states[i, 1]),
+            # the first reverse step reads the loss cotangents where they are and writes the running ones (no copy of 24 N bytes
+            # per trajectory); the others update the running ones in place
+            first = i == steps - 1
+            self.plan.call("mcpm_bullfrog_step_vjp_from_f32", self.p(self.states[i, 0]), self.p(self.states[i, 1]),
                            self.p(self.fmesh[i]), float(self.alphas[i]), float(self.betas[i]), float(tau), 2,
+                           self.p(self.pos_bar if first else self.xb), self.p(self.vel_bar if first else self.vb),
                            self.p(self.xb), self.p(self.vb), C.c_void_p(self.sbar.data_ptr() + 8 * i),
                            C.c_void_p(self.sbar.data_ptr() + 8 * (K + i)), 0.5 if i == K - 1 else 1.0,
                            C.c_void_p(self.sbar.data_ptr() + 8 * 2 * K))

@@ -326,6 +326,14 @@ int mcpm_bullfrog_step_f32(mcpm_plan *plan, const float *pos_in, const float *ve
 int mcpm_bullfrog_step_vjp_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in, const float *force_meshes,
                                double alpha, double beta, double tau, int paint_order, float *pos_bar,
                                float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg, double *dg_bar);
+/* The same with the incoming cotangents read from (pos_bar_src, vel_bar_src) and the outgoing ones written to (pos_bar,
+   vel_bar): the first reverse step of a trajectory can take the loss cotangents where they are instead of a copy of them (the
+   cotangents of JAX's reverse sweep are fresh arrays at every step anyway: nbody.py:933-944 under jax.vjp).  src == out is the
+   in-place form above. */
+int mcpm_bullfrog_step_vjp_from_f32(mcpm_plan *plan, const float *pos_in, const float *vel_in, const float *force_meshes,
+                                    double alpha, double beta, double tau, int paint_order, const float *pos_bar_src,
+                                    const float *vel_bar_src, float *pos_bar, float *vel_bar, double *alpha_bar, double *beta_bar,
+                                    double dtau_ddg, double *dg_bar);
 /* Optional chaining of consecutive adjoint steps: call this before the adjoint of step i with beta and tau of step
    i-1; the particle kernel then also writes step i-1's force cotangent beta'(v_bar + tau' x_bar), and the next
    mcpm_bullfrog_step_vjp_f32 call skips its own pass over the cotangents IF it is given the same pos_bar / vel_bar

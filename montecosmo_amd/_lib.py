@@ -96,6 +96,7 @@ SIGNATURES = {
     "mcpm_stage_name": (C.c_char_p, [C.c_int]),
     "mcpm_bullfrog_step_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, _f32p]),
     "mcpm_bullfrog_step_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
+    "mcpm_bullfrog_step_vjp_from_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "mcpm_plan_hint_next_adjoint": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "mcpm_step_adjoint_particles_il_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "mcpm_step_adjoint_particles_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_double, C.c_double, C.c_double, C.c_int, _f32p, _f32p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),

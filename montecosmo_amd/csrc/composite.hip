@@ -183,7 +183,7 @@ __device__ __forceinline__ void absmax_commit(float a, float b, float c, unsigne
 
 template <int ORDER, bool IL>
 __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *__restrict__ x, const float *__restrict__ v,
-                                                           float *__restrict__ xb, float *__restrict__ vb,
+                                                           const float *xb_src, const float *vb_src, float *xb, float *vb,
                                                            const float *__restrict__ fm, const float *__restrict__ rho_bar,
                                                            int64_t M, float alpha, float beta, float tau,
                                                            double *slots, float *__restrict__ fb_next, float beta_next,
@@ -193,12 +193,12 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
     P3 fbn = {0.f, 0.f, 0.f};
     if (pi.valid) {
         P3 d, vi, xbi, vbi;
-        if (nt & 1) load3_nt4(x, v, xb, vb, pi.i, d, vi, xbi, vbi);      // streaming: each is read once by this kernel
+        if (nt & 1) load3_nt4(x, v, xb_src, vb_src, pi.i, d, vi, xbi, vbi);      // streaming: each is read once by this kernel
         else {
             d = load3(x, pi.i);
             vi = load3(v, pi.i);
-            xbi = load3(xb, pi.i);
-            vbi = load3(vb, pi.i);
+            xbi = load3(xb_src, pi.i);
+            vbi = load3(vb_src, pi.i);
         }
         const P3 xin = xbi;
         int c[3];
@@ -427,7 +427,8 @@ static int lpt_vjp_device(mcpm_plan *p, const float *init_mesh, int lpt_order, c
 
 static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes, int layout,
                                   const float *rho_bar, double alpha, double beta, double tau, int paint_order, float *pos_bar,
-                                  float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg, double *dg_bar);
+                                  float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg, double *dg_bar,
+                                  const float *pos_bar_src, const float *vel_bar_src);
 // force-mesh layout of the steppers' checkpoints: 1 = interleaved [cell][3] (hand-written Poisson solve), 0 = three meshes
 static inline int step_layout(const mcpm_plan *p) { return mcpm_fftpm_supported(p) ? 1 : 0; }
 
@@ -588,11 +589,13 @@ int mcpm_bullfrog_step_f32(mcpm_plan *p, const float *pos_in, const float *vel_i
     return MCPM_OK;
 }
 
-int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes,
-                               double alpha, double beta, double tau, int paint_order, float *pos_bar, float *vel_bar,
-                               double *alpha_bar, double *beta_bar, double dtau_ddg, double *dg_bar) {
+int mcpm_bullfrog_step_vjp_from_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes,
+                                    double alpha, double beta, double tau, int paint_order, const float *pos_bar_src,
+                                    const float *vel_bar_src, float *pos_bar, float *vel_bar, double *alpha_bar, double *beta_bar,
+                                    double dtau_ddg, double *dg_bar) {
     if (!p) return MCPM_E_ARG;
-    MCPM_REQUIRE(p, pos_in && vel_in && force_meshes && pos_bar && vel_bar, MCPM_E_ARG, "mcpm_bullfrog_step_vjp_f32: null buffer");
+    MCPM_REQUIRE(p, pos_in && vel_in && force_meshes && pos_bar && vel_bar && pos_bar_src && vel_bar_src, MCPM_E_ARG,
+                 "mcpm_bullfrog_step_vjp_f32: null buffer");
     MCPM_REQUIRE(p, paint_order >= 1 && paint_order <= 4, MCPM_E_ORDER, "mcpm_bullfrog_step_vjp_f32: paint_order must be 1..4");
     MCPM_TRY(ensure_pscratch(p));
     const int64_t N = p->Np;
@@ -600,14 +603,21 @@ int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *v
     const float b = (float)beta, t = (float)tau;
     // force cotangent F_bar = beta (v_bar + tau x_bar), scattered onto three meshes (adjoint of read); already written
     // by the previous call's particle kernel when the caller chained the steps (mcpm_plan_hint_next_adjoint)
-    if (!(p->fb_valid && p->fb_beta == b && p->fb_tau == t && p->fb_xb == pos_bar && p->fb_vb == vel_bar))
-        MCPM_TRY(axpby(p, vel_bar, pos_bar, 3 * N, b, b * t, Fb, true));
+    if (!(p->fb_valid && p->fb_beta == b && p->fb_tau == t && p->fb_xb == pos_bar_src && p->fb_vb == vel_bar_src))
+        MCPM_TRY(axpby(p, vel_bar_src, pos_bar_src, 3 * N, b, b * t, Fb, true));
     p->fb_valid = 0;
     MCPM_TRY(mcpm_paint3_f32(p, pos_in, N, MCPM_POS_LATTICE, Fb, paint_order, p->fmesh, 0));
     // adjoint of 3 C2R + k-space + R2C: rho_bar = C2R( (1/M) sum_c conj(m_c) R2C(f_bar_c) )
     MCPM_TRY(mcpm_force_meshes_vjp_f32(p, p->fmesh, p->rho));
     return step_adjoint_particles(p, pos_in, vel_in, force_meshes, step_layout(p), p->rho, alpha, beta, tau, paint_order, pos_bar,
-                                  vel_bar, alpha_bar, beta_bar, dtau_ddg, dg_bar);
+                                  vel_bar, alpha_bar, beta_bar, dtau_ddg, dg_bar, pos_bar_src, vel_bar_src);
+}
+
+int mcpm_bullfrog_step_vjp_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes,
+                               double alpha, double beta, double tau, int paint_order, float *pos_bar, float *vel_bar,
+                               double *alpha_bar, double *beta_bar, double dtau_ddg, double *dg_bar) {
+    return mcpm_bullfrog_step_vjp_from_f32(p, pos_in, vel_in, force_meshes, alpha, beta, tau, paint_order, pos_bar, vel_bar, pos_bar, vel_bar,
+                                           alpha_bar, beta_bar, dtau_ddg, dg_bar);
 }
 
 // The force cotangent F_bar = beta (v_bar + tau x_bar) of the NEXT adjoint step, if the previous
@@ -635,7 +645,7 @@ int mcpm_step_adjoint_particles_f32(mcpm_plan *p, const float *pos_in, const flo
                                     float *pos_bar, float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg,
                                     double *dg_bar) {
     return step_adjoint_particles(p, pos_in, vel_in, force_meshes, 0, rho_bar, alpha, beta, tau, paint_order, pos_bar, vel_bar,
-                                  alpha_bar, beta_bar, dtau_ddg, dg_bar);
+                                  alpha_bar, beta_bar, dtau_ddg, dg_bar, nullptr, nullptr);
 }
 
 }  // extern "C"
@@ -647,13 +657,17 @@ extern "C" int mcpm_step_adjoint_particles_il_f32(mcpm_plan *p, const float *pos
                                                   float *pos_bar, float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg,
                                                   double *dg_bar) {
     return step_adjoint_particles(p, pos_in, vel_in, force_mesh_il, 1, rho_bar, alpha, beta, tau, paint_order, pos_bar, vel_bar,
-                                  alpha_bar, beta_bar, dtau_ddg, dg_bar);
+                                  alpha_bar, beta_bar, dtau_ddg, dg_bar, nullptr, nullptr);
 }
 
+// pos_bar_src / vel_bar_src: where the incoming cotangents are read (NULL: pos_bar / vel_bar, in place)
 static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float *vel_in, const float *force_meshes, int layout,
                                   const float *rho_bar, double alpha, double beta, double tau, int paint_order, float *pos_bar,
-                                  float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg, double *dg_bar) {
+                                  float *vel_bar, double *alpha_bar, double *beta_bar, double dtau_ddg, double *dg_bar,
+                                  const float *pos_bar_src, const float *vel_bar_src) {
     if (!p) return MCPM_E_ARG;
+    if (!pos_bar_src) pos_bar_src = pos_bar;
+    if (!vel_bar_src) vel_bar_src = vel_bar;
     MCPM_REQUIRE(p, pos_in && vel_in && force_meshes && rho_bar && pos_bar && vel_bar, MCPM_E_ARG,
                  "mcpm_step_adjoint_particles_f32: null buffer");
     MCPM_REQUIRE(p, paint_order >= 1 && paint_order <= 4, MCPM_E_ORDER, "mcpm_step_adjoint_particles_f32: paint_order must be 1..4");
@@ -683,9 +697,9 @@ static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float
     const int ntp = N < ((int64_t)1 << 23) ? 0 : ntp_env;      // not for problems that live in the caches
     double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);   // zero on entry (reduce_slots_kernel leaves them so)
 #define ADJ(OR)                                                                                                                   \
-    if (layout) step_adjoint_kernel<OR, true><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
+    if (layout) step_adjoint_kernel<OR, true><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar_src, vel_bar_src, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
                                                            slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max, ntp);  \
-    else step_adjoint_kernel<OR, false><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
+    else step_adjoint_kernel<OR, false><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar_src, vel_bar_src, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
                                                            slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max, ntp)
     if (paint_order == 2) ADJ(2);
     else if (paint_order == 1) ADJ(1);

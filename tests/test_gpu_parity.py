@@ -780,3 +780,34 @@ def test_kaiser_bessel_paint_read_and_vjps(nb, order):
     pb_o, wb_o = o.nufft_vjp(posf.astype(np.float32).astype(np.float64), fshape, w64, sb.astype(np.complex128), order, 2, paint_shape=1.5,
                              kernel_type="kaiser_bessel")
     assert rel_l2(to_np(pb), pb_o) < 5e-5 and rel_l2(to_np(wb), wb_o) < 2e-5
+
+
+def test_adjoint_step_reading_its_cotangents_elsewhere_equals_the_in_place_form(gpu):
+    """`mcpm_bullfrog_step_vjp_from_f32` (incoming cotangents read from one pair of arrays, outgoing written to another) against
+    a copy followed by the in-place `mcpm_bullfrog_step_vjp_f32`: same kernels, same arithmetic -> bitwise equal cotangents and
+    scalar cotangents over a whole reverse sweep (bench.py uses the former for the first reverse step of every trajectory)."""
+    import ctypes as C
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    K = 4
+    r = bench.Runner(64, K, torch.device("cuda", 0))
+    r.forward(K)
+    r.sbar.zero_()
+    r.backward(K)                                  # first step out of place, the rest in place
+    torch.cuda.synchronize()
+    xb1, vb1, sb1 = r.xb.clone(), r.vb.clone(), r.sbar.clone()
+    assert bool(torch.isfinite(xb1).all()) and float(xb1.abs().max()) > 0 and not torch.equal(xb1, r.pos_bar)
+    r.sbar.zero_()
+    r.xb.copy_(r.pos_bar)
+    r.vb.copy_(r.vel_bar)
+    for i in reversed(range(K)):
+        tau = r.dg / 2 if i == K - 1 else r.dg
+        if i > 0:
+            r.plan.call("mcpm_plan_hint_next_adjoint", float(r.betas[i - 1]), float(r.dg))
+        r.plan.call("mcpm_bullfrog_step_vjp_f32", r.p(r.states[i, 0]), r.p(r.states[i, 1]), r.p(r.fmesh[i]), float(r.alphas[i]),
+                    float(r.betas[i]), float(tau), 2, r.p(r.xb), r.p(r.vb), C.c_void_p(r.sbar.data_ptr() + 8 * i),
+                    C.c_void_p(r.sbar.data_ptr() + 8 * (K + i)), 0.5 if i == K - 1 else 1.0, C.c_void_p(r.sbar.data_ptr() + 8 * 2 * K))
+    torch.cuda.synchronize()
+    assert torch.equal(r.xb, xb1) and torch.equal(r.vb, vb1) and torch.equal(r.sbar, sb1)
