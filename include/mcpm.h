@@ -80,6 +80,11 @@ int mcpm_plan_last_bucketed(mcpm_plan *plan, int64_t *count);
    displacement (default 1; 0 = on the tile itself, which needs halo 4 at the benchmark's 2-cell rms displacement). */
 int mcpm_plan_set_halo(mcpm_plan *plan, int halo);
 int mcpm_plan_set_centre(mcpm_plan *plan, int centre);
+/* Thread -> particle map of the lattice-mode particle kernels (read, kick+drift, adjoint step, ...): 1 (default where px, py are
+   even and pz is a multiple of 64; MCPM_LATTICE_PATCH=0 turns it off) = the four waves of a workgroup take a 2 x 2 (x, y) patch
+   of lattice rows, 64 consecutive z each, so that the mesh rows their CIC stencils share (9 instead of 16) are fetched into
+   the CU's L1 once; 0 = 256 consecutive z of one row.  A permutation of the work: results do not depend on it.  A/B knob. */
+int mcpm_plan_set_lattice_patch(mcpm_plan *plan, int on);
 /* Accumulator of the tiled three-component paint (mcpm_paint3_f32, the adjoint of the force read): 1 = fixed point
    (default: 32-bit fields in 64-bit integer LDS atomics, exact order-independent sums, overflow proven per tile by a
    bound field, flagged tiles repainted in f64; particles.hip), 0 = f64 tiles.  mcpm_plan_last_redo returns how many

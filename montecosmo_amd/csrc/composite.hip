@@ -283,12 +283,6 @@ __global__ void axpby_kernel(const float *__restrict__ x, const float *__restric
     if (out_max) absmax_commit(__uint_as_float(r), 0.f, 0.f, out_max);
 }
 
-static inline void lattice_launch(const Geom &g, dim3 &grid, dim3 &block) {
-    int bs = g.pz >= 256 ? 256 : ((g.pz + 63) / 64) * 64;
-    int cpr = (g.pz + bs - 1) / bs;
-    block = dim3(bs);
-    grid = dim3((unsigned)((int64_t)g.px * g.py * cpr));
-}
 
 // adjoint of the NGP lattice read: a plain store per cell on the identity lattice, fixed-point sums otherwise
 static int lattice_scatter(mcpm_plan *p, const float *xb, const float *vb, float a, float b, float *meshes3) {

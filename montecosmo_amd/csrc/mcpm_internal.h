@@ -45,6 +45,8 @@ struct Geom {
     int same_lattice; // px==nx && py==ny && pz==nz (unit lattice spacing)
     int xoff;         // slab mode: mesh plane of lattice plane 0 (= ghost width); 0 otherwise
     int xslab;        // slab mode: x is NOT periodic on this (ghost-extended) mesh
+    int patch;        // lattice-mode particle kernels: a 256-thread workgroup is four waves on a 2 x 2 (x, y) patch of lattice rows
+                      // (64 consecutive z each) instead of 256 consecutive z of one row (particles_dev.h::particle_index)
 };
 
 #define MCPM_FX_SLOTS 64

@@ -425,12 +425,6 @@ __global__ __launch_bounds__(256) void kick_drift_kernel(Geom g, const float *__
 
 // ------------------------------------------------------------------------------------------------
 // launch helpers
-static inline void lattice_launch(const Geom &g, dim3 &grid, dim3 &block) {
-    int bs = g.pz >= 256 ? 256 : ((g.pz + 63) / 64) * 64;
-    int cpr = (g.pz + bs - 1) / bs;
-    block = dim3(bs);
-    grid = dim3((unsigned)((int64_t)g.px * g.py * cpr));
-}
 static int fxg_prepare(mcpm_plan *p);
 static inline int fxg_q(int64_t deposits);
 static inline void flat_launch(int64_t n, dim3 &grid, dim3 &block) {

@@ -123,7 +123,26 @@ struct PIdx {
 template <int MODE>
 __device__ __forceinline__ PIdx particle_index(const Geom &g, int64_t n) {
     PIdx r;
-    if (MODE == MCPM_POS_LATTICE) {
+    if (MODE == MCPM_POS_LATTICE && g.patch) {
+        // A workgroup = four waves on a 2 x 2 (x, y) patch of lattice rows, 64 consecutive z each (lattice_launch: 256 threads).
+        // What bounds the CIC gathers is the mesh rows a wave pulls into the CU's L1 -- 4 (x, y) rows of ~900 bytes per wave; a
+        // second corner in a row already fetched is nearly free (tools/gather_pair_bench.hip) -- and the four waves of a patch
+        // touch 3 x 3 rows between them instead of 4 x 4.  Blocks b, b+8, ... share an XCD: each XCD gets a contiguous run of
+        // virtual blocks, in which four consecutive x pairs (8 planes) of one (y pair, z chunk) come first (rows re-read from L2).
+        const unsigned nb = gridDim.x, b = blockIdx.x;
+        const unsigned vb = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+        const unsigned nxp = g.px >> 1, nyp = g.py >> 1, nzc = g.pz >> 6;
+        const unsigned XB = (nxp % 4 == 0) ? 4 : 1;
+        const unsigned xi = vb % XB, r1 = vb / XB;
+        const unsigned zc = r1 % nzc, r2 = r1 / nzc;
+        const unsigned yp = r2 % nyp, xp = (r2 / nyp) * XB + xi;
+        const unsigned w = threadIdx.x >> 6;
+        r.ipx = 2 * xp + (w & 1);
+        r.ipy = 2 * yp + (w >> 1);
+        r.ipz = zc * 64 + (threadIdx.x & 63);
+        r.valid = true;
+        r.i = ((int64_t)r.ipx * g.py + r.ipy) * g.pz + r.ipz;
+    } else if (MODE == MCPM_POS_LATTICE) {
         // Block -> (lattice row, z chunk).  Two locality remaps, speed only:
         //  * blocks b, b+8, ... share an XCD (and its L2): give each XCD a contiguous run of virtual blocks;
         //  * within the run, 8 consecutive x planes of one (y, z chunk) come first, so that the mesh rows a
@@ -145,6 +164,19 @@ __device__ __forceinline__ PIdx particle_index(const Geom &g, int64_t n) {
         r.valid = r.i < n;
     }
     return r;
+}
+
+// Launch shape of the lattice-mode kernels (host side of particle_index)
+static inline void lattice_launch(const Geom &g, dim3 &grid, dim3 &block) {
+    if (g.patch) {
+        block = dim3(256);
+        grid = dim3((unsigned)((int64_t)(g.px / 2) * (g.py / 2) * (g.pz / 64)));
+        return;
+    }
+    int bs = g.pz >= 256 ? 256 : ((g.pz + 63) / 64) * 64;
+    int cpr = (g.pz + bs - 1) / bs;
+    block = dim3(bs);
+    grid = dim3((unsigned)((int64_t)g.px * g.py * cpr));
 }
 
 // Base cell + fractions of one particle.

@@ -83,7 +83,11 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     if ((int64_t)px * py * pz >= (int64_t)1 << 31) return mcpm_fail(nullptr, MCPM_E_SHAPE, "more than 2^31 particles per plan");
     mcpm_plan *p = new (std::nothrow) mcpm_plan();
     if (!p) return mcpm_fail(nullptr, MCPM_E_NOMEM, "host allocation");
-    p->g = Geom{nx, ny, nz, px, py, pz, nz / 2 + 1, ((slab || px == nx) && py == ny && pz == nz) ? 1 : 0, slab ? ghost : 0, slab ? 1 : 0};
+    p->g = Geom{nx, ny, nz, px, py, pz, nz / 2 + 1, ((slab || px == nx) && py == ny && pz == nz) ? 1 : 0, slab ? ghost : 0, slab ? 1 : 0, 0};
+    {   // see mcpm_plan_set_lattice_patch
+        const char *e = getenv("MCPM_LATTICE_PATCH");
+        p->g.patch = (px % 2 == 0 && py % 2 == 0 && pz % 64 == 0 && !(e && atoi(e) == 0)) ? 1 : 0;
+    }
     p->nranks = nranks;
     p->rank = rank;
     p->ghost = ghost;
@@ -207,6 +211,14 @@ int mcpm_plan_set_halo(mcpm_plan *p, int halo) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, halo == 1 || halo == 2 || halo == 3 || halo == 4 || halo == 6, MCPM_E_ARG, "halo must be 1, 2, 3, 4 or 6");
     p->halo = halo;
+    return MCPM_OK;
+}
+
+int mcpm_plan_set_lattice_patch(mcpm_plan *p, int on) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, !on || (p->g.px % 2 == 0 && p->g.py % 2 == 0 && p->g.pz % 64 == 0), MCPM_E_SHAPE,
+                 "mcpm_plan_set_lattice_patch: needs an even px, py and pz a multiple of 64");
+    p->g.patch = on ? 1 : 0;
     return MCPM_OK;
 }
 
