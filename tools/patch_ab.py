@@ -8,6 +8,7 @@ import bench
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+MODES = tuple(int(c) for c in (sys.argv[3] if len(sys.argv) > 3 else "01"))
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 r = bench.Runner(n, 10, dev, stagger=4352 if n >= 256 else 0)
@@ -16,7 +17,7 @@ torch.cuda.synchronize()
 keys = ("kick_drift", "step_adjoint", "read", "paint", "paint3")
 digest = {}
 for rd in range(rounds):
-    for on in (0, 1):
+    for on in MODES:
         r.plan.call("mcpm_plan_set_lattice_patch", on)
         r.run(10)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,4 +37,4 @@ for rd in range(rounds):
         torch.cuda.synchronize()
         digest[on] = hashlib.sha1(r.xb.cpu().numpy().tobytes()).hexdigest()[:16]
         print(f"round {rd} patch={on}: step {ms_step:.3f} ms, pm_forces {fc:.4f} ms, stages {st}, pos_bar sha1 {digest[on]}", flush=True)
-print("gradients bitwise equal between the two maps:", digest[0] == digest[1])
+print("gradients bitwise equal between the maps:", len(set(digest.values())) == 1)
