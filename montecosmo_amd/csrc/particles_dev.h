@@ -127,15 +127,14 @@ __device__ __forceinline__ PIdx particle_index(const Geom &g, int64_t n) {
         // A workgroup = four waves on a 2 x 2 (x, y) patch of lattice rows, 64 consecutive z each (lattice_launch: 256 threads).
         // What bounds the CIC gathers is the mesh rows a wave pulls into the CU's L1 -- 4 (x, y) rows of ~900 bytes per wave; a
         // second corner in a row already fetched is nearly free (tools/gather_pair_bench.hip) -- and the four waves of a patch
-        // touch 3 x 3 rows between them instead of 4 x 4.  Blocks b, b+8, ... share an XCD: each XCD gets a contiguous run of
-        // virtual blocks, in which four consecutive x pairs (8 planes) of one (y pair, z chunk) come first (rows re-read from L2).
-        const unsigned nb = gridDim.x, b = blockIdx.x;
-        const unsigned vb = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
-        const unsigned nxp = g.px >> 1, nyp = g.py >> 1, nzc = g.pz >> 6;
-        const unsigned XB = (nxp % 4 == 0) ? 4 : 1;
-        const unsigned xi = vb % XB, r1 = vb / XB;
-        const unsigned zc = r1 % nzc, r2 = r1 / nzc;
-        const unsigned yp = r2 % nyp, xp = (r2 / nyp) * XB + xi;
+        // touch 3 x 3 rows between them instead of 4 x 4.  Workgroups in plain memory order (z chunk, then y pair, then x
+        // pair), consecutive ones on consecutive XCDs as the hardware deals them: the kernels' four to seven particle streams
+        // walk their arrays sequentially over the whole chip.  (Per-XCD contiguous runs of that order: pm_forces 4.14 against
+        // 4.08 ms, step 11.15 against 11.10; runs with 2 / 4 / 8 / 16 x pairs grouped first, which re-read the shared x rows
+        // from one L2: kick+drift 1.48 / 1.55 / 1.56 / 1.54 against 1.46 ms.)
+        const unsigned b = blockIdx.x, nyp = g.py >> 1, nzc = g.pz >> 6;
+        const unsigned zc = b % nzc, r2 = b / nzc;
+        const unsigned yp = r2 % nyp, xp = r2 / nyp;
         const unsigned w = threadIdx.x >> 6;
         r.ipx = 2 * xp + (w & 1);
         r.ipy = 2 * yp + (w >> 1);
