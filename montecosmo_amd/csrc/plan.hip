@@ -68,6 +68,16 @@ int mcpm_plan_create_slab(int nx, int ny, int nz, int nranks, int rank, int ghos
     return plan_create_impl(nx, ny, nz, nxl, ny, nz, nranks, rank, ghost, stream, out);
 }
 
+// Halo H of the tiled paints' windows ((16 + 2H + 1)^3 lattice points per tile).  What it should be depends on how much the
+// displacements vary within a tile's neighbourhood: every cell of halo costs visits ((25/23)^3 = +28 % from 3 to 4), every
+// particle the windows miss costs the exact coverage test and a bucket deposit.  On the benchmark family (rms displacement 2
+// cells; the smaller the mesh, the rougher the field per cell) 4 wins up to 256^3 and 3 above: 64^3 6725 vs 6314 steps/s, 128^3
+// 3635 vs 3231, 192^3 993 vs 864, 256^3 689 vs 703 (but pm_forces on the evolved particles 0.552 vs 0.630 ms), 512^3 87.8 vs 90.0.
+// The choice never changes a result beyond the last bit (the sums are exact; the split between tile and bucket deposits moves).
+// A data-driven choice would have to be made on the device to stay deterministic; until then: this default, MCPM_PAINT_HALO,
+// mcpm_plan_set_halo.
+static int default_halo(int64_t M) { return M <= ((int64_t)1 << 24) ? 4 : 3; }
+
 // nranks == 1, ghost == 0: ordinary periodic plan.  Otherwise (slab): (nx, ny, nz) is the GLOBAL mesh, the local
 // mesh is the ghost-extended slab (nx/nranks + 2 ghost, ny, nz) and the lattice (px, py, pz) = (nx/nranks, ny, nz).
 static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int nranks, int rank, int ghost, void *stream,
@@ -102,8 +112,9 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->M = (int64_t)nx * ny * nz;
     p->Mh = (int64_t)nx * ny * p->g.nzh;
     p->Np = (int64_t)px * py * pz;
-    p->halo = 3;      // with windows centred on the bulk displacement; windows on the tile itself (centre = 0) need halo 4 at the
-    p->centre = 1;    // benchmark's 2-cell rms displacement (bench 512^3: 12.10 vs 12.42 ms per step, pm_forces 4.38 vs 4.48 ms)
+    p->halo = default_halo(p->M);
+    p->centre = 1;    // windows centred on the bulk displacement; on the tile itself (centre = 0) they need one more cell of halo at the
+                      // benchmark's 2-cell rms displacement (bench 512^3: 12.10 vs 12.42 ms per step, pm_forces 4.38 vs 4.48 ms)
     if (const char *e = getenv("MCPM_PAINT_CENTRE")) p->centre = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MCPM_PAINT_HALO")) { const int h = atoi(e); if (h == 1 || h == 2 || h == 3 || h == 4 || h == 6) p->halo = h; }
     p->tile_off = p->bucket_cnt = p->bucket = p->bucket_tiles = nullptr;
@@ -209,8 +220,8 @@ int mcpm_plan_destroy(mcpm_plan *p) {
 
 int mcpm_plan_set_halo(mcpm_plan *p, int halo) {
     if (!p) return MCPM_E_ARG;
-    MCPM_REQUIRE(p, halo == 1 || halo == 2 || halo == 3 || halo == 4 || halo == 6, MCPM_E_ARG, "halo must be 1, 2, 3, 4 or 6");
-    p->halo = halo;
+    MCPM_REQUIRE(p, halo == 0 || halo == 1 || halo == 2 || halo == 3 || halo == 4 || halo == 6, MCPM_E_ARG, "halo must be 0 (default), 1, 2, 3, 4 or 6");
+    p->halo = halo ? halo : default_halo(p->M);
     return MCPM_OK;
 }
 

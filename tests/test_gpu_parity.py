@@ -159,7 +159,7 @@ def test_paint_tiled_lattice(nb, n, halo, sigma):
         assert rel_l2(gotw, o.paint(pos64, shape, w.astype(np.float64))) < 2e-6
         assert np.array_equal(gotw, to_np(nb.paint(lp, shape, w)))
     finally:
-        plan.call("mcpm_plan_set_halo", 3)
+        plan.call("mcpm_plan_set_halo", 0)      # back to the default
 
 
 @pytest.mark.parametrize("n", [64, 96])
@@ -201,7 +201,7 @@ def test_paint_windows_follow_the_bulk_displacement(nb, n):
         assert rel_l2(got0, want) < 2e-6 and abs(got0.sum() / N - 1) < 1e-6
     finally:
         plan.call("mcpm_plan_set_centre", 1)
-        plan.call("mcpm_plan_set_halo", 3)
+        plan.call("mcpm_plan_set_halo", 0)      # back to the default
 
 
 def test_paint_non_finite_displacement_is_visible(nb):
