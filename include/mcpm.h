@@ -76,7 +76,8 @@ const char *mcpm_version(void);
    absurd displacements, bucket overflow).  Both synchronise the host. */
 int mcpm_plan_last_outliers(mcpm_plan *plan, int64_t *count);
 int mcpm_plan_last_bucketed(mcpm_plan *plan, int64_t *count);
-/* Tuning knobs: halo radius (1, 2, 3, 4 or 6 cells; 0 = the default: 4 for meshes up to 2^24 cells, 3 above) and whether windows are centred on the local bulk
+/* Tuning knobs: halo radius (1, 2, 3, 4 or 6 cells; 0 = the default: chosen among 2, 3, 4 for every input ON THE DEVICE from the roughness of its
+   displacement field -- same input, same halo, so results stay bitwise reproducible; slab plans: 4 up to 2^24 cells, 3 above) and whether windows are centred on the local bulk
    displacement (default 1; 0 = on the tile itself, which needs halo 4 at the benchmark's 2-cell rms displacement). */
 int mcpm_plan_set_halo(mcpm_plan *plan, int halo);
 int mcpm_plan_set_centre(mcpm_plan *plan, int centre);

@@ -49,6 +49,7 @@ struct Geom {
                       // (64 consecutive z each) instead of 256 consecutive z of one row (particles_dev.h::particle_index)
 };
 
+#define MCPM_HSEL_INTS (32 + 3 * 64 * 32)   // paint_tiled.hip::halo_select_kernel: [0] H, [4] ticket, 3 x 64 count slots a cache line apart
 #define MCPM_FX_SLOTS 64
 #define MCPM_FX_STRIDE 32   // unsigned per slot: one 128-byte line each
 
@@ -60,6 +61,7 @@ struct mcpm_plan {
     int64_t Np;  // px*py*pz
     int halo;    // halo radius H of the tiled paints: a tile's window is (16 + 2H + 1)^3 lattice points
     int centre;  // tiled paints: windows centred on the local bulk displacement (paint_tiled.hip); 0 = on the tile itself
+    int *halo_sel;    // [0] window halo chosen on the device for the current paint, [1..3] unsure-sample counts, [4] ticket
     int *tile_off;    // packed window offsets per 16^3 tile (device; NULL if the mesh cannot be tiled)
     int *bucket_cnt;  // per-tile bucket fill counts
     int *bucket;      // [tile][bucket_cap] particles a tile's window misses
@@ -147,6 +149,7 @@ extern thread_local std::string g_mcpm_create_error;
 
 int mcpm_fail(mcpm_plan *plan, int code, const std::string &msg);
 void mcpm_slab_state_free(mcpm_plan *p);   // slab.hip
+static inline int mcpm_default_halo(int64_t M) { return M <= ((int64_t)1 << 24) ? 4 : 3; }   // the static rule (plan.hip: where it comes from)
 
 // hand-written FFT Poisson solve (fftpm.hip); power-of-two axes only
 bool mcpm_fftpm_supported(const mcpm_plan *p);

@@ -122,6 +122,99 @@ __global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The window halo this input needs, chosen on the device (DESIGN finding 31).  Every cell of halo costs window visits
+// ((16 + 2H + 1)^3 per tile), every particle the windows are not SURE to contain costs the exact coverage test and possibly a
+// bucket deposit; which H is cheapest follows the roughness of the displacement field, and that changes along a trajectory.
+// Sixteen lanes per tile re-read one of the prologue's four sample rows and apply the tile kernel's own test -- |floor(d)_a - o_a| <= H - D_a
+// with D_a the largest offset difference to the 26 neighbouring tiles (sure_interval) -- for H = 2, 3, 4; halo_decide_kernel then
+// picks the smallest H whose share of unsure samples is at most `limit` (4 %: on the bench trajectories the per-step
+// optimum switches between 2.5 and 7.7 % (512^3, H 2 -> 3), 0.9 and 6.1 %, 3.1 and 7.0 % (256^3, 2 -> 3 and 3 -> 4)) and leaves it
+// in hs[0], where the tiled kernels of THIS paint read it.  Same input, same H: results stay bitwise reproducible, and the
+// host is not involved.
+#define HSEL_SLOT0 32      // hs: [0] the halo, from HSEL_SLOT0 on 3 x 64 count slots of 32 ints each (zero between paints); MCPM_HSEL_INTS in all
+#define HSEL_SAMPLES 16    // samples per tile: one of the prologue's four z rows (16 lanes per tile, 16 tiles per workgroup)
+__global__ __launch_bounds__(256) void halo_select_kernel(Geom g, const float *__restrict__ disp, const int *__restrict__ toff, int ntiles,
+                                                          int *__restrict__ hs) {
+    const int tile = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
+    bool unsure[3] = {false, false, false};
+    if (tile < ntiles) {
+        const int ntz = g.nz / MCPM_TILE, nty = g.ny / MCPM_TILE, ntx = g.nx / MCPM_TILE;
+        const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
+        // the sample: row (4 or 12, 4 or 12) of the tile by its parity, so that all four rows are used over the mesh
+        int gx = tx * MCPM_TILE + 4 + 8 * (tz & 1) - g.xoff;
+        const int gy = ty * MCPM_TILE + 4 + 8 * (tx & 1), gz = tz * MCPM_TILE + l16;
+        if (g.xslab) gx = min(max(gx, 0), g.px - 1);
+        const P3 d = load3(disp, ((int64_t)gx * g.ny + gy) * g.nz + gz);
+        int o[3] = {0, 0, 0}, lo[3] = {127, 127, 127}, hi[3] = {-127, -127, -127};
+        if (toff) {
+            unpack_off(toff[tile], o[0], o[1], o[2]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {      // 27 neighbours over the tile's 16 lanes
+                const int q = l16 + 16 * h;
+                if (q < 27) {
+                    const int a = q / 9 - 1, b = (q / 3) % 3 - 1, e = q % 3 - 1;
+                    const int Tx = g.xslab ? min(max(tx + a, 0), ntx - 1) : pymod(tx + a, ntx);
+                    int n3[3];
+                    unpack_off(toff[(Tx * nty + pymod(ty + b, nty)) * ntz + pymod(tz + e, ntz)], n3[0], n3[1], n3[2]);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) lo[c] = min(lo[c], n3[c]), hi[c] = max(hi[c], n3[c]);
+                }
+            }
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    lo[c] = min(lo[c], __shfl_xor(lo[c], m));
+                    hi[c] = max(hi[c], __shfl_xor(hi[c], m));
+                }
+        } else
+            lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0;
+        const float f[3] = {floorf(d.x), floorf(d.y), floorf(d.z)};
+#pragma unroll
+        for (int H = 2; H <= 4; ++H) {
+            bool sure = true;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int D = max(hi[c] - o[c], o[c] - lo[c]);
+                sure = sure && f[c] >= (float)(o[c] - (H - D)) && f[c] <= (float)(o[c] + (H - D));      // NaN: not sure
+            }
+            unsure[H - 2] = !sure;
+        }
+    }
+    // workgroup totals -> one of 64 slots per H, a cache line apart (per-tile atomics on three addresses took 0.2-0.3 ms: they
+    // serialise at the memory side); halo_decide_kernel adds the slots up
+    __shared__ int part[4][3];
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int n = __popcll(__ballot(unsure[k]));
+        if (lane == 0) part[threadIdx.x >> 6][k] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int n = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (n) atomicAdd(hs + HSEL_SLOT0 + ((int)threadIdx.x * 64 + (int)(blockIdx.x & 63)) * 32, n);
+    }
+}
+
+// adds the slots up, leaves the halo in hs[0] and the slots zero (a ticket in halo_select_kernel instead -- "the last workgroup
+// decides" -- is 8192 serialised atomics on one address at 512^3: 0.2 ms)
+__global__ __launch_bounds__(192) void halo_decide_kernel(int *__restrict__ hs, int ntiles, float limit) {
+    __shared__ int tot[3];
+    int *slot = hs + HSEL_SLOT0 + (int)threadIdx.x * 32;
+    int v = *slot;
+    *slot = 0;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float lim = limit * (float)HSEL_SAMPLES * (float)ntiles;
+        hs[0] = (float)tot[0] <= lim ? 2 : ((float)tot[1] <= lim ? 3 : 4);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // scale of the weighted fixed-point accumulators: S = 2^(28 - e), 2^e <= max|w| < 2^(e+1): one deposit is below 2^29, an
 // int64 cell holds 2^34 of them (n < 2^31 particles x 8 corners).  mode: 0 = all weights zero, 1 = fixed point, 2 = non-finite
 struct TScale {
@@ -157,7 +250,23 @@ struct TileLists {
     int listcap;
     int *cnts;
     int order;         // order of the tile pencils within an XCD's slab (tile_of_block)
+    int hfix;          // window halo H of this paint if > 0, else
+    const int *hsel;   // ... the one halo_select_kernel left in hsel[0] for THIS input (2, 3 or 4)
 };
+
+// the window halo of this launch (wave-uniform)
+__device__ __forceinline__ int tile_halo(const TileLists &L) { return L.hfix > 0 ? L.hfix : __builtin_amdgcn_readfirstlane(L.hsel[0]); }
+// kernels are instantiated for three candidate halos (HA, HB, HC; all equal when the halo is fixed) and branch once, uniformly
+#define HALO_SWITCH(Hrt, CALL)  \
+    do {                        \
+        if ((Hrt) == HA) {      \
+            CALL(HA);           \
+        } else if ((Hrt) == HB) { \
+            CALL(HB);           \
+        } else {                \
+            CALL(HC);           \
+        }                       \
+    } while (0)
 
 __device__ __forceinline__ void append_wild(const TileLists &L, int gi) {
     const int k = atomicAdd(L.cnts + C_WILD, 1);
@@ -235,7 +344,7 @@ __device__ __forceinline__ bool is_wild(const Geom &g, const P3 &d, int x0, int 
 // Exact coverage test of the suspects: append each to the bucket of every tile whose window misses it.  A full bucket keeps
 // counting (bcnt > cap marks the tile for the repair pass, which then deposits ALL of that tile's pairs).
 template <int H>
-__global__ __launch_bounds__(256) void coverage_duty_kernel(Geom g, const float *__restrict__ disp, TileLists L) {
+__device__ __forceinline__ void coverage_duty_body(const Geom &g, const float *__restrict__ disp, const TileLists &L) {
     const int ns = min(L.cnts[C_SUSPECTS], L.listcap);
     const int ntx = g.nx / MCPM_TILE, nty = g.ny / MCPM_TILE, ntz = g.nz / MCPM_TILE;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < ns; k += gridDim.x * blockDim.x) {
@@ -255,6 +364,14 @@ __global__ __launch_bounds__(256) void coverage_duty_kernel(Geom g, const float 
                              else atomicAdd(L.cnts + C_PAIRS, 1);
                          });
     }
+}
+
+template <int HA, int HB, int HC>
+__global__ __launch_bounds__(256) void coverage_duty_kernel(Geom g, const float *__restrict__ disp, TileLists L) {
+    const int Hrt = tile_halo(L);
+#define CALL(HH) coverage_duty_body<HH>(g, disp, L)
+    HALO_SWITCH(Hrt, CALL);
+#undef CALL
 }
 
 // Range of the window offsets over the 27 tiles around (tx, ty, tz) (the destinations of every home particle displaced by
@@ -364,15 +481,11 @@ struct WinIter {
 // the max|w| scale; 2: weighted, f64 accumulators (non-finite weights only: runs when tile_scale().mode == 2, WMODE 1 otherwise)
 // (amdgpu_num_sgpr: with more than 80 scalar registers a CU admits 7 waves per SIMD instead of 8, i.e. three of these
 // 512-thread workgroups instead of four -- measured +45 % on the kernel; MI355X_MICROARCH.md "Residency")
-template <int H, int WMODE, int THREADS, int U, bool FAST = false>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void paint_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
-                                                             int64_t wstride, float wscalar, float *__restrict__ mesh,
-                                                             int accumulate, TileLists L, const unsigned *__restrict__ wmax_bits,
-                                                             int duty) {
+template <int H, int WMODE, int THREADS, int U, bool FAST>
+__device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w,
+                                                int64_t wstride, float wscalar, float *__restrict__ mesh, int accumulate, const TileLists &L,
+                                                const unsigned *__restrict__ wmax_bits, int duty, u64 *tile, int *sh27, int *sus) {
     constexpr int B = MCPM_TILE, W = B + 2 * H + 1, NW = W * W * W, NT = B * B * B;
-    __shared__ u64 tile[NT];
-    __shared__ int sh27[27];
-    __shared__ int sus[MCPM_SUS + 2];
     double *dtile = reinterpret_cast<double *>(tile);
     TScale sc = {1073741824.f, 9.313225746154785e-10, 1};
     if (WMODE != 0) {
@@ -506,6 +619,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
         }
         *dst = v;      // (a streaming store here is slower: 0.915 vs 0.902 ms at 512^3)
     }
+}
+
+template <int HA, int HB, int HC, int WMODE, int THREADS, int U, bool FAST = false>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void paint_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
+                                                             int64_t wstride, float wscalar, float *__restrict__ mesh,
+                                                             int accumulate, TileLists L, const unsigned *__restrict__ wmax_bits,
+                                                             int duty) {
+    __shared__ u64 tile[MCPM_TILE * MCPM_TILE * MCPM_TILE];
+    __shared__ int sh27[27];
+    __shared__ int sus[MCPM_SUS + 2];
+    const int Hrt = tile_halo(L);
+#define CALL(HH) paint_tile_body<HH, WMODE, THREADS, U, FAST>(g, disp, w, wstride, wscalar, mesh, accumulate, L, wmax_bits, duty, tile, sh27, sus)
+    HALO_SWITCH(Hrt, CALL);
+#undef CALL
 }
 
 // base cell of a bucketed particle relative to the tile origin, brought into [-1, n-1) (the tile sees it at c in [-1, 16))
@@ -660,13 +787,18 @@ __device__ __forceinline__ void paint_leftover_body(const Geom &g, const float *
 // launch costs about as much as the kernel): blocks [0, nbk) deposit the buckets, blocks [nbk, nbk + nlo) run the
 // global-atomic leftovers (wild particles, overflowed buckets).  The two touch disjoint (particle, tile) pairs and both only
 // read what the coverage kernel left, so they need no order between them.
-template <int H, int WMODE>
+template <int HA, int HB, int HC, int WMODE>
 __global__ __launch_bounds__(256) void paint_epilogue_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
                                                              int64_t wstride, float wscalar, float *__restrict__ mesh, int64_t M,
                                                              TileLists L, const unsigned *__restrict__ wmax_bits, int nbk) {
     __shared__ u64 tile[MCPM_TILE * MCPM_TILE * MCPM_TILE];
     if ((int)blockIdx.x < nbk) paint_bucket_body<WMODE>(g, disp, w, wstride, wscalar, mesh, L, wmax_bits, tile, (int)blockIdx.x, nbk);
-    else paint_leftover_body<H, 1>(g, disp, w, wstride, wscalar, mesh, M, L, (int)blockIdx.x - nbk, (int)gridDim.x - nbk);
+    else {
+        const int Hrt = tile_halo(L);
+#define CALL(HH) paint_leftover_body<HH, 1>(g, disp, w, wstride, wscalar, mesh, M, L, (int)blockIdx.x - nbk, (int)gridDim.x - nbk)
+        HALO_SWITCH(Hrt, CALL);
+#undef CALL
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -922,8 +1054,9 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
 // redo_in == nullptr: the first pass, one workgroup per tile.  Otherwise the f64 repaint of the tiles listed in redo_in
 // ([0] = count, then indices): a small grid that walks the list (it is empty on every PM workload: a whole-mesh launch of
 // workgroups that return at once cost 30 us per adjoint step at 512^3).
-template <int H, bool F64, int THREADS, int U, bool FAST = false>
-__global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
+// (four waves per SIMD = two 512-thread workgroups per CU: with three candidate bodies the allocator would take 133 registers)
+template <int HA, int HB, int HC, bool F64, int THREADS, int U, bool FAST = false>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) void paint3_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
                                                               float *__restrict__ mesh, int64_t M, int accumulate, TileLists L,
                                                               const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out,
                                                               const int *__restrict__ redo_in, int duty) {
@@ -932,14 +1065,18 @@ __global__ __launch_bounds__(THREADS) void paint3_tile_kernel(Geom g, const floa
     __shared__ int flagged;
     __shared__ int sh27[27];
     __shared__ int sus[MCPM_SUS + 2];
+    const int Hrt = tile_halo(L);
     if (!redo_in) {
-        paint3_tile_body<H, F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, -1, duty, tile, flagged, sh27, sus);
+#define CALL(HH) paint3_tile_body<HH, F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, -1, duty, tile, flagged, sh27, sus)
+        HALO_SWITCH(Hrt, CALL);
+#undef CALL
         return;
     }
     const int n = redo_in[0];
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
-        paint3_tile_body<H, F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, redo_in[1 + k], duty, tile, flagged,
-                                                   sh27, sus);
+#define CALL(HH) paint3_tile_body<HH, F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, redo_in[1 + k], duty, tile, flagged, sh27, sus)
+        HALO_SWITCH(Hrt, CALL);
+#undef CALL
         __syncthreads();
     }
 }
@@ -1013,13 +1150,13 @@ __device__ __forceinline__ void paint3_bucket_body(const Geom &g, const float *_
 // adjoint particle kernel, axpby) commits its maximum without a memset launch in front of it.
 __global__ __launch_bounds__(256) void paint3_epilogue_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
                                                               float *__restrict__ mesh, int64_t M, TileLists L,
-                                                              unsigned *__restrict__ wmax_bits, int nbk, int H, unsigned *__restrict__ done) {
+                                                              unsigned *__restrict__ wmax_bits, int nbk, unsigned *__restrict__ done) {
     __shared__ u64 tile[3 * MCPM_TILE * MCPM_TILE * MCPM_TILE];
     __shared__ int last;
     if ((int)blockIdx.x < nbk) paint3_bucket_body(g, disp, w3, mesh, M, L, wmax_bits, tile, (int)blockIdx.x, nbk);
     else {
         const int bid = (int)blockIdx.x - nbk, nblk = (int)gridDim.x - nbk;
-        switch (H) {
+        switch (tile_halo(L)) {
             case 1: paint_leftover_body<1, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
             case 2: paint_leftover_body<2, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
             case 3: paint_leftover_body<3, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
@@ -1070,8 +1207,20 @@ static int tile_order() {
     return o;
 }
 
+// The halo of the next tiled paint: p->halo if the caller fixed one (mcpm_plan_set_halo, MCPM_PAINT_HALO), else 0 = chosen on the
+// device for every input by halo_select_kernel (periodic plans of 2048 tiles or more; MCPM_PAINT_ADAPT=0, a slab plan or a
+// smaller mesh: the static rule of plan.hip)
+static int halo_of(const mcpm_plan *p) {
+    static const int adapt = [] { const char *e = getenv("MCPM_PAINT_ADAPT"); return e ? atoi(e) : 1; }();
+    if (p->halo > 0) return p->halo;
+    // below ~2000 tiles every tile is resident at once and a tile's time is latency, not visits: the extra visits of a wide
+    // halo are free there and the particles a narrow one misses are not (128^3: 3511 steps/s chosen per input, 3597 at H = 4)
+    const int64_t ntiles = p->M / (MCPM_TILE * MCPM_TILE * MCPM_TILE);
+    return (adapt && !p->g.xslab && p->halo_sel && ntiles >= 2048) ? 0 : mcpm_default_halo(p->M);
+}
+
 static TileLists tile_lists(const mcpm_plan *p) {
-    return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, p->outliers + p->Np, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count, tile_order()};
+    return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, p->outliers + p->Np, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count, tile_order(), halo_of(p), p->halo_sel};
 }
 
 static void tiled_prologue(mcpm_plan *p, const float *pos, int *redo = nullptr) {
@@ -1079,15 +1228,22 @@ static void tiled_prologue(mcpm_plan *p, const float *pos, int *redo = nullptr) 
     const int ntiles = (g.nx / MCPM_TILE) * (g.ny / MCPM_TILE) * (g.nz / MCPM_TILE);
     tile_prologue_kernel<<<(ntiles + 3) / 4, 256, 0, p->stream>>>(g, pos, p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->outlier_count,
                                                                   ntiles, 8, redo);
+    if (halo_of(p) == 0) {
+        static const float limit = [] { const char *e = getenv("MCPM_HALO_LIMIT"); return e ? (float)atof(e) : 0.04f; }();
+        halo_select_kernel<<<(ntiles + 15) / 16, 256, 0, p->stream>>>(g, pos, p->centre ? p->tile_off : nullptr, ntiles, p->halo_sel);
+        halo_decide_kernel<<<1, 192, 0, p->stream>>>(p->halo_sel, ntiles, limit);
+    }
 }
 
-#define DISPATCH_H(HH, CALL) \
-    switch (HH) {            \
-        case 1: CALL(1) break; \
-        case 2: CALL(2) break; \
-        case 3: CALL(3) break; \
-        case 4: CALL(4) break; \
-        default: CALL(6) break; \
+// CALL(HA, HB, HC): the kernels' three candidate halos -- all equal for a fixed halo, (2, 3, 4) when the device chooses (0)
+#define DISPATCH_H(HH, CALL)        \
+    switch (HH) {                   \
+        case 0: CALL(2, 3, 4) break; \
+        case 1: CALL(1, 1, 1) break; \
+        case 2: CALL(2, 2, 2) break; \
+        case 3: CALL(3, 3, 3) break; \
+        case 4: CALL(4, 4, 4) break; \
+        default: CALL(6, 6, 6) break; \
     }
 
 // Tiled density paint if the geometry allows; returns false if the caller must use the generic path.
@@ -1107,27 +1263,27 @@ bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t ws
     if (w) {
         (void)hipMemsetAsync(p->gx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream);
         absmax_kernel<<<2048, 256, 0, p->stream>>>(w, wstride, p->Np, p->gx_wmax);
-#define CALLW(HH)                                                                                                                  \
+#define CALLW(HA_, HB_, HC_)                                                                                                                  \
     {                                                                                                                              \
-        paint_tile_kernel<HH, 1, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
-        paint_tile_kernel<HH, 2, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+        paint_tile_kernel<HA_, HB_, HC_, 1, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+        paint_tile_kernel<HA_, HB_, HC_, 2, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
     }
-        DISPATCH_H(p->halo, CALLW)
+        DISPATCH_H(halo_of(p), CALLW)
 #undef CALLW
     } else {
-#define CALLU(HH)                                                                                                                    \
-    if (fast) paint_tile_kernel<HH, 0, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
-    else paint_tile_kernel<HH, 0, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
-        DISPATCH_H(p->halo, CALLU)
+#define CALLU(HA_, HB_, HC_)                                                                                                                    \
+    if (fast) paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+    else paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
+        DISPATCH_H(halo_of(p), CALLU)
 #undef CALLU
     }
-#define CALLD(HH) coverage_duty_kernel<HH><<<1024, 256, 0, p->stream>>>(g, pos, L);
-    DISPATCH_H(p->halo, CALLD)
+#define CALLD(HA_, HB_, HC_) coverage_duty_kernel<HA_, HB_, HC_><<<1024, 256, 0, p->stream>>>(g, pos, L);
+    DISPATCH_H(halo_of(p), CALLD)
 #undef CALLD
-#define CALLE(HH)                                                                                                                          \
-    if (w) paint_epilogue_kernel<HH, 1><<<nbk + nlo, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L, p->gx_wmax, (int)nbk); \
-    else paint_epilogue_kernel<HH, 0><<<nbk + nlo, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L, p->gx_wmax, (int)nbk);
-    DISPATCH_H(p->halo, CALLE)
+#define CALLE(HA_, HB_, HC_)                                                                                                                          \
+    if (w) paint_epilogue_kernel<HA_, HB_, HC_, 1><<<nbk + nlo, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L, p->gx_wmax, (int)nbk); \
+    else paint_epilogue_kernel<HA_, HB_, HC_, 0><<<nbk + nlo, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L, p->gx_wmax, (int)nbk);
+    DISPATCH_H(halo_of(p), CALLE)
 #undef CALLE
     return true;
 }
@@ -1148,25 +1304,25 @@ bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, fl
     }
     p->fx_src = nullptr;
     if (p->paint3_variant == 4) {   // fixed-point tiles; the tiles they flag (and every tile if max|w| is unusable) in f64
-#define CALLFX(HH)                                                                                                                \
+#define CALLFX(HA_, HB_, HC_)                                                                                                                \
     {                                                                                                                             \
-        if (fast) paint3_tile_kernel<HH, false, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
-        else paint3_tile_kernel<HH, false, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
-        paint3_tile_kernel<HH, true, 1024, 4><<<nb < 256u ? nb : 256u, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, p->fx_redo, 0); \
+        if (fast) paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
+        else paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
+        paint3_tile_kernel<HA_, HB_, HC_, true, 1024, 4><<<nb < 256u ? nb : 256u, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, p->fx_redo, 0); \
     }
-        DISPATCH_H(p->halo, CALLFX)
+        DISPATCH_H(halo_of(p), CALLFX)
 #undef CALLFX
     } else {   // f64 tiles everywhere (A/B and tests)
-#define CALLF64(HH) paint3_tile_kernel<HH, true, 1024, 4><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, nullptr, 1);
-        DISPATCH_H(p->halo, CALLF64)
+#define CALLF64(HA_, HB_, HC_) paint3_tile_kernel<HA_, HB_, HC_, true, 1024, 4><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, nullptr, 1);
+        DISPATCH_H(halo_of(p), CALLF64)
 #undef CALLF64
     }
-#define CALLD(HH) coverage_duty_kernel<HH><<<1024, 256, 0, p->stream>>>(g, pos, L);
-    DISPATCH_H(p->halo, CALLD)
+#define CALLD(HA_, HB_, HC_) coverage_duty_kernel<HA_, HB_, HC_><<<1024, 256, 0, p->stream>>>(g, pos, L);
+    DISPATCH_H(halo_of(p), CALLD)
 #undef CALLD
     const unsigned nlo = 64u;     // see mcpm_paint_tiled
     // buckets | leftovers in one launch; its last block leaves the max|w| slots zero for the next producer
-    paint3_epilogue_kernel<<<nbk + nlo, 256, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, L, p->fx_wmax, (int)nbk, p->halo,
+    paint3_epilogue_kernel<<<nbk + nlo, 256, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, L, p->fx_wmax, (int)nbk,
                                                              (unsigned *)(p->outlier_count + 7));
     p->fx_clean = 1;
     return true;

@@ -74,9 +74,9 @@ int mcpm_plan_create_slab(int nx, int ny, int nz, int nranks, int rank, int ghos
 // cells; the smaller the mesh, the rougher the field per cell) 4 wins up to 256^3 and 3 above: 64^3 6725 vs 6314 steps/s, 128^3
 // 3635 vs 3231, 192^3 993 vs 864, 256^3 689 vs 703 (but pm_forces on the evolved particles 0.552 vs 0.630 ms), 512^3 87.8 vs 90.0.
 // The choice never changes a result beyond the last bit (the sums are exact; the split between tile and bucket deposits moves).
-// A data-driven choice would have to be made on the device to stay deterministic; until then: this default, MCPM_PAINT_HALO,
-// mcpm_plan_set_halo.
-static int default_halo(int64_t M) { return M <= ((int64_t)1 << 24) ? 4 : 3; }
+// This static rule is what slab plans and MCPM_PAINT_ADAPT=0 use; periodic plans choose H per input on the device
+// (paint_tiled.hip::halo_select_kernel).  MCPM_PAINT_HALO / mcpm_plan_set_halo fix it.
+// (mcpm_default_halo: mcpm_internal.h)
 
 // nranks == 1, ghost == 0: ordinary periodic plan.  Otherwise (slab): (nx, ny, nz) is the GLOBAL mesh, the local
 // mesh is the ghost-extended slab (nx/nranks + 2 ghost, ny, nz) and the lattice (px, py, pz) = (nx/nranks, ny, nz).
@@ -112,12 +112,12 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->M = (int64_t)nx * ny * nz;
     p->Mh = (int64_t)nx * ny * p->g.nzh;
     p->Np = (int64_t)px * py * pz;
-    p->halo = default_halo(p->M);
+    p->halo = 0;      // 0: chosen per input on the device (paint_tiled.hip::halo_of / halo_select_kernel), else mcpm_default_halo
     p->centre = 1;    // windows centred on the bulk displacement; on the tile itself (centre = 0) they need one more cell of halo at the
                       // benchmark's 2-cell rms displacement (bench 512^3: 12.10 vs 12.42 ms per step, pm_forces 4.38 vs 4.48 ms)
     if (const char *e = getenv("MCPM_PAINT_CENTRE")) p->centre = atoi(e) ? 1 : 0;
     if (const char *e = getenv("MCPM_PAINT_HALO")) { const int h = atoi(e); if (h == 1 || h == 2 || h == 3 || h == 4 || h == 6) p->halo = h; }
-    p->tile_off = p->bucket_cnt = p->bucket = p->bucket_tiles = nullptr;
+    p->tile_off = p->bucket_cnt = p->bucket = p->bucket_tiles = p->halo_sel = nullptr;
     p->bucket_cap = 0;
     p->paint_variant = 0;
     if (const char *e = getenv("MCPM_PAINT_VARIANT")) p->paint_variant = atoi(e);
@@ -159,6 +159,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
         p->bucket_cap = 1024;
         if (const char *e = getenv("MCPM_BUCKET_CAP")) { const int c = atoi(e); if (c >= 64 && c <= 65536) p->bucket_cap = c; }
         alloc((void **)&p->tile_off, sizeof(int) * ntiles);
+        alloc((void **)&p->halo_sel, sizeof(int) * MCPM_HSEL_INTS);
         alloc((void **)&p->bucket_cnt, sizeof(int) * ntiles);
         alloc((void **)&p->bucket_tiles, sizeof(int) * ntiles);
         alloc((void **)&p->bucket, sizeof(int) * ntiles * p->bucket_cap);
@@ -174,6 +175,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
         return mcpm_fail(nullptr, MCPM_E_NOMEM, msg);
     }
     (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int) * 8, p->stream);
+    if (p->halo_sel) (void)hipMemsetAsync(p->halo_sel, 0, sizeof(int) * MCPM_HSEL_INTS, p->stream);
     (void)hipMemsetAsync(p->fx_redo, 0, sizeof(int), p->stream);
     (void)hipMemsetAsync(p->reduce, 0, sizeof(double) * MCPM_NREDUCE, p->stream);   // the slot area stays zero between uses
     *out = p;
@@ -203,6 +205,7 @@ int mcpm_plan_destroy(mcpm_plan *p) {
     (void)hipFree(p->outliers);
     (void)hipFree(p->outlier_count);
     (void)hipFree(p->tile_off);
+    (void)hipFree(p->halo_sel);
     (void)hipFree(p->bucket_cnt);
     (void)hipFree(p->bucket_tiles);
     (void)hipFree(p->bucket);
@@ -221,7 +224,7 @@ int mcpm_plan_destroy(mcpm_plan *p) {
 int mcpm_plan_set_halo(mcpm_plan *p, int halo) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, halo == 0 || halo == 1 || halo == 2 || halo == 3 || halo == 4 || halo == 6, MCPM_E_ARG, "halo must be 0 (default), 1, 2, 3, 4 or 6");
-    p->halo = halo ? halo : default_halo(p->M);
+    p->halo = halo;   // 0: per input, on the device
     return MCPM_OK;
 }
 
