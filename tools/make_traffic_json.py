@@ -16,10 +16,10 @@ stage_of = [("paint3_tile_kernel", "paint3"), ("paint3_bucket_kernel", "paint3")
             ("ycol_kernel<512, 1>", "fft_c2r"), ("ycol_kernel<256, 1>", "fft_c2r"), ("zinv_kernel", "fft_c2r"), ("zinv3_il_kernel", "fft_c2r"),
             ("xfused_kernel", "kspace"), ("kick_drift_kernel", "kick_drift"), ("step_adjoint_kernel", "step_adjoint"),
             ("axpby_kernel", "axpy"), ("axpy_kernel", "axpy")]
-shared_before = ("tile_prologue_kernel",)                                    # belongs to the NEXT tile kernel
+shared_before = ("tile_prologue_kernel", "halo_select_kernel", "halo_decide_kernel")   # belong to the NEXT tile kernel
 shared_after = ("coverage_duty_kernel", "paint_leftover_kernel", "absmax_kernel")   # belong to the PREVIOUS tile kernel
 # the kernels that count as "one launch of the stage" (its main kernel); the others only add their bytes
-main_kernels = ("paint_tile_kernel", "paint3_tile_kernel<3, false", "paint3_tile_kernel<4, false", "paint_atomic_kernel", "zfwd_kernel", "ycol2_kernel", "ycol_kernel",
+main_kernels = ("paint_tile_kernel", "paint3_tile_kernel<", "paint_atomic_kernel", "zfwd_kernel", "ycol2_kernel", "ycol_kernel",
                 "zinv_kernel", "zinv3_il_kernel", "xfused_kernel", "kick_drift_kernel", "step_adjoint_kernel", "axpby_kernel", "axpy_kernel")
 
 
@@ -54,8 +54,8 @@ for d, key in ((fetch_dir, "fetch_kb"), (write_dir, "write_kb")):
             current = st
         if st:
             tot[st][key] += v
-            if key == "fetch_kb" and any(m in nm for m in main_kernels):
-                tot[st]["launches"] += 1
+            if key == "fetch_kb" and any(m in nm for m in main_kernels) and not ("paint3_tile_kernel" in nm and ", true, 1024" in nm):
+                tot[st]["launches"] += 1      # (the f64 repaint launch of the three-component paint is not a paint of its own)
 method = (
     "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --no-sub-record --no-cpu-baseline --warmup 0 "
     "[--mesh 256]`; counters are KB; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
