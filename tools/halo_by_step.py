@@ -24,7 +24,7 @@ def stage(name):
     return float("nan")
 
 
-for H in (2, 3, 4):
+for H in tuple(int(c) for c in os.environ.get("HALOS", "234")):
     r.plan.call("mcpm_plan_set_halo", H)
     fw, bw = [], []
     for rep in range(2):
