@@ -1216,7 +1216,8 @@ static int halo_of(const mcpm_plan *p) {
     // below ~2000 tiles every tile is resident at once and a tile's time is latency, not visits: the extra visits of a wide
     // halo are free there and the particles a narrow one misses are not (128^3: 3511 steps/s chosen per input, 3597 at H = 4)
     const int64_t ntiles = p->M / (MCPM_TILE * MCPM_TILE * MCPM_TILE);
-    return (adapt && !p->g.xslab && p->halo_sel && ntiles >= 2048) ? 0 : mcpm_default_halo(p->M);
+    static const int slab_too = [] { const char *e = getenv("MCPM_PAINT_ADAPT_SLAB"); return e ? atoi(e) : 1; }();
+    return (adapt && (slab_too || !p->g.xslab) && p->halo_sel && ntiles >= 2048) ? 0 : mcpm_default_halo(p->M);
 }
 
 static TileLists tile_lists(const mcpm_plan *p) {
