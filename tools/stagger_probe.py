@@ -2,8 +2,8 @@
 x_i, v_i of every checkpoint in ONE tensor, 12 N bytes = 1.5 GiB apart at 512^3: every stream of the adjoint particle kernel
 (x, v, x_bar, v_bar in; x_bar, v_bar, F_bar out) then has the SAME low 29 address bits at the same time, and whether they meet in
 the same channel / bank is left to the upper physical bits -- the per-process placement that makes the kernel bimodal (DESIGN
-finding 25).  This probe re-lays the arrays with a per-array stagger of S bytes (array j starts j * S bytes later than in
-phase) and times the particle stages for several S in ONE process, alternating.  usage: python tools/stagger_probe.py [mesh=512]"""
+finding 25).  This probe lays the arrays out with a per-array stagger of S bytes (bench.Runner(stagger=S): array j starts j * S bytes later
+than in phase) and times the particle stages for several S in ONE process, alternating.  usage: python tools/stagger_probe.py [mesh=512]"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,37 +14,6 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 K = 10
-
-
-class Staggered(bench.Runner):
-    stagger = 0
-
-    def __init__(self, n, K, device):
-        super().__init__(n, K, device)
-
-    def relayout(self, S):
-        """Moves every particle array into one flat buffer, array j at j * (12 N + S) bytes."""
-        N = self.N
-        f = S // 4
-        na = 2 * (K + 1) + 4
-        flat = torch.empty(na * (3 * N + f) + 64, dtype=torch.float32, device=self.states.device)
-        def arr(j):
-            return flat[j * (3 * N + f): j * (3 * N + f) + 3 * N].view(N, 3)
-        old = self.states
-        views = [[arr(2 * i), arr(2 * i + 1)] for i in range(K + 1)]
-        for i in range(K + 1):
-            views[i][0].copy_(old[i, 0]); views[i][1].copy_(old[i, 1])
-        self._flat = flat
-        class S2:       # states[i, c] -> view
-            def __getitem__(s, key):
-                i, c = key
-                return views[i][c]
-        self.states = S2()
-        j = 2 * (K + 1)
-        pb, vb = arr(j), arr(j + 1)
-        pb.copy_(self.pos_bar); vb.copy_(self.vel_bar)
-        self.pos_bar, self.vel_bar = pb, vb
-        self.xb, self.vb = arr(j + 2), arr(j + 3)
 
 
 def stage_ms(r):
@@ -59,9 +28,7 @@ def stage_ms(r):
 
 res = {}
 for S in (0, 4096 + 256, 0, 4096 + 256, 16384 + 512, 65536 + 4096 + 256, 2048 + 128):
-    r = Staggered(n, K, dev)
-    if S or True:
-        r.relayout(S)
+    r = bench.Runner(n, K, dev, stagger=S)      # one flat buffer, array j at j * (12 N + S) bytes (bench.Runner._allocate)
     r.run(K); torch.cuda.synchronize()
     ms = []
     for rep in range(2):
