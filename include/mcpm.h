@@ -67,7 +67,7 @@ int mcpm_plan_slab_oob(mcpm_plan *plan, int64_t *count);
 int mcpm_plan_destroy(mcpm_plan *plan);
 const char *mcpm_last_error(const mcpm_plan *plan); /* plan may be NULL: last error of a failed create */
 /* ABI revision string; the Python loader (montecosmo_amd/_lib.py) refuses a library that reports another one. */
-#define MCPM_ABI_VERSION "mcpm 0.3 (gfx950)"
+#define MCPM_ABI_VERSION "mcpm 0.4 (gfx950)"
 const char *mcpm_version(void);
 /* Tiled CIC paints (montecosmo_amd/csrc/paint_tiled.hip).  A tile's window is (16 + 2 halo + 1)^3 lattice points wide,
    centred on the tile (or, optionally, on the local bulk displacement); what a window misses travels through per-tile

@@ -129,7 +129,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = "mcpm 0.3 (gfx950)"   # must equal mcpm_version() of the loaded library (include/mcpm.h MCPM_ABI_VERSION)
+ABI_VERSION = "mcpm 0.4 (gfx950)"   # must equal mcpm_version() of the loaded library (include/mcpm.h MCPM_ABI_VERSION)
 
 
 def _load():
