@@ -226,7 +226,10 @@ typedef struct mcpm_comm_ops {
                      int *ticket);
     /* Order `stream` after the batch `ticket`. */
     int (*wait)(void *ctx, int ticket, void *stream);
-    /* One small round of every exchange pattern of a slab step (equal-split all-to-all, both neighbour exchanges, max all-reduce) on
+    /* Replace the device float by its maximum over ranks, in stream order. */
+    int (*allreduce_max_f32)(void *ctx, float *dev_value, void *stream);
+} mcpm_comm_ops;
+/* One small round of every exchange pattern of a slab step (equal-split all-to-all, both neighbour exchanges, max all-reduce) on
    the plan's transport, verified on the host: MCPM_OK, or MCPM_E_RCCL with mcpm_last_error saying which pattern failed.
    Collective over the plan's ranks; synchronises the plan's stream.  dist.SlabPM runs it once after bringing the communicator up
    and, if any rank fails, keeps issuing the exchanges through torch.distributed instead (reference: there is none -- the
@@ -235,9 +238,6 @@ int mcpm_slab_comm_selftest(mcpm_plan *plan);
 /* Gives the plan's transport up (communicator, communication stream, events) after draining the plan's stream; the plan itself
    stays usable, and mcpm_slab_comm_init_* may be called again.  mcpm_plan_destroy does this too. */
 int mcpm_slab_comm_shutdown(mcpm_plan *plan);
-/* Replace the device float by its maximum over ranks, in stream order. */
-    int (*allreduce_max_f32)(void *ctx, float *dev_value, void *stream);
-} mcpm_comm_ops;
 int mcpm_slab_rccl_unique_id(void *id128);
 int mcpm_slab_comm_init_local(mcpm_plan *plan);
 int mcpm_slab_comm_init_rccl(mcpm_plan *plan, const void *id128);

@@ -29,6 +29,26 @@ def test_library_exports_every_declared_symbol(libmod):
     assert declared == set(libmod.SIGNATURES), declared ^ set(libmod.SIGNATURES)
 
 
+@pytest.mark.parametrize("compiler,flags", [("gcc", ["-std=c99", "-pedantic-errors"]), ("g++", ["-x", "c++", "-std=c++11"])])
+def test_header_compiles_as_c_and_cpp(tmp_path, compiler, flags):
+    """include/mcpm.h is the boundary of a C ABI: it has to be valid C99 and C++ on its own, and every declared function has to
+    be a FREE function (round 3 left two prototypes inside `struct mcpm_comm_ops`, which the symbol regex above cannot see)."""
+    import shutil
+    import subprocess
+    if shutil.which(compiler) is None:
+        pytest.skip(f"{compiler} absent")
+    header = open(os.path.join(ROOT, "include", "mcpm.h")).read()
+    names = sorted(set(re.findall(r"\b(mcpm_[a-z0-9_]+)\s*\(", header)))
+    src = tmp_path / "use_mcpm.c"
+    # taking the address of every function fails to compile if one of them is not declared at file scope
+    src.write_text('#include "mcpm.h"\nvoid *table[] = {\n' + "".join(f"    (void *) {n},\n" for n in names) +
+                   "};\nint main(void) { mcpm_comm_ops ops; ops.ctx = 0; return table[0] == 0 || ops.ctx != 0; }\n")
+    flags = [f for f in flags if f != "-pedantic-errors"]       # function -> void * casts are not strictly ISO
+    r = subprocess.run([compiler, *flags, "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_error_codes_without_crash(libmod):
     lib = libmod.lib
     h = C.c_void_p()
