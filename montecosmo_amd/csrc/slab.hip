@@ -156,10 +156,22 @@ int xfer_begin(mcpm_plan *p, const Batch &b, int *ticket) {
     if (b.a2a_in && a->AllToAll) {
         RCCL_TRY(p, a->AllToAll(b.a2a_in, b.a2a_out, (size_t)b.a2a_bytes, ncclInt8, s->comm, s->cs));
     } else {
+        // a failing Send / Recv must not leave the group open (every later call on this thread would join it): remember the
+        // first error, close the group whatever happened, report afterwards
         RCCL_TRY(p, a->GroupStart());
-        for (size_t i = 0; i < b.sp.size(); ++i) RCCL_TRY(p, a->Send(b.sp[i], (size_t)b.sb[i], ncclInt8, b.speer[i], s->comm, s->cs));
-        for (size_t i = 0; i < b.rp.size(); ++i) RCCL_TRY(p, a->Recv(b.rp[i], (size_t)b.rb[i], ncclInt8, b.rpeer[i], s->comm, s->cs));
-        RCCL_TRY(p, a->GroupEnd());
+        ncclResult_t first = ncclSuccess;
+        const char *what = "";
+        for (size_t i = 0; i < b.sp.size() && first == ncclSuccess; ++i) {
+            first = a->Send(b.sp[i], (size_t)b.sb[i], ncclInt8, b.speer[i], s->comm, s->cs);
+            what = "ncclSend";
+        }
+        for (size_t i = 0; i < b.rp.size() && first == ncclSuccess; ++i) {
+            first = a->Recv(b.rp[i], (size_t)b.rb[i], ncclInt8, b.rpeer[i], s->comm, s->cs);
+            what = "ncclRecv";
+        }
+        const ncclResult_t end = a->GroupEnd();
+        if (first != ncclSuccess) return rccl_fail(p, first, what);
+        if (end != ncclSuccess) return rccl_fail(p, end, "ncclGroupEnd");
     }
     MCPM_HIP(p, hipEventRecord(s->done[t], s->cs));
     *ticket = t;

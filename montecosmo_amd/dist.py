@@ -427,10 +427,13 @@ class SlabPM(HaloMixin, PlaneHalo):
         import os
         asked = native is not None or "MCPM_SLAB_NATIVE" in os.environ
         if native is None:
-            native = os.environ.get("MCPM_SLAB_NATIVE", "1") != "0"
+            # Default: on wherever the library's transport has been exercised (one rank; several ranks through host callbacks),
+            # OPT-IN (native=True / MCPM_SLAB_NATIVE=1) for RCCL with more than one rank: that branch of csrc/slab.hip has
+            # never run on hardware (no multi-GPU box has been available to the builder), torch.distributed's RCCL path has.
+            rccl_multi = not isinstance(self.comm, LocalComm) and not getattr(self.comm, "stage", False) and P > 1
+            native = os.environ.get("MCPM_SLAB_NATIVE", "0" if rccl_multi else "1") != "0"
         self.native = bool(native)
         self.native_fallback = None        # why the library's transport was given up for torch.distributed, if it was
-        self._mq = []                      # sequence numbers of the library's pending ghost-depth measurements
         if self.native:
             self._bring_up_native(strict=asked)
 
@@ -467,7 +470,17 @@ class SlabPM(HaloMixin, PlaneHalo):
             self._host_ops = HostStagedOps(comm)
             check(lib.mcpm_slab_comm_init_ops(h, C.byref(self._host_ops.struct)), h, "mcpm_slab_comm_init_ops")
         else:                                                   # RCCL: the plan gets its own communicator
+            # Ordering against torch's communicator: every torch collective this class issues is waited for by the CURRENT
+            # stream before anything else is enqueued on it (all_reduce_sum is stream-synchronous; all_reduce_max_async
+            # calls .wait() on its work), and every library exchange starts behind an event recorded on that stream
+            # (slab.hip xfer_begin) -- so a library exchange never runs beside an outstanding torch collective of this rank.
             td = comm.td
+            # The ranks agree that EVERY one of them can open librccl before any of them enters a library collective
+            # (ncclCommInitRank, the self-test): a rank that failed alone would leave the others waiting inside it.
+            probe = torch.zeros(128, dtype=torch.uint8)
+            mine = 0.0 if lib.mcpm_slab_rccl_unique_id(C.c_void_p(probe.data_ptr())) == 0 else 1.0
+            if comm.all_reduce_max_float(mine) != 0.0:
+                raise RuntimeError("librccl is missing or unusable on " + ("this rank" if mine else "another rank") + " (MCPM_E_RCCL)")
             idt = torch.zeros(129, dtype=torch.uint8)           # ncclUniqueId + "rank 0 has one" (a rank that raised before the
             if comm.rank == 0:                                  # broadcast would leave the others waiting in it)
                 idt[128] = 1 if lib.mcpm_slab_rccl_unique_id(C.c_void_p(idt.data_ptr())) == 0 else 0
@@ -799,7 +812,6 @@ class SlabPM(HaloMixin, PlaneHalo):
     def reset_depth(self):
         """Forget the displacement history (call before the first step of a new trajectory: its depth is then the full G)."""
         self._dhist, self._dpending, self._dused = [], None, []
-        self._mq = []
 
     def _harvest_depth(self):
         """Collects the measurement enqueued by the previous `set_depth` (its device work was enqueued a whole step ago, so
@@ -844,10 +856,12 @@ class SlabPM(HaloMixin, PlaneHalo):
             self.reset_depth()
         self._harvest_depth()
         tok, self._dmax_token = self._dmax_token, None
-        if (self.native and tok is not None and isinstance(tok[0], str) and tok[1] == x.data_ptr() and tok[2] == self._kd_gen
-                and self._mq):
-            # x came out of the latest native step, which enqueued max |d_x| over ranks itself (no collective from here)
-            self._dpending = ("native", self._mq.pop(0), paint_order)
+        if (self.native and tok is not None and isinstance(tok[0], str) and tok[1].data_ptr() == x.data_ptr()
+                and tok[1].shape == x.shape and tok[2] == x._version and tok[3] == self._kd_gen):
+            # x came out of the latest native step (the token keeps that tensor alive, so the address cannot have been reused,
+            # and torch has not written to it since: version counter), which enqueued max |d_x| over ranks itself under the
+            # sequence number the token carries (no collective from here)
+            self._dpending = ("native", tok[4], paint_order)
             self._predict_depth(paint_order)
             return
         if tok is not None and not isinstance(tok[0], torch.Tensor):
@@ -896,8 +910,9 @@ class SlabPM(HaloMixin, PlaneHalo):
             self._dmax_token = None
             self._native_call("mcpm_slab_step_f32", _p(x), _p(v), float(alpha), float(beta), float(tau), int(paint_order), int(self.ge),
                               _p(f3_out), _p(x_out), _p(v_out))
-            self._mq = (self._mq + [seq])[-2:]          # this step's measurement (of x_out); at most one older one is still unread
-            self._dmax_token = ("native", x_out.data_ptr(), self._kd_gen)
+            # this step's measurement (of x_out) is number `seq` of the library's ring; a step whose input misses the token
+            # simply never reads its predecessor's entry (the ring is overwritten after four)
+            self._dmax_token = ("native", x_out, x_out._version, self._kd_gen, seq)
             return
         self.call("mcpm_paint_f32", _p(x), self.Nl, POS_LATTICE, None, 1, 1.0, paint_order, _p(self.rho), 0)
         yield from self.force_meshes_gen(self.rho, f3_out, rho_add=self.halo_add_x(self.rho, async_op=True), il=True)

@@ -365,7 +365,17 @@ class FieldLevelLogDensity:
                 lp += l
                 ngb_prior_grad[i], ngb_dbase[i] = gl, d1
         if lp == -math.inf:      # a latent sits in a saturated tail: zero density whatever the field (no forward model needed)
-            return -math.inf, {}
+            # the gradient keeps its full structure (zeros), so that callers which index it before looking at the value --
+            # jax_bridge.logdensity_fn builds a tuple over all names -- get a rejected proposal, not a KeyError
+            if not need_grad:
+                return -math.inf, None
+            zgrad = {name + "_": 0.0 for name in self.latents}
+            if self.ngb_lat is not None:
+                zgrad["ngbars_"] = np.zeros(self.n_rbins)
+            w0 = sample["white_mesh_"]
+            zgrad["white_mesh_"] = (torch.zeros_like(w0) if torch.is_tensor(w0)
+                                    else torch.zeros(fwd.init_shape, dtype=torch.float32, device=nbody._device()))
+            return -math.inf, zgrad
         w = nbody._f32(sample["white_mesh_"], fwd.init_shape)
         if self.scale is None:
             lp += float(-0.5 * LOG2PI * w.numel() - 0.5 * (w.double() ** 2).sum())

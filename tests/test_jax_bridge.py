@@ -101,5 +101,12 @@ def test_bridge_rules_execute_under_a_jax_stand_in(gpu):
         for k in g:
             ref = g_ref[k].cpu().numpy() if torch.is_tensor(g_ref[k]) else np.float32(g_ref[k])
             assert np.array_equal(np.asarray(g[k]), 2.0 * np.asarray(ref, dtype=np.float32)), k
+        # a proposal far in a saturated tail: the value is -inf and the gradient keeps its structure (zeros), so
+        # the chain rejects the proposal instead of dying in the callback
+        far = dict(sample)
+        far["sigma8_"] = -4000.0      # 40 prior sigmas below the lower bound of the truncated-normal latent
+        assert float(f(far)) == -np.inf
+        _, (g,) = js.vjp_of_call(f, (far,), np.float32(1.0))
+        assert set(g) == set(ld.names()) and all(not np.any(np.asarray(g[k])) for k in g)
     finally:
         js.uninstall()
