@@ -67,7 +67,7 @@ int mcpm_plan_slab_oob(mcpm_plan *plan, int64_t *count);
 int mcpm_plan_destroy(mcpm_plan *plan);
 const char *mcpm_last_error(const mcpm_plan *plan); /* plan may be NULL: last error of a failed create */
 /* ABI revision string; the Python loader (montecosmo_amd/_lib.py) refuses a library that reports another one. */
-#define MCPM_ABI_VERSION "mcpm 0.4 (gfx950)"
+#define MCPM_ABI_VERSION "mcpm 0.5 (gfx950)"
 const char *mcpm_version(void);
 /* Tiled CIC paints (montecosmo_amd/csrc/paint_tiled.hip).  A tile's window is (16 + 2 halo + 1)^3 lattice points wide,
    centred on the tile (or, optionally, on the local bulk displacement); what a window misses travels through per-tile
@@ -262,6 +262,13 @@ int mcpm_slab_step_vjp_f32(mcpm_plan *plan, const float *x, const float *v, cons
    step late (montecosmo_amd/dist.py) the wait is free and the host never stops for the depth. */
 int64_t mcpm_slab_dmax_seq(const mcpm_plan *plan);
 int mcpm_slab_dmax_read(mcpm_plan *plan, int64_t seq, float *value, int *valid);
+/* Self-test of the library's hand-written 12-byte streaming store (global_store_dwordx3 ... nt by inline asm, whose store-data
+   hazard the compiler cannot pad: csrc/mcpm_internal.h MCPM_STORE_DATA_HAZARD_NOP).  Writes record i = ((3i, 3i+1, 3i+2) mod 2^24)
+   as floats into out[3n] on `stream`.  mode 0: plain compiler store (the twin to compare with); 1: the asm store followed at once
+   by VALU writes of its three data registers (must equal mode 0); 2: the same WITHOUT the wait states (informational only: shows
+   whether the part exhibits the hazard); 3: the library's own store helper followed by VALU writes of its sources.  No reference
+   counterpart (test infrastructure of the boundary). */
+int mcpm_selftest_store3_nt(void *stream, float *out, int64_t n, int mode);
 /* out = a x + b y over n floats (the ghost-plane additions of the slab steps; also the drift / kick building block). */
 int mcpm_axpby_f32(mcpm_plan *plan, const float *x, const float *y, int64_t n, float a, float b, float *out);
 

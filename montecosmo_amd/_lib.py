@@ -123,13 +123,14 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_double, C.c_double]),
     "mcpm_slab_dmax_seq": (C.c_int64, [C.c_void_p]),
     "mcpm_slab_dmax_read": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mcpm_selftest_store3_nt": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int]),
     "mcpm_axpby_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int64, C.c_float, C.c_float, _f32p]),
     "mcpm_growth_table": (C.c_int, [C.c_double] * 6 + [C.c_int] + [_f64p] * 7),
     "mcpm_distance_table": (C.c_int, [C.c_double] * 6 + [C.c_int] + [_f64p] * 2),
 }
 
 
-ABI_VERSION = "mcpm 0.4 (gfx950)"   # must equal mcpm_version() of the loaded library (include/mcpm.h MCPM_ABI_VERSION)
+ABI_VERSION = "mcpm 0.5 (gfx950)"   # must equal mcpm_version() of the loaded library (include/mcpm.h MCPM_ABI_VERSION)
 
 
 def _load():

@@ -202,9 +202,10 @@ __global__ __launch_bounds__(256) void zinv3_il_kernel(FGeom g, const cf *__rest
         if (NTOUT) {
             typedef float f3v __attribute__((ext_vector_type(3)));
             const f3v va = {r[0][m].x, r[1][m].x, r[2][m].x}, vb = {r[0][m].y, r[1][m].y, r[2][m].y};
-            // (s_nop: the store-data hazard of > 8-byte stores, invisible to the compiler inside inline asm; see store3_nt)
-            asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 2" : : "v"(&a[u + T * m]), "v"(va) : "memory");
-            asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 2" : : "v"(&b[u + T * m]), "v"(vb) : "memory");
+            // (the store-data hazard of > 8-byte stores, invisible to the compiler inside inline asm: the rule and its wait
+            // states are at MCPM_STORE_DATA_HAZARD_NOP in particles_dev.h)
+            asm volatile("global_store_dwordx3 %0, %1, off nt\n\t" MCPM_STORE_DATA_HAZARD_NOP : : "v"(&a[u + T * m]), "v"(va) : "memory");
+            asm volatile("global_store_dwordx3 %0, %1, off nt\n\t" MCPM_STORE_DATA_HAZARD_NOP : : "v"(&b[u + T * m]), "v"(vb) : "memory");
         } else {
             a[u + T * m] = F3{r[0][m].x, r[1][m].x, r[2][m].x};
             b[u + T * m] = F3{r[0][m].y, r[1][m].y, r[2][m].y};

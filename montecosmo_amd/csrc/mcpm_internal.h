@@ -11,6 +11,19 @@
 
 #include "../../include/mcpm.h"
 
+// The store-data hazard of wide vector-memory stores.  The rule (LLVM AMDGPU GCNHazardRecognizer::checkVALUHazardsHelper /
+// createsVALUHazard, "VMEM instructions that store more than 8 bytes can have their store data overwritten by the next
+// instruction"): a FLAT / global / buffer store whose data operand is wider than 64 bits reads its data VGPRs after issue, and a
+// VALU instruction that WRITES one of them must be at least VALUWaitStates behind the store -- 1 wait state up to gfx90a, **2 on
+// parts with the gfx940 instruction set (ST.hasGFX940Insts(), which gfx950 has)**.  The compiler pads its own stores; it does
+// not look inside inline asm, so every hand-written global_store_dwordx3 below carries the padding itself: `s_nop 2` = 3 wait
+// states (s_nop N idles N + 1), one more than the rule asks.  Without it a few cells in ten thousand received whatever the
+// next instructions had put into the data registers (round 3, gpurun_out/r03l).  mcpm_selftest_store3_nt (particles.hip) runs
+// this exact sequence with the data registers overwritten by the very next instructions; tests/test_gpu_parity.py holds it to
+// a plain-store twin over 2^26 records.
+#define MCPM_STORE_DATA_HAZARD_NOP "s_nop 2"
+
+
 #define MCPM_NREDUCE 6144   // [0, 3072): scalar outputs and the bias / observe slot rows; [3072, 6144): the 3 x MCPM_NSLOT step-adjoint slots (kept zero between uses)
 #ifndef MCPM_NZPAD
 #define MCPM_NZPAD 16  // complex elements added to the nz/2 pitch of the internal spectra

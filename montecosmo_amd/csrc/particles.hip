@@ -468,6 +468,37 @@ static int check_particles(mcpm_plan *p, const void *pos, int64_t n, int mode, i
         }                                                  \
     } while (0)
 
+// ---- self-test of the hand-written 12-byte streaming store ---------------------------------------------
+// Record i receives the three floats (3i, 3i+1, 3i+2) mod 2^24 (exact in fp32).  MODE 0: plain compiler store (the twin);
+// 1: the store3_nt sequence on pinned registers v[40:42] whose NEXT instructions overwrite all three data registers -- the
+// situation the s_nop of MCPM_STORE_DATA_HAZARD_NOP exists for; 2: the same without the s_nop (informational: shows whether
+// this part exhibits the hazard; never used by the product); 3: store3_nt itself followed by VALU writes of its source values.
+template <int MODE>
+__global__ void __launch_bounds__(256) store3_hazard_kernel(float *out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a = (float)(int)((3 * i) & 0xFFFFFF), b = (float)(int)((3 * i + 1) & 0xFFFFFF), c = (float)(int)((3 * i + 2) & 0xFFFFFF);
+    float *q = out + 3 * i;
+    if (MODE == 0) {
+        q[0] = a, q[1] = b, q[2] = c;
+    } else if (MODE == 1) {
+        asm volatile("v_mov_b32 v40, %1\n\tv_mov_b32 v41, %2\n\tv_mov_b32 v42, %3\n\t"
+                     "global_store_dwordx3 %0, v[40:42], off nt\n\t" MCPM_STORE_DATA_HAZARD_NOP "\n\t"
+                     "v_mov_b32 v40, -1.0\n\tv_mov_b32 v41, -1.0\n\tv_mov_b32 v42, -1.0"
+                     : : "v"(q), "v"(a), "v"(b), "v"(c) : "v40", "v41", "v42", "memory");
+    } else if (MODE == 2) {
+        asm volatile("v_mov_b32 v40, %1\n\tv_mov_b32 v41, %2\n\tv_mov_b32 v42, %3\n\t"
+                     "global_store_dwordx3 %0, v[40:42], off nt\n\t"
+                     "v_mov_b32 v40, -1.0\n\tv_mov_b32 v41, -1.0\n\tv_mov_b32 v42, -1.0"
+                     : : "v"(q), "v"(a), "v"(b), "v"(c) : "v40", "v41", "v42", "memory");
+    } else {
+        store3_nt(out, i, a, b, c);
+        asm volatile("v_mov_b32 %0, -1.0\n\tv_mov_b32 %1, -1.0\n\tv_mov_b32 %2, -1.0" : "+v"(a), "+v"(b), "+v"(c));
+        if (a != -1.f || b != -1.f || c != -1.f) q[0] = a + b + c;      // keeps the overwrites alive; never taken
+    }
+}
+
+
 extern "C" {
 
 int mcpm_cell_index(mcpm_plan *p, const float *pos, int64_t n, int mode, int order, int16_t *idx) {
@@ -680,6 +711,20 @@ int mcpm_kick_drift_il_f32(mcpm_plan *p, const float *pos_in, const float *vel_i
 int mcpm_plan_track_dmax(mcpm_plan *p, unsigned *slots) {
     if (!p) return MCPM_E_ARG;
     p->dmax = slots;
+    return MCPM_OK;
+}
+
+int mcpm_selftest_store3_nt(void *stream, float *out, int64_t n, int mode) {
+    if (!out || n < 0 || mode < 0 || mode > 3) return mcpm_fail(nullptr, MCPM_E_ARG, "mcpm_selftest_store3_nt: bad argument");
+    if (n == 0) return MCPM_OK;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) store3_hazard_kernel<0><<<grid, block, 0, st>>>(out, n);
+    else if (mode == 1) store3_hazard_kernel<1><<<grid, block, 0, st>>>(out, n);
+    else if (mode == 2) store3_hazard_kernel<2><<<grid, block, 0, st>>>(out, n);
+    else store3_hazard_kernel<3><<<grid, block, 0, st>>>(out, n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mcpm_fail(nullptr, MCPM_E_HIP, std::string("store3_hazard_kernel: ") + hipGetErrorString(e));
     return MCPM_OK;
 }
 

@@ -17,6 +17,7 @@ __device__ __forceinline__ void store3(float *__restrict__ p, int64_t i, P3 v) {
 // store has no 96-bit form, hence the instruction itself.
 typedef float mcpm_f3v __attribute__((ext_vector_type(3)));
 // two / four 12-byte streaming loads issued together (one wait): a particle kernel's first loads
+// (MCPM_STORE_DATA_HAZARD_NOP: mcpm_internal.h)
 __device__ __forceinline__ void load3_nt2(const float *a, const float *b, int64_t i, P3 &A, P3 &B) {
     mcpm_f3v va, vb;
     const float *qa = a + 3 * i, *qb = b + 3 * i;
@@ -47,10 +48,7 @@ __device__ __forceinline__ P3 load3_nt(const float *p, int64_t i) {
 __device__ __forceinline__ void store3_nt(float *p, int64_t i, float a, float b, float c) {
     const mcpm_f3v v = {a, b, c};
     float *q = p + 3 * i;
-    // s_nop: a store of more than 8 bytes reads its data registers a cycle or two after issue, and the compiler's hazard
-    // recognizer, which keeps VALU writes away from them, cannot see into inline asm (without it a few cells in ten thousand
-    // received whatever the next instructions had put into those registers)
-    asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 2" : : "v"(q), "v"(v) : "memory");
+    asm volatile("global_store_dwordx3 %0, %1, off nt\n\t" MCPM_STORE_DATA_HAZARD_NOP : : "v"(q), "v"(v) : "memory");
 }
 
 // Python-style modulo for |c| < 2^16, n < 2^15.

@@ -811,3 +811,33 @@ def test_adjoint_step_reading_its_cotangents_elsewhere_equals_the_in_place_form(
                     C.c_void_p(r.sbar.data_ptr() + 8 * (K + i)), 0.5 if i == K - 1 else 1.0, C.c_void_p(r.sbar.data_ptr() + 8 * 2 * K))
     torch.cuda.synchronize()
     assert torch.equal(r.xb, xb1) and torch.equal(r.vb, vb1) and torch.equal(r.sbar, sb1)
+
+
+def test_streaming_store_data_hazard_is_padded(gpu):
+    """The hand-written 12-byte streaming store (`global_store_dwordx3 ... nt` by inline asm in store3_nt and in the interleaved
+    z C2R pass) reads its data registers after issue; on gfx940-class parts a VALU write of them needs two wait states behind
+    the store (LLVM GCNHazardRecognizer, VMEM store data wider than 64 bits), which the compiler cannot insert inside inline
+    asm, so the asm carries `s_nop 2` itself (csrc/mcpm_internal.h MCPM_STORE_DATA_HAZARD_NOP).  Round 3's corruption was caught
+    by a golden fixture by luck of register allocation; this test forces the situation: the instructions right behind the store
+    overwrite all three data registers, over 2^26 records, against a plain-store twin."""
+    import ctypes as C
+    import torch
+    from montecosmo_amd._lib import lib, check
+    n = 1 << 26
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ref = torch.empty(3 * n, dtype=torch.float32, device=gpu)
+    check(lib.mcpm_selftest_store3_nt(st, C.c_void_p(ref.data_ptr()), n, 0), None, "mcpm_selftest_store3_nt")
+    head = (np.arange(3 * 4096, dtype=np.int64) & 0xFFFFFF).astype(np.float32)       # the twin itself against the definition
+    assert np.array_equal(ref[:3 * 4096].cpu().numpy(), head)
+    tail = ((3 * (n - 4096) + np.arange(3 * 4096, dtype=np.int64)) & 0xFFFFFF).astype(np.float32)
+    assert np.array_equal(ref[-3 * 4096:].cpu().numpy(), tail)
+    out = torch.empty_like(ref)
+    for mode in (1, 3):                 # pinned registers + the padding macro; the library's own helper
+        for rep in range(3):
+            out.fill_(-7.0)
+            check(lib.mcpm_selftest_store3_nt(st, C.c_void_p(out.data_ptr()), n, mode), None, "mcpm_selftest_store3_nt")
+            bad = int((out != ref).sum())
+            assert bad == 0, f"mode {mode}: {bad} of {3 * n} floats differ from the plain-store twin"
+    out.fill_(-7.0)                     # without the wait states: informational (printed with -s), not asserted
+    check(lib.mcpm_selftest_store3_nt(st, C.c_void_p(out.data_ptr()), n, 2), None, "mcpm_selftest_store3_nt")
+    print(f"store3 hazard, no wait states: {int((out != ref).sum())} of {3 * n} floats corrupted")
