@@ -469,6 +469,22 @@ int mcpm_observe_pos_f32(mcpm_plan *plan, const float *pos, const float *vel, co
 int mcpm_observe_pos_vjp_f32(mcpm_plan *plan, const float *pos, const float *vel, const float *dvel, int64_t n, int pos_mode,
                              const float *geom, int flags, const double *tables, int nchi, int ngrow, const float *out_bar,
                              float *pos_bar, float *vel_bar, float *dvel_bar, double *gf_bar);
+/* Light cone (a_obs = None, the reference's default: model.py:62): how the cosmology enters the per-particle look-ups.
+   The scale factor of a particle is chi2a(distance) and its growth quantities are table look-ups at that scale factor
+   (model.py:740-742 -> bricks.py:750-768 los_scalefactor_pos -> nbody.py:862-884 chi2a, :748-808 a2g ...; again at the evolved
+   positions for the RSD, model.py:781-784).  These two calls contract per-particle cotangents into the cotangents of the TABLES
+   themselves (float64 on the device; nodes of the chi -> a look-up and values of the growth tables), which the host chains to
+   cosmological parameters with the tables' finite-difference Jacobian (montecosmo_amd/model.py cosmo_vjp).
+   mcpm_lightcone_tables_vjp_f32: Lagrangian side.  r0 (n): particle distances; tables = chi[nchi] ascending, a(chi)[nchi],
+   a[ngrow], g, g2 (raw table, without the -3/7), f, f2 [ngrow each]; g_bar / g2_bar / dg2dg_bar (n floats; the last two may be
+   NULL): cotangents of a2g(a), a2g2(a), a2dg2dg(a).  table_bar (OVERWRITTEN): chi_bar[nchi], g_bar, g2_bar, f_bar, f2_bar [ngrow each].
+   mcpm_observe_pos_tables_vjp_f32: observation side, arguments of mcpm_observe_pos_vjp_f32 (flags must carry the light-cone bit);
+   table_bar (OVERWRITTEN): chi_bar[nchi], g_bar[ngrow], f_bar[ngrow]. */
+int mcpm_lightcone_tables_vjp_f32(mcpm_plan *plan, const float *r0, int64_t n, const double *tables, int nchi, int ngrow,
+                                  const float *g_bar, const float *g2_bar, const float *dg2dg_bar, double *table_bar);
+int mcpm_observe_pos_tables_vjp_f32(mcpm_plan *plan, const float *pos, const float *vel, const float *dvel, int64_t n, int pos_mode,
+                                    const float *geom, int flags, const double *tables, int nchi, int ngrow, const float *out_bar,
+                                    double *table_bar);
 
 /* chreshape (montecosmo/utils.py:924-1013): half-spectrum of a real (in_nx, in_ny, in_nz) mesh -> half-spectrum of a
    real (out_nx, out_ny, out_nz) mesh, truncating / zero-padding the centred wavevectors with the reference's Nyquist-plane

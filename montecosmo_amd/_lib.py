@@ -67,6 +67,9 @@ SIGNATURES = {
                                        C.c_void_p, C.c_int, C.c_int, _f32p]),
     "mcpm_observe_pos_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_int,
                                            C.c_void_p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
+    "mcpm_lightcone_tables_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_void_p, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_void_p]),
+    "mcpm_observe_pos_tables_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_int,
+                                                  C.c_void_p, C.c_int, C.c_int, _f32p, C.c_void_p]),
     "mcpm_rg2cgh_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
     "mcpm_rg2cgh_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
     "mcpm_cgh2rg_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),

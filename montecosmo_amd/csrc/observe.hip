@@ -182,21 +182,147 @@ __global__ __launch_bounds__(256) void observe_vjp_kernel(Geom g, Obs og, Tables
     block_add<1>(red, slots);
 }
 
-}  // namespace
 
-extern "C" {
+// ---- cotangents of the look-up TABLES (light cone: how the cosmology enters; model.py:740, :781, bricks.py:750-768) -----------
+// y = np.interp(x, xp, fp) = fp[lo] + (fp[lo+1] - fp[lo]) t,  t = (x - xp[lo]) / (xp[lo+1] - xp[lo]):
+//   dy/dfp[lo] = 1 - t, dy/dfp[lo+1] = t;   dy/dxp[lo] = -slope (1 - t), dy/dxp[lo+1] = -slope t;   dy/dx = slope
+// (clamped ends: y = fp[0] or fp[n-1], slope 0).  The kernels below contract those with per-particle cotangents into small
+// float64 table cotangents (LDS accumulators per workgroup, one global float64 atomic per non-zero entry and workgroup); the
+// host then contracts them with the tables' finite-difference Jacobian w.r.t. the cosmological parameters (model.py cosmo_vjp).
+struct Interp {
+    int lo;
+    bool clamped;
+    double t, slope, y;
+};
+__device__ __forceinline__ Interp interp_idx(double x, const double *xp, const double *fp, int n) {
+    Interp r;
+    r.clamped = true;
+    if (x <= xp[0]) { r.lo = 0, r.t = 0., r.slope = 0., r.y = fp[0]; return r; }
+    if (x >= xp[n - 1]) { r.lo = n - 2, r.t = 1., r.slope = 0., r.y = fp[n - 1]; return r; }
+    r.clamped = false;
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xp[mid] <= x) lo = mid; else hi = mid;
+    }
+    const double dx = xp[hi] - xp[lo];
+    r.lo = lo;
+    r.t = (x - xp[lo]) / dx;
+    r.slope = (fp[hi] - fp[lo]) / dx;
+    r.y = fp[lo] + r.slope * (x - xp[lo]);
+    return r;
+}
+// same bracket, another value table on the same nodes
+__device__ __forceinline__ void interp_at(const Interp &b, const double *xp, const double *fp, double &y, double &slope) {
+    const double dx = xp[b.lo + 1] - xp[b.lo];
+    const double d = fp[b.lo + 1] - fp[b.lo];
+    y = fp[b.lo] + d * b.t;
+    slope = b.clamped ? 0. : d / dx;
+}
+__device__ __forceinline__ void lds_add(double *sh, int i, double v) {
+    if (v != 0.) atomicAdd(sh + i, v);
+}
+// cotangent ybar of a value looked up at bracket b: into the value table's accumulator
+__device__ __forceinline__ void scatter_fp(double *sh, const Interp &b, double ybar) {
+    lds_add(sh, b.lo, ybar * (1. - b.t));
+    lds_add(sh, b.lo + 1, ybar * b.t);
+}
+// ... and, for a look-up whose NODES move with the cosmology (chi -> a), into the node table's accumulator
+__device__ __forceinline__ void scatter_xp(double *sh, const Interp &b, double ybar) {
+    lds_add(sh, b.lo, -ybar * b.slope * (1. - b.t));
+    lds_add(sh, b.lo + 1, -ybar * b.slope * b.t);
+}
 
-// geom (host, 19 floats) = R[9] row major, box_size[3], box_center[3], paint_shape[3] (as floats), g(a_obs) f(a_obs).
-// flags: bit 0 = curved sky, bit 1 = light cone (then the four tables, float64 on the DEVICE: chi ascending [nchi],
-// a(chi) [nchi], a [ngrow], g [ngrow], f [ngrow] -- the host's growth / distance tables).  pos / out follow pos_mode:
-// MCPM_POS_LATTICE: displacements from the plan's particle lattice on the evolution mesh in, displacements from the same
-// lattice scaled to the paint mesh out; MCPM_POS_ABSOLUTE: absolute cell coordinates in and out.
-int mcpm_observe_pos_f32(mcpm_plan *p, const float *pos, const float *vel, const float *dvel, int64_t n, int mode,
-                         const float *geom, int flags, const double *tables, int nchi, int ngrow, float *out) {
-    if (!p) return MCPM_E_ARG;
-    MCPM_REQUIRE(p, pos && vel && geom && out && n > 0, MCPM_E_ARG, "mcpm_observe_pos_f32: bad argument");
-    MCPM_REQUIRE(p, mode == MCPM_POS_ABSOLUTE || (mode == MCPM_POS_LATTICE && n == p->Np), MCPM_E_ARG, "mcpm_observe_pos_f32: bad pos_mode / count");
-    MCPM_REQUIRE(p, !(flags & 2) || (tables && nchi >= 2 && ngrow >= 2), MCPM_E_ARG, "mcpm_observe_pos_f32: light cone needs the tables");
+// Lagrangian side (model.py:740-764): a_q = chi2a(r0_q) kept in float32, then a2g(a_q) (bias weights and lpt), a2g2(a_q),
+// a2dg2dg(a_q) = safe_div(g2 f2, g f) (lpt).  Cotangents per particle: gB (of a2g), g2B (of a2g2 = -3/7 g2raw), dB (of a2dg2dg).
+// tables: chi[nchi] ascending, a(chi)[nchi], a[ng], g[ng], g2raw[ng], f[ng], f2[ng];  out: chi_bar[nchi], g_bar, g2raw_bar, f_bar, f2_bar.
+__global__ __launch_bounds__(256) void lightcone_tables_vjp_kernel(const float *__restrict__ r0, int64_t n, const double *__restrict__ tb,
+                                                                   int nchi, int ng, const float *__restrict__ gB,
+                                                                   const float *__restrict__ g2B, const float *__restrict__ dB,
+                                                                   double *__restrict__ out) {
+    extern __shared__ double sh[];
+    const int ntot = nchi + 4 * ng;
+    for (int i = threadIdx.x; i < ntot; i += 256) sh[i] = 0.;
+    __syncthreads();
+    const double *chi = tb, *aoc = tb + nchi, *ag = tb + 2 * nchi, *tg = ag + ng, *tg2 = tg + ng, *tf = tg2 + ng, *tf2 = tf + ng;
+    double *s_chi = sh, *s_g = sh + nchi, *s_g2 = s_g + ng, *s_f = s_g2 + ng, *s_f2 = s_f + ng;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const Interp ba = interp_idx((double)r0[i], chi, aoc, nchi);
+        const double a = (double)(float)ba.y;                 // the forward pass hands a on as float32 (mcpm_interp_f32)
+        const Interp bg = interp_idx(a, ag, tg, ng);
+        double g = bg.y, sg = bg.slope, g2r, sg2, f, sf, f2, sf2;
+        interp_at(bg, ag, tg2, g2r, sg2);
+        interp_at(bg, ag, tf, f, sf);
+        interp_at(bg, ag, tf2, f2, sf2);
+        double gb = (double)gB[i], g2rb = 0., fb = 0., f2b = 0.;
+        if (g2B) g2rb += (-3. / 7.) * (double)g2B[i];
+        if (dB) {
+            const double den = g * f, db = (double)dB[i];
+            if (den != 0.) {                                   // a2dg2dg = (-3/7 g2r f2) / (g f), safe_div
+                const double q = (-3. / 7.) * g2r * f2 / den;
+                gb += -db * q / g;
+                fb += -db * q / f;
+                g2rb += db * (-3. / 7.) * f2 / den;
+                f2b += db * (-3. / 7.) * g2r / den;
+            }
+        }
+        scatter_fp(s_g, bg, gb);
+        scatter_fp(s_g2, bg, g2rb);
+        scatter_fp(s_f, bg, fb);
+        scatter_fp(s_f2, bg, f2b);
+        const double ab = gb * sg + g2rb * sg2 + fb * sf + f2b * sf2;
+        scatter_xp(s_chi, ba, ab);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntot; i += 256)
+        if (sh[i] != 0.) atomicAdd(out + i, sh[i]);
+}
+
+// Eulerian side (model.py:781-784): gf_p = a2g(a_p) a2f(a_p), a_p = chi2a(r_p) at the evolved particle's distance.
+// tables as in observe_kernel (chi, a(chi), a, g, f);  out: chi_bar[nchi], g_bar[ngrow], f_bar[ngrow].
+template <int MODE>
+__global__ __launch_bounds__(256) void observe_tables_vjp_kernel(Geom g, Obs og, Tables tb, const float *__restrict__ pos,
+                                                                 const float *__restrict__ vel, const float *__restrict__ dvel, int64_t n,
+                                                                 const float *__restrict__ ob, double *__restrict__ out) {
+    extern __shared__ double sh[];
+    const int ntot = og.nchi + 2 * og.ngrow;
+    for (int i = threadIdx.x; i < ntot; i += 256) sh[i] = 0.;
+    __syncthreads();
+    double *s_chi = sh, *s_g = sh + og.nchi, *s_f = s_g + og.ngrow;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float q[3] = {0.f, 0.f, 0.f}, x[3], v[3], dv[3] = {0.f, 0.f, 0.f}, o[3];
+        if (MODE == MCPM_POS_LATTICE) lattice_point(g, i, q);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            x[a] = q[a] + pos[3 * i + a];
+            v[a] = vel[3 * i + a];
+            if (dvel) dv[a] = dvel[3 * i + a];
+            o[a] = ob[3 * i + a];
+        }
+        Fwd w;
+        forward(og, tb, x, v, dv, w);
+        float t[3], Db[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t[a] = o[a] / og.cp[a];
+        rot(og.R, t, Db);
+        const float sb = Db[0] * w.l[0] + Db[1] * w.l[1] + Db[2] * w.l[2];
+        const double gfb = (double)sb * ((double)w.l[0] * w.Vr[0] + (double)w.l[1] * w.Vr[1] + (double)w.l[2] * w.Vr[2]);
+        const Interp ba = interp_idx((double)w.r, tb.chi, tb.a_of_chi, og.nchi);
+        const Interp bg = interp_idx(ba.y, tb.a, tb.g, og.ngrow);
+        double f, sf;
+        interp_at(bg, tb.a, tb.f, f, sf);
+        const double gb = gfb * f, fb = gfb * bg.y;
+        scatter_fp(s_g, bg, gb);
+        scatter_fp(s_f, bg, fb);
+        scatter_xp(s_chi, ba, gb * bg.slope + fb * sf);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntot; i += 256)
+        if (sh[i] != 0.) atomicAdd(out + i, sh[i]);
+}
+
+
+Obs make_obs(const mcpm_plan *p, const float *geom, int flags, int nchi, int ngrow) {
     Obs og;
     for (int i = 0; i < 9; ++i) og.R[i] = geom[i];
     const int ms[3] = {p->g.nx, p->g.ny, p->g.nz};
@@ -215,6 +341,25 @@ int mcpm_observe_pos_f32(mcpm_plan *p, const float *pos, const float *vel, const
     og.gf = geom[18];
     og.nchi = nchi;
     og.ngrow = ngrow;
+    return og;
+}
+
+}  // namespace
+
+extern "C" {
+
+// geom (host, 19 floats) = R[9] row major, box_size[3], box_center[3], paint_shape[3] (as floats), g(a_obs) f(a_obs).
+// flags: bit 0 = curved sky, bit 1 = light cone (then the four tables, float64 on the DEVICE: chi ascending [nchi],
+// a(chi) [nchi], a [ngrow], g [ngrow], f [ngrow] -- the host's growth / distance tables).  pos / out follow pos_mode:
+// MCPM_POS_LATTICE: displacements from the plan's particle lattice on the evolution mesh in, displacements from the same
+// lattice scaled to the paint mesh out; MCPM_POS_ABSOLUTE: absolute cell coordinates in and out.
+int mcpm_observe_pos_f32(mcpm_plan *p, const float *pos, const float *vel, const float *dvel, int64_t n, int mode,
+                         const float *geom, int flags, const double *tables, int nchi, int ngrow, float *out) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, pos && vel && geom && out && n > 0, MCPM_E_ARG, "mcpm_observe_pos_f32: bad argument");
+    MCPM_REQUIRE(p, mode == MCPM_POS_ABSOLUTE || (mode == MCPM_POS_LATTICE && n == p->Np), MCPM_E_ARG, "mcpm_observe_pos_f32: bad pos_mode / count");
+    MCPM_REQUIRE(p, !(flags & 2) || (tables && nchi >= 2 && ngrow >= 2), MCPM_E_ARG, "mcpm_observe_pos_f32: light cone needs the tables");
+    Obs og = make_obs(p, geom, flags, nchi, ngrow);
     Tables tb{tables, tables ? tables + nchi : nullptr, tables ? tables + 2 * nchi : nullptr,
               tables ? tables + 2 * nchi + ngrow : nullptr, tables ? tables + 2 * nchi + 2 * ngrow : nullptr};
     const unsigned nb = (unsigned)((n + 255) / 256);
@@ -236,24 +381,7 @@ int mcpm_observe_pos_vjp_f32(mcpm_plan *p, const float *pos, const float *vel, c
     MCPM_REQUIRE(p, mode == MCPM_POS_ABSOLUTE || (mode == MCPM_POS_LATTICE && n == p->Np), MCPM_E_ARG, "mcpm_observe_pos_vjp_f32: bad pos_mode / count");
     MCPM_REQUIRE(p, !(flags & 2) || (tables && nchi >= 2 && ngrow >= 2), MCPM_E_ARG, "mcpm_observe_pos_vjp_f32: light cone needs the tables");
     MCPM_REQUIRE(p, (dvel == nullptr) == (dvel_bar == nullptr), MCPM_E_ARG, "mcpm_observe_pos_vjp_f32: dvel and dvel_bar go together");
-    Obs og;
-    for (int i = 0; i < 9; ++i) og.R[i] = geom[i];
-    const int ms[3] = {p->g.nx, p->g.ny, p->g.nz};
-    float cn = 0.f;
-    for (int a = 0; a < 3; ++a) {
-        og.ce[a] = geom[9 + a] / (float)ms[a];
-        og.cp[a] = geom[9 + a] / geom[15 + a];
-        og.hb[a] = 0.5f * geom[9 + a];
-        og.ctr[a] = geom[12 + a];
-        cn += geom[12 + a] * geom[12 + a];
-    }
-    cn = sqrtf(cn);
-    for (int a = 0; a < 3; ++a) og.lf[a] = cn == 0.f ? 0.f : geom[12 + a] / cn;
-    og.curved = flags & 1;
-    og.lightcone = (flags >> 1) & 1;
-    og.gf = geom[18];
-    og.nchi = nchi;
-    og.ngrow = ngrow;
+    Obs og = make_obs(p, geom, flags, nchi, ngrow);
     Tables tb{tables, tables ? tables + nchi : nullptr, tables ? tables + 2 * nchi : nullptr,
               tables ? tables + 2 * nchi + ngrow : nullptr, tables ? tables + 2 * nchi + 2 * ngrow : nullptr};
     double *slots = p->reduce;
@@ -266,6 +394,46 @@ int mcpm_observe_pos_vjp_f32(mcpm_plan *p, const float *pos, const float *vel, c
         observe_vjp_kernel<MCPM_POS_ABSOLUTE><<<nb, 256, 0, p->stream>>>(p->g, og, tb, pos, vel, dvel, n, out_bar, pos_bar, vel_bar, dvel_bar, slots);
     fold_kernel<<<1, NSLOT, 0, p->stream>>>(slots, 1, 1.0, gf_bar);
     MCPM_LAUNCH_CHECK(p, "observe_vjp_kernel");
+    return MCPM_OK;
+}
+
+// Light cone, Lagrangian side: table cotangents of the look-ups a_q = chi2a(r0_q), a2g / a2g2 / a2dg2dg (a_q) (see
+// lightcone_tables_vjp_kernel).  tables (device float64): chi[nchi] ascending, a(chi)[nchi], a[ngrow], g, g2 (raw table, without
+// the -3/7), f, f2 [ngrow each]; g_bar (n) is required, g2_bar / dg2dg_bar may be NULL.  table_bar (device float64, OVERWRITTEN):
+// chi_bar[nchi], g_bar[ngrow], g2_bar[ngrow], f_bar[ngrow], f2_bar[ngrow].
+int mcpm_lightcone_tables_vjp_f32(mcpm_plan *p, const float *r0, int64_t n, const double *tables, int nchi, int ngrow,
+                                  const float *g_bar, const float *g2_bar, const float *dg2dg_bar, double *table_bar) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, r0 && tables && g_bar && table_bar && n > 0 && nchi >= 2 && ngrow >= 2, MCPM_E_ARG, "mcpm_lightcone_tables_vjp_f32: bad argument");
+    const size_t ntot = (size_t)nchi + 4 * (size_t)ngrow;
+    MCPM_REQUIRE(p, ntot * sizeof(double) <= 60 * 1024, MCPM_E_ARG, "mcpm_lightcone_tables_vjp_f32: tables exceed the LDS accumulators");
+    MCPM_HIP(p, hipMemsetAsync(table_bar, 0, ntot * sizeof(double), p->stream));
+    const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    lightcone_tables_vjp_kernel<<<nb, 256, ntot * sizeof(double), p->stream>>>(r0, n, tables, nchi, ngrow, g_bar, g2_bar, dg2dg_bar, table_bar);
+    MCPM_LAUNCH_CHECK(p, "lightcone_tables_vjp_kernel");
+    return MCPM_OK;
+}
+
+// Light cone, observation side: table cotangents of gf_p = a2g(a_p) a2f(a_p), a_p = chi2a(|P_p|) inside mcpm_observe_pos_f32 (same
+// arguments; flags must have the light-cone bit).  table_bar (device float64, OVERWRITTEN): chi_bar[nchi], g_bar[ngrow], f_bar[ngrow].
+int mcpm_observe_pos_tables_vjp_f32(mcpm_plan *p, const float *pos, const float *vel, const float *dvel, int64_t n, int mode,
+                                    const float *geom, int flags, const double *tables, int nchi, int ngrow, const float *out_bar,
+                                    double *table_bar) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, pos && vel && geom && out_bar && table_bar && n > 0, MCPM_E_ARG, "mcpm_observe_pos_tables_vjp_f32: bad argument");
+    MCPM_REQUIRE(p, mode == MCPM_POS_ABSOLUTE || (mode == MCPM_POS_LATTICE && n == p->Np), MCPM_E_ARG, "mcpm_observe_pos_tables_vjp_f32: bad pos_mode / count");
+    MCPM_REQUIRE(p, (flags & 2) && tables && nchi >= 2 && ngrow >= 2, MCPM_E_ARG, "mcpm_observe_pos_tables_vjp_f32: light cone only (flags bit 1, tables)");
+    const size_t ntot = (size_t)nchi + 2 * (size_t)ngrow;
+    MCPM_REQUIRE(p, ntot * sizeof(double) <= 60 * 1024, MCPM_E_ARG, "mcpm_observe_pos_tables_vjp_f32: tables exceed the LDS accumulators");
+    Obs og = make_obs(p, geom, flags, nchi, ngrow);
+    Tables tb{tables, tables + nchi, tables + 2 * nchi, tables + 2 * nchi + ngrow, tables + 2 * nchi + 2 * ngrow};
+    MCPM_HIP(p, hipMemsetAsync(table_bar, 0, ntot * sizeof(double), p->stream));
+    const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    if (mode == MCPM_POS_LATTICE)
+        observe_tables_vjp_kernel<MCPM_POS_LATTICE><<<nb, 256, ntot * sizeof(double), p->stream>>>(p->g, og, tb, pos, vel, dvel, n, out_bar, table_bar);
+    else
+        observe_tables_vjp_kernel<MCPM_POS_ABSOLUTE><<<nb, 256, ntot * sizeof(double), p->stream>>>(p->g, og, tb, pos, vel, dvel, n, out_bar, table_bar);
+    MCPM_LAUNCH_CHECK(p, "observe_tables_vjp_kernel");
     return MCPM_OK;
 }
 

@@ -211,7 +211,7 @@ class FieldLevelForward:
         init_k = self._power_mult(ctx.white, cosmo)
         s8b = float((init_b.conj() * init_k).real.sum().item()) / float(cosmo.sigma8)
         return {"white_mesh": white_b, "bias": bias_bar, "sigma8": s8b, "growth": growth, "bias_growth": bg_bar, "gf": gfb,
-                "init_bar": init_b}
+                "init_bar": init_b, "obs_bar": pb if self.a_obs is None else None}
 
     def cosmo_vjp(self, ctx, grads, params=("Omega_m",), rel_eps=1e-5):
         """Chains the growth cotangents of `evolve_vjp` to cosmological parameters (fixed a_obs): besides sigma8 and the
@@ -219,10 +219,11 @@ class FieldLevelForward:
         field on the device) the cosmology enters evolve through host float64 scalars looked up in the 128-point growth tables -- the
         BullFrog coefficients and the 2LPT start (nbody.cosmo_vjp), a2g(a_obs) in the bias weights, a2g a2f in the
         RSD -- so dL/dtheta = sum_s s_bar ds/dtheta with the table Jacobian taken by central finite differences.
-        `params`: attribute names of the cosmology object; 'Omega_m' varies Omega_c at fixed Omega_b."""
+        `params`: attribute names of the cosmology object; 'Omega_m' varies Omega_c at fixed Omega_b.  On the light cone
+        (a_obs = None) the look-ups are per particle: `_cosmo_vjp_lightcone`."""
         import copy
         if self.a_obs is None:
-            raise NotImplementedError("light cone: the cosmology dependence of the distance / growth look-ups is not propagated")
+            return self._cosmo_vjp_lightcone(ctx, grads, params, rel_eps)
         cosmo, a = ctx.cosmo, self.a_obs
 
         def scalars(c):
@@ -265,4 +266,67 @@ class FieldLevelForward:
             if inits:
                 out[name] += float((grads["init_bar"].conj() * (inits[0] - inits[1])).real.sum().item()) / (2 * h)
         cosmo._workspace = {}
+        return out
+
+    # ---- light cone: the cosmology enters through per-particle table look-ups -----------------------------------------
+    _LC_TABLES = ("chi", "g", "g2", "f", "f2")
+
+    def _lightcone_tables(self, cosmo):
+        """The five cosmology-dependent tables the light-cone look-ups read (host float64): chi ascending (the nodes of
+        chi2a, nbody.py:862-884; its values, the scale-factor grid, do not move) and g, g2 (raw), f, f2 on the growth grid."""
+        d, gt = nbody._dist_cache(cosmo), nbody._growth_cache(cosmo)
+        return {"chi": d["chi"][::-1].copy(), "g": gt["g"], "g2": gt["g2"], "f": gt["f"], "f2": gt["f2"]}
+
+    def lightcone_table_bars(self, ctx, grads):
+        """Cotangents of those tables (dict of float64 arrays): the Lagrangian look-ups a_q = chi2a(r0_q) -> a2g (bias weights,
+        model.py:756, and lpt), a2g2, a2dg2dg (lpt, nbody.py:652-666) contracted with the per-particle cotangents of
+        `evolve_vjp` (mcpm_lightcone_tables_vjp_f32), plus the observation-side a2g a2f at the evolved positions
+        (model.py:781-784; mcpm_observe_pos_tables_vjp_f32)."""
+        cosmo = ctx.cosmo
+        d, gt = nbody._dist_cache(cosmo), nbody._growth_cache(cosmo)
+        nchi, ng = len(d["chi"]), len(gt["a"])
+        dev = ctx.evol_k.device
+        tabs = torch.from_numpy(np.concatenate([d["chi"][::-1], d["a"][::-1], gt["a"], gt["g"], gt["g2"], gt["f"], gt["f2"]])).to(dev)
+        plan = nbody.get_plan(self.evol_shape, self.ptcl_shape)
+        n = plan.N
+        g = grads["growth"]
+        gB = (nbody._f32(grads["bias_growth"]).reshape(-1) + nbody._f32(g["g"]).reshape(-1)).contiguous()
+        g2B, dB = nbody._f32(g["g2"]).reshape(-1).contiguous(), nbody._f32(g["dg2dg"]).reshape(-1).contiguous()
+        tbL = torch.empty(nchi + 4 * ng, dtype=torch.float64, device=dev)
+        plan.call("mcpm_lightcone_tables_vjp_f32", nbody._ptr(self._r0), n, nbody._ptr(tabs), nchi, ng, nbody._ptr(gB), nbody._ptr(g2B),
+                  nbody._ptr(dB), nbody._ptr(tbL))
+        o = ctx.octx
+        tbO = torch.empty(nchi + 2 * ng, dtype=torch.float64, device=dev)
+        o.plan.call("mcpm_observe_pos_tables_vjp_f32", nbody._ptr(o.p), nbody._ptr(o.v), nbody._ptr(o.dv), o.n, o.mode, o.geom, o.flags,
+                    nbody._ptr(o.tables), o.nchi, o.ngrow, nbody._ptr(grads["obs_bar"]), nbody._ptr(tbO))
+        L, O = tbL.cpu().numpy(), tbO.cpu().numpy()
+        out = {"chi": L[:nchi] + O[:nchi], "g": L[nchi:nchi + ng] + O[nchi:nchi + ng], "g2": L[nchi + ng:nchi + 2 * ng],
+               "f": L[nchi + 2 * ng:nchi + 3 * ng] + O[nchi + ng:], "f2": L[nchi + 3 * ng:]}
+        return out
+
+    def _cosmo_vjp_lightcone(self, ctx, grads, params, rel_eps):
+        """cosmo_vjp on the light cone (a_obs = None, the reference's default configuration, model.py:45, :62): dL/dtheta =
+        sum over the five tables of <table_bar, d table / d theta>, the table Jacobian by central differences of the host
+        float64 RK4 tables (256-point distance table, 128-point growth tables), plus the Eisenstein-Hu term as at fixed a_obs."""
+        import copy
+        if self.evolution != 'lpt':
+            raise NotImplementedError("light cone is built for evolution='lpt' (model.py:770 asserts the same for 'nbody')")
+        cosmo = ctx.cosmo
+        bars = self.lightcone_table_bars(ctx, grads)
+        out = {}
+        for name in params:
+            attr = "Omega_c" if name == "Omega_m" else name
+            base = float(getattr(cosmo, attr))
+            h = rel_eps * max(abs(base), 1e-2)
+            tabs, inits = [], []
+            for sgn in (+1, -1):
+                c = copy.copy(cosmo)
+                c._workspace = {}
+                setattr(c, attr, base + sgn * h)
+                tabs.append(self._lightcone_tables(c))
+                if self.lin_kpow is None:
+                    inits.append(self._power_mult(ctx.white, c))
+            out[name] = float(sum(np.dot(bars[k], (tabs[0][k] - tabs[1][k]) / (2 * h)) for k in self._LC_TABLES))
+            if inits:
+                out[name] += float((grads["init_bar"].conj() * (inits[0] - inits[1])).real.sum().item()) / (2 * h)
         return out

@@ -30,7 +30,7 @@ def rotvec_matrix(rotvec):
 def bias_fields(lin_mesh, box_size):
     """The real-space fields lagrangian_bias reads (bricks.py:350-352, :372-399, :438-441):
     delta, shear^2, 3 det(shear), laplacian(delta) (h/Mpc)^2, grad(delta) (h/Mpc).  Returns (fields dict, parts)."""
-    delta = np.fft.irfftn(lin_mesh)
+    delta = o._irfftn(lin_mesh)
     shape = delta.shape
     kvec = o.rfftk(shape, box_size)
     k2 = sum(ki ** 2 for ki in kvec)
@@ -38,16 +38,16 @@ def bias_fields(lin_mesh, box_size):
     sh = {}
     for i in range(2):
         nabi = o.gradient_hat(kvec, i)
-        sh[(i, i)] = np.fft.irfftn(nabi ** 2 * pot - lin_mesh / 3)
+        sh[(i, i)] = o._irfftn(nabi ** 2 * pot - lin_mesh / 3)
         for j in range(i + 1, 3):
-            sh[(i, j)] = np.fft.irfftn(nabi * o.gradient_hat(kvec, j) * pot)
+            sh[(i, j)] = o._irfftn(nabi * o.gradient_hat(kvec, j) * pot)
     sh[(2, 2)] = -(sh[(0, 0)] + sh[(1, 1)])
     a, b, c = sh[(0, 0)], sh[(1, 1)], sh[(2, 2)]
     d, e, f = sh[(0, 1)], sh[(0, 2)], sh[(1, 2)]
     shear2 = a ** 2 + b ** 2 + c ** 2 + 2 * (d ** 2 + e ** 2 + f ** 2)
     shear3 = 3 * (a * (b * c - f ** 2) - d * (d * c - e * f) + e * (d * f - b * e))
-    nab2 = np.fft.irfftn(-k2 * lin_mesh)
-    grad = [np.fft.irfftn(o.gradient_hat(kvec, i) * lin_mesh) for i in range(3)]
+    nab2 = o._irfftn(-k2 * lin_mesh)
+    grad = [o._irfftn(o.gradient_hat(kvec, i) * lin_mesh) for i in range(3)]
     return dict(delta=delta, shear2=shear2, shear3=shear3, nab2=nab2, grad=grad), (a, b, c, d, e, f)
 
 
@@ -229,7 +229,7 @@ def evolve(cfg, cosmo, bias, white_mesh):
         los = R.T @ o.safe_div(c, np.linalg.norm(c))
         boost = kaiser_boost(cosmo, cfg["a_obs"], cfg["evol_shape"], box, 1. + bias["b1"], los)
         cosmo._workspace = {}
-        return 1. + np.fft.irfftn(init_mesh * boost, s=tuple(cfg["evol_shape"]), axes=(0, 1, 2)), None
+        return 1. + o._irfftn(init_mesh * boost, s=tuple(cfg["evol_shape"]), axes=(0, 1, 2)), None
     pos = o.regular_pos(cfg["evol_shape"], cfg["ptcl_shape"])
     _, a = los_scalefactor_pos(pos, ctr, R, box, cfg["evol_shape"], cosmo, cfg["a_obs"], cfg["curved_sky"])
     w, dvel = lagrangian_bias(o.a2g(cosmo, a), pos, box, init_mesh, bias, read_order=1)
@@ -248,7 +248,7 @@ def evolve(cfg, cosmo, bias, white_mesh):
                   interlace_order=cfg["interlace_order"], paint_deconv=cfg["paint_deconv"])
     gxy = gxy * np.divide(cfg["init_shape"], cfg["ptcl_shape"]).prod()
     gxy = o.chreshape(gxy, o.r2chshape(cfg["paint_shape"]))
-    return np.fft.irfftn(gxy, s=tuple(cfg["paint_shape"]), axes=(0, 1, 2)), dict(init_mesh=init_mesh, weights=w, pos=pos_c)
+    return o._irfftn(gxy, s=tuple(cfg["paint_shape"]), axes=(0, 1, 2)), dict(init_mesh=init_mesh, weights=w, pos=pos_c)
 
 
 # --------------------------------------------------------------------------- log density (model.py:640-679, :840-908)
@@ -391,12 +391,13 @@ def set_radial_count(mesh, rmesh, redges, rcounts):
     return out
 
 
-def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo):
+def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo, aux=None):
     """log p(sample params, count_obs) of the field-level model for Normal or truncated-Normal latents (model.py:1105-1125 prior in
     sample space; bricks.py:255-287 affine reparametrisation; model.py:1127-1148 'fourier' / 'real' / 'kaiser'
     preconditioning; model.py:686-838 evolve; model.py:840-908 'quad_gauss' likelihood with no mask, unit selection, one radial
     bin and phi = 0).  `latents`: name -> dict(loc, scale, loc_fid, scale_fid); `fixed`: name -> value of the base
-    parameters that are not sampled; `sample`: name_ -> value (scalars) and 'white_mesh_' (real, init_shape)."""
+    parameters that are not sampled; `sample`: name_ -> value (scalars) and 'white_mesh_' (real, init_shape).  `aux`: an optional
+    dict that receives the intermediates a test may want ('gxy': evolve's output, 'white': its input, 'count': the mean counts)."""
     lp = 0.0
     base = dict(fixed)
     scalar_items = []
@@ -436,14 +437,16 @@ def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo):
         cosmo_fid = make_cosmo(fiduc)
     scale, transfer = precond_scale_and_transfer(cfg, fiduc, cosmo_fid)
     lp += np.sum(-0.5 * np.log(2 * np.pi) - np.log(scale) - 0.5 * (w / scale) ** 2)     # model.py:666-672
-    white = (o.rg2cgh(w) if cfg["precond"] != "real" else np.fft.rfftn(w)) * transfer
+    white = (o.rg2cgh(w) if cfg["precond"] != "real" else o._rfftn(w)) * transfer
     cosmo = make_cosmo(base)
     bias = {k: base[k] for k in BIAS_KEYS}
     gxy, _ = evolve(cfg, cosmo, bias, white)
+    if aux is not None:
+        aux.update(gxy=gxy, white=white, base=base)
     # likelihood (model.py:852-866, :893-908): selection mesh (paint_shape or scalar 1), mask over the final cells,
     # radial shells with their own mean densities; count_obs is the full final mesh (only its unmasked cells are used)
     final = tuple(cfg["final_shape"])
-    down = lambda m: np.fft.irfftn(o.chreshape(np.fft.rfftn(m), o.r2chshape(final)), s=final, axes=(0, 1, 2))
+    down = lambda m: o._irfftn(o.chreshape(o._rfftn(m), o.r2chshape(final)), s=final, axes=(0, 1, 2))
     sel = cfg.get("selec_mesh")
     mask = np.ones(final, bool) if cfg.get("mask_mesh") is None else np.asarray(cfg["mask_mesh"], bool)
     rcounts = np.atleast_1d(np.asarray(base["ngbars"], float)) * cfg["cell_length"] ** 3
@@ -453,6 +456,8 @@ def log_density(cfg, latents, fixed, sample, count_obs, make_cosmo):
     rmesh = radius_mesh(cfg, final)
     cm = set_radial_count(down(gxy if sel is None else gxy * sel), rmesh, redges, rcounts)
     selec = np.mean(rcounts) if sel is None else np.abs(set_radial_count(down(sel), rmesh, redges, rcounts))
+    if aux is not None:
+        aux.update(count=cm)
     delta = cm / selec - 1
     scale1 = (np.abs(base["s_e"] + base["s_ed"] * delta) + 1e-9) * selec ** .5
     scale2 = base["s_e2"] * selec ** .5 * np.ones(final)

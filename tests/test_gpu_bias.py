@@ -105,3 +105,95 @@ def test_observe_pos_forward_and_vjp(gpu, curved, lightcone, lattice):
         assert abs(fd - gfb) < 2e-3 * abs(fd)
     else:
         assert gfb == 0.0
+
+
+def test_lightcone_table_cotangents(gpu):
+    """The cotangents of the look-up TABLES themselves (how the cosmology enters on the light cone, model.py:740, :781):
+    mcpm_lightcone_tables_vjp_f32 (a_q = chi2a(r0_q) -> a2g, a2g2, a2dg2dg) and mcpm_observe_pos_tables_vjp_f32 (a2g a2f at the
+    evolved positions) against float64 directional finite differences of the same chains in numpy, perturbing every table along
+    a random direction."""
+    import torch
+    from montecosmo_amd import bricks, nbody
+    rng = np.random.default_rng(23)
+    cosmo = bricks.Planck18()
+    d, gt = nbody._dist_cache(cosmo), nbody._growth_cache(cosmo)
+    chi, aoc = d["chi"][::-1].copy(), d["a"][::-1].copy()
+    ag = gt["a"]
+    T0 = {"chi": chi, "g": gt["g"].copy(), "g2": gt["g2"].copy(), "f": gt["f"].copy(), "f2": gt["f2"].copy()}
+    nchi, ng = len(chi), len(ag)
+    N = 20000
+    r0 = rng.uniform(800., 2600., N).astype(np.float32)          # 0.45 < a < 0.8: inside both tables
+    r0[:8] = [0., 1e-3, 5e5, 9e5, chi[5], chi[6], 0.5 * (chi[5] + chi[6]), chi[-1]]      # clamped ends and nodes
+    gB, g2B, dB = (rng.standard_normal(N).astype(np.float32) for _ in range(3))
+
+    def L_lagr(T, round32=True):
+        a = np.interp(r0.astype(np.float64), T["chi"], aoc)
+        if round32:
+            a = a.astype(np.float32).astype(np.float64)
+        g, g2, f, f2 = (np.interp(a, ag, T[k]) for k in ("g", "g2", "f", "f2"))
+        g2 = -3 / 7 * g2
+        return float((gB * g).sum() + (g2B * g2).sum() + (dB * o.safe_div(g2 * f2, g * f)).sum())
+
+    dev = gpu
+    tabs = torch.from_numpy(np.concatenate([chi, aoc, ag, T0["g"], T0["g2"], T0["f"], T0["f2"]])).to(dev)
+    out = torch.empty(nchi + 4 * ng, dtype=torch.float64, device=dev)
+    plan = nbody.get_plan((16, 16, 16))
+    t = lambda x: torch.from_numpy(x).to(dev)
+    r0d, gBd, g2Bd, dBd = t(r0), t(gB), t(g2B), t(dB)
+    plan.call("mcpm_lightcone_tables_vjp_f32", nbody._ptr(r0d), N, nbody._ptr(tabs), nchi, ng, nbody._ptr(gBd), nbody._ptr(g2Bd),
+              nbody._ptr(dBd), nbody._ptr(out))
+    bar = out.cpu().numpy()
+    bars = {"chi": bar[:nchi], "g": bar[nchi:nchi + ng], "g2": bar[nchi + ng:nchi + 2 * ng], "f": bar[nchi + 2 * ng:nchi + 3 * ng],
+            "f2": bar[nchi + 3 * ng:]}
+
+    def check(L, bars, keys, tag):
+        for k in keys:
+            dirn = rng.standard_normal(len(T0[k])) * (np.abs(np.gradient(T0[k])) if k == "chi" else np.abs(T0[k]))
+            eps = 1e-6
+            Tp, Tm = dict(T0), dict(T0)
+            Tp[k], Tm[k] = T0[k] + eps * dirn, T0[k] - eps * dirn
+            fd = (L(Tp) - L(Tm)) / (2 * eps)
+            an = float(np.dot(bars[k], dirn))
+            scale = np.linalg.norm(bars[k] * dirn) + 1e-30
+            assert abs(fd - an) < 2e-3 * max(abs(fd), scale), (tag, k, fd, an)
+
+    check(L_lagr, bars, ("g", "g2", "f", "f2"), "lagrangian")
+    # chi moves a itself: differentiate the chain without the float32 rounding of a (which makes L piecewise constant in chi; the
+    # kernel's slopes are taken at the rounded a, 3e-8 away)
+    check(lambda T: L_lagr(T, round32=False), bars, ("chi",), "lagrangian chi")
+    # NULL g2 / dg2dg cotangents = zeros
+    plan.call("mcpm_lightcone_tables_vjp_f32", nbody._ptr(r0d), N, nbody._ptr(tabs), nchi, ng, nbody._ptr(gBd), None, None, nbody._ptr(out))
+    only_g = out.cpu().numpy()
+    assert not np.any(only_g[nchi + ng:]) and np.any(only_g[nchi:nchi + ng])
+
+    # observation side: positions on a 16^3 lattice far enough for 0.4 < a < 0.8
+    evol, paint = (16, 16, 16), (24, 20, 16)
+    box, center, rotvec = (640., 640., 640.), (100., -50., 1500.), (0.2, -0.1, 0.3)
+    R = bo.rotvec_matrix(rotvec)
+    Np = 16 ** 3
+    disp = (1.5 * rng.standard_normal((Np, 3))).astype(np.float32)
+    vel = (3.0 * rng.standard_normal((Np, 3))).astype(np.float32)
+    dvel = (0.5 * rng.standard_normal((Np, 3))).astype(np.float32)
+    lp = nbody.LatticePos(disp, evol)
+    x64 = lp.to_absolute().cpu().numpy()
+    _, octx = bricks.observe_pos(cosmo, lp, vel, center, rotvec, box, evol, paint, a_obs=None, curved_sky=True, dvel=dvel, return_ctx=True)
+    ob = rng.standard_normal((Np, 3)).astype(np.float32)
+    outO = torch.empty(nchi + 2 * ng, dtype=torch.float64, device=dev)
+    obd = t(ob)
+    octx.plan.call("mcpm_observe_pos_tables_vjp_f32", nbody._ptr(octx.p), nbody._ptr(octx.v), nbody._ptr(octx.dv), Np, octx.mode, octx.geom,
+                   octx.flags, nbody._ptr(octx.tables), nchi, ng, nbody._ptr(obd), nbody._ptr(outO))
+    bo_ = outO.cpu().numpy()
+    barsO = {"chi": bo_[:nchi], "g": bo_[nchi:nchi + ng], "f": bo_[nchi + ng:]}
+
+    def L_obs(T):
+        # bo.observe_pos with chi2a / a2g / a2f evaluated on the perturbed tables
+        P = bo.cell2phys_pos(x64, center, R, box, evol)
+        r = np.linalg.norm(P, axis=-1)
+        los = P / r[:, None]
+        a = np.interp(r, T["chi"], aoc)
+        gf = np.interp(a, ag, T["g"]) * np.interp(a, ag, T["f"])
+        V = bo.cell2phys_vel(vel.astype(np.float64), R, box, evol) * gf[:, None] + dvel
+        dpos = (V * los).sum(-1, keepdims=True) * los
+        out_ = bo.phys2cell_pos(P + dpos, center, R, box, paint)
+        return float((out_ * ob).sum())
+    check(L_obs, barsO, ("chi", "g", "f"), "observe")

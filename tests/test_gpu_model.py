@@ -59,16 +59,18 @@ def test_evolve_forward_and_vjp(gpu, evolution, a_obs, curved, ptcl):
     assert abs(fds - grads["sigma8"]) < 3e-3 * abs(fds), ("sigma8", fds, grads["sigma8"])
 
 
-    if a_obs is not None:      # cosmology through the growth tables (finite-difference Jacobian of host scalars)
-        got = fwd.cosmo_vjp(ctx, grads, params=("Omega_m",))["Omega_m"]
+    # cosmology: through the growth tables at fixed a_obs (finite-difference Jacobian of host scalars), and on the light cone
+    # (a_obs = None, the reference's default, model.py:62) through the per-particle chi2a / a2g / a2g2 / a2f look-ups, whose table
+    # cotangents are formed on the device (mcpm_lightcone_tables_vjp_f32, mcpm_observe_pos_tables_vjp_f32)
+    got = fwd.cosmo_vjp(ctx, grads, params=("Omega_m",))["Omega_m"]
 
-        def L_om(dom):
-            c = obg.Planck18(Omega_c=cosmo.Omega_c + dom)
-            c.sigma8 = cosmo.sigma8
-            return float((gb * bo.evolve(cfg, c, BIAS, white)[0]).sum())
-        h = 1e-4
-        fdo = (L_om(h) - L_om(-h)) / (2 * h)
-        assert abs(fdo - got) < 1e-2 * abs(fdo), ("Omega_m", fdo, got)
+    def L_om(dom):
+        c = obg.Planck18(Omega_c=cosmo.Omega_c + dom)
+        c.sigma8 = cosmo.sigma8
+        return float((gb * bo.evolve(cfg, c, BIAS, white)[0]).sum())
+    h = 1e-4
+    fdo = (L_om(h) - L_om(-h)) / (2 * h)
+    assert abs(fdo - got) < 1e-2 * abs(fdo), ("Omega_m", fdo, got)
 
 
 def _with_s8(c, s8):
@@ -85,7 +87,8 @@ def _with_s8(c, s8):
 def test_log_density_and_gradient(gpu, evolution, s_e2, precond, a_obs, survey):
     """Prior + evolve + 'quad_gauss' likelihood (model.py:640-679, :840-908) on the HIP path against the float64
     restatement; gradient w.r.t. every sampled parameter against central differences of that restatement.  'kaiser':
-    the reference's default preconditioning (model.py:1134-1147), once at fixed a_obs and once on the light cone.
+    the reference's default preconditioning (model.py:1134-1147), once at fixed a_obs and once on the light cone (a_obs = None, the
+    reference's default, with Omega_m sampled: its gradient runs through the light-cone look-up tables).
     "eh": lin_kpow = None, the linear power is the Eisenstein-Hu fit of the sampled cosmology.  evolution "kaiser": the linear
     Kaiser model on the flat sky (bricks.py:170-198), gradients w.r.t. b1 and the cosmology through its growth and growth rate.
     survey: a selection mesh on the paint mesh, a mask over the final cells and two radial shells with their own mean
@@ -120,8 +123,6 @@ def test_log_density_and_gradient(gpu, evolution, s_e2, precond, a_obs, survey):
         fixed.pop("ngbars")
         lat["ngbars"] = dict(loc=np.array([1e-3, 1.4e-3]), scale=1e-2, loc_fid=np.array([1e-3, 1.4e-3]), scale_fid=1e-5, low=0., high=np.inf)
         extra["n_rbins"] = 2
-    if a_obs is None:      # light cone: the cosmology dependence of the look-ups is not propagated -> Omega_m stays fixed
-        fixed["Omega_m"] = lat.pop("Omega_m")["loc_fid"]
     make_cosmo = lambda base: _cos(obg.Planck18(Omega_c=base["Omega_m"] - 0.0490), base["sigma8"])
     sample = {k + "_": (float(rng.normal(0, 1.0)) if k != "ngbars" else rng.normal(0, 1.0, 2)) for k in lat}
     sample["white_mesh_"] = rng.standard_normal((12, 12, 12))
