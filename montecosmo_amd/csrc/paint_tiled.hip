@@ -635,6 +635,191 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
 #undef CALL
 }
 
+// ------------------------------------------------------------------------------------------------
+// Unweighted density paint with PAIR SLOTS: 4 LDS atomics per particle instead of 8.
+//
+// The deposits of this kernel are bound by the rate of LDS atomic INSTRUCTIONS (tools/lds_atomic_bench.hip: 3.9 lane-atomics per
+// clock and CU for ds_add_u64 whatever the number of active lanes; the classic tile spends 8 per particle: 0.45 of its 0.8 ms at
+// 512^3).  The two z corners of an (x, y) corner are neighbouring cells, so they can share one 64-bit atomic: the tile is an array
+// of slots indexed by the BASE cell (cx, cy, cz), cz = -1 .. 15 (17 slots per (x, y) row, which also takes the rows off each
+// other's LDS banks), and a deposit adds  lo = round(S w_xy (1 - t_z)) | hi = round(S w_xy t_z) << 32:  the low field of slot
+// cz collects what base cells at cz give to cell cz, the high field what they give to cell cz + 1, and cell z of the mesh is
+// lo(slot z) + hi(slot z - 1).  Contributions to cells outside the tile are zeroed before packing.  S = 2^24: one field holds
+// 256 full weights, rounding is 3e-8 of a particle's weight per deposit (the classic tile: 2^-30), sums are exact integers and
+// independent of the arrival order, so the paint stays bitwise reproducible.
+//
+// OVERFLOW PROOF.  All contributions are non-negative.  A low field that exceeds 32 bits carries into its high field (the decoded
+// fields then sum to 2^32 - 1 LESS than what was deposited), a high field that does wraps out of the word (2^32 less); errors
+// cannot cancel.  Every thread keeps the exact integer total of what it deposited; the workgroup compares it with the decoded
+// total of the slots before anything is written.  A tile that fails (a cell holding the weight of more than 256 particles:
+// nothing the bench trajectories produce) is painted again, in the same workgroup, by the classic 64-bit body.
+#define MCPM_PAIR_ROW (MCPM_TILE + 1)
+#define MCPM_PAIR_SLOTS (MCPM_TILE * MCPM_TILE * MCPM_PAIR_ROW)
+
+__device__ __forceinline__ unsigned wave_sum_u32_dpp(unsigned v) {      // total in lane 63; every lane active
+    v += (unsigned)dpp_i<0x111, 0xf>((int)v);
+    v += (unsigned)dpp_i<0x112, 0xf>((int)v);
+    v += (unsigned)dpp_i<0x114, 0xf>((int)v);
+    v += (unsigned)dpp_i<0x118, 0xf>((int)v);
+    v += (unsigned)dpp_i<0x142, 0xa>((int)v);
+    v += (unsigned)dpp_i<0x143, 0xc>((int)v);
+    return v;
+}
+// adds the workgroup's sum of `t` (< 2^48 per thread) to *acc (LDS): 24-bit pieces so that a wave's sums fit 32 bits
+__device__ __forceinline__ void block_sum_u64(u64 t, u64 *acc) {
+    const unsigned lo = wave_sum_u32_dpp((unsigned)t & 0xffffffu), hi = wave_sum_u32_dpp((unsigned)(t >> 24) & 0xffffffu);
+    if ((threadIdx.x & 63) == 63) atomicAdd(acc, (u64)lo + ((u64)hi << 24));
+}
+
+// returns false (uniformly) if the overflow proof failed: nothing has been written, the caller repaints the tile
+template <int H, int THREADS, int U, bool FAST>
+__device__ __forceinline__ bool paint_tile_pair_body(const Geom &g, const float *__restrict__ disp, float wscalar, float *__restrict__ mesh,
+                                                     int accumulate, const TileLists &L, int duty, u64 *tile, int *sh27, int *sus, u64 *chk) {
+    constexpr int B = MCPM_TILE, W = B + 2 * H + 1, NW = W * W * W, NT = B * B * B, PR = MCPM_PAIR_ROW, NS = MCPM_PAIR_SLOTS;
+    constexpr float S = 16777216.f;      // 2^24
+    const int ntx = g.nx / B, nty = g.ny / B, ntz = g.nz / B;
+    int tx, ty, tz;
+    tile_of_block(ntx, nty, ntz, tx, ty, tz, L.order);
+    const int x0 = tx * B, y0 = ty * B, z0 = tz * B;
+    for (int i = threadIdx.x; i < NS; i += THREADS) tile[i] = 0ull;
+    if (threadIdx.x == 0) {
+        sus[MCPM_SUS] = 0;
+        chk[0] = chk[1] = 0ull;
+    }
+    int ox = 0, oy = 0, oz = 0;
+    float slo[3] = {(float)-H, (float)-H, (float)-H}, shi[3] = {(float)H, (float)H, (float)H};
+    if (L.toff) {
+        unpack_off(L.toff[(tx * nty + ty) * ntz + tz], ox, oy, oz);
+        int omin[3], omax[3];
+        neighbour_offset_range(g, L, tx, ty, tz, ntx, nty, ntz, sh27, omin, omax);
+        sure_interval<H>(ox, omin[0], omax[0], slo[0], shi[0]);
+        sure_interval<H>(oy, omin[1], omax[1], slo[1], shi[1]);
+        sure_interval<H>(oz, omin[2], omax[2], slo[2], shi[2]);
+    }
+    __syncthreads();
+
+    u64 tot = 0ull;
+    WinIter<H, THREADS> wi(threadIdx.x);
+    for (int j0 = threadIdx.x; j0 < NW; j0 += THREADS * U) {
+        P3 d[U];
+        int rxs[U], rys[U], rzs[U], gis[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * THREADS;
+            if (FAST) {
+                gis[u] = wi.valid() ? wi.point_fast(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
+                wi.next();
+            } else
+                gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
+            d[u] = gis[u] >= 0 ? load3(disp, gis[u]) : P3{0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (gis[u] < 0) continue;
+            const int rx = rxs[u], ry = rys[u], rz = rzs[u];
+            const float fx = floorf(d[u].x), fy = floorf(d[u].y), fz = floorf(d[u].z);
+            // coverage duty and slab rules: exactly those of paint_tile_body
+            const bool unsure = !(fx >= slo[0] && fx <= shi[0] && fy >= slo[1] && fy <= shi[1] && fz >= slo[2] && fz <= shi[2]);
+            const bool home = (unsigned)rx < (unsigned)B && (unsigned)ry < (unsigned)B && (unsigned)rz < (unsigned)B;
+            if (unsure && !(fabsf(d[u].x) < MCPM_TAME && fabsf(d[u].y) < MCPM_TAME && fabsf(d[u].z) < MCPM_TAME)) {   // wild
+                if (duty && home) append_suspect(L, sus, gis[u]);
+                continue;
+            }
+            const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
+            const bool beyond = !FAST && g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
+            if ((unsure || beyond) && duty && home) append_suspect(L, sus, gis[u]);
+            if (beyond) continue;
+            if (cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
+                const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
+                const float kx[2] = {(1.f - tx1) * S, tx1 * S}, ky[2] = {1.f - ty1, ty1};
+                const float kz0 = cz >= 0 ? 1.f - tz1 : 0.f, kz1 = cz < B - 1 ? tz1 : 0.f;     // cells outside the tile get nothing
+                const bool vx[2] = {cx >= 0, cx < B - 1}, vy[2] = {cy >= 0, cy < B - 1};
+                const int base = (cx * B + cy) * PR + cz + 1;
+                unsigned psum = 0u;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb)
+                        if (vx[a] && vy[bb]) {
+                            const float wxy = kx[a] * ky[bb];
+                            const unsigned lo = (unsigned)cvt_rpi(wxy * kz0), hi = (unsigned)cvt_rpi(wxy * kz1);
+                            atomicAdd(tile + base + (a * B + bb) * PR, ((u64)hi << 32) | (u64)lo);
+                            psum += lo + hi;
+                        }
+                tot += psum;
+            }
+        }
+    }
+    if (duty && (abs(ox) > H || abs(oy) > H || abs(oz) > H)) {      // home lattice points outside the own window: all suspects
+        for (int j = threadIdx.x; j < NT; j += THREADS) {
+            const int rz = j % B, rr = j / B, ry = rr % B, rx = rr / B;
+            const bool inwin = (unsigned)(rx + ox + H + 1) < (unsigned)W && (unsigned)(ry + oy + H + 1) < (unsigned)W &&
+                               (unsigned)(rz + oz + H + 1) < (unsigned)W;
+            if (inwin) continue;
+            int gx = x0 + rx;
+            if (g.xslab) {
+                gx -= g.xoff;
+                if ((unsigned)gx >= (unsigned)g.px) continue;
+            }
+            append_suspect(L, sus, (gx * g.ny + y0 + ry) * g.nz + z0 + rz);
+        }
+    }
+    __syncthreads();
+    flush_suspects(L, sus);
+
+    // overflow proof: what was deposited against what the fields decode to
+    u64 dec = 0ull;
+    for (int i = threadIdx.x; i < NS; i += THREADS) {
+        const u64 v = tile[i];
+        dec += (v & 0xffffffffull) + (v >> 32);
+    }
+    block_sum_u64(tot, chk);
+    block_sum_u64(dec, chk + 1);
+    __syncthreads();
+    if (chk[0] != chk[1]) return false;
+
+    const double s = (double)wscalar * 5.9604644775390625e-08;      // 2^-24
+    for (int i = threadIdx.x; i < NT / 4; i += THREADS) {
+        const int lz = (i % (B / 4)) * 4, r = i / (B / 4), ly = r % B, lx = r / B;
+        const u64 *row = tile + r * PR + lz;      // slots of base cells lz - 1 .. lz + 3
+        u64 wv[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) wv[q] = row[q];
+        float c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = (float)((double)((wv[q + 1] & 0xffffffffull) + (wv[q] >> 32)) * s);
+        float4 v = make_float4(c[0], c[1], c[2], c[3]);
+        float4 *dst = reinterpret_cast<float4 *>(mesh + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz);
+        if (accumulate) {
+            const float4 o = *dst;
+            v.x += o.x;
+            v.y += o.y;
+            v.z += o.z;
+            v.w += o.w;
+        }
+        *dst = v;
+    }
+    return true;
+}
+
+template <int HA, int HB, int HC, int THREADS, int U, bool FAST>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void paint_tile_pair_kernel(Geom g, const float *__restrict__ disp, float wscalar,
+                                                                                                    float *__restrict__ mesh, int accumulate, TileLists L,
+                                                                                                    int duty) {
+    __shared__ u64 tile[MCPM_PAIR_SLOTS];      // 34 KB: four workgroups per CU, like the classic tile
+    __shared__ u64 chk[2];
+    __shared__ int sh27[27];
+    __shared__ int sus[MCPM_SUS + 2];
+    const int Hrt = tile_halo(L);
+#define CALL(HH)                                                                                                                   \
+    if (!paint_tile_pair_body<HH, THREADS, U, FAST>(g, disp, wscalar, mesh, accumulate, L, duty, tile, sh27, sus, chk)) {              \
+        __syncthreads();                                                                                                           \
+        paint_tile_body<HH, 0, THREADS, U, FAST>(g, disp, nullptr, 0, wscalar, mesh, accumulate, L, nullptr, 0, tile, sh27, sus);   \
+    }
+    HALO_SWITCH(Hrt, CALL);
+#undef CALL
+}
+
 // base cell of a bucketed particle relative to the tile origin, brought into [-1, n-1) (the tile sees it at c in [-1, 16))
 __device__ __forceinline__ bool bucket_cell(const Geom &g, int gi, const P3 &d, int x0, int y0, int z0, int &cx, int &cy, int &cz) {
     const int qz = gi % g.nz, r = gi / g.nz, qy = r % g.ny, qx = r / g.ny;   // lattice == mesh
@@ -1272,8 +1457,12 @@ bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t ws
         DISPATCH_H(halo_of(p), CALLW)
 #undef CALLW
     } else {
+        // pair slots (4 LDS atomics per particle) unless MCPM_PAINT_PAIR=0 asks for the classic tile (8; A/B runs)
+        static const int pair = [] { const char *e = getenv("MCPM_PAINT_PAIR"); return e ? atoi(e) : 1; }();
 #define CALLU(HA_, HB_, HC_)                                                                                                                    \
-    if (fast) paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+    if (pair && fast) paint_tile_pair_kernel<HA_, HB_, HC_, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, wscalar, mesh, accumulate, L, 1); \
+    else if (pair) paint_tile_pair_kernel<HA_, HB_, HC_, 512, 4, false><<<nb, 512, 0, p->stream>>>(g, pos, wscalar, mesh, accumulate, L, 1);   \
+    else if (fast) paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
     else paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
         DISPATCH_H(halo_of(p), CALLU)
 #undef CALLU
