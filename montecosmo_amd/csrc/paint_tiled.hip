@@ -92,9 +92,10 @@ __device__ __forceinline__ void tile_of_block(int ntx, int nty, int ntz, int &tx
 // o_T = rounded mean displacement of 64 lattice points (four z rows) of the Lagrangian block at tile T.
 __global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float *__restrict__ disp, int *__restrict__ toff,
                                                             int *__restrict__ bcnt, int *__restrict__ cnts, int ntiles, int maxoff,
-                                                            int *__restrict__ redo) {
+                                                            int *__restrict__ redo, int *__restrict__ hs) {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x < 8 && threadIdx.x != C_LAST && threadIdx.x != C_OOB) cnts[threadIdx.x] = 0;
+    if (hs && blockIdx.x == 0 && threadIdx.x < 192) hs[32 + (int)threadIdx.x * 32] = 0;   // halo_select_kernel's count slots (HSEL_SLOT0)
     if (redo && blockIdx.x == 0 && threadIdx.x == 8) redo[0] = 0;   // empty list of tiles for the f64 repaint (paint3)
     if (tile >= ntiles) return;
     if (lane == 0) bcnt[tile] = 0;
@@ -127,11 +128,12 @@ __global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float 
 // bucket deposit; which H is cheapest follows the roughness of the displacement field, and that changes along a trajectory.
 // Sixteen lanes per tile re-read one of the prologue's four sample rows and apply the tile kernel's own test -- |floor(d)_a - o_a| <= H - D_a
 // with D_a the largest offset difference to the 26 neighbouring tiles (sure_interval) -- for H = 2, 3, 4; halo_decide_kernel then
-// picks the smallest H whose share of unsure samples is at most `limit` (4 %: on the bench trajectories the per-step
-// optimum switches between 2.5 and 7.7 % (512^3, H 2 -> 3), 0.9 and 6.1 %, 3.1 and 7.0 % (256^3, 2 -> 3 and 3 -> 4)) and leaves it
-// in hs[0], where the tiled kernels of THIS paint read it.  Same input, same H: results stay bitwise reproducible, and the
-// host is not involved.
-#define HSEL_SLOT0 32      // hs: [0] the halo, from HSEL_SLOT0 on 3 x 64 count slots of 32 ints each (zero between paints); MCPM_HSEL_INTS in all
+// it leaves workgroup totals in 3 x 64 count slots, and every tiled kernel of THIS paint (tile, coverage, epilogue) adds the slots
+// up itself and takes the smallest H whose share of unsure samples is at most `limit` (tile_halo; 4 %: on the bench trajectories
+// the per-step optimum switches between 2.5 and 7.7 % (512^3, H 2 -> 3), 0.9 and 6.1 %, 3.1 and 7.0 % (256^3, 2 -> 3 and 3 -> 4)).
+// Round 3 had a one-block halo_decide_kernel between the two: a launch of 5 us per paint for 192 additions (two paints per
+// forward+adjoint step: 0.7 % of a 256^3 step).  Same input, same H: results stay bitwise reproducible, and the host is not involved.
+#define HSEL_SLOT0 32      // hs: from HSEL_SLOT0 on 3 x 64 count slots of 32 ints each (zeroed by the prologue of every paint); MCPM_HSEL_INTS in all
 #define HSEL_SAMPLES 16    // samples per tile: one of the prologue's four z rows (16 lanes per tile, 16 tiles per workgroup)
 __global__ __launch_bounds__(256) void halo_select_kernel(Geom g, const float *__restrict__ disp, const int *__restrict__ toff, int ntiles,
                                                           int *__restrict__ hs) {
@@ -197,23 +199,6 @@ __global__ __launch_bounds__(256) void halo_select_kernel(Geom g, const float *_
     }
 }
 
-// adds the slots up, leaves the halo in hs[0] and the slots zero (a ticket in halo_select_kernel instead -- "the last workgroup
-// decides" -- is 8192 serialised atomics on one address at 512^3: 0.2 ms)
-__global__ __launch_bounds__(192) void halo_decide_kernel(int *__restrict__ hs, int ntiles, float limit) {
-    __shared__ int tot[3];
-    int *slot = hs + HSEL_SLOT0 + (int)threadIdx.x * 32;
-    int v = *slot;
-    *slot = 0;
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
-    if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float lim = limit * (float)HSEL_SAMPLES * (float)ntiles;
-        hs[0] = (float)tot[0] <= lim ? 2 : ((float)tot[1] <= lim ? 3 : 4);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // scale of the weighted fixed-point accumulators: S = 2^(28 - e), 2^e <= max|w| < 2^(e+1): one deposit is below 2^29, an
 // int64 cell holds 2^34 of them (n < 2^31 particles x 8 corners).  mode: 0 = all weights zero, 1 = fixed point, 2 = non-finite
@@ -251,11 +236,25 @@ struct TileLists {
     int *cnts;
     int order;         // order of the tile pencils within an XCD's slab (tile_of_block)
     int hfix;          // window halo H of this paint if > 0, else
-    const int *hsel;   // ... the one halo_select_kernel left in hsel[0] for THIS input (2, 3 or 4)
+    const int *hsel;   // ... decided from the counts halo_select_kernel left for THIS input (2, 3 or 4)
+    float hlim;        // largest number of unsure samples an H may have (limit x samples per tile x tiles)
 };
 
-// the window halo of this launch (wave-uniform)
-__device__ __forceinline__ int tile_halo(const TileLists &L) { return L.hfix > 0 ? L.hfix : __builtin_amdgcn_readfirstlane(L.hsel[0]); }
+// the window halo of this launch (wave-uniform; every lane of the wave active): fixed, or the smallest candidate whose count of
+// unsure samples (64 slots per candidate, summed here by every wave: 3 loads per lane) stays below the limit
+__device__ __forceinline__ int tile_halo(const TileLists &L) {
+    if (L.hfix > 0) return L.hfix;
+    const int lane = threadIdx.x & 63;
+    int c2 = L.hsel[HSEL_SLOT0 + (0 * 64 + lane) * 32], c3 = L.hsel[HSEL_SLOT0 + (1 * 64 + lane) * 32];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        c2 += __shfl_xor(c2, m);
+        c3 += __shfl_xor(c3, m);
+    }
+    c2 = __builtin_amdgcn_readfirstlane(c2);
+    c3 = __builtin_amdgcn_readfirstlane(c3);
+    return (float)c2 <= L.hlim ? 2 : ((float)c3 <= L.hlim ? 3 : 4);
+}
 // kernels are instantiated for three candidate halos (HA, HB, HC; all equal when the halo is fixed) and branch once, uniformly
 #define HALO_SWITCH(Hrt, CALL)  \
     do {                        \
@@ -466,15 +465,25 @@ struct WinIter {
         jy -= cy ? W : 0;
         jx += DX + cy;
     }
-    // lattice point relative to the tile (r) and flat lattice index of the current point; power-of-two periodic mesh
+    // lattice point relative to the tile (r) and flat lattice index of the current point; power-of-two periodic mesh: the index is
+    // assembled with shifts (two v_lshl_or instead of two quarter-rate v_mad_u64_u32; the kernels are bound by VALU issue)
     __device__ __forceinline__ int point_fast(const Geom &g, int x0, int y0, int z0, int ox, int oy, int oz, int &rx, int &ry, int &rz) const {
         rx = jx - (H + 1) - ox;
         ry = jy - (H + 1) - oy;
         rz = jz - (H + 1) - oz;
         const int gx = (x0 + rx) & (g.nx - 1), gy = (y0 + ry) & (g.ny - 1), gz = (z0 + rz) & (g.nz - 1);
-        return (gx * g.ny + gy) * g.nz + gz;
+        const int lz = __builtin_ctz((unsigned)g.nz), ly = __builtin_ctz((unsigned)g.ny);      // uniform: scalar registers
+        return (((gx << ly) | gy) << lz) | gz;
     }
 };
+// 12-byte particle record i of an array of fewer than 2^32 / 12 records (what the FAST instantiations are launched for): uniform
+// base + 32-bit byte offset, so the address costs two full-rate shifts / adds instead of a quarter-rate 64-bit multiply-add
+// (round 4: density paint 0.81 -> 0.79 ms, three-component paint 1.93 -> 1.82 ms at 512^3, same box)
+template <bool FAST>
+__device__ __forceinline__ P3 load3w(const float *__restrict__ p, int i) {
+    if (FAST) return *reinterpret_cast<const P3 *>(reinterpret_cast<const char *>(p) + (((unsigned)i << 3) + ((unsigned)i << 2)));
+    return load3(p, i);
+}
 
 // ------------------------------------------------------------------------------------------------
 // density paint.  WMODE 0: unweighted (2^-30 fixed point, scalar weight applied at the flush); 1: weighted, fixed point with
@@ -524,7 +533,7 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
             } else
                 gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
             if (gis[u] >= 0) {
-                d[u] = load3(disp, gis[u]);
+                d[u] = load3w<FAST>(disp, gis[u]);
                 wt[u] = WMODE ? w[(int64_t)gis[u] * wstride] : 1.f;
             } else {
                 d[u] = P3{0.f, 0.f, 0.f};
@@ -631,191 +640,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
     __shared__ int sus[MCPM_SUS + 2];
     const int Hrt = tile_halo(L);
 #define CALL(HH) paint_tile_body<HH, WMODE, THREADS, U, FAST>(g, disp, w, wstride, wscalar, mesh, accumulate, L, wmax_bits, duty, tile, sh27, sus)
-    HALO_SWITCH(Hrt, CALL);
-#undef CALL
-}
-
-// ------------------------------------------------------------------------------------------------
-// Unweighted density paint with PAIR SLOTS: 4 LDS atomics per particle instead of 8.
-//
-// The deposits of this kernel are bound by the rate of LDS atomic INSTRUCTIONS (tools/lds_atomic_bench.hip: 3.9 lane-atomics per
-// clock and CU for ds_add_u64 whatever the number of active lanes; the classic tile spends 8 per particle: 0.45 of its 0.8 ms at
-// 512^3).  The two z corners of an (x, y) corner are neighbouring cells, so they can share one 64-bit atomic: the tile is an array
-// of slots indexed by the BASE cell (cx, cy, cz), cz = -1 .. 15 (17 slots per (x, y) row, which also takes the rows off each
-// other's LDS banks), and a deposit adds  lo = round(S w_xy (1 - t_z)) | hi = round(S w_xy t_z) << 32:  the low field of slot
-// cz collects what base cells at cz give to cell cz, the high field what they give to cell cz + 1, and cell z of the mesh is
-// lo(slot z) + hi(slot z - 1).  Contributions to cells outside the tile are zeroed before packing.  S = 2^24: one field holds
-// 256 full weights, rounding is 3e-8 of a particle's weight per deposit (the classic tile: 2^-30), sums are exact integers and
-// independent of the arrival order, so the paint stays bitwise reproducible.
-//
-// OVERFLOW PROOF.  All contributions are non-negative.  A low field that exceeds 32 bits carries into its high field (the decoded
-// fields then sum to 2^32 - 1 LESS than what was deposited), a high field that does wraps out of the word (2^32 less); errors
-// cannot cancel.  Every thread keeps the exact integer total of what it deposited; the workgroup compares it with the decoded
-// total of the slots before anything is written.  A tile that fails (a cell holding the weight of more than 256 particles:
-// nothing the bench trajectories produce) is painted again, in the same workgroup, by the classic 64-bit body.
-#define MCPM_PAIR_ROW (MCPM_TILE + 1)
-#define MCPM_PAIR_SLOTS (MCPM_TILE * MCPM_TILE * MCPM_PAIR_ROW)
-
-__device__ __forceinline__ unsigned wave_sum_u32_dpp(unsigned v) {      // total in lane 63; every lane active
-    v += (unsigned)dpp_i<0x111, 0xf>((int)v);
-    v += (unsigned)dpp_i<0x112, 0xf>((int)v);
-    v += (unsigned)dpp_i<0x114, 0xf>((int)v);
-    v += (unsigned)dpp_i<0x118, 0xf>((int)v);
-    v += (unsigned)dpp_i<0x142, 0xa>((int)v);
-    v += (unsigned)dpp_i<0x143, 0xc>((int)v);
-    return v;
-}
-// adds the workgroup's sum of `t` (< 2^48 per thread) to *acc (LDS): 24-bit pieces so that a wave's sums fit 32 bits
-__device__ __forceinline__ void block_sum_u64(u64 t, u64 *acc) {
-    const unsigned lo = wave_sum_u32_dpp((unsigned)t & 0xffffffu), hi = wave_sum_u32_dpp((unsigned)(t >> 24) & 0xffffffu);
-    if ((threadIdx.x & 63) == 63) atomicAdd(acc, (u64)lo + ((u64)hi << 24));
-}
-
-// returns false (uniformly) if the overflow proof failed: nothing has been written, the caller repaints the tile
-template <int H, int THREADS, int U, bool FAST>
-__device__ __forceinline__ bool paint_tile_pair_body(const Geom &g, const float *__restrict__ disp, float wscalar, float *__restrict__ mesh,
-                                                     int accumulate, const TileLists &L, int duty, u64 *tile, int *sh27, int *sus, u64 *chk) {
-    constexpr int B = MCPM_TILE, W = B + 2 * H + 1, NW = W * W * W, NT = B * B * B, PR = MCPM_PAIR_ROW, NS = MCPM_PAIR_SLOTS;
-    constexpr float S = 16777216.f;      // 2^24
-    const int ntx = g.nx / B, nty = g.ny / B, ntz = g.nz / B;
-    int tx, ty, tz;
-    tile_of_block(ntx, nty, ntz, tx, ty, tz, L.order);
-    const int x0 = tx * B, y0 = ty * B, z0 = tz * B;
-    for (int i = threadIdx.x; i < NS; i += THREADS) tile[i] = 0ull;
-    if (threadIdx.x == 0) {
-        sus[MCPM_SUS] = 0;
-        chk[0] = chk[1] = 0ull;
-    }
-    int ox = 0, oy = 0, oz = 0;
-    float slo[3] = {(float)-H, (float)-H, (float)-H}, shi[3] = {(float)H, (float)H, (float)H};
-    if (L.toff) {
-        unpack_off(L.toff[(tx * nty + ty) * ntz + tz], ox, oy, oz);
-        int omin[3], omax[3];
-        neighbour_offset_range(g, L, tx, ty, tz, ntx, nty, ntz, sh27, omin, omax);
-        sure_interval<H>(ox, omin[0], omax[0], slo[0], shi[0]);
-        sure_interval<H>(oy, omin[1], omax[1], slo[1], shi[1]);
-        sure_interval<H>(oz, omin[2], omax[2], slo[2], shi[2]);
-    }
-    __syncthreads();
-
-    u64 tot = 0ull;
-    WinIter<H, THREADS> wi(threadIdx.x);
-    for (int j0 = threadIdx.x; j0 < NW; j0 += THREADS * U) {
-        P3 d[U];
-        int rxs[U], rys[U], rzs[U], gis[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + u * THREADS;
-            if (FAST) {
-                gis[u] = wi.valid() ? wi.point_fast(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
-                wi.next();
-            } else
-                gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
-            d[u] = gis[u] >= 0 ? load3(disp, gis[u]) : P3{0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (gis[u] < 0) continue;
-            const int rx = rxs[u], ry = rys[u], rz = rzs[u];
-            const float fx = floorf(d[u].x), fy = floorf(d[u].y), fz = floorf(d[u].z);
-            // coverage duty and slab rules: exactly those of paint_tile_body
-            const bool unsure = !(fx >= slo[0] && fx <= shi[0] && fy >= slo[1] && fy <= shi[1] && fz >= slo[2] && fz <= shi[2]);
-            const bool home = (unsigned)rx < (unsigned)B && (unsigned)ry < (unsigned)B && (unsigned)rz < (unsigned)B;
-            if (unsure && !(fabsf(d[u].x) < MCPM_TAME && fabsf(d[u].y) < MCPM_TAME && fabsf(d[u].z) < MCPM_TAME)) {   // wild
-                if (duty && home) append_suspect(L, sus, gis[u]);
-                continue;
-            }
-            const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
-            const bool beyond = !FAST && g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
-            if ((unsure || beyond) && duty && home) append_suspect(L, sus, gis[u]);
-            if (beyond) continue;
-            if (cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
-                const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
-                const float kx[2] = {(1.f - tx1) * S, tx1 * S}, ky[2] = {1.f - ty1, ty1};
-                const float kz0 = cz >= 0 ? 1.f - tz1 : 0.f, kz1 = cz < B - 1 ? tz1 : 0.f;     // cells outside the tile get nothing
-                const bool vx[2] = {cx >= 0, cx < B - 1}, vy[2] = {cy >= 0, cy < B - 1};
-                const int base = (cx * B + cy) * PR + cz + 1;
-                unsigned psum = 0u;
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int bb = 0; bb < 2; ++bb)
-                        if (vx[a] && vy[bb]) {
-                            const float wxy = kx[a] * ky[bb];
-                            const unsigned lo = (unsigned)cvt_rpi(wxy * kz0), hi = (unsigned)cvt_rpi(wxy * kz1);
-                            atomicAdd(tile + base + (a * B + bb) * PR, ((u64)hi << 32) | (u64)lo);
-                            psum += lo + hi;
-                        }
-                tot += psum;
-            }
-        }
-    }
-    if (duty && (abs(ox) > H || abs(oy) > H || abs(oz) > H)) {      // home lattice points outside the own window: all suspects
-        for (int j = threadIdx.x; j < NT; j += THREADS) {
-            const int rz = j % B, rr = j / B, ry = rr % B, rx = rr / B;
-            const bool inwin = (unsigned)(rx + ox + H + 1) < (unsigned)W && (unsigned)(ry + oy + H + 1) < (unsigned)W &&
-                               (unsigned)(rz + oz + H + 1) < (unsigned)W;
-            if (inwin) continue;
-            int gx = x0 + rx;
-            if (g.xslab) {
-                gx -= g.xoff;
-                if ((unsigned)gx >= (unsigned)g.px) continue;
-            }
-            append_suspect(L, sus, (gx * g.ny + y0 + ry) * g.nz + z0 + rz);
-        }
-    }
-    __syncthreads();
-    flush_suspects(L, sus);
-
-    // overflow proof: what was deposited against what the fields decode to
-    u64 dec = 0ull;
-    for (int i = threadIdx.x; i < NS; i += THREADS) {
-        const u64 v = tile[i];
-        dec += (v & 0xffffffffull) + (v >> 32);
-    }
-    block_sum_u64(tot, chk);
-    block_sum_u64(dec, chk + 1);
-    __syncthreads();
-    if (chk[0] != chk[1]) return false;
-
-    const double s = (double)wscalar * 5.9604644775390625e-08;      // 2^-24
-    for (int i = threadIdx.x; i < NT / 4; i += THREADS) {
-        const int lz = (i % (B / 4)) * 4, r = i / (B / 4), ly = r % B, lx = r / B;
-        const u64 *row = tile + r * PR + lz;      // slots of base cells lz - 1 .. lz + 3
-        u64 wv[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) wv[q] = row[q];
-        float c[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) c[q] = (float)((double)((wv[q + 1] & 0xffffffffull) + (wv[q] >> 32)) * s);
-        float4 v = make_float4(c[0], c[1], c[2], c[3]);
-        float4 *dst = reinterpret_cast<float4 *>(mesh + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz);
-        if (accumulate) {
-            const float4 o = *dst;
-            v.x += o.x;
-            v.y += o.y;
-            v.z += o.z;
-            v.w += o.w;
-        }
-        *dst = v;
-    }
-    return true;
-}
-
-template <int HA, int HB, int HC, int THREADS, int U, bool FAST>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void paint_tile_pair_kernel(Geom g, const float *__restrict__ disp, float wscalar,
-                                                                                                    float *__restrict__ mesh, int accumulate, TileLists L,
-                                                                                                    int duty) {
-    __shared__ u64 tile[MCPM_PAIR_SLOTS];      // 34 KB: four workgroups per CU, like the classic tile
-    __shared__ u64 chk[2];
-    __shared__ int sh27[27];
-    __shared__ int sus[MCPM_SUS + 2];
-    const int Hrt = tile_halo(L);
-#define CALL(HH)                                                                                                                   \
-    if (!paint_tile_pair_body<HH, THREADS, U, FAST>(g, disp, wscalar, mesh, accumulate, L, duty, tile, sh27, sus, chk)) {              \
-        __syncthreads();                                                                                                           \
-        paint_tile_body<HH, 0, THREADS, U, FAST>(g, disp, nullptr, 0, wscalar, mesh, accumulate, L, nullptr, 0, tile, sh27, sus);   \
-    }
     HALO_SWITCH(Hrt, CALL);
 #undef CALL
 }
@@ -1090,8 +914,8 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
             } else
                 gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
             if (gis[u] >= 0) {
-                d[u] = load3(disp, gis[u]);
-                wt[u] = load3(w3, gis[u]);
+                d[u] = load3w<FAST>(disp, gis[u]);
+                wt[u] = load3w<FAST>(w3, gis[u]);
             } else {
                 d[u] = P3{0.f, 0.f, 0.f};
                 wt[u] = P3{0.f, 0.f, 0.f};
@@ -1257,6 +1081,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
 #undef CALL
         return;
     }
+    if (!F64) return;      // only the f64 instance repaints (the fixed-point one would carry three more window-walk bodies, and their
+                           // scalar-register pressure, for a branch it never takes)
     const int n = redo_in[0];
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
 #define CALL(HH) paint3_tile_body<HH, F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, redo_in[1 + k], duty, tile, flagged, sh27, sus)
@@ -1384,7 +1210,8 @@ static bool tiled_fast(const mcpm_plan *p) {
     static const int on = [] { const char *e = getenv("MCPM_PAINT_FAST"); return e ? atoi(e) : 1; }();
     const Geom &g = p->g;
     auto pow2 = [](int n) { return (n & (n - 1)) == 0; };
-    return on && !g.xslab && pow2(g.nx) && pow2(g.ny) && pow2(g.nz);
+    // (12-byte records addressed with 32-bit byte offsets: load3w)
+    return on && !g.xslab && pow2(g.nx) && pow2(g.ny) && pow2(g.nz) && p->Np * 12 < ((int64_t)1 << 32);
 }
 
 static int tile_order() {
@@ -1405,20 +1232,24 @@ static int halo_of(const mcpm_plan *p) {
     return (adapt && (slab_too || !p->g.xslab) && p->halo_sel && ntiles >= 2048) ? 0 : mcpm_default_halo(p->M);
 }
 
+// share of unsure samples a window halo may leave (halo_select_kernel / tile_halo)
+static float halo_limit() {
+    static const float limit = [] { const char *e = getenv("MCPM_HALO_LIMIT"); return e ? (float)atof(e) : 0.04f; }();
+    return limit;
+}
+
 static TileLists tile_lists(const mcpm_plan *p) {
-    return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, p->outliers + p->Np, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count, tile_order(), halo_of(p), p->halo_sel};
+    return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, p->outliers + p->Np, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count, tile_order(), halo_of(p), p->halo_sel,
+                     halo_limit() * (float)HSEL_SAMPLES * (float)(p->M / (MCPM_TILE * MCPM_TILE * MCPM_TILE))};
 }
 
 static void tiled_prologue(mcpm_plan *p, const float *pos, int *redo = nullptr) {
     const Geom &g = p->g;
     const int ntiles = (g.nx / MCPM_TILE) * (g.ny / MCPM_TILE) * (g.nz / MCPM_TILE);
+    const bool adapt = halo_of(p) == 0;
     tile_prologue_kernel<<<(ntiles + 3) / 4, 256, 0, p->stream>>>(g, pos, p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->outlier_count,
-                                                                  ntiles, 8, redo);
-    if (halo_of(p) == 0) {
-        static const float limit = [] { const char *e = getenv("MCPM_HALO_LIMIT"); return e ? (float)atof(e) : 0.04f; }();
-        halo_select_kernel<<<(ntiles + 15) / 16, 256, 0, p->stream>>>(g, pos, p->centre ? p->tile_off : nullptr, ntiles, p->halo_sel);
-        halo_decide_kernel<<<1, 192, 0, p->stream>>>(p->halo_sel, ntiles, limit);
-    }
+                                                                  ntiles, 8, redo, adapt ? p->halo_sel : nullptr);
+    if (adapt) halo_select_kernel<<<(ntiles + 15) / 16, 256, 0, p->stream>>>(g, pos, p->centre ? p->tile_off : nullptr, ntiles, p->halo_sel);
 }
 
 // CALL(HA, HB, HC): the kernels' three candidate halos -- all equal for a fixed halo, (2, 3, 4) when the device chooses (0)
@@ -1457,12 +1288,8 @@ bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t ws
         DISPATCH_H(halo_of(p), CALLW)
 #undef CALLW
     } else {
-        // pair slots (4 LDS atomics per particle) unless MCPM_PAINT_PAIR=0 asks for the classic tile (8; A/B runs)
-        static const int pair = [] { const char *e = getenv("MCPM_PAINT_PAIR"); return e ? atoi(e) : 1; }();
 #define CALLU(HA_, HB_, HC_)                                                                                                                    \
-    if (pair && fast) paint_tile_pair_kernel<HA_, HB_, HC_, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, wscalar, mesh, accumulate, L, 1); \
-    else if (pair) paint_tile_pair_kernel<HA_, HB_, HC_, 512, 4, false><<<nb, 512, 0, p->stream>>>(g, pos, wscalar, mesh, accumulate, L, 1);   \
-    else if (fast) paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+    if (fast) paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
     else paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
         DISPATCH_H(halo_of(p), CALLU)
 #undef CALLU
