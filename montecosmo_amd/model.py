@@ -76,8 +76,9 @@ class FieldLevelForward:
         from . import power
         return power.lin_power_table(cosmo)
 
-    def _power_mult(self, spec, cosmo):
-        """white2lin (bricks.py:149-154): spec * sqrt(sigma8^2 P(|k|)); real multiplier, self-adjoint."""
+    def _power_mult(self, spec, cosmo, sigma8=None):
+        """white2lin (bricks.py:149-154): spec * sqrt(sigma8^2 P(|k|)); real multiplier, self-adjoint.  `sigma8` overrides the
+        cosmology's (1.0 gives d init_mesh / d sigma8, which stays finite where a bounded latent has walked to sigma8 = 0)."""
         key = None if self.lin_kpow is not None else (float(cosmo.Omega_c), float(cosmo.Omega_b), float(cosmo.h), float(cosmo.n_s))
         tab = self._dev_kpow.get(key)
         if tab is None:
@@ -88,7 +89,7 @@ class FieldLevelForward:
         plan = nbody.get_plan(self.init_shape)
         out = torch.empty_like(spec)
         kp = self._kphys(self.init_shape)
-        plan.call("mcpm_power_mult_f32", nbody._ptr(spec), kp[0], kp[1], kp[2], float(cosmo.sigma8) ** 2, nbody._ptr(tab),
+        plan.call("mcpm_power_mult_f32", nbody._ptr(spec), kp[0], kp[1], kp[2], float(cosmo.sigma8 if sigma8 is None else sigma8) ** 2, nbody._ptr(tab),
                   nbody.C.c_void_p(tab.data_ptr() + 8 * nt), nt, nbody._ptr(out))
         return out
 
@@ -142,7 +143,7 @@ class FieldLevelForward:
         c1 = float((prod.real * self._mu2_mesh(kb.device)).double().sum())    # d/d(D f)
         init_b = chreshape_vjp(kb * boost, r2chshape(self.init_shape))
         white_b = self._power_mult(init_b, cosmo)
-        s8b = float((init_b.conj() * self._power_mult(ctx.white, cosmo)).real.sum().item()) / float(cosmo.sigma8)
+        s8b = float((init_b.conj() * self._power_mult(ctx.white, cosmo, sigma8=1.0)).real.sum().item())
         bias_bar = {k: 0.0 for k in bricks.BIAS_KEYS}
         bias_bar["b1"] = D * c0
         return {"white_mesh": white_b, "bias": bias_bar, "sigma8": s8b, "init_bar": init_b,
@@ -208,8 +209,7 @@ class FieldLevelForward:
         init_b = chreshape_vjp(mesh_b, r2chshape(self.init_shape))
         white_b = self._power_mult(init_b, cosmo)
         # d/d sigma8: init_mesh is linear in sigma8
-        init_k = self._power_mult(ctx.white, cosmo)
-        s8b = float((init_b.conj() * init_k).real.sum().item()) / float(cosmo.sigma8)
+        s8b = float((init_b.conj() * self._power_mult(ctx.white, cosmo, sigma8=1.0)).real.sum().item())
         return {"white_mesh": white_b, "bias": bias_bar, "sigma8": s8b, "growth": growth, "bias_growth": bg_bar, "gf": gfb,
                 "init_bar": init_b, "obs_bar": pb if self.a_obs is None else None}
 

@@ -1,19 +1,23 @@
 """Small field-level posterior (16^3 final mesh): does the chain's sigma8 posterior cover the truth?  Exploration script behind
-tests/test_gpu_samplers.py::test_posterior_of_sigma8_covers_the_truth.  usage: python tools/posterior_probe.py [nuts|mclmc] [n_warm] [n_samp] [depth]"""
+tests/test_gpu_samplers.py::test_posterior_of_sigma8_covers_the_truth and ::test_posterior_with_omega_m_covers_the_truth.
+usage: python tools/posterior_probe.py [nuts|mclmc] [n_warm] [n_samp] [depth] [final_n=16] [lpt|nbody] [a_obs|lightcone] [om] [seed]"""
 import sys, time, json
 import numpy as np, torch
 sys.path.insert(0, ".")
 from montecosmo_amd import model, logdensity, samplers, bricks, utils, nbody
 
 
-def build(nf=16, seed=0, evolution="lpt"):
+def build(nf=16, seed=0, evolution="lpt", a_obs=0.65, sample_om=False):
     ks = np.logspace(-3, 1, 128)
     kpow = (ks, 3.0e4 * (ks / 0.02) / (1 + (ks / 0.02) ** 2.6))
     fwd = model.FieldLevelForward(final_shape=(nf,) * 3, cell_length=40., box_center=(0., 0., 2500.), evolution=evolution,
-                                  nbody_n_steps=3, lpt_order=2, a_obs=0.65, lin_kpow=kpow)
+                                  nbody_n_steps=3, lpt_order=2, a_obs=a_obs, lin_kpow=kpow, nbody_a_start=0.1)
     lat = {"sigma8": dict(loc=0.8102, scale=0.1, loc_fid=0.8102, scale_fid=1e-2, low=0., high=np.inf),
            "b1": dict(loc=1., scale=1e2, loc_fid=1., scale_fid=1e-2)}
     fixed = dict(Omega_m=0.3111, b2=0., bs2=0., bn2=0., b3=0., bds2=0., bs3=0., bnpar=0., ngbars=1e-3, s_e=1.0, s_ed=0., s_e2=0.)
+    if sample_om:      # montecosmo/model.py:76-83: truncated normal on [0.05, 1]
+        lat = dict({"Omega_m": dict(loc=0.3111, scale=0.1, loc_fid=0.3111, scale_fid=1e-2, low=0.05, high=1.)}, **lat)
+        fixed.pop("Omega_m")
     g = torch.Generator(device="cuda").manual_seed(seed)
     truth = {k + "_": 0.0 for k in lat}
     ld0 = logdensity.FieldLevelLogDensity(fwd, torch.zeros(fwd.final_shape), lat, fixed, precond="kaiser")
@@ -37,7 +41,12 @@ if __name__ == "__main__":
     nw = int(sys.argv[2]) if len(sys.argv) > 2 else 150
     nsamp = int(sys.argv[3]) if len(sys.argv) > 3 else 150
     depth = int(sys.argv[4]) if len(sys.argv) > 4 else 6
-    fwd, ld, flat, q0, truth = build()
+    nf = int(sys.argv[5]) if len(sys.argv) > 5 else 16
+    evolution = sys.argv[6] if len(sys.argv) > 6 else "lpt"
+    a_obs = None if (len(sys.argv) > 7 and sys.argv[7] == "lightcone") else (float(sys.argv[7]) if len(sys.argv) > 7 else 0.65)
+    sample_om = len(sys.argv) > 8 and sys.argv[8] == "om"
+    seed = int(sys.argv[9]) if len(sys.argv) > 9 else 0
+    fwd, ld, flat, q0, truth = build(nf, seed, evolution, a_obs, sample_om)
     ns = len(flat.scalars)
     print("scalars", flat.scalars, "dimension", q0.numel(), "shapes", fwd.final_shape, fwd.init_shape, fwd.evol_shape, flush=True)
     t0 = time.perf_counter()
