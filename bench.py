@@ -87,17 +87,16 @@ class Runner:
     Layout of the particle arrays (DESIGN finding 29).  The step kernels stream four to seven (N, 3) arrays at the same particle
     index at the same time.  Laid out back to back they are 12 N bytes apart -- 1.5 GiB at 512^3 --, i.e. IN PHASE in every
     low address bit, and whether the streams then meet in the same memory channel is decided by the upper physical bits: the
-    per-process placement that made the adjoint particle kernel bimodal (2.45 or 2.75 ms).  The runner therefore keeps its
-    arrays in one flat buffer with array j shifted by j * `stagger` bytes, and, when `stagger` is None (the default), tries the
-    candidate shifts `STAGGERS` on this process's placement during set-up (one untimed forward+adjoint block each) and keeps
-    the fastest; meshes below 2^23 particles, whose arrays live in the caches, use 0.  The choice is reported
-    (`layout` in the JSON line)."""
+    per-process placement that made the adjoint particle kernel bimodal (2.45 or 2.75 ms).  The placement logic lives in the
+    LIBRARY since round 4: the runner allocates one flat buffer, hands it to `mcpm_plan_probe_particle_pitch` (which times the
+    adjoint particle kernel on it for three candidate pitches and keeps the fastest) and lays its arrays out at the pitch that
+    comes back; `MCPM_PARTICLE_PITCH` (floats) fixes it.  The choice is reported (`layout` in the JSON line)."""
 
     forward_only = False
-    STAGGERS = (0, 4352, 69888)       # bytes per array: in phase; 4 KB + 256 B; 64 KB + 4 KB + 256 B
 
-    def __init__(self, n, K, device, stagger=None, forward_only=False):
+    def __init__(self, n, K, device, forward_only=False):
         from montecosmo_amd import nbody, bricks, synth
+        from montecosmo_amd._lib import lib
         self.forward_only = bool(forward_only)
         self.nbody = nbody
         self.n, self.K = n, K
@@ -112,62 +111,34 @@ class Runner:
         self.spec = torch.from_numpy(spec).to(device)
         f32 = dict(dtype=torch.float32, device=device)
         self.fmesh = torch.empty((K, 3, n, n, n), **f32)          # force meshes per step
-        rng = np.random.default_rng(1)
-        self._pos_bar0 = torch.from_numpy(rng.standard_normal((N, 3), dtype=np.float32)).to(device)
-        self._vel_bar0 = torch.from_numpy(rng.standard_normal((N, 3), dtype=np.float32)).to(device)
         self.sbar = torch.zeros((2 * K + 1,), dtype=torch.float64, device=device)
-        env = os.environ.get("MCPM_BENCH_STAGGER")
-        if stagger is None and env is not None:
-            stagger = int(env)
-        self.layout = {"stagger_bytes": None, "probed_ms_per_step": None}
-        if stagger is None and N >= (1 << 23) and not self.forward_only:
-            probed, best = {}, None
-            for S in self.STAGGERS:
-                lay = self._allocate(S)
-                self._use(lay)
-                self.init_state()
-                self.run(K)                                   # warm: first touch, plan workspace
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                self.run(K)
-                e1.record()
-                e1.synchronize()
-                probed[S] = round(e0.elapsed_time(e1) / K, 4)
-                if best is None or probed[S] < best[0]:
-                    best = (probed[S], S, lay)     # THIS allocation is kept: a fresh one of the same shape may be placed elsewhere
-                del lay
-                torch.cuda.empty_cache()
-            stagger = best[1]
-            self.layout["probed_ms_per_step"] = {str(k): v for k, v in probed.items()}
-            self._use(best[2])
-            del best
+        # one flat buffer for the 2 (K + 1) checkpoint arrays, the two loss cotangents and the two running cotangents, sized for the
+        # largest pitch the library may choose (3 N + 17472 floats)
+        narr = 2 * (K + 1) + 4
+        flat = torch.empty(narr * (3 * N + 17472), dtype=torch.float32, device=device)
+        pitch = C.c_int64()
+        env = os.environ.get("MCPM_PARTICLE_PITCH")
+        if env is not None:
+            self.plan.call("mcpm_plan_set_particle_pitch", int(env))
+            self.plan.call("mcpm_plan_particle_pitch", C.byref(pitch))
+            source = "MCPM_PARTICLE_PITCH"
+        elif self.forward_only:
+            self.plan.call("mcpm_plan_particle_pitch", C.byref(pitch))
+            source = "default (forward only: nothing to probe)"
         else:
-            stagger = 0 if stagger is None else int(stagger)
-            self._use(self._allocate(stagger))
-        self.layout["stagger_bytes"] = int(stagger)
-        del self._pos_bar0, self._vel_bar0
-        self.sbar.zero_()          # the adjoint steps ADD their scalar cotangents; the probe blocks above left theirs
-        self.init_state()
-
-    def _allocate(self, stagger):
-        """One flat buffer: the 2 (K + 1) checkpoint arrays, the two loss cotangents and the two running cotangents, array j at
-        j * (12 N + stagger) bytes."""
-        assert stagger % 16 == 0
-        N, K = self.N, self.K
-        pitch = 3 * N + stagger // 4
-        flat = torch.empty((2 * (K + 1) + 4) * pitch, dtype=torch.float32, device=self.device)
+            self.plan.call("mcpm_plan_probe_particle_pitch", self.p(flat), flat.numel(), C.byref(pitch))
+            source = "mcpm_plan_probe_particle_pitch"
+        pitch = int(pitch.value)
+        self.layout = {"pitch_floats": pitch, "shift_bytes": 4 * (pitch - 3 * N), "source": source}
         arr = lambda j: flat[j * pitch: j * pitch + 3 * N].view(N, 3)
         j = 2 * (K + 1)
-        lay = {"flat": flat, "states": _States([(arr(2 * i), arr(2 * i + 1)) for i in range(K + 1)]),       # (x'_i, v_i) checkpoints
-               "pos_bar": arr(j), "vel_bar": arr(j + 1), "xb": arr(j + 2), "vb": arr(j + 3)}
-        lay["pos_bar"].copy_(self._pos_bar0)
-        lay["vel_bar"].copy_(self._vel_bar0)
-        return lay
-
-    def _use(self, lay):
-        self._flat, self.states = lay["flat"], lay["states"]
-        self.pos_bar, self.vel_bar, self.xb, self.vb = lay["pos_bar"], lay["vel_bar"], lay["xb"], lay["vb"]
+        self._flat = flat
+        self.states = _States([(arr(2 * i), arr(2 * i + 1)) for i in range(K + 1)])       # (x'_i, v_i) checkpoints
+        self.pos_bar, self.vel_bar, self.xb, self.vb = arr(j), arr(j + 1), arr(j + 2), arr(j + 3)
+        rng = np.random.default_rng(1)
+        self.pos_bar.copy_(torch.from_numpy(rng.standard_normal((N, 3), dtype=np.float32)))
+        self.vel_bar.copy_(torch.from_numpy(rng.standard_normal((N, 3), dtype=np.float32)))
+        self.init_state()
 
     def p(self, t):
         return C.c_void_p(t.data_ptr())
@@ -270,15 +241,16 @@ class SlabRunner:
         self.dg, self.alphas, self.betas, self.lpt_s = nbody._step_scalars(cosmo, 0.0, 1.0, K, "bullfrog")
         spec = torch.from_numpy(synth.init_mesh(n, seed=seed, rms_disp=2.0)).to(device)
         f32 = dict(dtype=torch.float32, device=device)
-        # particle arrays: one flat buffer, array j shifted by j * 4352 bytes, so that the streams of a step kernel are not in
-        # phase in every low address bit (Runner's doc string; no per-process probe here: the ranks would have to agree on it)
-        stagger = int(os.environ.get("MCPM_BENCH_STAGGER", "4352"))
-        assert stagger % 16 == 0
-        pitch = 3 * pm.Nl + stagger // 4
+        # particle arrays: one flat buffer at a fixed pitch of 3 N + 1088 floats (4 KB + 256 B), so that the streams of a step
+        # kernel are not in phase in every low address bit (Runner's doc string; no per-process probe here: the ranks would have
+        # to agree on it)
+        shift = int(os.environ.get("MCPM_PARTICLE_SHIFT_FLOATS", "1088"))
+        assert shift % 4 == 0
+        pitch = 3 * pm.Nl + shift
         self._flat = torch.empty((2 * (K + 1) + 4) * pitch, **f32)
         arr = lambda j: self._flat[j * pitch: j * pitch + 3 * pm.Nl].view(pm.Nl, 3)
         self.states = _States([(arr(2 * i), arr(2 * i + 1)) for i in range(K + 1)])
-        self.layout = {"stagger_bytes": stagger, "probed_ms_per_step": None}
+        self.layout = {"pitch_floats": pitch, "shift_bytes": 4 * shift, "source": "fixed (slab ranks must agree)"}
         self.f3s = torch.zeros((K, pm.nxe, n, n, 3), **f32)          # interleaved force meshes per step
         # slab-decomposed LPT start (untimed set-up) + first half drift
         pm.lpt(spec, 2, self.lpt_s[0], self.lpt_s[1], self.lpt_s[2], self.states[0, 0], self.states[0, 1])
@@ -654,8 +626,8 @@ def main():
                                        "pm_forces_GBps": round(B_PER_CELL_CYCLE * M / (pmf_ms * 1e-3) / 1e9, 1),
                                        "pm_forces_frac_of_hbm_peak": round(B_PER_CELL_CYCLE * M / (pmf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
         if True:
-            out["layout"] = dict(r.layout, note="particle arrays in one flat buffer, array j shifted by j * stagger_bytes; None probed = fixed "
-                                             "(MCPM_BENCH_STAGGER, a small mesh or forward only); probed: one untimed forward+adjoint block per candidate during set-up")
+            out["layout"] = dict(r.layout, note="particle arrays in one flat buffer, array j at j * pitch_floats; the pitch is chosen by the library "
+                                             "(mcpm_plan_probe_particle_pitch: adjoint particle kernel timed on this buffer for 3 candidate pitches, untimed set-up)")
         if slab:
             out["comm_and_host_ms_per_step"] = round(dt / K * 1e3 - step_ms, 3)   # wall minus rank-0 kernel stages
             out["deposits_beyond_ghost_rank0"] = r.pm.out_of_ghost()                # must be 0

@@ -393,6 +393,22 @@ int mcpm_nbody_bf_f32(mcpm_plan *plan, const float *init_mesh, int n_steps, cons
                       const double *beta, double dg, const double *lpt_scalars, int lpt_order, int paint_order,
                       float *pos_out, float *vel_out, float *ckpt);
 int64_t mcpm_nbody_ckpt_floats(const mcpm_plan *plan, int n_steps, int lpt_order);
+/* Layout of the particle arrays the composite entry points stream (the checkpoint states x'_i, v_i inside `ckpt`; the plan's own
+   running cotangents): consecutive (N, 3) arrays are `pitch` floats apart, 3 N (back to back) by default.  The step kernels read
+   and write four to seven such arrays at the SAME particle index; back to back they are in phase in every low address bit, and
+   on some memory placements that a process draws they then meet in one memory channel (adjoint particle kernel 2.45 or 2.75 ms at
+   512^3; DESIGN finding 29).  No shift is right everywhere, but a process can find out:
+   mcpm_plan_probe_particle_pitch  times the adjoint particle kernel on the caller's checkpoint buffer `flat` (at least
+       mcpm_nbody_ckpt_floats() floats; it is ZEROED -- call before filling it) for the pitches 3 N, 3 N + 1088 and 3 N + 17472
+       floats, keeps the fastest for the following mcpm_nbody_bf_f32 / _vjp_f32 calls of this plan and returns it (meshes below
+       2^23 particles, whose arrays live in the caches: 3 N, nothing is timed);
+   mcpm_plan_set_particle_pitch    fixes it (0 = back to back; else 3 N <= pitch <= 3 N + 17472, a multiple of 4);
+   mcpm_plan_particle_pitch        the pitch in force: state (x'_i, v_i) of a checkpoint = arrays 2 i and 2 i + 1 of `ckpt`.
+   Callers of the step-level entry points (mcpm_bullfrog_step_f32 ...) own their arrays: the same advice applies to them
+   (INTEGRATION.md).  No reference counterpart (XLA places the reference's buffers). */
+int mcpm_plan_probe_particle_pitch(mcpm_plan *plan, float *flat, int64_t flat_floats, int64_t *pitch_floats);
+int mcpm_plan_set_particle_pitch(mcpm_plan *plan, int64_t pitch_floats);
+int mcpm_plan_particle_pitch(const mcpm_plan *plan, int64_t *pitch_floats);
 /* Reverse sweep: cotangents of (pos_out, vel_out) -> init_mesh_bar (half-spectrum, real-pair convention
    dL = Re sum conj(bar) dz) and host scalar bars (may be NULL; forces a stream sync when given):
    scalar_bars[0..n_steps) = alpha_bar, [n_steps..2 n_steps) = beta_bar, then {g_bar, g2_bar, dg2dg_bar, dg_bar}

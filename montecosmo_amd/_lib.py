@@ -113,6 +113,9 @@ SIGNATURES = {
     "mcpm_lpt_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _f32p, _f32p]),
     "mcpm_nbody_bf_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f64p, C.c_double, _f64p, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
     "mcpm_nbody_ckpt_floats": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    "mcpm_plan_probe_particle_pitch": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.POINTER(C.c_int64)]),
+    "mcpm_plan_set_particle_pitch": (C.c_int, [C.c_void_p, C.c_int64]),
+    "mcpm_plan_particle_pitch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mcpm_nbody_bf_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f64p, C.c_double, _f64p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _f64p]),
     "mcpm_slab_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "mcpm_slab_comm_init_local": (C.c_int, [C.c_void_p]),

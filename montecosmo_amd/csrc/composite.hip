@@ -368,8 +368,10 @@ static int ensure_pscratch_n(mcpm_plan *p, int64_t nfloats) {
     return MCPM_OK;
 }
 
+// x_bar, v_bar, F_bar of the composite adjoint: array j of the plan's particle scratch, mcpm_pitch() floats apart
+static inline float *ps_arr(const mcpm_plan *p, int j) { return p->pscratch + j * mcpm_pitch(p); }
 static int ensure_pscratch(mcpm_plan *p) {
-    if (!p->pscratch && hipMalloc((void **)&p->pscratch, sizeof(float) * 9 * p->Np) != hipSuccess)
+    if (!p->pscratch && hipMalloc((void **)&p->pscratch, sizeof(float) * 3 * mcpm_pitch_max(p)) != hipSuccess)
         return mcpm_fail(p, MCPM_E_NOMEM, "adjoint particle scratch");
     return MCPM_OK;
 }
@@ -593,7 +595,7 @@ int mcpm_bullfrog_step_vjp_from_f32(mcpm_plan *p, const float *pos_in, const flo
     MCPM_REQUIRE(p, paint_order >= 1 && paint_order <= 4, MCPM_E_ORDER, "mcpm_bullfrog_step_vjp_f32: paint_order must be 1..4");
     MCPM_TRY(ensure_pscratch(p));
     const int64_t N = p->Np;
-    float *Fb = p->pscratch + 6 * N;
+    float *Fb = ps_arr(p, 2);
     const float b = (float)beta, t = (float)tau;
     // force cotangent F_bar = beta (v_bar + tau x_bar), scattered onto three meshes (adjoint of read); already written
     // by the previous call's particle kernel when the caller chained the steps (mcpm_plan_hint_next_adjoint)
@@ -629,7 +631,7 @@ int mcpm_plan_chained_fb(mcpm_plan *p, double beta, double tau, const float *pos
     if (!p || !fb) return MCPM_E_ARG;
     *fb = nullptr;
     if (p->fb_valid && p->fb_beta == (float)beta && p->fb_tau == (float)tau && p->fb_xb == pos_bar && p->fb_vb == vel_bar && p->pscratch)
-        *fb = p->pscratch + 6 * p->Np;
+        *fb = ps_arr(p, 2);
     p->fb_valid = 0;
     return MCPM_OK;
 }
@@ -673,7 +675,7 @@ static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float
     float *fb_next = nullptr;
     if (p->hint_set) {
         MCPM_TRY(ensure_pscratch(p));
-        fb_next = p->pscratch + 6 * N;
+        fb_next = ps_arr(p, 2);
         p->fb_valid = 1;
         p->fb_beta = p->hint_beta;
         p->fb_tau = p->hint_tau;
@@ -764,10 +766,76 @@ int mcpm_pm_forces_vjp_opts_f32(mcpm_plan *p, const float *pos, int64_t n, int m
     return axpby(p, pos_bar, pb2, 3 * n, 1.f, 1.f, pos_bar);
 }
 
+// checkpoint layout: states (x'_i, v_i) as arrays 2 i and 2 i + 1, mcpm_pitch() floats apart, in a region sized for the largest
+// candidate pitch (so that the buffer does not depend on the pitch chosen later); then the n_steps force meshes
 int64_t mcpm_nbody_ckpt_floats(const mcpm_plan *p, int n_steps, int lpt_order) {
     (void)lpt_order;
     if (!p || n_steps < 1) return 0;
-    return (int64_t)n_steps * (6 * p->Np + 3 * p->M);
+    return (int64_t)n_steps * (2 * mcpm_pitch_max(p) + 3 * p->M);
+}
+
+int mcpm_plan_set_particle_pitch(mcpm_plan *p, int64_t pitch_floats) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, pitch_floats == 0 || (pitch_floats >= 3 * p->Np && pitch_floats <= mcpm_pitch_max(p) && pitch_floats % 4 == 0), MCPM_E_ARG,
+                 "mcpm_plan_set_particle_pitch: 0, or 3 N <= pitch <= 3 N + 17472, a multiple of 4 floats");
+    p->ppitch = pitch_floats;
+    p->fb_valid = 0;
+    return MCPM_OK;
+}
+
+int mcpm_plan_particle_pitch(const mcpm_plan *p, int64_t *pitch_floats) {
+    if (!p || !pitch_floats) return MCPM_E_ARG;
+    *pitch_floats = mcpm_pitch(p);
+    return MCPM_OK;
+}
+
+// Times the adjoint particle kernel (the one whose speed follows the placement: 2.45 or 2.75 ms at 512^3) with the checkpoint
+// arrays of `flat` and the plan's own cotangent scratch laid out at each candidate pitch, and keeps the fastest.  The buffer is
+// zeroed (zero displacements are valid particles); call it on the buffer that will hold the checkpoints, before filling it.
+int mcpm_plan_probe_particle_pitch(mcpm_plan *p, float *flat, int64_t flat_floats, int64_t *pitch_floats) {
+    if (!p || !flat) return MCPM_E_ARG;
+    const int64_t N = p->Np, M = p->M;
+    int64_t best = 3 * N;
+    if (N >= ((int64_t)1 << 23) && p->g.same_lattice && flat_floats >= 2 * mcpm_pitch_max(p)) {
+        MCPM_TRY(ensure_pscratch(p));
+        static const int64_t shifts[3] = {0, 1088, MCPM_PITCH_MAX_SHIFT};      // in phase; 4 KB + 256 B; 64 KB + 4 KB + 256 B
+        hipEvent_t e0, e1;
+        MCPM_HIP(p, hipEventCreate(&e0));
+        MCPM_HIP(p, hipEventCreate(&e1));
+        const int64_t keep = p->ppitch;
+        float best_ms = 0.f;
+        int rc = MCPM_OK;
+        // force mesh and rho_bar: the plan's scratch meshes, zeroed (the kernel's gathers then read finite numbers)
+        if (hipMemsetAsync(p->fmesh, 0, sizeof(float) * 3 * M, p->stream) != hipSuccess || hipMemsetAsync(p->rho, 0, sizeof(float) * M, p->stream) != hipSuccess)
+            rc = mcpm_fail(p, MCPM_E_HIP, "mcpm_plan_probe_particle_pitch: memset");
+        for (int c = 0; c < 3 && rc == MCPM_OK; ++c) {
+            p->ppitch = 3 * N + shifts[c];
+            const int64_t pitch = p->ppitch;
+            (void)hipMemsetAsync(flat, 0, sizeof(float) * 2 * pitch, p->stream);
+            (void)hipMemsetAsync(p->pscratch, 0, sizeof(float) * 3 * pitch, p->stream);
+            for (int rep = 0; rep < 4 && rc == MCPM_OK; ++rep) {      // the first call warms up
+                if (rep == 1) (void)hipEventRecord(e0, p->stream);
+                p->hint_set = 1, p->hint_beta = 0.f, p->hint_tau = 0.f;      // as inside a reverse sweep: the kernel also writes F_bar
+                rc = step_adjoint_particles(p, flat, flat + pitch, p->fmesh, step_layout(p), p->rho, 1.0, 0.0, 0.0, 2, ps_arr(p, 0), ps_arr(p, 1),
+                                            nullptr, nullptr, 1.0, nullptr, nullptr, nullptr);
+            }
+            if (rc != MCPM_OK) break;
+            (void)hipEventRecord(e1, p->stream);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = mcpm_fail(p, MCPM_E_HIP, "mcpm_plan_probe_particle_pitch: event"); break; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (c == 0 || ms < best_ms) best_ms = ms, best = pitch;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        p->fb_valid = 0;
+        p->fx_src = nullptr;
+        p->ppitch = keep;
+        if (rc != MCPM_OK) return rc;
+    }
+    p->ppitch = best == 3 * N ? 0 : best;
+    if (pitch_floats) *pitch_floats = best;
+    return MCPM_OK;
 }
 
 int mcpm_nbody_bf_f32(mcpm_plan *p, const float *init_mesh, int n_steps, const double *alpha, const double *beta,
@@ -778,9 +846,10 @@ int mcpm_nbody_bf_f32(mcpm_plan *p, const float *init_mesh, int n_steps, const d
     MCPM_REQUIRE(p, n_steps >= 1, MCPM_E_ARG, "mcpm_nbody_bf_f32: n_steps must be >= 1");
     MCPM_REQUIRE(p, paint_order >= 1 && paint_order <= 4, MCPM_E_ORDER, "mcpm_nbody_bf_f32: paint_order must be 1..4");
     const int64_t N = p->Np, M = p->M;
-    auto state_x = [&](int i) { return ckpt + (int64_t)i * 6 * N; };
-    auto state_v = [&](int i) { return ckpt + (int64_t)i * 6 * N + 3 * N; };
-    auto force_m = [&](int i) { return ckpt + (int64_t)n_steps * 6 * N + (int64_t)i * 3 * M; };
+    const int64_t pitch = mcpm_pitch(p);
+    auto state_x = [&](int i) { return ckpt + (int64_t)(2 * i) * pitch; };
+    auto state_v = [&](int i) { return ckpt + (int64_t)(2 * i + 1) * pitch; };
+    auto force_m = [&](int i) { return ckpt + (int64_t)n_steps * 2 * mcpm_pitch_max(p) + (int64_t)i * 3 * M; };
     float *x = ckpt ? state_x(0) : pos_out, *v = ckpt ? state_v(0) : vel_out;
     MCPM_TRY(mcpm_lpt_f32(p, init_mesh, lpt_order, (float)lpt_scalars[0], (float)lpt_scalars[1], (float)lpt_scalars[2],
                           MCPM_FD_INF, MCPM_FD_INF, x, v));
@@ -807,19 +876,20 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: lpt_order must be 1 or 2");
     const int64_t N = p->Np, M = p->M;
     MCPM_TRY(ensure_pscratch(p));
-    float *xb = p->pscratch, *vb = p->pscratch + 3 * N;
-    auto state_x = [&](int i) { return ckpt + (int64_t)i * 6 * N; };
-    auto state_v = [&](int i) { return ckpt + (int64_t)i * 6 * N + 3 * N; };
-    auto force_m = [&](int i) { return ckpt + (int64_t)n_steps * 6 * N + (int64_t)i * 3 * M; };
-    MCPM_HIP(p, hipMemcpyAsync(xb, pos_bar, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, p->stream));
-    MCPM_HIP(p, hipMemcpyAsync(vb, vel_bar, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, p->stream));
+    float *xb = ps_arr(p, 0), *vb = ps_arr(p, 1);
+    const int64_t pitch = mcpm_pitch(p);
+    auto state_x = [&](int i) { return ckpt + (int64_t)(2 * i) * pitch; };
+    auto state_v = [&](int i) { return ckpt + (int64_t)(2 * i + 1) * pitch; };
+    auto force_m = [&](int i) { return ckpt + (int64_t)n_steps * 2 * mcpm_pitch_max(p) + (int64_t)i * 3 * M; };
     MCPM_HIP(p, hipMemsetAsync(p->reduce, 0, sizeof(double) * (2 * n_steps + 4 + 256), p->stream));
     p->fb_valid = 0;
     for (int i = n_steps - 1; i >= 0; --i) {
         if (i > 0) MCPM_TRY(mcpm_plan_hint_next_adjoint(p, beta[i - 1], dg));
-        MCPM_TRY(mcpm_bullfrog_step_vjp_f32(p, state_x(i), state_v(i), force_m(i), alpha[i], beta[i],
-                                            (i == n_steps - 1) ? dg / 2 : dg, paint_order, xb, vb, p->reduce + i,
-                                            p->reduce + n_steps + i, (i == n_steps - 1) ? 0.5 : 1.0, p->reduce + 2 * n_steps + 3));
+        // the first reverse step READS the loss cotangents where the caller has them and writes the running ones (no copy of 24 N bytes)
+        const bool first = i == n_steps - 1;
+        MCPM_TRY(mcpm_bullfrog_step_vjp_from_f32(p, state_x(i), state_v(i), force_m(i), alpha[i], beta[i], first ? dg / 2 : dg, paint_order,
+                                                 first ? pos_bar : xb, first ? vel_bar : vb, xb, vb, p->reduce + i, p->reduce + n_steps + i,
+                                                 first ? 0.5 : 1.0, p->reduce + 2 * n_steps + 3));
     }
     // initial half drift x'_0 = x_0 + v_0 dg/2 (its explicit dg dependence: <x_bar, v_0> / 2)
     {

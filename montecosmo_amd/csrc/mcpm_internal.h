@@ -115,7 +115,13 @@ struct mcpm_plan {
     int *outliers;   // lists of the tiled paint: suspects (Np ints), then wild particles (Np ints)
     int *outlier_count;  // device counters (8 ints, see paint_tiled.hip: wild, last, slab oob, overflow pairs, dropped, bucketed)
     double *reduce;  // device accumulators for scalar cotangents (MCPM_NREDUCE doubles)
-    float *pscratch; // 9*Np floats, allocated on first VJP (adjoint state + force cotangent)
+    float *pscratch; // 3 (N, 3) arrays mcpm_pitch_max() apart, allocated on first VJP (adjoint state x_bar, v_bar + force cotangent F_bar)
+    // Pitch (floats) between consecutive (N, 3) particle arrays of the composite entry points' checkpoint (mcpm_nbody_bf_f32: x'_0, v_0,
+    // x'_1, ...) and of pscratch; 0 = contiguous (3 N).  The step kernels stream four to seven such arrays at the same particle index:
+    // back to back they are IN PHASE in every low address bit and may meet in one memory channel, depending on where the process's
+    // memory was placed (DESIGN finding 29); a pitch of 3 N + a few KB takes them out of phase.  mcpm_plan_probe_particle_pitch
+    // measures the candidates on the caller's buffer; mcpm_plan_set_particle_pitch fixes one.
+    int64_t ppitch;
     float *vscratch;  // variable-size particle scratch (pm_forces_vjp)
     int64_t vscratch_n;
     float *tw[3];    // twiddle tables exp(-2 pi i j / n) of the hand-written FFT, per axis (x, y, z)
@@ -162,6 +168,9 @@ extern thread_local std::string g_mcpm_create_error;
 
 int mcpm_fail(mcpm_plan *plan, int code, const std::string &msg);
 void mcpm_slab_state_free(mcpm_plan *p);   // slab.hip
+#define MCPM_PITCH_MAX_SHIFT 17472      // floats: 64 KB + 4 KB + 256 B, the largest candidate shift between particle arrays
+static inline int64_t mcpm_pitch_max(const mcpm_plan *p) { return 3 * p->Np + MCPM_PITCH_MAX_SHIFT; }
+static inline int64_t mcpm_pitch(const mcpm_plan *p) { return p->ppitch > 0 ? p->ppitch : 3 * p->Np; }
 static inline int mcpm_default_halo(int64_t M) { return M <= ((int64_t)1 << 24) ? 4 : 3; }   // the static rule (plan.hip: where it comes from)
 
 // hand-written FFT Poisson solve (fftpm.hip); power-of-two axes only

@@ -136,6 +136,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->gx_wmax = nullptr;
     p->reduce = nullptr;
     p->pscratch = nullptr;
+    p->ppitch = 0;
     p->vscratch = nullptr;
     p->vscratch_n = 0;
     p->tw[0] = p->tw[1] = p->tw[2] = nullptr;

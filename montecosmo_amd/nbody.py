@@ -12,6 +12,7 @@ as in the reference where they are numpy / 128-entry tables.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from itertools import product
 
 import numpy as np
@@ -833,6 +834,12 @@ class NbodyCtx:
     def __init__(self, **kw):
         self.__dict__.update(kw)
 
+    def state(self, i):
+        """Checkpoint i of the composite path as (x'_i, v_i) views: x'_i = x_i + v_i dg / 2, the position offsets the step's paint
+        and read use (arrays 2 i and 2 i + 1 of `ckpt`, `pitch` floats apart: include/mcpm.h mcpm_plan_particle_pitch)."""
+        N, pt = self.plan.N, self.pitch
+        return (self.ckpt[2 * i * pt: 2 * i * pt + 3 * N].view(N, 3), self.ckpt[(2 * i + 1) * pt: (2 * i + 1) * pt + 3 * N].view(N, 3))
+
 
 def _step_scalars(cosmo, a0, a1, n_steps, integrator):
     """Host float64 scalars of the Euler/BullFrog loop, with diffrax's accumulated time (nbody.py:974-976, :999)."""
@@ -919,13 +926,25 @@ def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 
     if return_ctx or want_snaps:
         nck = lib.mcpm_nbody_ckpt_floats(plan.h, n_steps, lpt_order)
         ckpt = torch.empty((nck,), dtype=torch.float32, device=spec.device)
+        if not getattr(plan, "_pitch_probed", False):
+            # once per plan: the library times its adjoint particle kernel on THIS buffer for three layouts of the checkpoint
+            # arrays (back to back, or shifted against each other by a few KB) and keeps the fastest (include/mcpm.h
+            # mcpm_plan_probe_particle_pitch; meshes below 2^23 particles keep the plain layout, nothing is timed)
+            plan._pitch_probed = True
+            if os.environ.get("MCPM_PARTICLE_PITCH") is not None:
+                plan.call("mcpm_plan_set_particle_pitch", int(os.environ["MCPM_PARTICLE_PITCH"]))
+            else:
+                plan.call("mcpm_plan_probe_particle_pitch", _ptr(ckpt), nck, None)
+    pitch = C.c_int64()
+    plan.call("mcpm_plan_particle_pitch", C.byref(pitch))
+    pitch = int(pitch.value)
     plan.call("mcpm_nbody_bf_f32", _ptr(spec), n_steps, _dptr(alphas), _dptr(betas), float(dg), _dptr(lpt_s),
               int(lpt_order), int(paint_order), _ptr(x), _ptr(v), _ptr(ckpt))
     lp = LatticePos(x, mesh_shape, ptcl_shape)
     if want_snaps:
         if lattice_out:
             raise NotImplementedError("snapshots are returned as absolute positions")
-        out = _snapshots(cosmo, snapshots, a0, a1, n_steps, dg, ckpt, N, lp, v)
+        out = _snapshots(cosmo, snapshots, a0, a1, n_steps, dg, ckpt, N, lp, v, pitch=pitch)
     else:
         out = (lp, v) if lattice_out else (lp.to_absolute()[None], v[None])
     if fn is not None:
@@ -933,7 +952,7 @@ def nbody_bf(cosmo, init_mesh, pos, a0=0., a1=1., n_steps=5, paint_order: int = 
     if return_ctx:
         ctx = NbodyCtx(plan=plan, init_mesh=spec, n_steps=n_steps, dg=dg, alphas=alphas, betas=betas, lpt_s=lpt_s,
                        lpt_order=int(lpt_order), paint_order=int(paint_order), ckpt=ckpt, cosmo=cosmo, a0=a0, a1=a1,
-                       integrator=integrator)
+                       integrator=integrator, pitch=pitch)
         return out, ctx
     return out
 
@@ -985,7 +1004,7 @@ def _nbody_bf_opts_vjp(ctx, xb, vb):
     return out, {"alpha": abar, "beta": bbar, "g": sb[0], "g2": sb[1], "dg2dg": sb[2], "dg": dgbar}
 
 
-def _snapshots(cosmo, snapshots, a0, a1, n_steps, dg, ckpt, N, lp_final, v_final):
+def _snapshots(cosmo, snapshots, a0, a1, n_steps, dg, ckpt, N, lp_final, v_final, pitch=None):
     """diffrax SaveAt(ts=...) on the Euler solution (nbody.py:990-997): linear interpolation between the step states.
     Step state i is rebuilt from the checkpoint (x'_i - v_i dg/2, v_i); the last one is the returned state."""
     g0, g1 = float(a2g(cosmo, a0)), float(a2g(cosmo, a1))
@@ -1001,8 +1020,9 @@ def _snapshots(cosmo, snapshots, a0, a1, n_steps, dg, ckpt, N, lp_final, v_final
     def state(i):
         if i == n_steps:
             return lp_final.disp.double(), v_final.double()
-        xs = ckpt[i * 6 * N: i * 6 * N + 3 * N].view(N, 3).double()
-        vs = ckpt[i * 6 * N + 3 * N: (i + 1) * 6 * N].view(N, 3).double()
+        pt = 3 * N if pitch is None else pitch      # floats between consecutive (N, 3) arrays (mcpm_plan_particle_pitch)
+        xs = ckpt[2 * i * pt: 2 * i * pt + 3 * N].view(N, 3).double()
+        vs = ckpt[(2 * i + 1) * pt: (2 * i + 1) * pt + 3 * N].view(N, 3).double()
         return xs - vs * (dg / 2), vs
 
     pos_out, vel_out = [], []
@@ -1029,6 +1049,7 @@ def nbody_bf_vjp(ctx, pos_bar, vel_bar):
         return _nbody_bf_opts_vjp(ctx, xb, vb)
     out = torch.empty(tuple(ctx.init_mesh.shape), dtype=torch.complex64, device=xb.device)
     sb = np.zeros(2 * n + 4)
+    plan.call("mcpm_plan_set_particle_pitch", 0 if ctx.pitch == 3 * plan.N else ctx.pitch)      # the layout this checkpoint was written in
     plan.call("mcpm_nbody_bf_vjp_f32", _ptr(ctx.init_mesh), n, _dptr(ctx.alphas), _dptr(ctx.betas), float(ctx.dg),
               _dptr(ctx.lpt_s), ctx.lpt_order, ctx.paint_order, _ptr(ctx.ckpt), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
     bars = {"alpha": sb[:n].copy(), "beta": sb[n:2 * n].copy(), "g": sb[2 * n], "g2": sb[2 * n + 1], "dg2dg": sb[2 * n + 2],

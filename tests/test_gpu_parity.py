@@ -841,3 +841,46 @@ def test_streaming_store_data_hazard_is_padded(gpu):
     out.fill_(-7.0)                     # without the wait states: informational (printed with -s), not asserted
     check(lib.mcpm_selftest_store3_nt(st, C.c_void_p(out.data_ptr()), n, 2), None, "mcpm_selftest_store3_nt")
     print(f"store3 hazard, no wait states: {int((out != ref).sum())} of {3 * n} floats corrupted")
+
+
+def test_particle_pitch_changes_the_layout_not_the_results(gpu, nb):
+    """mcpm_plan_set_particle_pitch / mcpm_plan_probe_particle_pitch (the layout fix for C-ABI callers, not
+    just for bench.py): the composite forward + reverse sweep gives bitwise the same states and gradients whatever the pitch
+    between its checkpoint arrays; the probe keeps the plain layout for a mesh whose arrays live in the caches and zeroes the
+    buffer it is given; NbodyCtx.state(i) follows the pitch."""
+    import ctypes as C
+    import torch
+    from montecosmo_amd import bricks, synth
+    n, K = 32, 3
+    shape = (n, n, n)
+    spec = synth.init_mesh(n, seed=3, rms_disp=1.5)
+    pos = bricks.regular_pos(shape)
+    plan = nb.get_plan(shape)
+    rng = np.random.default_rng(2)
+    xb, vb = rng.standard_normal((n ** 3, 3)).astype(np.float32), rng.standard_normal((n ** 3, 3)).astype(np.float32)
+    res = {}
+    try:
+        for pitch in (0, 3 * n ** 3 + 1088, 3 * n ** 3 + 17472):
+            plan._pitch_probed = True              # this test sets the pitch itself
+            plan.call("mcpm_plan_set_particle_pitch", pitch)
+            (lp, vel), ctx = nb.nbody_bf(bricks.Planck18(), spec, pos, a0=0.1, a1=1., n_steps=K, return_ctx=True, lattice_out=True)
+            assert ctx.pitch == (pitch or 3 * n ** 3)
+            mb, sb = nb.nbody_bf_vjp(ctx, xb, vb)
+            x1, v1 = ctx.state(1)
+            res[pitch] = (lp.disp.clone(), vel.clone(), mb.clone(), sb, x1.clone(), v1.clone())
+        ref = res[0]
+        for pitch, r in res.items():
+            for a, b in zip(r[:3] + r[4:], ref[:3] + ref[4:]):
+                assert torch.equal(a, b), pitch
+            assert all(np.array_equal(r[3][k], ref[3][k]) for k in ref[3]), pitch
+        # out-of-range pitches are refused
+        from montecosmo_amd._lib import lib
+        assert lib.mcpm_plan_set_particle_pitch(plan.h, 3 * n ** 3 - 4) == -6 and lib.mcpm_plan_set_particle_pitch(plan.h, 3 * n ** 3 + 17476) == -6
+        # the probe: small mesh -> plain layout, buffer zeroed or untouched but usable
+        nck = lib.mcpm_nbody_ckpt_floats(plan.h, K, 2)
+        buf = torch.full((nck,), 7.0, dtype=torch.float32, device=gpu)
+        got = C.c_int64()
+        plan.call("mcpm_plan_probe_particle_pitch", C.c_void_p(buf.data_ptr()), nck, C.byref(got))
+        assert got.value == 3 * n ** 3
+    finally:
+        plan.call("mcpm_plan_set_particle_pitch", 0)

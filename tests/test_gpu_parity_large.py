@@ -75,8 +75,7 @@ def _gradient_anatomy(nb, n, K, shape, spec, pos, ctx, cos, traj, ts, dg):
     ck = ctx.ckpt
     xbb, vbb, flips = xb.copy(), vb.copy(), 0.0
     for i in reversed(range(K)):
-        xh = ck[i * 6 * N: i * 6 * N + 3 * N].view(N, 3).double().cpu().numpy()
-        v = ck[i * 6 * N + 3 * N: (i + 1) * 6 * N].view(N, 3).double().cpu().numpy()
+        xh, v = (t.double().cpu().numpy() for t in ctx.state(i))
         r = (ts[i + 1] - ts[i]) / dg
         xb2, vb2, _, _, _ = o.dkd_vjp(pos + xh - v * (dg / 2), v, r * xbb, r * vbb, dg, float(o.alpha_bf(cos, ts[i], dg)),
                                       ts[i] + dg / 2, shape)

@@ -34,8 +34,7 @@ print(f"{n}^3, {K} steps; oracle forward + reverse {time.time() - t0:.0f} s", fl
 print("A  GPU gradient vs float64 oracle              rel L2 =", rel(mb_g, mb_o))
 # B: float64 reverse sweep on the GPU's trajectory
 ck = ctx.ckpt
-state = lambda i: (ck[i * 6 * N: i * 6 * N + 3 * N].view(N, 3).double().cpu().numpy(),
-                   ck[i * 6 * N + 3 * N: (i + 1) * 6 * N].view(N, 3).double().cpu().numpy())
+state = lambda i: tuple(t.double().cpu().numpy() for t in ctx.state(i))
 xbb, vbb = xb.copy(), vb.copy()
 flips = []
 for i in reversed(range(K)):

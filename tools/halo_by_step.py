@@ -10,7 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 K = 10
-r = bench.Runner(n, K, dev, stagger=4352 if n >= 256 else 0)
+r = bench.Runner(n, K, dev)
 r.run(K)
 torch.cuda.synchronize()
 

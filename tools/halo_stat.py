@@ -10,7 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 K = 10
-r = bench.Runner(n, K, dev, stagger=0)
+r = bench.Runner(n, K, dev)
 r.forward(K)
 torch.cuda.synchronize()
 nt = n // 16

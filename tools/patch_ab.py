@@ -11,7 +11,7 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 MODES = (0, 1)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-r = bench.Runner(n, 10, dev, stagger=4352 if n >= 256 else 0)
+r = bench.Runner(n, 10, dev)
 r.run(10)
 torch.cuda.synchronize()
 keys = ("kick_drift", "step_adjoint", "read", "paint", "paint3")
