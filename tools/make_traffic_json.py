@@ -48,7 +48,9 @@ for d, key in ((fetch_dir, "fetch_kb"), (write_dir, "write_kb")):
             continue
         st = stage(nm)
         if st in ("paint", "paint3") and "tile_kernel" in nm:
-            if "paint3_tile_kernel" not in nm or ", false" in nm:    # the f64 repaint launch follows its fixed-point pass
+            # the f64 repaint launch (template arguments <HA, HB, HC, F64 = true, 1024 threads, U, FAST = false>) follows its
+            # fixed-point pass (<..., false, 512, 4, true | false>): only the first pass opens a new paint
+            if not ("paint3_tile_kernel" in nm and ", true, 1024" in nm):
                 tot[st][key] += pending
                 pending = 0.0
             current = st
