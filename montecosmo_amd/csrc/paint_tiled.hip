@@ -1288,8 +1288,12 @@ bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t ws
         DISPATCH_H(halo_of(p), CALLW)
 #undef CALLW
     } else {
+        // meshes of at most 1024 tiles (128^3: 512) leave half of the CUs' wave slots empty with 512 threads per tile, and a tile's
+        // time is latency there: 1024 threads per tile halve it (two such workgroups still fit a CU: 49 VGPRs, 37 KB of LDS)
+        const bool wide = fast && nb <= 1024u;
 #define CALLU(HA_, HB_, HC_)                                                                                                                    \
-    if (fast) paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+    if (wide) paint_tile_kernel<HA_, HB_, HC_, 0, 1024, 4, true><<<nb, 1024, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+    else if (fast) paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
     else paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
         DISPATCH_H(halo_of(p), CALLU)
 #undef CALLU
