@@ -5,20 +5,17 @@ left at the reference's value (blackjax's default max_num_doublings = 10: montec
 diagonal mass matrix, samplers.py:44), several independent chains from dispersed starting points, split-R-hat and effective
 sample sizes of the scalar latents.  The 256^3 run of tools/run_nuts_field.py stays what it is labelled: a throughput figure.
 
-usage: python tools/run_nuts_convergence.py [final_n=36] [chains=4 | a list "0,1"] [n_warmup=200] [n_samples=200] [max_depth=10] [out.json] [draws_dir]
+usage: python tools/run_nuts_convergence.py [final_n=36] [chains: 4 | c2 | 0,1,2,3] [n_warmup=200] [n_samples=200] [max_depth=10] [out.json] [draws_dir]
 A gpurun call lasts 20 minutes at most and a chain about ten: with `draws_dir` every chain's draws are kept as <draws_dir>/chain<c>.npz,
-chains found there are not run again, and the summary is written once all the listed ones exist -- so "0", "1", "2", "3" and then
-"0,1,2,3" in five calls give the four-chain summary."""
+chains found there are not run again -- so "c0", "c1", "c2", "c3" and then "0,1,2,3" in five calls give the four-chain summary."""
 import json, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 from montecosmo_amd import model, logdensity, samplers, bricks, utils, nbody
 
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 36
-chains = [int(c) for c in sys.argv[2].split(",")] if (len(sys.argv) > 2 and "," in sys.argv[2]) else None
-if chains is None:
-    k = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    chains = list(range(k)) if (len(sys.argv) <= 7 or k > 3) else [k]      # with a draws_dir a single small number names ONE chain
+arg = sys.argv[2] if len(sys.argv) > 2 else "4"      # "4": chains 0..3; "c2": chain 2 alone; "0,1,2,3": these chains
+chains = [int(arg[1:])] if arg.startswith("c") else ([int(c) for c in arg.split(",")] if "," in arg else list(range(int(arg))))
 n_chains = len(chains)
 n_warm = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 n_samp = int(sys.argv[4]) if len(sys.argv) > 4 else 200
