@@ -671,7 +671,9 @@ static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float
     const float a = (float)alpha, b = (float)beta, t = (float)tau;
     dim3 grid, block;
     lattice_launch(p->g, grid, block);
-    StageTimer st_(p, ST_STEPADJ, 72.0 * N + 16.0 * M);
+    // algorithmic bytes: x, v, x_bar, v_bar in (48 N), x_bar, v_bar out (24 N), three force meshes + rho_bar gathered once (16 M); in a
+    // chained reverse sweep the kernel also WRITES the next step's force cotangent (12 N: the axpby pass it replaces)
+    StageTimer st_(p, ST_STEPADJ, 72.0 * N + 16.0 * M + (p->hint_set ? 12.0 * N : 0.0));
     float *fb_next = nullptr;
     if (p->hint_set) {
         MCPM_TRY(ensure_pscratch(p));

@@ -475,11 +475,21 @@ struct WinIter {
         const int lz = __builtin_ctz((unsigned)g.nz), ly = __builtin_ctz((unsigned)g.ny);      // uniform: scalar registers
         return (((gx << ly) | gy) << lz) | gz;
     }
+    // the same on a slab plan (FAST = 2): y and z periodic powers of two, x the ghost-extended, NON-periodic local planes whose
+    // lattice planes are mesh planes [xoff, xoff + px): -1 where the window leaves them
+    __device__ __forceinline__ int point_slab(const Geom &g, int x0, int y0, int z0, int ox, int oy, int oz, int &rx, int &ry, int &rz) const {
+        rx = jx - (H + 1) - ox;
+        ry = jy - (H + 1) - oy;
+        rz = jz - (H + 1) - oz;
+        const int gx = x0 + rx - g.xoff, gy = (y0 + ry) & (g.ny - 1), gz = (z0 + rz) & (g.nz - 1);
+        const int lz = __builtin_ctz((unsigned)g.nz), ly = __builtin_ctz((unsigned)g.ny);
+        return (unsigned)gx < (unsigned)g.px ? ((((gx << ly) | gy) << lz) | gz) : -1;
+    }
 };
 // 12-byte particle record i of an array of fewer than 2^32 / 12 records (what the FAST instantiations are launched for): uniform
 // base + 32-bit byte offset, so the address costs two full-rate shifts / adds instead of a quarter-rate 64-bit multiply-add
 // (round 4: density paint 0.81 -> 0.79 ms, three-component paint 1.93 -> 1.82 ms at 512^3, same box)
-template <bool FAST>
+template <int FAST>
 __device__ __forceinline__ P3 load3w(const float *__restrict__ p, int i) {
     if (FAST) return *reinterpret_cast<const P3 *>(reinterpret_cast<const char *>(p) + (((unsigned)i << 3) + ((unsigned)i << 2)));
     return load3(p, i);
@@ -490,7 +500,7 @@ __device__ __forceinline__ P3 load3w(const float *__restrict__ p, int i) {
 // the max|w| scale; 2: weighted, f64 accumulators (non-finite weights only: runs when tile_scale().mode == 2, WMODE 1 otherwise)
 // (amdgpu_num_sgpr: with more than 80 scalar registers a CU admits 7 waves per SIMD instead of 8, i.e. three of these
 // 512-thread workgroups instead of four -- measured +45 % on the kernel; MI355X_MICROARCH.md "Residency")
-template <int H, int WMODE, int THREADS, int U, bool FAST>
+template <int H, int WMODE, int THREADS, int U, int FAST>
 __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w,
                                                 int64_t wstride, float wscalar, float *__restrict__ mesh, int accumulate, const TileLists &L,
                                                 const unsigned *__restrict__ wmax_bits, int duty, u64 *tile, int *sh27, int *sus) {
@@ -528,7 +538,8 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u * THREADS;
             if (FAST) {
-                gis[u] = wi.valid() ? wi.point_fast(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
+                gis[u] = !wi.valid() ? -1 : (FAST == 2 ? wi.point_slab(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u])
+                                                       : wi.point_fast(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]));
                 wi.next();
             } else
                 gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
@@ -559,7 +570,7 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
                 continue;
             }
             const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
-            const bool beyond = !FAST && g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
+            const bool beyond = FAST != 1 && g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
             if ((unsure || beyond) && duty && home) append_suspect(L, sus, gis[u]);
             if (beyond) continue;   // clamped + counted by paint_leftover_kernel
             if (cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
@@ -630,7 +641,7 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
     }
 }
 
-template <int HA, int HB, int HC, int WMODE, int THREADS, int U, bool FAST = false>
+template <int HA, int HB, int HC, int WMODE, int THREADS, int U, int FAST = 0>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void paint_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
                                                              int64_t wstride, float wscalar, float *__restrict__ mesh,
                                                              int accumulate, TileLists L, const unsigned *__restrict__ wmax_bits,
@@ -842,7 +853,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ w
 // redo: nullptr = first (fixed-point) pass over all tiles, appending flagged tiles to `redo_out`; otherwise the f64 pass
 // over the tiles listed in redo ([0] = count, then indices).  F64: accumulators are doubles (96 KB) instead of packed fields.
 // One tile of the three-component paint (redo_tile < 0: the tile of this block; else the given tile, for the f64 repaint).
-template <int H, bool F64, int THREADS, int U, bool FAST>
+template <int H, bool F64, int THREADS, int U, int FAST>
 __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w3,
                                                  float *__restrict__ mesh, int64_t M, int accumulate, const TileLists &L,
                                                  const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out, int redo_tile, int duty,
@@ -909,7 +920,8 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u * THREADS;
             if (FAST) {
-                gis[u] = wi.valid() ? wi.point_fast(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
+                gis[u] = !wi.valid() ? -1 : (FAST == 2 ? wi.point_slab(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u])
+                                                       : wi.point_fast(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]));
                 wi.next();
             } else
                 gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
@@ -940,7 +952,7 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
                 continue;
             }
             const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
-            const bool beyond = !FAST && g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
+            const bool beyond = FAST != 1 && g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
             if ((unsure || beyond) && duty && home) append_suspect(L, sus, gis[u]);
             if (beyond) continue;   // clamped + counted by paint_leftover_kernel
             if (deposit && cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
@@ -1064,7 +1076,7 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
 // ([0] = count, then indices): a small grid that walks the list (it is empty on every PM workload: a whole-mesh launch of
 // workgroups that return at once cost 30 us per adjoint step at 512^3).
 // (four waves per SIMD = two 512-thread workgroups per CU: with three candidate bodies the allocator would take 133 registers)
-template <int HA, int HB, int HC, bool F64, int THREADS, int U, bool FAST = false>
+template <int HA, int HB, int HC, bool F64, int THREADS, int U, int FAST = 0>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) void paint3_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
                                                               float *__restrict__ mesh, int64_t M, int accumulate, TileLists L,
                                                               const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out,
@@ -1205,13 +1217,17 @@ static bool tiled_geometry_ok(const mcpm_plan *p, const void *mesh) {
     return p->bucket != nullptr;
 }
 
-// the FAST instantiations of the tile kernels: periodic power-of-two meshes (MCPM_PAINT_FAST=0: the generic ones, A/B runs)
-static bool tiled_fast(const mcpm_plan *p) {
+// the FAST instantiations of the tile kernels (add-and-carry window walk, shift-built indices, 32-bit byte offsets): 1 = periodic
+// power-of-two meshes, 2 = slab plans whose y and z axes are powers of two (x: the ghost-extended local planes, not periodic);
+// 0 = the generic walk (MCPM_PAINT_FAST=0 forces it: A/B runs)
+static int tiled_fast(const mcpm_plan *p) {
     static const int on = [] { const char *e = getenv("MCPM_PAINT_FAST"); return e ? atoi(e) : 1; }();
     const Geom &g = p->g;
     auto pow2 = [](int n) { return (n & (n - 1)) == 0; };
     // (12-byte records addressed with 32-bit byte offsets: load3w)
-    return on && !g.xslab && pow2(g.nx) && pow2(g.ny) && pow2(g.nz) && p->Np * 12 < ((int64_t)1 << 32);
+    if (!on || !pow2(g.ny) || !pow2(g.nz) || p->Np * 12 >= ((int64_t)1 << 32)) return 0;
+    if (g.xslab) return 2;
+    return pow2(g.nx) ? 1 : 0;
 }
 
 static int tile_order() {
@@ -1270,7 +1286,7 @@ bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t ws
     const unsigned nb = (unsigned)((g.nx / MCPM_TILE) * (g.ny / MCPM_TILE) * (g.nz / MCPM_TILE));
     tiled_prologue(p, pos);
     const TileLists L = tile_lists(p);
-    const bool fast = tiled_fast(p);
+    const int fast = tiled_fast(p);
     // bucket blocks walk the list of non-empty buckets (grid-stride); every block of the epilogue launch is scheduled with the
     // bucket tile's LDS whether it finds work or not, so small meshes (few non-empty buckets) get few of them
     const unsigned nbk = nb <= 4096u ? (nb < 256u ? nb : 256u) : 1024u;
@@ -1290,10 +1306,11 @@ bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t ws
     } else {
         // meshes of at most 1024 tiles (128^3: 512) leave half of the CUs' wave slots empty with 512 threads per tile, and a tile's
         // time is latency there: 1024 threads per tile halve it (two such workgroups still fit a CU: 49 VGPRs, 37 KB of LDS)
-        const bool wide = fast && nb <= 1024u;
+        const bool wide = fast == 1 && nb <= 1024u;
 #define CALLU(HA_, HB_, HC_)                                                                                                                    \
-    if (wide) paint_tile_kernel<HA_, HB_, HC_, 0, 1024, 4, true><<<nb, 1024, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
-    else if (fast) paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+    if (wide) paint_tile_kernel<HA_, HB_, HC_, 0, 1024, 4, 1><<<nb, 1024, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+    else if (fast == 1) paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4, 1><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+    else if (fast == 2) paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4, 2><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
     else paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
         DISPATCH_H(halo_of(p), CALLU)
 #undef CALLU
@@ -1317,7 +1334,7 @@ bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, fl
     if (p->fx_tiles < (int)nb) return false;
     tiled_prologue(p, pos, p->fx_redo);
     const TileLists L = tile_lists(p);
-    const bool fast = tiled_fast(p);
+    const int fast = tiled_fast(p);
     const unsigned nbk = nb <= 4096u ? (nb < 256u ? nb : 256u) : 1024u;   // see mcpm_paint_tiled
     if (p->fx_src != weights3) {   // max|w| not left behind by the kernel that produced the weights
         if (!p->fx_clean) (void)hipMemsetAsync(p->fx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream);
@@ -1327,7 +1344,8 @@ bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, fl
     if (p->paint3_variant == 4) {   // fixed-point tiles; the tiles they flag (and every tile if max|w| is unusable) in f64
 #define CALLFX(HA_, HB_, HC_)                                                                                                                \
     {                                                                                                                             \
-        if (fast) paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4, true><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
+        if (fast == 1) paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4, 1><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
+        else if (fast == 2) paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4, 2><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
         else paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
         paint3_tile_kernel<HA_, HB_, HC_, true, 1024, 4><<<nb < 256u ? nb : 256u, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, p->fx_redo, 0); \
     }

@@ -49,14 +49,14 @@ for d, key in ((fetch_dir, "fetch_kb"), (write_dir, "write_kb")):
         st = stage(nm)
         if st in ("paint", "paint3") and "tile_kernel" in nm:
             # the f64 repaint launch (template arguments <HA, HB, HC, F64 = true, 1024 threads, U, FAST = false>) follows its
-            # fixed-point pass (<..., false, 512, 4, true | false>): only the first pass opens a new paint
-            if not ("paint3_tile_kernel" in nm and ", true, 1024" in nm):
+            # fixed-point pass (<..., false, 512, 4, 0 | 1 | 2>): only the first pass opens a new paint
+            if not ("paint3_tile_kernel" in nm and ", true, 1024," in nm):
                 tot[st][key] += pending
                 pending = 0.0
             current = st
         if st:
             tot[st][key] += v
-            if key == "fetch_kb" and any(m in nm for m in main_kernels) and not ("paint3_tile_kernel" in nm and ", true, 1024" in nm):
+            if key == "fetch_kb" and any(m in nm for m in main_kernels) and not ("paint3_tile_kernel" in nm and ", true, 1024," in nm):
                 tot[st]["launches"] += 1      # (the f64 repaint launch of the three-component paint is not a paint of its own)
 method = (
     "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --no-sub-record --no-cpu-baseline --warmup 0 "
