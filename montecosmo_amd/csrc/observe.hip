@@ -219,33 +219,89 @@ __device__ __forceinline__ void interp_at(const Interp &b, const double *xp, con
     y = fp[b.lo] + d * b.t;
     slope = b.clamped ? 0. : d / dx;
 }
-__device__ __forceinline__ void lds_add(double *sh, int i, double v) {
-    if (v != 0.) atomicAdd(sh + i, v);
+// ORDER-INDEPENDENT SUMS.  The table cotangents end up in d logp / d Omega_m, and every gradient of this build is bitwise the same
+// call after call; float64 atomics are not (the first version of these kernels changed the last bits of Omega_m's gradient between
+// two calls).  So the contributions are summed as INTEGERS: pass 0 takes the maximum |contribution| of every table (order-independent
+// by nature), pass 1 rounds each contribution to 2^(e - 30) units (2^e >= that maximum, so a contribution is below 2^30 and a table
+// entry holds 2^32 of them) and adds it with 64-bit integer LDS / global atomics, and a last kernel scales the integers back.
+// Resolution: 10^-9 of the largest contribution per term.  A non-finite maximum makes the whole table NaN.
+#define LC_KINDS 5
+struct Acc {      // PASS 0: per-thread maxima;  PASS 1: integer accumulators in LDS
+    double mx[LC_KINDS];
+    unsigned long long *sh;
+    double scale[LC_KINDS];
+};
+template <int PASS>
+__device__ __forceinline__ void acc_add(Acc &A, int kind, int off, int idx, double v) {
+    if (PASS == 0) A.mx[kind] = fmax(A.mx[kind], fabs(v));      // (fmax drops a NaN operand: caught below by v != v)
+    else if (v != 0.) atomicAdd(A.sh + off + idx, (unsigned long long)__double2ll_rn(v * A.scale[kind]));
 }
-// cotangent ybar of a value looked up at bracket b: into the value table's accumulator
-__device__ __forceinline__ void scatter_fp(double *sh, const Interp &b, double ybar) {
-    lds_add(sh, b.lo, ybar * (1. - b.t));
-    lds_add(sh, b.lo + 1, ybar * b.t);
+template <int PASS>
+__device__ __forceinline__ void scatter_fp(Acc &A, int kind, int off, const Interp &b, double ybar) {
+    acc_add<PASS>(A, kind, off, b.lo, ybar * (1. - b.t));
+    acc_add<PASS>(A, kind, off, b.lo + 1, ybar * b.t);
 }
 // ... and, for a look-up whose NODES move with the cosmology (chi -> a), into the node table's accumulator
-__device__ __forceinline__ void scatter_xp(double *sh, const Interp &b, double ybar) {
-    lds_add(sh, b.lo, -ybar * b.slope * (1. - b.t));
-    lds_add(sh, b.lo + 1, -ybar * b.slope * b.t);
+template <int PASS>
+__device__ __forceinline__ void scatter_xp(Acc &A, int kind, int off, const Interp &b, double ybar) {
+    acc_add<PASS>(A, kind, off, b.lo, -ybar * b.slope * (1. - b.t));
+    acc_add<PASS>(A, kind, off, b.lo + 1, -ybar * b.slope * b.t);
+}
+// mxbits: float bits (rounded up) of the maxima, one per kind; a NaN / inf contribution sets 0x7f800000 or above
+__device__ __forceinline__ void acc_begin(Acc &A, unsigned long long *sh, int ntot, const unsigned *mxbits, int pass) {
+    A.sh = sh;
+    for (int k = 0; k < LC_KINDS; ++k) {
+        A.mx[k] = 0.;
+        const int be = pass ? (int)(mxbits[k] >> 23) : 0;                 // biased exponent of the maximum: max < 2^(be - 126)
+        A.scale[k] = (be == 0 || be >= 255) ? 0. : __longlong_as_double((long long)(1023 + 30 - (be - 126)) << 52);      // 2^(30 - e)
+    }
+    if (pass) {
+        for (int i = threadIdx.x; i < ntot; i += blockDim.x) sh[i] = 0ull;
+        __syncthreads();
+    }
+}
+template <int PASS>
+__device__ __forceinline__ void acc_end(Acc &A, int ntot, unsigned *mxbits, unsigned long long *out, bool bad) {
+    if (PASS == 0) {
+        for (int k = 0; k < LC_KINDS; ++k) {
+            unsigned b = bad ? 0x7fc00000u : __float_as_uint(__double2float_ru(A.mx[k]));
+            if (!(A.mx[k] < 3.0e38)) b = 0x7fc00000u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+            if ((threadIdx.x & 63) == 0 && b) atomicMax(mxbits + k, b);
+        }
+    } else {
+        __syncthreads();
+        for (int i = threadIdx.x; i < ntot; i += blockDim.x)
+            if (A.sh[i] != 0ull) atomicAdd(out + i, A.sh[i]);
+    }
+}
+// out[i] = integer sum scaled back; kind_end[k]: one past the last entry of kind k
+__global__ void lc_scale_kernel(const unsigned long long *__restrict__ acc, const unsigned *__restrict__ mxbits, int ntot, int e0, int e1,
+                                int e2, int e3, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntot) return;
+    const int k = i < e0 ? 0 : (i < e1 ? 1 : (i < e2 ? 2 : (i < e3 ? 3 : 4)));
+    const int be = (int)(mxbits[k] >> 23);
+    if (be >= 255) { out[i] = __longlong_as_double(0x7ff8000000000000ll); return; }
+    out[i] = be == 0 ? 0. : (double)(long long)acc[i] * __longlong_as_double((long long)(1023 - 30 + (be - 126)) << 52);
 }
 
 // Lagrangian side (model.py:740-764): a_q = chi2a(r0_q) kept in float32, then a2g(a_q) (bias weights and lpt), a2g2(a_q),
 // a2dg2dg(a_q) = safe_div(g2 f2, g f) (lpt).  Cotangents per particle: gB (of a2g), g2B (of a2g2 = -3/7 g2raw), dB (of a2dg2dg).
-// tables: chi[nchi] ascending, a(chi)[nchi], a[ng], g[ng], g2raw[ng], f[ng], f2[ng];  out: chi_bar[nchi], g_bar, g2raw_bar, f_bar, f2_bar.
+// tables: chi[nchi] ascending, a(chi)[nchi], a[ng], g[ng], g2raw[ng], f[ng], f2[ng];  accumulators: chi_bar[nchi], g_bar, g2raw_bar, f_bar, f2_bar.
+template <int PASS>
 __global__ __launch_bounds__(256) void lightcone_tables_vjp_kernel(const float *__restrict__ r0, int64_t n, const double *__restrict__ tb,
                                                                    int nchi, int ng, const float *__restrict__ gB,
                                                                    const float *__restrict__ g2B, const float *__restrict__ dB,
-                                                                   double *__restrict__ out) {
-    extern __shared__ double sh[];
+                                                                   unsigned *__restrict__ mxbits, unsigned long long *__restrict__ out) {
+    extern __shared__ unsigned long long shl[];
     const int ntot = nchi + 4 * ng;
-    for (int i = threadIdx.x; i < ntot; i += 256) sh[i] = 0.;
-    __syncthreads();
+    Acc A;
+    acc_begin(A, shl, ntot, mxbits, PASS);
     const double *chi = tb, *aoc = tb + nchi, *ag = tb + 2 * nchi, *tg = ag + ng, *tg2 = tg + ng, *tf = tg2 + ng, *tf2 = tf + ng;
-    double *s_chi = sh, *s_g = sh + nchi, *s_g2 = s_g + ng, *s_f = s_g2 + ng, *s_f2 = s_f + ng;
+    const int o_chi = 0, o_g = nchi, o_g2 = nchi + ng, o_f = nchi + 2 * ng, o_f2 = nchi + 3 * ng;
+    bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const Interp ba = interp_idx((double)r0[i], chi, aoc, nchi);
         const double a = (double)(float)ba.y;                 // the forward pass hands a on as float32 (mcpm_interp_f32)
@@ -266,29 +322,30 @@ __global__ __launch_bounds__(256) void lightcone_tables_vjp_kernel(const float *
                 f2b += db * (-3. / 7.) * g2r / den;
             }
         }
-        scatter_fp(s_g, bg, gb);
-        scatter_fp(s_g2, bg, g2rb);
-        scatter_fp(s_f, bg, fb);
-        scatter_fp(s_f2, bg, f2b);
         const double ab = gb * sg + g2rb * sg2 + fb * sf + f2b * sf2;
-        scatter_xp(s_chi, ba, ab);
+        bad = bad || !(gb == gb && g2rb == g2rb && fb == fb && f2b == f2b && ab == ab);
+        scatter_fp<PASS>(A, 1, o_g, bg, gb);
+        scatter_fp<PASS>(A, 2, o_g2, bg, g2rb);
+        scatter_fp<PASS>(A, 3, o_f, bg, fb);
+        scatter_fp<PASS>(A, 4, o_f2, bg, f2b);
+        scatter_xp<PASS>(A, 0, o_chi, ba, ab);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < ntot; i += 256)
-        if (sh[i] != 0.) atomicAdd(out + i, sh[i]);
+    acc_end<PASS>(A, ntot, mxbits, out, bad);
 }
 
 // Eulerian side (model.py:781-784): gf_p = a2g(a_p) a2f(a_p), a_p = chi2a(r_p) at the evolved particle's distance.
-// tables as in observe_kernel (chi, a(chi), a, g, f);  out: chi_bar[nchi], g_bar[ngrow], f_bar[ngrow].
-template <int MODE>
+// tables as in observe_kernel (chi, a(chi), a, g, f);  accumulators: chi_bar[nchi], g_bar[ngrow], f_bar[ngrow] (kinds 0, 1, 2).
+template <int MODE, int PASS>
 __global__ __launch_bounds__(256) void observe_tables_vjp_kernel(Geom g, Obs og, Tables tb, const float *__restrict__ pos,
                                                                  const float *__restrict__ vel, const float *__restrict__ dvel, int64_t n,
-                                                                 const float *__restrict__ ob, double *__restrict__ out) {
-    extern __shared__ double sh[];
+                                                                 const float *__restrict__ ob, unsigned *__restrict__ mxbits,
+                                                                 unsigned long long *__restrict__ out) {
+    extern __shared__ unsigned long long shl[];
     const int ntot = og.nchi + 2 * og.ngrow;
-    for (int i = threadIdx.x; i < ntot; i += 256) sh[i] = 0.;
-    __syncthreads();
-    double *s_chi = sh, *s_g = sh + og.nchi, *s_f = s_g + og.ngrow;
+    Acc A;
+    acc_begin(A, shl, ntot, mxbits, PASS);
+    const int o_chi = 0, o_g = og.nchi, o_f = og.nchi + og.ngrow;
+    bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float q[3] = {0.f, 0.f, 0.f}, x[3], v[3], dv[3] = {0.f, 0.f, 0.f}, o[3];
         if (MODE == MCPM_POS_LATTICE) lattice_point(g, i, q);
@@ -311,16 +368,14 @@ __global__ __launch_bounds__(256) void observe_tables_vjp_kernel(Geom g, Obs og,
         const Interp bg = interp_idx(ba.y, tb.a, tb.g, og.ngrow);
         double f, sf;
         interp_at(bg, tb.a, tb.f, f, sf);
-        const double gb = gfb * f, fb = gfb * bg.y;
-        scatter_fp(s_g, bg, gb);
-        scatter_fp(s_f, bg, fb);
-        scatter_xp(s_chi, ba, gb * bg.slope + fb * sf);
+        const double gb = gfb * f, fb = gfb * bg.y, ab = gb * bg.slope + fb * sf;
+        bad = bad || !(gb == gb && fb == fb && ab == ab);
+        scatter_fp<PASS>(A, 1, o_g, bg, gb);
+        scatter_fp<PASS>(A, 2, o_f, bg, fb);
+        scatter_xp<PASS>(A, 0, o_chi, ba, ab);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < ntot; i += 256)
-        if (sh[i] != 0.) atomicAdd(out + i, sh[i]);
+    acc_end<PASS>(A, ntot, mxbits, out, bad);
 }
-
 
 Obs make_obs(const mcpm_plan *p, const float *geom, int flags, int nchi, int ngrow) {
     Obs og;
@@ -406,10 +461,15 @@ int mcpm_lightcone_tables_vjp_f32(mcpm_plan *p, const float *r0, int64_t n, cons
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, r0 && tables && g_bar && table_bar && n > 0 && nchi >= 2 && ngrow >= 2, MCPM_E_ARG, "mcpm_lightcone_tables_vjp_f32: bad argument");
     const size_t ntot = (size_t)nchi + 4 * (size_t)ngrow;
-    MCPM_REQUIRE(p, ntot * sizeof(double) <= 60 * 1024, MCPM_E_ARG, "mcpm_lightcone_tables_vjp_f32: tables exceed the LDS accumulators");
-    MCPM_HIP(p, hipMemsetAsync(table_bar, 0, ntot * sizeof(double), p->stream));
+    MCPM_REQUIRE(p, ntot + 8 <= 3072 && ntot * sizeof(double) <= 60 * 1024, MCPM_E_ARG, "mcpm_lightcone_tables_vjp_f32: tables exceed the accumulators");
+    // integer accumulators and the maxima: the plan's reduction scratch (free between the model-side calls)
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(p->reduce);
+    unsigned *mx = reinterpret_cast<unsigned *>(acc + ntot);
+    MCPM_HIP(p, hipMemsetAsync(acc, 0, (ntot + 4) * sizeof(double), p->stream));
     const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
-    lightcone_tables_vjp_kernel<<<nb, 256, ntot * sizeof(double), p->stream>>>(r0, n, tables, nchi, ngrow, g_bar, g2_bar, dg2dg_bar, table_bar);
+    lightcone_tables_vjp_kernel<0><<<nb, 256, 0, p->stream>>>(r0, n, tables, nchi, ngrow, g_bar, g2_bar, dg2dg_bar, mx, acc);
+    lightcone_tables_vjp_kernel<1><<<nb, 256, ntot * sizeof(double), p->stream>>>(r0, n, tables, nchi, ngrow, g_bar, g2_bar, dg2dg_bar, mx, acc);
+    lc_scale_kernel<<<(unsigned)((ntot + 255) / 256), 256, 0, p->stream>>>(acc, mx, (int)ntot, nchi, nchi + ngrow, nchi + 2 * ngrow, nchi + 3 * ngrow, table_bar);
     MCPM_LAUNCH_CHECK(p, "lightcone_tables_vjp_kernel");
     return MCPM_OK;
 }
@@ -424,15 +484,20 @@ int mcpm_observe_pos_tables_vjp_f32(mcpm_plan *p, const float *pos, const float 
     MCPM_REQUIRE(p, mode == MCPM_POS_ABSOLUTE || (mode == MCPM_POS_LATTICE && n == p->Np), MCPM_E_ARG, "mcpm_observe_pos_tables_vjp_f32: bad pos_mode / count");
     MCPM_REQUIRE(p, (flags & 2) && tables && nchi >= 2 && ngrow >= 2, MCPM_E_ARG, "mcpm_observe_pos_tables_vjp_f32: light cone only (flags bit 1, tables)");
     const size_t ntot = (size_t)nchi + 2 * (size_t)ngrow;
-    MCPM_REQUIRE(p, ntot * sizeof(double) <= 60 * 1024, MCPM_E_ARG, "mcpm_observe_pos_tables_vjp_f32: tables exceed the LDS accumulators");
+    MCPM_REQUIRE(p, ntot + 8 <= 3072 && ntot * sizeof(double) <= 60 * 1024, MCPM_E_ARG, "mcpm_observe_pos_tables_vjp_f32: tables exceed the accumulators");
     Obs og = make_obs(p, geom, flags, nchi, ngrow);
     Tables tb{tables, tables + nchi, tables + 2 * nchi, tables + 2 * nchi + ngrow, tables + 2 * nchi + 2 * ngrow};
-    MCPM_HIP(p, hipMemsetAsync(table_bar, 0, ntot * sizeof(double), p->stream));
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(p->reduce);
+    unsigned *mx = reinterpret_cast<unsigned *>(acc + ntot);
+    MCPM_HIP(p, hipMemsetAsync(acc, 0, (ntot + 4) * sizeof(double), p->stream));
     const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
-    if (mode == MCPM_POS_LATTICE)
-        observe_tables_vjp_kernel<MCPM_POS_LATTICE><<<nb, 256, ntot * sizeof(double), p->stream>>>(p->g, og, tb, pos, vel, dvel, n, out_bar, table_bar);
-    else
-        observe_tables_vjp_kernel<MCPM_POS_ABSOLUTE><<<nb, 256, ntot * sizeof(double), p->stream>>>(p->g, og, tb, pos, vel, dvel, n, out_bar, table_bar);
+#define LAUNCH(MO)                                                                                                                              \
+    observe_tables_vjp_kernel<MO, 0><<<nb, 256, 0, p->stream>>>(p->g, og, tb, pos, vel, dvel, n, out_bar, mx, acc);                              \
+    observe_tables_vjp_kernel<MO, 1><<<nb, 256, ntot * sizeof(double), p->stream>>>(p->g, og, tb, pos, vel, dvel, n, out_bar, mx, acc)
+    if (mode == MCPM_POS_LATTICE) { LAUNCH(MCPM_POS_LATTICE); } else { LAUNCH(MCPM_POS_ABSOLUTE); }
+#undef LAUNCH
+    // kinds 0, 1, 2 = chi, g, f (the scale kernel's last two boundaries coincide with the end)
+    lc_scale_kernel<<<(unsigned)((ntot + 255) / 256), 256, 0, p->stream>>>(acc, mx, (int)ntot, nchi, nchi + ngrow, (int)ntot, (int)ntot, table_bar);
     MCPM_LAUNCH_CHECK(p, "observe_tables_vjp_kernel");
     return MCPM_OK;
 }

@@ -89,6 +89,9 @@ def test_log_density_and_gradient_at_config5_size(gpu, threads, evolution, a_obs
     torch.cuda.synchronize()
     t_grad = time.perf_counter() - t0
     assert lp2 == lp and all(g2[k] == g[k] for k in g if k != "white_mesh_") and torch.equal(g2["white_mesh_"], g["white_mesh_"])   # bitwise repeatable
+    for _ in range(10):      # ... call after call, the float64 scalars included (the light-cone table cotangents are integer sums for this)
+        lp3, g3 = ld.logdensity_and_grad(point)
+        assert lp3 == lp and all(g3[k] == g[k] for k in g if k != "white_mesh_") and torch.equal(g3["white_mesh_"], g["white_mesh_"])
     # ---- forward against the float64 restatement (threaded back end) -------------------------------------------------
     cfg = dict(fwd.config(), final_shape=fwd.final_shape, cell_length=fwd.cell_length, precond="kaiser")
     make_cosmo = lambda base: _cos(obg.Planck18(Omega_c=base["Omega_m"] - 0.0490), base["sigma8"])
