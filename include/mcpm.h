@@ -490,7 +490,8 @@ int mcpm_observe_pos_vjp_f32(mcpm_plan *plan, const float *pos, const float *vel
    (model.py:740-742 -> bricks.py:750-768 los_scalefactor_pos -> nbody.py:862-884 chi2a, :748-808 a2g ...; again at the evolved
    positions for the RSD, model.py:781-784).  These two calls contract per-particle cotangents into the cotangents of the TABLES
    themselves (float64 on the device; nodes of the chi -> a look-up and values of the growth tables), which the host chains to
-   cosmological parameters with the tables' finite-difference Jacobian (montecosmo_amd/model.py cosmo_vjp).
+   cosmological parameters with the tables' finite-difference Jacobian (montecosmo_amd/model.py cosmo_vjp).  The sums are taken
+   in 64-bit fixed point (a first pass finds the scale), so they are bitwise the same call after call.
    mcpm_lightcone_tables_vjp_f32: Lagrangian side.  r0 (n): particle distances; tables = chi[nchi] ascending, a(chi)[nchi],
    a[ngrow], g, g2 (raw table, without the -3/7), f, f2 [ngrow each]; g_bar / g2_bar / dg2dg_bar (n floats; the last two may be
    NULL): cotangents of a2g(a), a2g2(a), a2dg2dg(a).  table_bar (OVERWRITTEN): chi_bar[nchi], g_bar, g2_bar, f_bar, f2_bar [ngrow each].
