@@ -1104,6 +1104,23 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
 }
 
+// The fixed-point first pass with 1024 threads per tile, for meshes of at most 1024 tiles (128^3: 512 tiles, two per CU, and a tile's
+// time is latency): two such workgroups per CU need eight waves per SIMD, i.e. at most 64 VGPRs (the 512-thread instance takes 75).
+template <int HA, int HB, int HC, int FAST>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void paint3_tile_wide_kernel(Geom g, const float *__restrict__ disp,
+                                                              const float *__restrict__ w3, float *__restrict__ mesh, int64_t M, int accumulate,
+                                                              TileLists L, const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out, int duty) {
+    constexpr int NT = MCPM_TILE * MCPM_TILE * MCPM_TILE;
+    __shared__ u64 tile[2 * NT];
+    __shared__ int flagged;
+    __shared__ int sh27[27];
+    __shared__ int sus[MCPM_SUS + 2];
+    const int Hrt = tile_halo(L);
+#define CALL(HH) paint3_tile_body<HH, false, 1024, 2, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, -1, duty, tile, flagged, sh27, sus)
+    HALO_SWITCH(Hrt, CALL);
+#undef CALL
+}
+
 // buckets of the three-component paint: int64 fixed point with the max|w| 2^-28 scale, doubles when the weights are non-finite
 __device__ __forceinline__ void paint3_bucket_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w3,
                                                    float *__restrict__ mesh, int64_t M, const TileLists &L,
@@ -1344,7 +1361,8 @@ bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, fl
     if (p->paint3_variant == 4) {   // fixed-point tiles; the tiles they flag (and every tile if max|w| is unusable) in f64
 #define CALLFX(HA_, HB_, HC_)                                                                                                                \
     {                                                                                                                             \
-        if (fast == 1) paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4, 1><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
+        if (fast == 1 && nb <= 1024u) paint3_tile_wide_kernel<HA_, HB_, HC_, 1><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, 1); \
+        else if (fast == 1) paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4, 1><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
         else if (fast == 2) paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4, 2><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
         else paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
         paint3_tile_kernel<HA_, HB_, HC_, true, 1024, 4><<<nb < 256u ? nb : 256u, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, p->fx_redo, 0); \
