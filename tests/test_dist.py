@@ -168,6 +168,19 @@ def test_slab_path_at_the_8_gpu_slab_shape(gpu):
 
 
 @pytest.mark.gpu
+def test_slab_path_at_config4_mesh_size(gpu):
+    """BASELINE config 4's MESH (512^3) through the slab path under -m gpu (what's weak 3: it existed only as
+    tools/check_slab_large.py): two ranks sharing cuda:0 through gloo, local slabs of 256 planes, against the single-GPU path.  The
+    eight-rank split of the same mesh has the slab shape of the test above (64 planes); RCCL with more than one rank cannot run on a
+    one-GPU box.  Tolerances as above (measured: forward 1e-7 / 1.7e-7, gradient 8e-5)."""
+    from _dist_worker import gpu_slab_worker
+    out = _spawn(gpu_slab_worker, 2, 512, 2)
+    res = json.load(open(os.path.join(out, "result.json")))
+    assert res["disp"] < 2e-7 and res["vel"] < 4e-7, res
+    assert res["grad"] < 1e-3 and res["alpha"] < 2e-3 and res["beta"] < 2e-3 and res["lpt_scalars"] < 2e-3, res
+
+
+@pytest.mark.gpu
 def test_predicted_ghost_depth_is_verified(gpu):
     """The exchanged ghost depth of a step is predicted from the previous steps' displacement maxima (no host stop per
     step) and verified one step later: smooth growth stays within the prediction with a spare plane, a jump beyond it is
