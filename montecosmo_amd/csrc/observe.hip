@@ -187,8 +187,8 @@ __global__ __launch_bounds__(256) void observe_vjp_kernel(Geom g, Obs og, Tables
 // y = np.interp(x, xp, fp) = fp[lo] + (fp[lo+1] - fp[lo]) t,  t = (x - xp[lo]) / (xp[lo+1] - xp[lo]):
 //   dy/dfp[lo] = 1 - t, dy/dfp[lo+1] = t;   dy/dxp[lo] = -slope (1 - t), dy/dxp[lo+1] = -slope t;   dy/dx = slope
 // (clamped ends: y = fp[0] or fp[n-1], slope 0).  The kernels below contract those with per-particle cotangents into small
-// float64 table cotangents (LDS accumulators per workgroup, one global float64 atomic per non-zero entry and workgroup); the
-// host then contracts them with the tables' finite-difference Jacobian w.r.t. the cosmological parameters (model.py cosmo_vjp).
+// table cotangents (integer accumulators, see ORDER-INDEPENDENT SUMS below); the host then contracts them with the tables'
+// finite-difference Jacobian w.r.t. the cosmological parameters (model.py cosmo_vjp).
 struct Interp {
     int lo;
     bool clamped;
@@ -233,7 +233,7 @@ struct Acc {      // PASS 0: per-thread maxima;  PASS 1: integer accumulators in
 };
 template <int PASS>
 __device__ __forceinline__ void acc_add(Acc &A, int kind, int off, int idx, double v) {
-    if (PASS == 0) A.mx[kind] = fmax(A.mx[kind], fabs(v));      // (fmax drops a NaN operand: caught below by v != v)
+    if (PASS == 0) A.mx[kind] = fmax(A.mx[kind], fabs(v));      // (fmax drops a NaN operand: the callers' `bad` flag catches it)
     else if (v != 0.) atomicAdd(A.sh + off + idx, (unsigned long long)__double2ll_rn(v * A.scale[kind]));
 }
 template <int PASS>
