@@ -110,9 +110,7 @@ __global__ __launch_bounds__(256) void zfwd_kernel(FGeom g, const float *__restr
     }
 }
 
-// VEC: the two real lines of a pair leave through LDS as 16-byte stores (4 per thread) instead of sixteen 4-byte ones -- the
-// single-mesh C2R ran at 3.9 TB/s where the R2C (same bytes) reaches 5.3 and the three-mesh interleaved C2R 5.0 (round 4)
-template <int N, bool VEC = true>
+template <int N>
 __global__ __launch_bounds__(256) void zinv_kernel(FGeom g, const cf *__restrict__ spec, float *__restrict__ real,
                                                    const cf *__restrict__ W, int64_t npairs, ZBatch zb) {
     constexpr int T = FftShape<N>::T, PAIRS = 256 / T;
@@ -145,25 +143,8 @@ __global__ __launch_bounds__(256) void zinv_kernel(FGeom g, const cf *__restrict
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = lds[tile(u + T * m)];
     fft_line<N, +1>(v, lds, W, u, tile);
-    float *a = real + bi * zb.real_bstride + lm * N;      // line b follows line a: 2 N contiguous floats per pair
-    if (VEC) {
-        float *lf = reinterpret_cast<float *>(lds) + (size_t)pl * 2 * TL::NP;      // this pair's 2 NP floats of the tile
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            lf[u + T * m] = v[m].x;
-            lf[N + u + T * m] = v[m].y;
-        }
-        __syncthreads();
-        if (!ok) return;
-        const float4 *l4 = reinterpret_cast<const float4 *>(lf);
-        float4 *o4 = reinterpret_cast<float4 *>(a);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o4[u + T * j] = l4[u + T * j];      // 2 N floats = N / 2 float4 = 4 per thread
-        return;
-    }
     if (!ok) return;
-    float *b = a + N;
+    float *a = real + bi * zb.real_bstride + lm * N, *b = a + N;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         a[u + T * m] = v[m].x;
@@ -655,14 +636,10 @@ static int z_inverse(mcpm_plan *p, const cf *spec, float *real, int64_t real_bst
     spec += (int64_t)p->xw0 * g.ny * g.nzp;
     const int64_t npairs = (int64_t)batch * zb.lines / 2;
     StageTimer st_(p, ST_C2R, pass_bytes(p, batch));
-    // 16-byte stores need the real lines 16-byte aligned (MCPM_ZINV_VEC=0: the 4-byte stores, A/B runs)
-    static const int vec_env = [] { const char *e = getenv("MCPM_ZINV_VEC"); return e ? atoi(e) : 1; }();
-    const bool zinv_vec = vec_env && (((uintptr_t)real) & 15) == 0 && (real_bstride % 4) == 0;
 #define CALL(NN)                                                                                                   \
     {                                                                                                              \
         constexpr int PAIRS = 256 / (NN / 8);                                                                      \
-        if (zinv_vec) zinv_kernel<NN, true><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, spec, real, (const cf *)p->tw[2], npairs, zb); \
-        else zinv_kernel<NN, false><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, spec, real, (const cf *)p->tw[2], npairs, zb); \
+        zinv_kernel<NN><<<(unsigned)((npairs + PAIRS - 1) / PAIRS), 256, 0, p->stream>>>(g, spec, real, (const cf *)p->tw[2], npairs, zb); \
     }
     DISPATCH_N(g.nz, CALL)
 #undef CALL
