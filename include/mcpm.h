@@ -76,8 +76,14 @@ const char *mcpm_version(void);
    absurd displacements, bucket overflow).  Both synchronise the host. */
 int mcpm_plan_last_outliers(mcpm_plan *plan, int64_t *count);
 int mcpm_plan_last_bucketed(mcpm_plan *plan, int64_t *count);
-/* Tuning knobs: halo radius (1, 2, 3, 4 or 6 cells; 0 = the default: chosen among 2, 3, 4 for every input ON THE DEVICE from the roughness of its
-   displacement field -- same input, same halo, so results stay bitwise reproducible; slab plans: 4 up to 2^24 cells, 3 above) and whether windows are centred on the local bulk
+/* Everything the last tiled paint counted, in one call (synchronises the host): out13[0..7] = wild particles, wild + overflow pairs,
+   slab deposits beyond the ghost planes (cumulative), appends that found their bucket full, tiles with a non-empty bucket, bucketed
+   pairs, suspects (particles handed to the exact coverage test), reserved; out13[8 + h], h = 0..4 = number of tiles whose window
+   halo is h (0: the halo was fixed, no per-tile choice). */
+int mcpm_plan_last_paint_stats(mcpm_plan *plan, int64_t *out13);
+/* Tuning knobs: halo radius (1, 2, 3, 4 or 6 cells; 0 = the default: chosen among 1, 2, 3, 4 ON THE DEVICE for every input and every TILE from the
+   sampled displacement ranges of the Lagrangian blocks around it -- same input, same halos, so results stay bitwise reproducible; meshes below 2048
+   tiles: 4 up to 2^24 cells, 3 above) and whether windows are centred on the local bulk
    displacement (default 1; 0 = on the tile itself, which needs halo 4 at the benchmark's 2-cell rms displacement). */
 int mcpm_plan_set_halo(mcpm_plan *plan, int halo);
 int mcpm_plan_set_centre(mcpm_plan *plan, int centre);

@@ -28,6 +28,7 @@ SIGNATURES = {
     "mcpm_version": (C.c_char_p, []),
     "mcpm_plan_last_outliers": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mcpm_plan_last_bucketed": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mcpm_plan_last_paint_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mcpm_plan_set_centre": (C.c_int, [C.c_void_p, C.c_int]),
     "mcpm_plan_set_lattice_patch": (C.c_int, [C.c_void_p, C.c_int]),
     "mcpm_plan_chained_fb": (C.c_int, [C.c_void_p, C.c_double, C.c_double, _f32p, _f32p, C.POINTER(C.c_void_p)]),

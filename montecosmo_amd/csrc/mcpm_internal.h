@@ -62,7 +62,6 @@ struct Geom {
                       // (64 consecutive z each) instead of 256 consecutive z of one row (particles_dev.h::particle_index)
 };
 
-#define MCPM_HSEL_INTS (32 + 3 * 64 * 32)   // paint_tiled.hip::halo_select_kernel: 3 x 64 count slots a cache line apart, from int 32 on
 #define MCPM_FX_SLOTS 64
 #define MCPM_FX_STRIDE 32   // unsigned per slot: one 128-byte line each
 
@@ -74,7 +73,7 @@ struct mcpm_plan {
     int64_t Np;  // px*py*pz
     int halo;    // halo radius H of the tiled paints: a tile's window is (16 + 2H + 1)^3 lattice points
     int centre;  // tiled paints: windows centred on the local bulk displacement (paint_tiled.hip); 0 = on the tile itself
-    int *halo_sel;    // unsure-sample counts of the current paint (halo_select_kernel), from which every tiled kernel takes the window halo
+    int *halo_sel;    // per 16^3 Lagrangian block: sampled range of floor(d) per axis ([ntiles] minima, [ntiles] maxima), from which halo_tile_kernel sizes every tile's window
     int *tile_off;    // packed window offsets per 16^3 tile (device; NULL if the mesh cannot be tiled)
     int *bucket_cnt;  // per-tile bucket fill counts
     int *bucket;      // [tile][bucket_cap] particles a tile's window misses

@@ -44,6 +44,8 @@ __device__ __forceinline__ void unpack_off(int v, int &ox, int &oy, int &oz) {
     oy = (int)(signed char)((v >> 8) & 0xff);
     oz = (int)(signed char)((v >> 16) & 0xff);
 }
+// byte 3 of a tile's packed word: the window halo H of THAT tile (per-tile choice, finding 43); 0 = not set
+__device__ __forceinline__ int word_halo(int v) { return (v >> 24) & 0xff; }
 __device__ __forceinline__ int pymod(int a, int n) {
     int r = a % n;
     return r < 0 ? r + n : r;
@@ -92,10 +94,9 @@ __device__ __forceinline__ void tile_of_block(int ntx, int nty, int ntz, int &tx
 // o_T = rounded mean displacement of 64 lattice points (four z rows) of the Lagrangian block at tile T.
 __global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float *__restrict__ disp, int *__restrict__ toff,
                                                             int *__restrict__ bcnt, int *__restrict__ cnts, int ntiles, int maxoff,
-                                                            int *__restrict__ redo, int *__restrict__ hs) {
+                                                            int *__restrict__ redo, int *__restrict__ rng) {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x < 8 && threadIdx.x != C_LAST && threadIdx.x != C_OOB) cnts[threadIdx.x] = 0;
-    if (hs && blockIdx.x == 0 && threadIdx.x < 192) hs[32 + (int)threadIdx.x * 32] = 0;   // halo_select_kernel's count slots (HSEL_SLOT0)
     if (redo && blockIdx.x == 0 && threadIdx.x == 8) redo[0] = 0;   // empty list of tiles for the f64 repaint (paint3)
     if (tile >= ntiles) return;
     if (lane == 0) bcnt[tile] = 0;
@@ -120,82 +121,76 @@ __global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float 
         toff[tile] = pack_off((int)rintf(fminf(fmaxf(sx * (1.f / 64.f), -m), m)), (int)rintf(fminf(fmaxf(sy * (1.f / 64.f), -m), m)),
                               (int)rintf(fminf(fmaxf(sz * (1.f / 64.f), -m), m)));
     }
+    if (!rng) return;
+    // range of floor(d) over the same 64 samples, per axis (clamped to +-100; a NaN sample widens it to the clamp): what
+    // halo_tile_kernel sizes the windows of the tiles around this block with
+    const float f3[3] = {floorf(d.x), floorf(d.y), floorf(d.z)};
+    float lo[3], hi[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const bool ok = f3[c] == f3[c];
+        const float v = fminf(fmaxf(f3[c], -100.f), 100.f);
+        lo[c] = ok ? v : -100.f;
+        hi[c] = ok ? v : 100.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = fminf(lo[c], __shfl_xor(lo[c], o));
+            hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o));
+        }
+    if (lane == 0) {
+        rng[tile] = pack_off((int)lo[0], (int)lo[1], (int)lo[2]);
+        rng[ntiles + tile] = pack_off((int)hi[0], (int)hi[1], (int)hi[2]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// The window halo this input needs, chosen on the device (DESIGN finding 31).  Every cell of halo costs window visits
-// ((16 + 2H + 1)^3 per tile), every particle the windows are not SURE to contain costs the exact coverage test and possibly a
-// bucket deposit; which H is cheapest follows the roughness of the displacement field, and that changes along a trajectory.
-// Sixteen lanes per tile re-read one of the prologue's four sample rows and apply the tile kernel's own test -- |floor(d)_a - o_a| <= H - D_a
-// with D_a the largest offset difference to the 26 neighbouring tiles (sure_interval) -- for H = 2, 3, 4; halo_decide_kernel then
-// it leaves workgroup totals in 3 x 64 count slots, and every tiled kernel of THIS paint (tile, coverage, epilogue) adds the slots
-// up itself and takes the smallest H whose share of unsure samples is at most `limit` (tile_halo; 4 %: on the bench trajectories
-// the per-step optimum switches between 2.5 and 7.7 % (512^3, H 2 -> 3), 0.9 and 6.1 %, 3.1 and 7.0 % (256^3, 2 -> 3 and 3 -> 4)).
-// Round 3 had a one-block halo_decide_kernel between the two: a launch of 5 us per paint for 192 additions (two paints per
-// forward+adjoint step: 0.7 % of a 256^3 step).  Same input, same H: results stay bitwise reproducible, and the host is not involved.
-#define HSEL_SLOT0 32      // hs: from HSEL_SLOT0 on 3 x 64 count slots of 32 ints each (zeroed by the prologue of every paint); MCPM_HSEL_INTS in all
-#define HSEL_SAMPLES 16    // samples per tile: one of the prologue's four z rows (16 lanes per tile, 16 tiles per workgroup)
-__global__ __launch_bounds__(256) void halo_select_kernel(Geom g, const float *__restrict__ disp, const int *__restrict__ toff, int ntiles,
-                                                          int *__restrict__ hs) {
+// The window halo, chosen on the device for every input AND EVERY TILE (DESIGN findings 31, 43).  Every cell of halo costs window
+// visits ((16 + 2H + 1)^3 per tile), every particle a window misses costs the exact coverage test and a bucket deposit.  A particle
+// with floor(d) = fd lands in tile T inside T's window iff |fd_a - o_T,a| <= H_T on every axis, and the particles that land in T come
+// from the 27 Lagrangian blocks around it: H_T = the largest |fd - o_T| over the SAMPLED ranges of those blocks (tile_prologue_kernel:
+// 64 samples each), clamped to the instantiated halos 1 .. 4.  Round 3 chose ONE halo per input from the share of unsure samples
+// over the whole mesh (at most 4 %), so the roughest few per cent of the field set the window of every tile: 256^3 evolved
+// particles painted at H = 4 (3.8 window visits per particle) although most tiles need 2 or 3.  What the samples miss goes the way
+// of everything a window misses (suspects -> exact test -> buckets).  Same input, same halos: results stay bitwise reproducible, and
+// the host is not involved.  The halo rides in byte 3 of the tile's packed offset word.
+__global__ __launch_bounds__(256) void halo_tile_kernel(Geom g, int *__restrict__ toff, const int *__restrict__ rng, int ntiles) {
     const int tile = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
-    bool unsure[3] = {false, false, false};
-    if (tile < ntiles) {
-        const int ntz = g.nz / MCPM_TILE, nty = g.ny / MCPM_TILE, ntx = g.nx / MCPM_TILE;
-        const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
-        // the sample: row (4 or 12, 4 or 12) of the tile by its parity, so that all four rows are used over the mesh
-        int gx = tx * MCPM_TILE + 4 + 8 * (tz & 1) - g.xoff;
-        const int gy = ty * MCPM_TILE + 4 + 8 * (tx & 1), gz = tz * MCPM_TILE + l16;
-        if (g.xslab) gx = min(max(gx, 0), g.px - 1);
-        const P3 d = load3(disp, ((int64_t)gx * g.ny + gy) * g.nz + gz);
-        int o[3] = {0, 0, 0}, lo[3] = {127, 127, 127}, hi[3] = {-127, -127, -127};
-        if (toff) {
-            unpack_off(toff[tile], o[0], o[1], o[2]);
+    if (tile >= ntiles) return;      // (whole 16-lane groups leave together; the shuffles below stay within a group)
+    const int ntz = g.nz / MCPM_TILE, nty = g.ny / MCPM_TILE, ntx = g.nx / MCPM_TILE;
+    const int tz = tile % ntz, ty = (tile / ntz) % nty, tx = tile / (ntz * nty);
+    int lo[3] = {127, 127, 127}, hi[3] = {-127, -127, -127};
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {      // 27 neighbours over the tile's 16 lanes
-                const int q = l16 + 16 * h;
-                if (q < 27) {
-                    const int a = q / 9 - 1, b = (q / 3) % 3 - 1, e = q % 3 - 1;
-                    const int Tx = g.xslab ? min(max(tx + a, 0), ntx - 1) : pymod(tx + a, ntx);
-                    int n3[3];
-                    unpack_off(toff[(Tx * nty + pymod(ty + b, nty)) * ntz + pymod(tz + e, ntz)], n3[0], n3[1], n3[2]);
+    for (int h = 0; h < 2; ++h) {      // 27 neighbouring blocks over the tile's 16 lanes
+        const int q = l16 + 16 * h;
+        if (q < 27) {
+            const int a = q / 9 - 1, b = (q / 3) % 3 - 1, e = q % 3 - 1;
+            const int Tx = g.xslab ? min(max(tx + a, 0), ntx - 1) : pymod(tx + a, ntx);
+            const int nb = (Tx * nty + pymod(ty + b, nty)) * ntz + pymod(tz + e, ntz);
+            int l3[3], h3[3];
+            unpack_off(rng[nb], l3[0], l3[1], l3[2]);
+            unpack_off(rng[ntiles + nb], h3[0], h3[1], h3[2]);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) lo[c] = min(lo[c], n3[c]), hi[c] = max(hi[c], n3[c]);
-                }
-            }
-#pragma unroll
-            for (int m = 8; m > 0; m >>= 1)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    lo[c] = min(lo[c], __shfl_xor(lo[c], m));
-                    hi[c] = max(hi[c], __shfl_xor(hi[c], m));
-                }
-        } else
-            lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0;
-        const float f[3] = {floorf(d.x), floorf(d.y), floorf(d.z)};
-#pragma unroll
-        for (int H = 2; H <= 4; ++H) {
-            bool sure = true;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int D = max(hi[c] - o[c], o[c] - lo[c]);
-                sure = sure && f[c] >= (float)(o[c] - (H - D)) && f[c] <= (float)(o[c] + (H - D));      // NaN: not sure
-            }
-            unsure[H - 2] = !sure;
+            for (int c = 0; c < 3; ++c) lo[c] = min(lo[c], l3[c]), hi[c] = max(hi[c], h3[c]);
         }
     }
-    // workgroup totals -> one of 64 slots per H, a cache line apart (per-tile atomics on three addresses took 0.2-0.3 ms: they
-    // serialise at the memory side); halo_decide_kernel adds the slots up
-    __shared__ int part[4][3];
-    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int n = __popcll(__ballot(unsure[k]));
-        if (lane == 0) part[threadIdx.x >> 6][k] = n;
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const int n = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-        if (n) atomicAdd(hs + HSEL_SLOT0 + ((int)threadIdx.x * 64 + (int)(blockIdx.x & 63)) * 32, n);
+    for (int m = 8; m > 0; m >>= 1)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = min(lo[c], __shfl_xor(lo[c], m));
+            hi[c] = max(hi[c], __shfl_xor(hi[c], m));
+        }
+    if (l16 == 0) {
+        const int w = toff[tile];
+        int o[3];
+        unpack_off(w, o[0], o[1], o[2]);
+        int need = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) need = max(need, max(hi[c] - o[c], o[c] - lo[c]));
+        toff[tile] = (w & 0xffffff) | (min(max(need, 1), 4) << 24);
     }
 }
 
@@ -235,36 +230,38 @@ struct TileLists {
     int listcap;
     int *cnts;
     int order;         // order of the tile pencils within an XCD's slab (tile_of_block)
-    int hfix;          // window halo H of this paint if > 0, else
-    const int *hsel;   // ... decided from the counts halo_select_kernel left for THIS input (2, 3 or 4)
-    float hlim;        // largest number of unsure samples an H may have (limit x samples per tile x tiles)
+    int hfix;          // window halo H of this paint if > 0, else the one halo_tile_kernel left in byte 3 of every tile's word
 };
 
-// the window halo of this launch (wave-uniform; every lane of the wave active): fixed, or the smallest candidate whose count of
-// unsure samples (64 slots per candidate, summed here by every wave: 3 loads per lane) stays below the limit
-__device__ __forceinline__ int tile_halo(const TileLists &L) {
+// the window halo of tile `word` in this launch
+__device__ __forceinline__ int tile_halo(const TileLists &L, int word) { return L.hfix > 0 ? L.hfix : word_halo(word); }
+// the tile of this workgroup's window walk and its halo (wave-uniform)
+__device__ __forceinline__ int block_halo(const Geom &g, const TileLists &L, int tile_index = -1) {
     if (L.hfix > 0) return L.hfix;
-    const int lane = threadIdx.x & 63;
-    int c2 = L.hsel[HSEL_SLOT0 + (0 * 64 + lane) * 32], c3 = L.hsel[HSEL_SLOT0 + (1 * 64 + lane) * 32];
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-        c2 += __shfl_xor(c2, m);
-        c3 += __shfl_xor(c3, m);
+    if (tile_index < 0) {
+        int tx, ty, tz;
+        const int ntx = g.nx / MCPM_TILE, nty = g.ny / MCPM_TILE, ntz = g.nz / MCPM_TILE;
+        tile_of_block(ntx, nty, ntz, tx, ty, tz, L.order);
+        tile_index = (tx * nty + ty) * ntz + tz;
     }
-    c2 = __builtin_amdgcn_readfirstlane(c2);
-    c3 = __builtin_amdgcn_readfirstlane(c3);
-    return (float)c2 <= L.hlim ? 2 : ((float)c3 <= L.hlim ? 3 : 4);
+    return __builtin_amdgcn_readfirstlane(word_halo(L.toff[tile_index]));
 }
-// kernels are instantiated for three candidate halos (HA, HB, HC; all equal when the halo is fixed) and branch once, uniformly
-#define HALO_SWITCH(Hrt, CALL)  \
-    do {                        \
-        if ((Hrt) == HA) {      \
-            CALL(HA);           \
-        } else if ((Hrt) == HB) { \
-            CALL(HB);           \
-        } else {                \
-            CALL(HC);           \
-        }                       \
+// kernels are instantiated for a fixed halo (HA = HB = HC) or for the four candidates HA, HB, HC, HC + 1 (= 1, 2, 3, 4 when every
+// tile's halo is chosen on the device) and branch once per workgroup, uniformly
+#define HALO_SWITCH(Hrt, CALL)            \
+    do {                                  \
+        if (HA == HC) {                   \
+            CALL(HA);                     \
+        } else if ((Hrt) == HA) {         \
+            CALL(HA);                     \
+        } else if ((Hrt) == HB) {         \
+            CALL(HB);                     \
+        } else if ((Hrt) == HC) {         \
+            CALL(HC);                     \
+        } else {                          \
+            constexpr int HD_ = HC + 1;   \
+            CALL(HD_);                    \
+        }                                 \
     } while (0)
 
 __device__ __forceinline__ void append_wild(const TileLists &L, int gi) {
@@ -297,10 +294,9 @@ __device__ __forceinline__ void flush_suspects(const TileLists &L, int *sus) {
 // The tiles the CIC stencil of one particle touches whose window does NOT contain its lattice point.  (tx, ty, tz): home
 // tile of the lattice point, (r): lattice point relative to that tile's origin, (i): floor of the displacement.
 // f(tile index, base cell relative to that tile's origin) is called for each such tile.
-template <int H, class F>
+template <class F>
 __device__ __forceinline__ void for_uncovered(const Geom &g, const TileLists &L, int tx, int ty, int tz, int ntx, int nty, int ntz,
                                               int oself, int rx, int ry, int rz, int ix, int iy, int iz, F f) {
-    constexpr int W = MCPM_TILE + 2 * H + 1;
     const int cx = rx + ix, cy = ry + iy, cz = rz + iz;
     const int d0x = cx >> 4, d0y = cy >> 4, d0z = cz >> 4, mx = cx & 15, my = cy & 15, mz = cz & 15;
     const int nax = mx == 15 ? 2 : 1, nay = my == 15 ? 2 : 1, naz = mz == 15 ? 2 : 1;
@@ -319,9 +315,11 @@ __device__ __forceinline__ void for_uncovered(const Geom &g, const TileLists &L,
                 const int Tz = pymod(tz + dtz, ntz);
                 const int tidx = (Tx * nty + Ty) * ntz + Tz;
                 int ox, oy, oz;
-                unpack_off((dtx | dty | dtz) == 0 || !L.toff ? oself : L.toff[tidx], ox, oy, oz);
-                const bool covered = (unsigned)(rlx + ox + H + 1) < (unsigned)W && (unsigned)(rly + oy + H + 1) < (unsigned)W &&
-                                     (unsigned)(rlz + oz + H + 1) < (unsigned)W;
+                const int word = (dtx | dty | dtz) == 0 || !L.toff ? oself : L.toff[tidx];
+                unpack_off(word, ox, oy, oz);
+                const int H = tile_halo(L, word);          // the halo of the tile that would have to pull this particle
+                const unsigned W = (unsigned)(MCPM_TILE + 2 * H + 1);
+                const bool covered = (unsigned)(rlx + ox + H + 1) < W && (unsigned)(rly + oy + H + 1) < W && (unsigned)(rlz + oz + H + 1) < W;
                 if (!covered) f(tidx, a ? -1 : mx, b ? -1 : my, e ? -1 : mz);
             }
         }
@@ -342,7 +340,6 @@ __device__ __forceinline__ bool is_wild(const Geom &g, const P3 &d, int x0, int 
 
 // Exact coverage test of the suspects: append each to the bucket of every tile whose window misses it.  A full bucket keeps
 // counting (bcnt > cap marks the tile for the repair pass, which then deposits ALL of that tile's pairs).
-template <int H>
 __device__ __forceinline__ void coverage_duty_body(const Geom &g, const float *__restrict__ disp, const TileLists &L) {
     const int ns = min(L.cnts[C_SUSPECTS], L.listcap);
     const int ntx = g.nx / MCPM_TILE, nty = g.ny / MCPM_TILE, ntz = g.nz / MCPM_TILE;
@@ -355,8 +352,8 @@ __device__ __forceinline__ void coverage_duty_body(const Geom &g, const float *_
             append_wild(L, gi);
             continue;
         }
-        for_uncovered<H>(g, L, tx, ty, tz, ntx, nty, ntz, L.toff ? L.toff[(tx * nty + ty) * ntz + tz] : 0, qx & 15, qy & 15, qz & 15,
-                         (int)floorf(d.x), (int)floorf(d.y), (int)floorf(d.z), [&](int tidx, int, int, int) {
+        for_uncovered(g, L, tx, ty, tz, ntx, nty, ntz, L.toff ? L.toff[(tx * nty + ty) * ntz + tz] : 0, qx & 15, qy & 15, qz & 15,
+                      (int)floorf(d.x), (int)floorf(d.y), (int)floorf(d.z), [&](int tidx, int, int, int) {
                              const int kb = atomicAdd(L.bcnt + tidx, 1);
                              if (kb == 0) L.nonempty[atomicAdd(L.cnts + C_NTILES, 1)] = tidx;
                              if (kb < L.cap) L.bucket[(int64_t)tidx * L.cap + kb] = gi;
@@ -365,58 +362,46 @@ __device__ __forceinline__ void coverage_duty_body(const Geom &g, const float *_
     }
 }
 
-template <int HA, int HB, int HC>
-__global__ __launch_bounds__(256) void coverage_duty_kernel(Geom g, const float *__restrict__ disp, TileLists L) {
-    const int Hrt = tile_halo(L);
-#define CALL(HH) coverage_duty_body<HH>(g, disp, L)
-    HALO_SWITCH(Hrt, CALL);
-#undef CALL
-}
+__global__ __launch_bounds__(256) void coverage_duty_kernel(Geom g, const float *__restrict__ disp, TileLists L) { coverage_duty_body(g, disp, L); }
 
-// Range of the window offsets over the 27 tiles around (tx, ty, tz) (the destinations of every home particle displaced by
-// less than a tile): min in omin[3], max in omax[3].  Reduced by the first wave, broadcast through six LDS words.
-__device__ __forceinline__ void neighbour_offset_range(const Geom &g, const TileLists &L, int tx, int ty, int tz, int ntx, int nty,
-                                                       int ntz, int *sh27, int (&omin)[3], int (&omax)[3]) {
+// Conservative form of the coverage test, as cheap as the round-1 outlier test: a particle of the home block is covered by EVERY tile
+// its stencil can touch if |floor(d)_a - o_T',a| <= H_T' on each axis for each of the 27 tiles T' around the block, i.e. if floor(d)_a
+// lies in the INTERSECTION of their intervals [o_T',a - H_T', o_T',a + H_T'].  (With per-tile halos that intersection contains the
+// block's own sampled range by construction -- every T' sized its window with it -- whereas the symmetric interval of round 3,
+// o_a +- (H - max |o_T',a - o_a|), has no slack left when each H_T' is just large enough.)  slo / shi: the interval as floats, per axis
+// (empty when slo > shi: every home particle is then a suspect).  Reduced by the first wave, broadcast through LDS.
+__device__ __forceinline__ void sure_intervals(const Geom &g, const TileLists &L, int tx, int ty, int tz, int ntx, int nty, int ntz,
+                                               int *sh27, float (&slo)[3], float (&shi)[3]) {
     if (threadIdx.x < 64) {
-        int lo[3] = {127, 127, 127}, hi[3] = {-127, -127, -127};
+        int lo[3] = {-127, -127, -127}, hi[3] = {127, 127, 127};
         if (threadIdx.x < 27) {
             const int a = (int)threadIdx.x / 9 - 1, b = ((int)threadIdx.x / 3) % 3 - 1, e = (int)threadIdx.x % 3 - 1;
             const int Tx = g.xslab ? min(max(tx + a, 0), ntx - 1) : pymod(tx + a, ntx);
-            unpack_off(L.toff[(Tx * nty + pymod(ty + b, nty)) * ntz + pymod(tz + e, ntz)], lo[0], lo[1], lo[2]);
-            hi[0] = lo[0]; hi[1] = lo[1]; hi[2] = lo[2];
+            const int word = L.toff[(Tx * nty + pymod(ty + b, nty)) * ntz + pymod(tz + e, ntz)];
+            int n3[3];
+            unpack_off(word, n3[0], n3[1], n3[2]);
+            const int H = tile_halo(L, word);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lo[c] = n3[c] - H, hi[c] = n3[c] + H;
         }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                lo[c] = min(lo[c], __shfl_xor(lo[c], o));
-                hi[c] = max(hi[c], __shfl_xor(hi[c], o));
+                lo[c] = max(lo[c], __shfl_xor(lo[c], o));
+                hi[c] = min(hi[c], __shfl_xor(hi[c], o));
             }
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                sh27[c] = lo[c];
-                sh27[3 + c] = hi[c];
-            }
+            for (int c = 0; c < 3; ++c) sh27[c] = lo[c], sh27[3 + c] = hi[c];
         }
     }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        omin[c] = sh27[c];
-        omax[c] = sh27[3 + c];
+        slo[c] = (float)sh27[c];
+        shi[c] = (float)sh27[3 + c];
     }
-}
-
-// Conservative form of the coverage test, as cheap as the round-1 outlier test: a particle of the home block is covered by
-// EVERY tile its stencil touches if |floor(d)_a - o_T',a| <= H on each axis for each of them, which holds if
-// |floor(d)_a - o_a| <= H - D_a with o the home tile's offset and D_a the largest difference between o_a and the offsets of
-// the 27 neighbours (0 everywhere when the windows are not centred).  lo / hi: that interval as floats, per axis.
-template <int H>
-__device__ __forceinline__ void sure_interval(int o, int omin, int omax, float &lo, float &hi) {
-    const int D = max(omax - o, o - omin);
-    lo = (float)(o - (H - D));
-    hi = (float)(o + (H - D));
 }
 
 // window point j (flat, z fastest) of a tile whose window offset is (ox, oy, oz): lattice point relative to the tile (r),
@@ -521,11 +506,7 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
     float slo[3] = {(float)-H, (float)-H, (float)-H}, shi[3] = {(float)H, (float)H, (float)H};
     if (L.toff) {   // windows centred on the bulk displacement (optional)
         unpack_off(L.toff[(tx * nty + ty) * ntz + tz], ox, oy, oz);
-        int omin[3], omax[3];
-        neighbour_offset_range(g, L, tx, ty, tz, ntx, nty, ntz, sh27, omin, omax);
-        sure_interval<H>(ox, omin[0], omax[0], slo[0], shi[0]);
-        sure_interval<H>(oy, omin[1], omax[1], slo[1], shi[1]);
-        sure_interval<H>(oz, omin[2], omax[2], slo[2], shi[2]);
+        sure_intervals(g, L, tx, ty, tz, ntx, nty, ntz, sh27, slo, shi);
     }
     __syncthreads();
 
@@ -649,7 +630,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
     __shared__ u64 tile[MCPM_TILE * MCPM_TILE * MCPM_TILE];
     __shared__ int sh27[27];
     __shared__ int sus[MCPM_SUS + 2];
-    const int Hrt = tile_halo(L);
+    const int Hrt = block_halo(g, L);
 #define CALL(HH) paint_tile_body<HH, WMODE, THREADS, U, FAST>(g, disp, w, wstride, wscalar, mesh, accumulate, L, wmax_bits, duty, tile, sh27, sus)
     HALO_SWITCH(Hrt, CALL);
 #undef CALL
@@ -727,7 +708,7 @@ __device__ __forceinline__ void paint_bucket_body(const Geom &g, const float *__
 // What the integer tiles could not take, with f32 global atomics (counted): (1) wild particles, all eight corners;
 // (2) repair pass, only when some bucket overflowed: every (particle, tile) pair whose tile is marked (bcnt > cap) and whose
 // window misses the particle -- the same predicate as the coverage duty, re-evaluated over all particles.
-template <int H, int NC>
+template <int NC>
 __device__ __forceinline__ void paint_leftover_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w,
                                                     int64_t wstride, float wscalar, float *__restrict__ mesh, int64_t M,
                                                     const TileLists &L, const int bid, const int nblk) {
@@ -783,7 +764,7 @@ __device__ __forceinline__ void paint_leftover_body(const Geom &g, const float *
         if (is_wild(g, d, tx * MCPM_TILE, qx & 15)) continue;
         const float fx = floorf(d.x), fy = floorf(d.y), fz = floorf(d.z);
         const float kx[2] = {1.f - (d.x - fx), d.x - fx}, ky[2] = {1.f - (d.y - fy), d.y - fy}, kz[2] = {1.f - (d.z - fz), d.z - fz};
-        for_uncovered<H>(g, L, tx, ty, tz, ntx, nty, ntz, L.toff ? L.toff[(tx * nty + ty) * ntz + tz] : 0, qx & 15, qy & 15, qz & 15, (int)fx, (int)fy,
+        for_uncovered(g, L, tx, ty, tz, ntx, nty, ntz, L.toff ? L.toff[(tx * nty + ty) * ntz + tz] : 0, qx & 15, qy & 15, qz & 15, (int)fx, (int)fy,
                          (int)fz, [&](int tidx, int cx, int cy, int cz) {
                              if (L.bcnt[tidx] <= L.cap) return;      // that tile's bucket was deposited by the bucket kernel
                              const int x0 = (tidx / (ntz * nty)) * MCPM_TILE, y0 = ((tidx / ntz) % nty) * MCPM_TILE, z0 = (tidx % ntz) * MCPM_TILE;
@@ -807,17 +788,14 @@ __device__ __forceinline__ void paint_leftover_body(const Geom &g, const float *
 // launch costs about as much as the kernel): blocks [0, nbk) deposit the buckets, blocks [nbk, nbk + nlo) run the
 // global-atomic leftovers (wild particles, overflowed buckets).  The two touch disjoint (particle, tile) pairs and both only
 // read what the coverage kernel left, so they need no order between them.
-template <int HA, int HB, int HC, int WMODE>
+template <int WMODE>
 __global__ __launch_bounds__(256) void paint_epilogue_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
                                                              int64_t wstride, float wscalar, float *__restrict__ mesh, int64_t M,
                                                              TileLists L, const unsigned *__restrict__ wmax_bits, int nbk) {
     __shared__ u64 tile[MCPM_TILE * MCPM_TILE * MCPM_TILE];
     if ((int)blockIdx.x < nbk) paint_bucket_body<WMODE>(g, disp, w, wstride, wscalar, mesh, L, wmax_bits, tile, (int)blockIdx.x, nbk);
     else {
-        const int Hrt = tile_halo(L);
-#define CALL(HH) paint_leftover_body<HH, 1>(g, disp, w, wstride, wscalar, mesh, M, L, (int)blockIdx.x - nbk, (int)gridDim.x - nbk)
-        HALO_SWITCH(Hrt, CALL);
-#undef CALL
+        paint_leftover_body<1>(g, disp, w, wstride, wscalar, mesh, M, L, (int)blockIdx.x - nbk, (int)gridDim.x - nbk);
     }
 }
 
@@ -903,13 +881,7 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
     if (deposit)
         for (int i = threadIdx.x; i < (F64 ? 3 : 2) * NT; i += THREADS) tile[i] = 0ull;
     float slo[3] = {(float)-H, (float)-H, (float)-H}, shi[3] = {(float)H, (float)H, (float)H};
-    if (L.toff) {
-        int omin[3], omax[3];
-        neighbour_offset_range(g, L, tx, ty, tz, ntx, nty, ntz, sh27, omin, omax);
-        sure_interval<H>(ox, omin[0], omax[0], slo[0], shi[0]);
-        sure_interval<H>(oy, omin[1], omax[1], slo[1], shi[1]);
-        sure_interval<H>(oz, omin[2], omax[2], slo[2], shi[2]);
-    }
+    if (L.toff) sure_intervals(g, L, tx, ty, tz, ntx, nty, ntz, sh27, slo, shi);
     __syncthreads();
 
     WinIter<H, THREADS> wi(threadIdx.x);
@@ -1086,8 +1058,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
     __shared__ int flagged;
     __shared__ int sh27[27];
     __shared__ int sus[MCPM_SUS + 2];
-    const int Hrt = tile_halo(L);
     if (!redo_in) {
+        const int Hrt = block_halo(g, L);
 #define CALL(HH) paint3_tile_body<HH, F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, -1, duty, tile, flagged, sh27, sus)
         HALO_SWITCH(Hrt, CALL);
 #undef CALL
@@ -1097,6 +1069,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                            // scalar-register pressure, for a branch it never takes)
     const int n = redo_in[0];
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int Hrt = block_halo(g, L, redo_in[1 + k]);
 #define CALL(HH) paint3_tile_body<HH, F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, redo_in[1 + k], duty, tile, flagged, sh27, sus)
         HALO_SWITCH(Hrt, CALL);
 #undef CALL
@@ -1115,7 +1088,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     __shared__ int flagged;
     __shared__ int sh27[27];
     __shared__ int sus[MCPM_SUS + 2];
-    const int Hrt = tile_halo(L);
+    const int Hrt = block_halo(g, L);
 #define CALL(HH) paint3_tile_body<HH, false, 1024, 2, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, -1, duty, tile, flagged, sh27, sus)
     HALO_SWITCH(Hrt, CALL);
 #undef CALL
@@ -1196,13 +1169,7 @@ __global__ __launch_bounds__(256) void paint3_epilogue_kernel(Geom g, const floa
     if ((int)blockIdx.x < nbk) paint3_bucket_body(g, disp, w3, mesh, M, L, wmax_bits, tile, (int)blockIdx.x, nbk);
     else {
         const int bid = (int)blockIdx.x - nbk, nblk = (int)gridDim.x - nbk;
-        switch (tile_halo(L)) {
-            case 1: paint_leftover_body<1, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
-            case 2: paint_leftover_body<2, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
-            case 3: paint_leftover_body<3, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
-            case 4: paint_leftover_body<4, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
-            default: paint_leftover_body<6, 3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk); break;
-        }
+        paint_leftover_body<3>(g, disp, w3, 3, 0.f, mesh, M, L, bid, nblk);
     }
     // The bucket blocks that found work are the only readers of the max|w| slots in this launch (tile_scale at their top): the
     // last of THEM clears the slots (every block counting on one address cost 30 us: 1088 serialised atomics); with no reader
@@ -1253,7 +1220,7 @@ static int tile_order() {
 }
 
 // The halo of the next tiled paint: p->halo if the caller fixed one (mcpm_plan_set_halo, MCPM_PAINT_HALO), else 0 = chosen on the
-// device for every input by halo_select_kernel (periodic plans of 2048 tiles or more; MCPM_PAINT_ADAPT=0, a slab plan or a
+// device for every input by halo_tile_kernel (periodic plans of 2048 tiles or more; MCPM_PAINT_ADAPT=0, a slab plan or a
 // smaller mesh: the static rule of plan.hip)
 static int halo_of(const mcpm_plan *p) {
     static const int adapt = [] { const char *e = getenv("MCPM_PAINT_ADAPT"); return e ? atoi(e) : 1; }();
@@ -1262,33 +1229,27 @@ static int halo_of(const mcpm_plan *p) {
     // halo are free there and the particles a narrow one misses are not (128^3: 3511 steps/s chosen per input, 3597 at H = 4)
     const int64_t ntiles = p->M / (MCPM_TILE * MCPM_TILE * MCPM_TILE);
     static const int slab_too = [] { const char *e = getenv("MCPM_PAINT_ADAPT_SLAB"); return e ? atoi(e) : 1; }();
-    return (adapt && (slab_too || !p->g.xslab) && p->halo_sel && ntiles >= 2048) ? 0 : mcpm_default_halo(p->M);
-}
-
-// share of unsure samples a window halo may leave (halo_select_kernel / tile_halo)
-static float halo_limit() {
-    static const float limit = [] { const char *e = getenv("MCPM_HALO_LIMIT"); return e ? (float)atof(e) : 0.04f; }();
-    return limit;
+    // (the per-tile halos ride in the offset words of centred windows: p->centre)
+    return (adapt && (slab_too || !p->g.xslab) && p->halo_sel && p->centre && ntiles >= 2048) ? 0 : mcpm_default_halo(p->M);
 }
 
 static TileLists tile_lists(const mcpm_plan *p) {
-    return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, p->outliers + p->Np, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count, tile_order(), halo_of(p), p->halo_sel,
-                     halo_limit() * (float)HSEL_SAMPLES * (float)(p->M / (MCPM_TILE * MCPM_TILE * MCPM_TILE))};
+    return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, p->outliers + p->Np, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count, tile_order(), halo_of(p)};
 }
 
 static void tiled_prologue(mcpm_plan *p, const float *pos, int *redo = nullptr) {
     const Geom &g = p->g;
     const int ntiles = (g.nx / MCPM_TILE) * (g.ny / MCPM_TILE) * (g.nz / MCPM_TILE);
-    const bool adapt = halo_of(p) == 0;
+    const bool adapt = halo_of(p) == 0;      // p->halo_sel: the blocks' sampled floor(d) ranges, [ntiles] minima then [ntiles] maxima
     tile_prologue_kernel<<<(ntiles + 3) / 4, 256, 0, p->stream>>>(g, pos, p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->outlier_count,
                                                                   ntiles, 8, redo, adapt ? p->halo_sel : nullptr);
-    if (adapt) halo_select_kernel<<<(ntiles + 15) / 16, 256, 0, p->stream>>>(g, pos, p->centre ? p->tile_off : nullptr, ntiles, p->halo_sel);
+    if (adapt) halo_tile_kernel<<<(ntiles + 15) / 16, 256, 0, p->stream>>>(g, p->tile_off, p->halo_sel, ntiles);
 }
 
-// CALL(HA, HB, HC): the kernels' three candidate halos -- all equal for a fixed halo, (2, 3, 4) when the device chooses (0)
+// CALL(HA, HB, HC): the kernels' candidate halos -- all equal for a fixed halo, (1, 2, 3) [and 4: HALO_SWITCH] when the device chooses (0)
 #define DISPATCH_H(HH, CALL)        \
     switch (HH) {                   \
-        case 0: CALL(2, 3, 4) break; \
+        case 0: CALL(1, 2, 3) break; \
         case 1: CALL(1, 1, 1) break; \
         case 2: CALL(2, 2, 2) break; \
         case 3: CALL(3, 3, 3) break; \
@@ -1332,14 +1293,9 @@ bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t ws
         DISPATCH_H(halo_of(p), CALLU)
 #undef CALLU
     }
-#define CALLD(HA_, HB_, HC_) coverage_duty_kernel<HA_, HB_, HC_><<<1024, 256, 0, p->stream>>>(g, pos, L);
-    DISPATCH_H(halo_of(p), CALLD)
-#undef CALLD
-#define CALLE(HA_, HB_, HC_)                                                                                                                          \
-    if (w) paint_epilogue_kernel<HA_, HB_, HC_, 1><<<nbk + nlo, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L, p->gx_wmax, (int)nbk); \
-    else paint_epilogue_kernel<HA_, HB_, HC_, 0><<<nbk + nlo, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L, p->gx_wmax, (int)nbk);
-    DISPATCH_H(halo_of(p), CALLE)
-#undef CALLE
+    coverage_duty_kernel<<<1024, 256, 0, p->stream>>>(g, pos, L);
+    if (w) paint_epilogue_kernel<1><<<nbk + nlo, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L, p->gx_wmax, (int)nbk);
+    else paint_epilogue_kernel<0><<<nbk + nlo, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L, p->gx_wmax, (int)nbk);
     return true;
 }
 
@@ -1374,9 +1330,7 @@ bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, fl
         DISPATCH_H(halo_of(p), CALLF64)
 #undef CALLF64
     }
-#define CALLD(HA_, HB_, HC_) coverage_duty_kernel<HA_, HB_, HC_><<<1024, 256, 0, p->stream>>>(g, pos, L);
-    DISPATCH_H(halo_of(p), CALLD)
-#undef CALLD
+    coverage_duty_kernel<<<1024, 256, 0, p->stream>>>(g, pos, L);
     const unsigned nlo = 64u;     // see mcpm_paint_tiled
     // buckets | leftovers in one launch; its last block leaves the max|w| slots zero for the next producer
     paint3_epilogue_kernel<<<nbk + nlo, 256, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, L, p->fx_wmax, (int)nbk,

@@ -75,7 +75,7 @@ int mcpm_plan_create_slab(int nx, int ny, int nz, int nranks, int rank, int ghos
 // 3635 vs 3231, 192^3 993 vs 864, 256^3 689 vs 703 (but pm_forces on the evolved particles 0.552 vs 0.630 ms), 512^3 87.8 vs 90.0.
 // The choice never changes a result beyond the last bit (the sums are exact; the split between tile and bucket deposits moves).
 // This static rule is what slab plans and MCPM_PAINT_ADAPT=0 use; periodic plans choose H per input on the device
-// (paint_tiled.hip::halo_select_kernel).  MCPM_PAINT_HALO / mcpm_plan_set_halo fix it.
+// (paint_tiled.hip::halo_tile_kernel).  MCPM_PAINT_HALO / mcpm_plan_set_halo fix it.
 // (mcpm_default_halo: mcpm_internal.h)
 
 // nranks == 1, ghost == 0: ordinary periodic plan.  Otherwise (slab): (nx, ny, nz) is the GLOBAL mesh, the local
@@ -112,7 +112,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->M = (int64_t)nx * ny * nz;
     p->Mh = (int64_t)nx * ny * p->g.nzh;
     p->Np = (int64_t)px * py * pz;
-    p->halo = 0;      // 0: chosen per input on the device (paint_tiled.hip::halo_of / halo_select_kernel), else mcpm_default_halo
+    p->halo = 0;      // 0: chosen per input on the device (paint_tiled.hip::halo_of / halo_tile_kernel), else mcpm_default_halo
     p->centre = 1;    // windows centred on the bulk displacement; on the tile itself (centre = 0) they need one more cell of halo at the
                       // benchmark's 2-cell rms displacement (bench 512^3: 12.10 vs 12.42 ms per step, pm_forces 4.38 vs 4.48 ms)
     if (const char *e = getenv("MCPM_PAINT_CENTRE")) p->centre = atoi(e) ? 1 : 0;
@@ -160,7 +160,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
         p->bucket_cap = 1024;
         if (const char *e = getenv("MCPM_BUCKET_CAP")) { const int c = atoi(e); if (c >= 64 && c <= 65536) p->bucket_cap = c; }
         alloc((void **)&p->tile_off, sizeof(int) * ntiles);
-        alloc((void **)&p->halo_sel, sizeof(int) * MCPM_HSEL_INTS);
+        alloc((void **)&p->halo_sel, sizeof(int) * 2 * ntiles);      // sampled floor(d) ranges of the Lagrangian blocks (paint_tiled.hip)
         alloc((void **)&p->bucket_cnt, sizeof(int) * ntiles);
         alloc((void **)&p->bucket_tiles, sizeof(int) * ntiles);
         alloc((void **)&p->bucket, sizeof(int) * ntiles * p->bucket_cap);
@@ -176,7 +176,6 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
         return mcpm_fail(nullptr, MCPM_E_NOMEM, msg);
     }
     (void)hipMemsetAsync(p->outlier_count, 0, sizeof(int) * 8, p->stream);
-    if (p->halo_sel) (void)hipMemsetAsync(p->halo_sel, 0, sizeof(int) * MCPM_HSEL_INTS, p->stream);
     (void)hipMemsetAsync(p->fx_redo, 0, sizeof(int), p->stream);
     (void)hipMemsetAsync(p->reduce, 0, sizeof(double) * MCPM_NREDUCE, p->stream);   // the slot area stays zero between uses
     *out = p;
@@ -252,6 +251,24 @@ int mcpm_plan_last_bucketed(mcpm_plan *p, int64_t *count) {
     return MCPM_OK;
 }
 
+// out[0..7]: the last tiled paint's device counters (wild particles, last wild + overflow pairs, slab deposits beyond the ghost planes,
+// appends that found their bucket full, tiles with a non-empty bucket, bucketed pairs, suspects, -); out[8 + h], h = 0..4: tiles whose
+// window halo is h (0: no per-tile choice was made for this plan's last paint).  Synchronises the host.
+int mcpm_plan_last_paint_stats(mcpm_plan *p, int64_t *out13) {
+    if (!p || !out13) return MCPM_E_ARG;
+    int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    MCPM_HIP(p, hipMemcpyAsync(c, p->outlier_count, sizeof(c), hipMemcpyDeviceToHost, p->stream));
+    for (int i = 0; i < 13; ++i) out13[i] = 0;
+    std::vector<int> words;
+    if (p->tile_off) {
+        words.resize((size_t)(p->M / 4096));
+        MCPM_HIP(p, hipMemcpyAsync(words.data(), p->tile_off, sizeof(int) * words.size(), hipMemcpyDeviceToHost, p->stream));
+    }
+    MCPM_HIP(p, hipStreamSynchronize(p->stream));
+    for (int i = 0; i < 8; ++i) out13[i] = c[i];
+    for (int w : words) out13[8 + std::min((w >> 24) & 0xff, 4)] += 1;
+    return MCPM_OK;
+}
 
 int mcpm_plan_set_paint3_fixed(mcpm_plan *p, int fixed) {
     if (!p) return MCPM_E_ARG;

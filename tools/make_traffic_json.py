@@ -16,7 +16,7 @@ stage_of = [("paint3_tile_kernel", "paint3"), ("paint3_bucket_kernel", "paint3")
             ("ycol_kernel<512, 1>", "fft_c2r"), ("ycol_kernel<256, 1>", "fft_c2r"), ("zinv_kernel", "fft_c2r"), ("zinv3_il_kernel", "fft_c2r"),
             ("xfused_kernel", "kspace"), ("kick_drift_kernel", "kick_drift"), ("step_adjoint_kernel", "step_adjoint"),
             ("axpby_kernel", "axpy"), ("axpy_kernel", "axpy")]
-shared_before = ("tile_prologue_kernel", "halo_select_kernel", "halo_decide_kernel")   # belong to the NEXT tile kernel
+shared_before = ("tile_prologue_kernel", "halo_select_kernel", "halo_decide_kernel", "halo_tile_kernel")   # belong to the NEXT tile kernel
 shared_after = ("coverage_duty_kernel", "paint_leftover_kernel", "absmax_kernel")   # belong to the PREVIOUS tile kernel
 # the kernels that count as "one launch of the stage" (its main kernel); the others only add their bytes
 main_kernels = ("paint_tile_kernel", "paint3_tile_kernel<", "paint_atomic_kernel", "zfwd_kernel", "ycol2_kernel", "ycol_kernel",
