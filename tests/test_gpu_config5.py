@@ -88,10 +88,16 @@ def test_log_density_and_gradient_at_config5_size(gpu, threads, evolution, a_obs
     lp2, g2 = ld.logdensity_and_grad(point)
     torch.cuda.synchronize()
     t_grad = time.perf_counter() - t0
-    assert lp2 == lp and all(g2[k] == g[k] for k in g if k != "white_mesh_") and torch.equal(g2["white_mesh_"], g["white_mesh_"])   # bitwise repeatable
-    for _ in range(10):      # ... call after call, the float64 scalars included (the light-cone table cotangents are integer sums for this)
+    # Repeatable call after call: the log density and the field gradient bit for bit; the scalar gradients at the float32 precision the
+    # samplers carry them in (samplers.FlatLogDensity packs float32) -- they are float64 sums of per-workgroup partials added with float64
+    # atomics (bias.hip, composite.hip: alpha_bar / beta_bar slots), whose arrival order moves their last bit (measured: 4e-16 .. 7e-16
+    # relative in 3 of 11 repeats); the light-cone table cotangents and every paint are integer sums and do not move at all.
+    same = lambda ga, gb: all(np.float32(ga[k]) == np.float32(gb[k]) and abs(ga[k] - gb[k]) <= 4e-15 * abs(gb[k]) for k in gb if k != "white_mesh_") \
+        and torch.equal(ga["white_mesh_"], gb["white_mesh_"])
+    assert lp2 == lp and same(g2, g)
+    for _ in range(10):
         lp3, g3 = ld.logdensity_and_grad(point)
-        assert lp3 == lp and all(g3[k] == g[k] for k in g if k != "white_mesh_") and torch.equal(g3["white_mesh_"], g["white_mesh_"])
+        assert lp3 == lp and same(g3, g)
     # ---- forward against the float64 restatement (threaded back end) -------------------------------------------------
     cfg = dict(fwd.config(), final_shape=fwd.final_shape, cell_length=fwd.cell_length, precond="kaiser")
     make_cosmo = lambda base: _cos(obg.Planck18(Omega_c=base["Omega_m"] - 0.0490), base["sigma8"])
