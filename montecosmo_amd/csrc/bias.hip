@@ -154,14 +154,14 @@ struct Bias8 {
 };
 
 __global__ __launch_bounds__(256) void bias_moment_kernel(const float *__restrict__ dr, const float *__restrict__ gp, float gs,
-                                                          int64_t n, double *slots) {
+                                                          int64_t n, double *part) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double v[1] = {0.};
     if (i < n) {
         const float d = dr[i] * (gp ? gp[i] : gs);
         v[0] = (double)d * (double)d;
     }
-    block_add<1>(v, slots);
+    block_partial<1>(v, part, gridDim.x, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void bias_weights_kernel(const float *__restrict__ dr, const float *__restrict__ s2r,
@@ -188,14 +188,14 @@ __global__ __launch_bounds__(256) void bias_weights_kernel(const float *__restri
     dvel[3 * i + 2] = c * gr[ges * i + 2 * gcs];
 }
 
-// pass 1 of the VJP: the 8 bias cotangents and sigma2_bar (slots rows 0..8)
+// pass 1 of the VJP: the 8 bias cotangents and sigma2_bar (per-workgroup partials, rows 0..8; det_fold_kernel adds them up)
 __global__ __launch_bounds__(256) void bias_vjp_reduce_kernel(const float *__restrict__ dr, const float *__restrict__ s2r,
                                                               const float *__restrict__ s3r, const float *__restrict__ lr,
                                                               const float *__restrict__ gr, int64_t ges, int64_t gcs,
                                                               const float *__restrict__ gp, float gs,
                                                               Bias8 B, const double *__restrict__ sigma2p,
                                                               const float *__restrict__ wb, const float *__restrict__ vb,
-                                                              int64_t n, double *slots) {
+                                                              int64_t n, double *part) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double v[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
     if (i < n) {
@@ -213,10 +213,10 @@ __global__ __launch_bounds__(256) void bias_vjp_reduce_kernel(const float *__res
         const float dw_ds2 = B.bs2 + B.bds2 * d;
         v[8] = (double)(w * (-0.5f * B.b2 - 0.5f * B.b3 * d - (2.f / 3.f) * dw_ds2));
     }
-    block_add<9>(v, slots);
+    block_partial<9>(v, part, gridDim.x, blockIdx.x);
 }
 
-// pass 2: per-particle cotangents of the raw reads and of g (g_bar per particle, or block-summed into slots row 0)
+// pass 2: per-particle cotangents of the raw reads and of g (g_bar per particle, and its per-workgroup partial sums)
 __global__ __launch_bounds__(256) void bias_vjp_particles_kernel(const float *__restrict__ dr, const float *__restrict__ s2r,
                                                                  const float *__restrict__ s3r, const float *__restrict__ lr,
                                                                  const float *__restrict__ gr, int64_t ges, int64_t gcs,
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void bias_vjp_particles_kernel(const float *__
                                                                  const float *__restrict__ vb, int64_t n,
                                                                  float *__restrict__ drb, float *__restrict__ s2rb,
                                                                  float *__restrict__ s3rb, float *__restrict__ lrb,
-                                                                 float *__restrict__ grb, float *__restrict__ gbar, double *slots) {
+                                                                 float *__restrict__ grb, float *__restrict__ gbar, double *part) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double v[1] = {0.};
     if (i < n) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void bias_vjp_particles_kernel(const float *__
         if (gbar) gbar[i] = gb;
         v[0] = (double)gb;
     }
-    block_add<1>(v, slots);
+    block_partial<1>(v, part, gridDim.x, blockIdx.x);
 }
 
 // jnp.interp(x, xp, fp, left=0, right=0) on float64 device tables
@@ -404,12 +404,13 @@ int mcpm_bias_weights_f32(mcpm_plan *p, int64_t n, const float *dr, const float 
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, n > 0 && dr && s2r && s3r && lr && gr && bias8 && weights && dvel, MCPM_E_ARG, "mcpm_bias_weights_f32: bad argument");
     const Bias8 B{bias8[0], bias8[1], bias8[2], bias8[3], bias8[4], bias8[5], bias8[6], bias8[7]};
-    double *slots = p->reduce, *sig = p->reduce + 10 * NSLOT;
+    double *sig = p->reduce, *P, *Q;
+    unsigned *ticket, R;
     const unsigned nb = (unsigned)((n + 255) / 256);
     StageTimer st_(p, ST_LPT, 60.0 * n);
-    MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * NSLOT, p->stream));
-    bias_moment_kernel<<<nb, 256, 0, p->stream>>>(dr, growth, growth_scalar, n, slots);
-    fold_kernel<<<1, NSLOT, 0, p->stream>>>(slots, 1, 1.0 / (double)n, sig);
+    MCPM_TRY(mcpm_det_scratch(p, 1, nb, &P, &Q, &ticket, &R));
+    bias_moment_kernel<<<nb, 256, 0, p->stream>>>(dr, growth, growth_scalar, n, P);
+    det_fold_kernel<<<R, 256, 0, p->stream>>>(P, nb, 1, Q, ticket, 1.0 / (double)n, det_outs(sig));
     bias_weights_kernel<<<nb, 256, 0, p->stream>>>(dr, s2r, s3r, lr, gr, ges, gcs, growth, growth_scalar, B, sig, n, weights, dvel);
     MCPM_LAUNCH_CHECK(p, "bias_weights_kernel");
     if (sigma2_out) MCPM_HIP(p, hipMemcpyAsync(sigma2_out, sig, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
@@ -428,20 +429,21 @@ int mcpm_bias_weights_vjp_f32(mcpm_plan *p, int64_t n, const float *dr, const fl
     MCPM_REQUIRE(p, n > 0 && dr && s2r && s3r && lr && gr && bias8 && weights_bar && dvel_bar && drb && s2rb && s3rb && lrb && grb && scalars_out,
                  MCPM_E_ARG, "mcpm_bias_weights_vjp_f32: bad argument");
     const Bias8 B{bias8[0], bias8[1], bias8[2], bias8[3], bias8[4], bias8[5], bias8[6], bias8[7]};
-    double *slots = p->reduce;                 // 9 rows of NSLOT
+    double *P, *Q;
+    unsigned *ticket, R;
     const unsigned nb = (unsigned)((n + 255) / 256);
     StageTimer st_(p, ST_LPT, 120.0 * n);
-    MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 9 * NSLOT, p->stream));
-    bias_moment_kernel<<<nb, 256, 0, p->stream>>>(dr, growth, growth_scalar, n, slots);
-    fold_kernel<<<1, NSLOT, 0, p->stream>>>(slots, 1, 1.0 / (double)n, scalars_out + 9);
-    MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * NSLOT, p->stream));
+    MCPM_TRY(mcpm_det_scratch(p, 9, nb, &P, &Q, &ticket, &R));      // 9 rows of per-workgroup partials, summed in a fixed order
+    bias_moment_kernel<<<nb, 256, 0, p->stream>>>(dr, growth, growth_scalar, n, P);
+    det_fold_kernel<<<R, 256, 0, p->stream>>>(P, nb, 1, Q, ticket, 1.0 / (double)n, det_outs(scalars_out + 9));
     bias_vjp_reduce_kernel<<<nb, 256, 0, p->stream>>>(dr, s2r, s3r, lr, gr, ges, gcs, growth, growth_scalar, B, scalars_out + 9, weights_bar,
-                                                      dvel_bar, n, slots);
-    fold_kernel<<<1, NSLOT, 0, p->stream>>>(slots, 9, 1.0, scalars_out);   // [8] = sigma2_bar for now
-    MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * NSLOT, p->stream));
+                                                      dvel_bar, n, P);
+    DetOuts o9{};
+    for (int k = 0; k < 9; ++k) o9.p[k] = scalars_out + k;      // [8] = sigma2_bar for now
+    det_fold_kernel<<<R, 256, 0, p->stream>>>(P, nb, 9, Q, ticket, 1.0, o9);
     bias_vjp_particles_kernel<<<nb, 256, 0, p->stream>>>(dr, s2r, s3r, lr, gr, ges, gcs, growth, growth_scalar, B, scalars_out + 9, scalars_out + 8,
-                                                         weights_bar, dvel_bar, n, drb, s2rb, s3rb, lrb, grb, growth_bar, slots);
-    fold_kernel<<<1, NSLOT, 0, p->stream>>>(slots, 1, 1.0, scalars_out + 8);   // summed growth cotangent
+                                                         weights_bar, dvel_bar, n, drb, s2rb, s3rb, lrb, grb, growth_bar, P);
+    det_fold_kernel<<<R, 256, 0, p->stream>>>(P, nb, 1, Q, ticket, 1.0, det_outs(scalars_out + 8));   // summed growth cotangent
     MCPM_LAUNCH_CHECK(p, "bias_vjp_particles_kernel");
     return MCPM_OK;
 }

@@ -10,6 +10,7 @@
 // is written straight into the next checkpoint slot.  The three force meshes of each step are C2R-ed
 // straight into the checkpoint as well, so the adjoint needs no force recomputation.
 #include "particles_dev.h"
+#include "reduce_dev.h"
 
 // dpos = (init ? 0 : dpos) + ad * F(q), vel likewise with av; F from three contiguous meshes.
 __global__ __launch_bounds__(256) void lpt_accum_kernel(Geom g, const float *__restrict__ meshes, int64_t M, float ad,
@@ -44,71 +45,10 @@ __global__ __launch_bounds__(256) void lattice_scatter_kernel(Geom g, const floa
     out[2 * M + c] = a * x.z + b * v.z;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-
-#define MCPM_NSLOT 1024
-
-// sum the MCPM_NSLOT partial slots of the step adjoint into the accumulators, and leave the slots ZERO for their next
-// user (invariant of plan->reduce's slot area from mcpm_plan_create on: no memset launch per step)
-__global__ __launch_bounds__(MCPM_NSLOT) void reduce_slots_kernel(double *__restrict__ slots, double *out0, double *out1,
-                                                                  double *out2) {
-    __shared__ double sh[3][MCPM_NSLOT / 64];
-    const double s0 = slots[threadIdx.x], s1 = slots[MCPM_NSLOT + threadIdx.x], s2 = slots[2 * MCPM_NSLOT + threadIdx.x];
-    slots[threadIdx.x] = slots[MCPM_NSLOT + threadIdx.x] = slots[2 * MCPM_NSLOT + threadIdx.x] = 0.;
-    double a = wave_sum(s0), b = wave_sum(s1);
-    double c = wave_sum(s2);
-    int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 0) {
-        sh[0][w] = a;
-        sh[1][w] = b;
-        sh[2][w] = c;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double sa = 0., sb = 0., sc = 0.;
-        for (int i = 0; i < MCPM_NSLOT / 64; ++i) {
-            sa += sh[0][i];
-            sb += sh[1][i];
-            sc += sh[2][i];
-        }
-        if (out0) *out0 += sa;
-        if (out1) *out1 += sb;
-        if (out2) *out2 += sc;
-    }
-}
-
-// block-reduce two doubles and atomically add them to *out0, *out1.  Callers with many blocks pass per-slot
-// addresses: half a million blocks adding to ONE address serialise at the memory-side atomic unit.
-__device__ __forceinline__ void block_add2(double a, double b, double *out0, double *out1) {
-    __shared__ double sh[2][4];
-    a = wave_sum(a);
-    b = wave_sum(b);
-    int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 0) {
-        sh[0][w] = a;
-        sh[1][w] = b;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int nw = (blockDim.x + 63) >> 6;
-        double sa = 0., sb = 0.;
-        for (int i = 0; i < nw; ++i) {
-            sa += sh[0][i];
-            sb += sh[1][i];
-        }
-        if (out0) atomicAdd(out0, sa);
-        if (out1) atomicAdd(out1, sb);
-    }
-}
-
 // out0 += sum_i a[i].F(q_i), out1 += sum_i b[i].F(q_i)  (growth-scalar cotangents of lpt)
 __global__ __launch_bounds__(256) void lattice_dot_kernel(Geom g, const float *__restrict__ meshes, int64_t M,
                                                           const float *__restrict__ a, const float *__restrict__ b,
-                                                          double *slots) {
+                                                          double *__restrict__ P) {
     PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
     double ra = 0., rb = 0.;
     if (pi.valid) {
@@ -123,14 +63,14 @@ __global__ __launch_bounds__(256) void lattice_dot_kernel(Geom g, const float *_
             rb = (double)(x.x * F0 + x.y * F1 + x.z * F2);
         }
     }
-    const int slot = blockIdx.x % MCPM_NSLOT;   // spread: one address would serialise the blocks' atomics
-    block_add2(ra, rb, a ? slots + slot : nullptr, b ? slots + MCPM_NSLOT + slot : nullptr);
+    const double v[2] = {ra, rb};
+    block_partial<2>(v, P, gridDim.x, blockIdx.x);      // deterministic: one partial per workgroup, det_fold_kernel adds them up
 }
 
 // Sums of three per-lane values over the 256-thread workgroup (waves in f32 -- the lane values are f32 products already --,
-// the four waves and everything beyond in f64), added to three spread slots; optionally the workgroup maximum of |a|, |b|, |c|
-// (see absmax_commit).  One barrier.
-__device__ __forceinline__ void block_add3_max(float a, float b, float c, double *s0, double *s1, double *s2, float ma, float mb, float mc,
+// the four waves and everything beyond in f64), WRITTEN as this workgroup's partials P[k * nblk + block] (det_fold_kernel adds them
+// up in a fixed order: reduce_dev.h); optionally the workgroup maximum of |a|, |b|, |c| (see absmax_commit).  One barrier.
+__device__ __forceinline__ void block_add3_max(float a, float b, float c, double *__restrict__ P, unsigned nblk, float ma, float mb, float mc,
                                                unsigned *__restrict__ out_max) {
     __shared__ double sh[3][4];
     __shared__ unsigned shm[4];
@@ -149,8 +89,7 @@ __device__ __forceinline__ void block_add3_max(float a, float b, float c, double
     if (threadIdx.x < 3) {
         double t = 0.;
         for (int i = 0; i < nw; ++i) t += sh[threadIdx.x][i];
-        double *dst = threadIdx.x == 0 ? s0 : (threadIdx.x == 1 ? s1 : s2);
-        if (t != 0.) atomicAdd(dst, t);
+        P[(size_t)threadIdx.x * nblk + blockIdx.x] = t;
     } else if (threadIdx.x == 3 && out_max) {
         unsigned mm = 0u;
         for (int i = 0; i < nw; ++i) mm = max(mm, shm[i]);
@@ -186,7 +125,7 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
                                                            const float *xb_src, const float *vb_src, float *xb, float *vb,
                                                            const float *__restrict__ fm, const float *__restrict__ rho_bar,
                                                            int64_t M, float alpha, float beta, float tau,
-                                                           double *slots, float *__restrict__ fb_next, float beta_next,
+                                                           double *__restrict__ part, float *__restrict__ fb_next, float beta_next,
                                                            float tau_next, float dtau_ddg, unsigned *__restrict__ fb_max, int nt) {
     PIdx pi = particle_index<MCPM_POS_LATTICE>(g, 0);
     float ra = 0.f, rb = 0.f, rc = 0.f;
@@ -243,33 +182,14 @@ __global__ __launch_bounds__(256) void step_adjoint_kernel(Geom g, const float *
             else store3(fb_next, pi.i, fbn);
         }
     }
-    const int slot = blockIdx.x % MCPM_NSLOT;
-    block_add3_max(ra, rb, rc, slots + slot, slots + MCPM_NSLOT + slot, slots + 2 * MCPM_NSLOT + slot, fbn.x, fbn.y, fbn.z, fb_max);
+    block_add3_max(ra, rb, rc, part, gridDim.x, fbn.x, fbn.y, fbn.z, fb_max);
 }
 
-// *out += scale * sum_i a[i] b[i]  (a few thousand blocks: spread atomics are not needed)
-__global__ __launch_bounds__(256) void dot_scaled_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n,
-                                                         double scale, double *out) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    double r = i < n ? scale * (double)a[i] * (double)b[i] : 0.;
-    __shared__ double sh[4];
-    r = wave_sum(r);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = r;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = sh[0] + sh[1] + sh[2] + sh[3];
-        if (t != 0.) atomicAdd(out + 1 + (blockIdx.x & 255), t);
-    }
-}
-
-// folds the 256 spread partial sums behind *out into *out
-__global__ void fold256_kernel(double *out) {
-    double t = 0.;
-    for (int i = 0; i < 256; ++i) {
-        t += out[1 + i];
-        out[1 + i] = 0.;
-    }
-    out[0] += t;
+// partials of sum_i a[i] b[i] (det_fold_kernel scales and adds them up)
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n, double *__restrict__ P) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const double v[1] = {i < n ? (double)a[i] * (double)b[i] : 0.};
+    block_partial<1>(v, P, gridDim.x, blockIdx.x);
 }
 
 __global__ void axpby_kernel(const float *__restrict__ x, const float *__restrict__ y, int64_t n, float a, float b,
@@ -294,15 +214,27 @@ static int lattice_scatter(mcpm_plan *p, const float *xb, const float *vb, float
     return MCPM_OK;
 }
 
-// out0 += sum_i a[i].F(q_i), out1 += sum_i b[i].F(q_i) through MCPM_NSLOT spread partial sums
+// adds up the K per-workgroup partials a kernel with `nblk` workgroups left in P (reduce_dev.h): *outs[k] += scale sum (NULL: dropped)
+static int det_fold(mcpm_plan *p, const double *P, double *Q, unsigned *ticket, unsigned R, unsigned nblk, int K, double scale,
+                    double *o0, double *o1 = nullptr, double *o2 = nullptr) {
+    DetOuts o{};
+    o.p[0] = o0, o.p[1] = o1, o.p[2] = o2;
+    o.accumulate = 1;
+    det_fold_kernel<<<R, 256, 0, p->stream>>>(P, nblk, K, Q, ticket, scale, o);
+    MCPM_LAUNCH_CHECK(p, "det_fold_kernel");
+    return MCPM_OK;
+}
+
+// out0 += sum_i a[i].F(q_i), out1 += sum_i b[i].F(q_i), added up in a fixed order (deterministic grid sums, reduce_dev.h)
 static int lattice_dot(mcpm_plan *p, const float *meshes3, const float *a, const float *b, double *out0, double *out1) {
     dim3 grid, block;
     lattice_launch(p->g, grid, block);
-    double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);   // zero on entry, zeroed again by reduce_slots_kernel
-    lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, meshes3, p->M, a, b, slots);
+    double *P, *Q;
+    unsigned *ticket, R;
+    MCPM_TRY(mcpm_det_scratch(p, 2, grid.x, &P, &Q, &ticket, &R));
+    lattice_dot_kernel<<<grid, block, 0, p->stream>>>(p->g, meshes3, p->M, a, b, P);
     MCPM_LAUNCH_CHECK(p, "lattice_dot_kernel");
-    reduce_slots_kernel<<<1, MCPM_NSLOT, 0, p->stream>>>(slots, a ? out0 : nullptr, b ? out1 : nullptr, nullptr);
-    MCPM_LAUNCH_CHECK(p, "reduce_slots_kernel");
+    MCPM_TRY(det_fold(p, P, Q, ticket, R, grid.x, 2, 1.0, a ? out0 : nullptr, b ? out1 : nullptr));
     return MCPM_OK;
 }
 
@@ -693,12 +625,14 @@ static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float
     unsigned *fb_max = (fb_next && p->paint3_variant == 4) ? p->fx_wmax : nullptr;
     static const int ntp_env = [] { const char *e = getenv("MCPM_NT_PART"); return e ? atoi(e) : 3; }();     // streaming loads / stores: 2.80 -> 2.62 ms at 512^3
     const int ntp = N < ((int64_t)1 << 23) ? 0 : ntp_env;      // not for problems that live in the caches
-    double *slots = p->reduce + (MCPM_NREDUCE - 3 * MCPM_NSLOT);   // zero on entry (reduce_slots_kernel leaves them so)
+    double *P, *Q;      // this launch's per-workgroup partials of (alpha_bar, beta_bar, dg_bar)
+    unsigned *ticket, R;
+    MCPM_TRY(mcpm_det_scratch(p, 3, grid.x, &P, &Q, &ticket, &R));
 #define ADJ(OR)                                                                                                                   \
     if (layout) step_adjoint_kernel<OR, true><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar_src, vel_bar_src, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
-                                                           slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max, ntp);  \
+                                                           P, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max, ntp);  \
     else step_adjoint_kernel<OR, false><<<grid, block, 0, p->stream>>>(p->g, pos_in, vel_in, pos_bar_src, vel_bar_src, pos_bar, vel_bar, force_meshes, rho_bar, M, a, b, t, \
-                                                           slots, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max, ntp)
+                                                           P, fb_next, p->hint_beta, p->hint_tau, (float)dtau_ddg, fb_max, ntp)
     if (paint_order == 2) ADJ(2);
     else if (paint_order == 1) ADJ(1);
     else if (paint_order == 3) ADJ(3);
@@ -706,10 +640,7 @@ static int step_adjoint_particles(mcpm_plan *p, const float *pos_in, const float
 #undef ADJ
     MCPM_LAUNCH_CHECK(p, "step_adjoint_kernel");
     if (alpha_bar || beta_bar || dg_bar) {
-        reduce_slots_kernel<<<1, MCPM_NSLOT, 0, p->stream>>>(slots, alpha_bar, beta_bar, dg_bar);
-        MCPM_LAUNCH_CHECK(p, "reduce_slots_kernel");
-    } else {
-        MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * 3 * MCPM_NSLOT, p->stream));
+        MCPM_TRY(det_fold(p, P, Q, ticket, R, grid.x, 3, 1.0, alpha_bar, beta_bar, dg_bar));
     }
     return MCPM_OK;
 }
@@ -873,7 +804,7 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, init_mesh && alpha && beta && lpt_scalars && ckpt && pos_bar && vel_bar && init_mesh_bar, MCPM_E_ARG,
                  "mcpm_nbody_bf_vjp_f32: null argument");
-    MCPM_REQUIRE(p, n_steps >= 1 && 2 * n_steps + 4 + 256 <= MCPM_NREDUCE - 3 * MCPM_NSLOT, MCPM_E_ARG, "mcpm_nbody_bf_vjp_f32: bad n_steps");
+    MCPM_REQUIRE(p, n_steps >= 1 && 2 * n_steps + 4 <= MCPM_NREDUCE, MCPM_E_ARG, "mcpm_nbody_bf_vjp_f32: bad n_steps");
     MCPM_REQUIRE(p, paint_order >= 1 && paint_order <= 4, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: paint_order must be 1..4");
     MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_vjp_f32: lpt_order must be 1 or 2");
     const int64_t N = p->Np, M = p->M;
@@ -896,9 +827,12 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     // initial half drift x'_0 = x_0 + v_0 dg/2 (its explicit dg dependence: <x_bar, v_0> / 2)
     {
         unsigned nbk = (unsigned)((3 * N + 255) / 256);
-        dot_scaled_kernel<<<nbk, 256, 0, p->stream>>>(xb, state_v(0), 3 * N, 0.5, p->reduce + 2 * n_steps + 3);
-        fold256_kernel<<<1, 1, 0, p->stream>>>(p->reduce + 2 * n_steps + 3);
-        MCPM_LAUNCH_CHECK(p, "dot_scaled_kernel");
+        double *P, *Q;
+        unsigned *ticket, R;
+        MCPM_TRY(mcpm_det_scratch(p, 1, nbk, &P, &Q, &ticket, &R));
+        dot_partial_kernel<<<nbk, 256, 0, p->stream>>>(xb, state_v(0), 3 * N, P);
+        MCPM_LAUNCH_CHECK(p, "dot_partial_kernel");
+        MCPM_TRY(det_fold(p, P, Q, ticket, R, nbk, 1, 0.5, p->reduce + 2 * n_steps + 3));
     }
     MCPM_TRY(axpby(p, vb, xb, 3 * N, 1.f, (float)(dg / 2), vb));
 

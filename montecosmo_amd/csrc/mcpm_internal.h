@@ -122,6 +122,8 @@ struct mcpm_plan {
     // measures the candidates on the caller's buffer; mcpm_plan_set_particle_pitch fixes one.
     int64_t ppitch;
     float *vscratch;  // variable-size particle scratch (pm_forces_vjp)
+    double *part;     // per-workgroup partial sums of the deterministic grid reductions (reduce_dev.h), allocated on first use
+    int64_t part_n;
     int64_t vscratch_n;
     float *tw[3];    // twiddle tables exp(-2 pi i j / n) of the hand-written FFT, per axis (x, y, z)
 
@@ -166,6 +168,9 @@ struct StageTimer {
 extern thread_local std::string g_mcpm_create_error;
 
 int mcpm_fail(mcpm_plan *plan, int code, const std::string &msg);
+// Scratch of one deterministic grid reduction (reduce_dev.h): K values from nblk workgroups.  *P: K * nblk partials, *Q: K * R second-level
+// sums, *ticket: zero between launches; *R: workgroups of det_fold_kernel.  (plan.hip)
+int mcpm_det_scratch(mcpm_plan *p, int K, unsigned nblk, double **P, double **Q, unsigned **ticket, unsigned *R);
 void mcpm_slab_state_free(mcpm_plan *p);   // slab.hip
 #define MCPM_PITCH_MAX_SHIFT 17472      // floats: 64 KB + 4 KB + 256 B, the largest candidate shift between particle arrays
 static inline int64_t mcpm_pitch_max(const mcpm_plan *p) { return 3 * p->Np + MCPM_PITCH_MAX_SHIFT; }

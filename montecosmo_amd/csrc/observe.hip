@@ -128,7 +128,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void observe_vjp_kernel(Geom g, Obs og, Tables tb, const float *__restrict__ pos,
                                                           const float *__restrict__ vel, const float *__restrict__ dvel, int64_t n,
                                                           const float *__restrict__ ob, float *__restrict__ pos_bar,
-                                                          float *__restrict__ vel_bar, float *__restrict__ dvel_bar, double *slots) {
+                                                          float *__restrict__ vel_bar, float *__restrict__ dvel_bar, double *part) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double red[1] = {0.};
     if (i < n) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void observe_vjp_kernel(Geom g, Obs og, Tables
         for (int a = 0; a < 3; ++a) pos_bar[3 * i + a] = o[a] * (og.ce[a] / og.cp[a]) + xt[a] * og.ce[a];
         red[0] = og.lightcone ? 0. : (double)gfb;
     }
-    block_add<1>(red, slots);
+    block_partial<1>(red, part, gridDim.x, blockIdx.x);
 }
 
 
@@ -439,15 +439,16 @@ int mcpm_observe_pos_vjp_f32(mcpm_plan *p, const float *pos, const float *vel, c
     Obs og = make_obs(p, geom, flags, nchi, ngrow);
     Tables tb{tables, tables ? tables + nchi : nullptr, tables ? tables + 2 * nchi : nullptr,
               tables ? tables + 2 * nchi + ngrow : nullptr, tables ? tables + 2 * nchi + 2 * ngrow : nullptr};
-    double *slots = p->reduce;
+    double *P, *Q;
+    unsigned *ticket, R;
     const unsigned nb = (unsigned)((n + 255) / 256);
     StageTimer st_(p, ST_LPT, (dvel ? 84.0 : 60.0) * n);
-    MCPM_HIP(p, hipMemsetAsync(slots, 0, sizeof(double) * NSLOT, p->stream));
+    MCPM_TRY(mcpm_det_scratch(p, 1, nb, &P, &Q, &ticket, &R));
     if (mode == MCPM_POS_LATTICE)
-        observe_vjp_kernel<MCPM_POS_LATTICE><<<nb, 256, 0, p->stream>>>(p->g, og, tb, pos, vel, dvel, n, out_bar, pos_bar, vel_bar, dvel_bar, slots);
+        observe_vjp_kernel<MCPM_POS_LATTICE><<<nb, 256, 0, p->stream>>>(p->g, og, tb, pos, vel, dvel, n, out_bar, pos_bar, vel_bar, dvel_bar, P);
     else
-        observe_vjp_kernel<MCPM_POS_ABSOLUTE><<<nb, 256, 0, p->stream>>>(p->g, og, tb, pos, vel, dvel, n, out_bar, pos_bar, vel_bar, dvel_bar, slots);
-    fold_kernel<<<1, NSLOT, 0, p->stream>>>(slots, 1, 1.0, gf_bar);
+        observe_vjp_kernel<MCPM_POS_ABSOLUTE><<<nb, 256, 0, p->stream>>>(p->g, og, tb, pos, vel, dvel, n, out_bar, pos_bar, vel_bar, dvel_bar, P);
+    det_fold_kernel<<<R, 256, 0, p->stream>>>(P, nb, 1, Q, ticket, 1.0, det_outs(gf_bar));
     MCPM_LAUNCH_CHECK(p, "observe_vjp_kernel");
     return MCPM_OK;
 }

@@ -137,6 +137,8 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->reduce = nullptr;
     p->pscratch = nullptr;
     p->ppitch = 0;
+    p->part = nullptr;
+    p->part_n = 0;
     p->vscratch = nullptr;
     p->vscratch_n = 0;
     p->tw[0] = p->tw[1] = p->tw[2] = nullptr;
@@ -215,6 +217,7 @@ int mcpm_plan_destroy(mcpm_plan *p) {
     (void)hipFree(p->gx_wmax);
     (void)hipFree(p->reduce);
     (void)hipFree(p->pscratch);
+    (void)hipFree(p->part);
     (void)hipFree(p->vscratch);
     for (int a = 0; a < 3; ++a) (void)hipFree(p->tw[a]);
     delete p;
@@ -241,6 +244,32 @@ int mcpm_plan_set_centre(mcpm_plan *p, int centre) {
     p->centre = centre ? 1 : 0;
     return MCPM_OK;
 }
+
+}  // extern "C"
+
+int mcpm_det_scratch(mcpm_plan *p, int K, unsigned nblk, double **P, double **Q, unsigned **ticket, unsigned *R) {
+    const unsigned r = std::max(1u, std::min(256u, (nblk + 255u) / 256u));
+    // [ticket (one double slot, kept zero)] [Q: K * 256] [P: K * nblk]
+    const int64_t need = 1 + (int64_t)K * 256 + (int64_t)K * nblk;
+    if (p->part_n < need) {
+        if (p->part) {
+            MCPM_HIP(p, hipStreamSynchronize(p->stream));
+            (void)hipFree(p->part);
+            p->part = nullptr;
+        }
+        const int64_t n = need + need / 4;
+        if (hipMalloc((void **)&p->part, sizeof(double) * n) != hipSuccess) return mcpm_fail(p, MCPM_E_NOMEM, "reduction scratch");
+        p->part_n = n;
+        MCPM_HIP(p, hipMemsetAsync(p->part, 0, sizeof(double), p->stream));
+    }
+    *ticket = reinterpret_cast<unsigned *>(p->part);
+    *Q = p->part + 1;
+    *P = p->part + 1 + (int64_t)K * 256;
+    *R = r;
+    return MCPM_OK;
+}
+
+extern "C" {
 
 int mcpm_plan_last_bucketed(mcpm_plan *p, int64_t *count) {
     if (!p || !count) return MCPM_E_ARG;

@@ -1,9 +1,7 @@
-// Block / grid reductions in f64 shared by the model-side kernels (bias.hip, observe.hip): per-block sums are added to
-// NSLOT spread slots (one address would serialise at the memory-side atomic unit), then folded by one block.
+// Block / grid reductions in f64 shared by the adjoint kernels (composite.hip, bias.hip, observe.hip): every workgroup writes its
+// partial sums, det_fold_kernel adds them up in a fixed order (see DETERMINISTIC GRID SUMS below).
 #pragma once
 #include <hip/hip_runtime.h>
-
-#define NSLOT 256
 
 namespace {
 
@@ -26,9 +24,13 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// adds the block's sum of each of the K values to slots[k * NSLOT + blockIdx.x % NSLOT]
+// DETERMINISTIC GRID SUMS (round 4).  Round 3 added every workgroup's float64 partial to one of NSLOT spread slots with atomicAdd: several
+// workgroups per slot, in arrival order, so the last bit of a scalar cotangent moved from call to call (4e-16 .. 7e-16 relative; invisible at
+// the float32 the samplers carry, visible to a float64 equality).  Now every workgroup WRITES its partials (fixed tree inside the
+// workgroup) to P[k * nblk + block], and det_fold_kernel adds them up in a fixed order: R workgroups each sum a contiguous range of P into
+// Q[k * R + r], the last one to finish (an integer ticket) sums Q in index order.  No floating-point atomic is left on the gradient path.
 template <int K>
-__device__ __forceinline__ void block_add(const double (&v)[K], double *slots) {
+__device__ __forceinline__ void block_partial(const double (&v)[K], double *__restrict__ P, unsigned nblk, unsigned blk) {
     __shared__ double sh[K][4];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -37,26 +39,52 @@ __device__ __forceinline__ void block_add(const double (&v)[K], double *slots) {
     }
     __syncthreads();
     if (threadIdx.x < K) {
-        const double t = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
-        if (t != 0.) atomicAdd(slots + threadIdx.x * NSLOT + (blockIdx.x % NSLOT), t);
+        const int nw = (blockDim.x + 63) >> 6;
+        double t = 0.;
+        for (int w = 0; w < nw; ++w) t += sh[threadIdx.x][w];
+        P[(size_t)threadIdx.x * nblk + blk] = t;
     }
 }
 
-// out[k] = scale * sum of slot row k
-__global__ __launch_bounds__(NSLOT) void fold_kernel(const double *__restrict__ slots, int K, double scale, double *out) {
-    __shared__ double sh[NSLOT / 64];
+struct DetOuts {
+    double *p[10];      // destination of value k (NULL: dropped)
+    int accumulate;     // 1: *p[k] += scale sum, 0: *p[k] = scale sum
+};
+__host__ inline DetOuts det_outs(double *o0) {      // one value, stored (not accumulated)
+    DetOuts o{};
+    o.p[0] = o0;
+    return o;
+}
+// scratch behind P: Q (K * R doubles) and the ticket (one unsigned, zero between launches)
+__global__ __launch_bounds__(256) void det_fold_kernel(const double *__restrict__ P, unsigned nblk, int K, double *Q, unsigned *ticket, double scale,
+                                                       DetOuts o) {
+    const unsigned R = gridDim.x, r = blockIdx.x, C = (nblk + R - 1) / R, lo = r * C, hi = min(lo + C, nblk);
+    __shared__ double sh[4];
+    __shared__ int last;
     for (int k = 0; k < K; ++k) {
-        const double s = wave_sum(slots[k * NSLOT + threadIdx.x]);
-        if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = s;
+        double t = 0.;
+        for (unsigned i = lo + threadIdx.x; i < hi; i += 256) t += P[(size_t)k * nblk + i];
+        t = wave_sum(t);
+        if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = t;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.;
-            for (int i = 0; i < NSLOT / 64; ++i) t += sh[i];
-            out[k] = scale * t;
-        }
+        if (threadIdx.x == 0) Q[(size_t)k * R + r] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
         __syncthreads();
     }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == R - 1u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if ((int)threadIdx.x < K) {
+        const volatile double *q = Q + (size_t)threadIdx.x * R;
+        double t = 0.;
+        for (unsigned i = 0; i < R; ++i) t += q[i];
+        double *dst = o.p[threadIdx.x];
+        if (dst) *dst = (o.accumulate ? *dst : 0.) + scale * t;
+    }
+    if (threadIdx.x == 0) *ticket = 0u;
 }
-
 
 }  // namespace

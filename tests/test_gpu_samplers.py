@@ -57,6 +57,13 @@ def test_log_density_and_gradient_are_bitwise_reproducible(gpu):
         for _ in range(60):
             lp, g = flat(q)
             assert lp == lp0 and torch.equal(g, g0)
+        # ... and the float64 scalar cotangents before they are packed to float32: float64 sums of per-workgroup partials, added up in a
+        # fixed order (reduce_dev.h; added with float64 atomics until round 4, their last bit moved in about one call in four)
+        sample = flat.unpack(q)
+        _, d0 = flat.ld.logdensity_and_grad(sample)
+        for _ in range(40):
+            _, d = flat.ld.logdensity_and_grad(sample)
+            assert all(np.array_equal(np.asarray(d[k]), np.asarray(d0[k])) for k in flat.scalars)
 
 
 def test_nuts_chain_over_the_hip_log_density(gpu):
