@@ -19,6 +19,7 @@ python3 bench.py --mesh 256 --no-cpu-baseline > $O/bench256.json 2>> $O/bench.er
 python3 bench.py --mesh 128 --no-cpu-baseline > $O/bench128.json 2>> $O/bench.err && \
 python3 bench.py --mesh 256 --forward-only --no-cpu-baseline > $O/bench256_fwd.json 2>> $O/bench.err && \
 python3 bench.py --mesh 128 --forward-only --no-cpu-baseline > $O/bench128_fwd.json 2>> $O/bench.err && \
-python3 bench.py --force-slab --no-cpu-baseline > $O/bench512_slab1.json 2>> $O/bench.err; echo rc=$?
+python3 bench.py --force-slab --no-cpu-baseline > $O/bench512_slab1.json 2>> $O/bench.err && \
+(python3 tools/halo_tiles.py 512 && python3 tools/halo_tiles.py 256) > $O/halo_tiles.txt 2>> $O/bench.err; echo rc=$?
 # the raw counter csv files are large: keep the summaries only
 rm -rf $O/pmc_fetch512 $O/pmc_write512 $O/pmc_fetch256 $O/pmc_write256 $O/stats512/*trace.csv $O/stats256/*trace.csv $O/stats128/*trace.csv
