@@ -1230,7 +1230,8 @@ static int halo_of(const mcpm_plan *p) {
     const int64_t ntiles = p->M / (MCPM_TILE * MCPM_TILE * MCPM_TILE);
     static const int slab_too = [] { const char *e = getenv("MCPM_PAINT_ADAPT_SLAB"); return e ? atoi(e) : 1; }();
     // (the per-tile halos ride in the offset words of centred windows: p->centre)
-    return (adapt && (slab_too || !p->g.xslab) && p->halo_sel && p->centre && ntiles >= 2048) ? 0 : mcpm_default_halo(p->M);
+    static const int min_tiles = [] { const char *e = getenv("MCPM_PAINT_ADAPT_MIN_TILES"); return e ? atoi(e) : 2048; }();
+    return (adapt && (slab_too || !p->g.xslab) && p->halo_sel && p->centre && ntiles >= min_tiles) ? 0 : mcpm_default_halo(p->M);
 }
 
 static TileLists tile_lists(const mcpm_plan *p) {

@@ -248,9 +248,9 @@ int mcpm_plan_set_centre(mcpm_plan *p, int centre) {
 }  // extern "C"
 
 int mcpm_det_scratch(mcpm_plan *p, int K, unsigned nblk, double **P, double **Q, unsigned **ticket, unsigned *R) {
-    const unsigned r = std::max(1u, std::min(256u, (nblk + 255u) / 256u));
-    // [ticket (one double slot, kept zero)] [Q: K * 256] [P: K * nblk]
-    const int64_t need = 1 + (int64_t)K * 256 + (int64_t)K * nblk;
+    const unsigned r = std::max(1u, std::min(1024u, (nblk + 255u) / 256u));      // <= 1024: four values per lane in the last stage
+    // [ticket (one double slot, kept zero)] [Q: K * 1024] [P: K * nblk]
+    const int64_t need = 1 + (int64_t)K * 1024 + (int64_t)K * nblk;
     if (p->part_n < need) {
         if (p->part) {
             MCPM_HIP(p, hipStreamSynchronize(p->stream));
@@ -264,7 +264,7 @@ int mcpm_det_scratch(mcpm_plan *p, int K, unsigned nblk, double **P, double **Q,
     }
     *ticket = reinterpret_cast<unsigned *>(p->part);
     *Q = p->part + 1;
-    *P = p->part + 1 + (int64_t)K * 256;
+    *P = p->part + 1 + (int64_t)K * 1024;
     *R = r;
     return MCPM_OK;
 }

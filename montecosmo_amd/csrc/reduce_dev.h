@@ -28,7 +28,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // workgroups per slot, in arrival order, so the last bit of a scalar cotangent moved from call to call (4e-16 .. 7e-16 relative; invisible at
 // the float32 the samplers carry, visible to a float64 equality).  Now every workgroup WRITES its partials (fixed tree inside the
 // workgroup) to P[k * nblk + block], and det_fold_kernel adds them up in a fixed order: R workgroups each sum a contiguous range of P into
-// Q[k * R + r], the last one to finish (an integer ticket) sums Q in index order.  No floating-point atomic is left on the gradient path.
+// Q[k * R + r], the last one to finish (an integer ticket) sums Q with the same fixed tree.  No floating-point atomic is left on the gradient path.
 template <int K>
 __device__ __forceinline__ void block_partial(const double (&v)[K], double *__restrict__ P, unsigned nblk, unsigned blk) {
     __shared__ double sh[K][4];
@@ -55,21 +55,23 @@ __host__ inline DetOuts det_outs(double *o0) {      // one value, stored (not ac
     o.p[0] = o0;
     return o;
 }
-// scratch behind P: Q (K * R doubles) and the ticket (one unsigned, zero between launches)
+// scratch behind P: Q (K * R doubles) and the ticket (one unsigned, zero between launches).  K <= 10, R <= 1024.
+// (The last workgroup's sum over Q is a fixed TREE over 256 lanes, not a serial loop: 256 dependent-latency loads by one lane cost
+// 43 us at 256^3 and 55 us at 512^3 -- `profiles/r04_kernel_stats_*.csv` of the first version -- against 5 us for everything else.)
 __global__ __launch_bounds__(256) void det_fold_kernel(const double *__restrict__ P, unsigned nblk, int K, double *Q, unsigned *ticket, double scale,
                                                        DetOuts o) {
     const unsigned R = gridDim.x, r = blockIdx.x, C = (nblk + R - 1) / R, lo = r * C, hi = min(lo + C, nblk);
-    __shared__ double sh[4];
+    __shared__ double sh[10][4];
     __shared__ int last;
     for (int k = 0; k < K; ++k) {
         double t = 0.;
         for (unsigned i = lo + threadIdx.x; i < hi; i += 256) t += P[(size_t)k * nblk + i];
         t = wave_sum(t);
-        if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = t;
-        __syncthreads();
-        if (threadIdx.x == 0) Q[(size_t)k * R + r] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-        __syncthreads();
+        if ((threadIdx.x & 63) == 63) sh[k][threadIdx.x >> 6] = t;
     }
+    __syncthreads();
+    if ((int)threadIdx.x < K) Q[(size_t)threadIdx.x * R + r] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+    __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
         last = atomicAdd(ticket, 1u) == R - 1u;
@@ -77,10 +79,15 @@ __global__ __launch_bounds__(256) void det_fold_kernel(const double *__restrict_
     __syncthreads();
     if (!last) return;
     __threadfence();
-    if ((int)threadIdx.x < K) {
-        const volatile double *q = Q + (size_t)threadIdx.x * R;
+    for (int k = 0; k < K; ++k) {      // lane i holds Q[k][i] (+ Q[k][i + 256] ..., in that order); the same DPP tree and wave order as above
         double t = 0.;
-        for (unsigned i = 0; i < R; ++i) t += q[i];
+        for (unsigned i = threadIdx.x; i < R; i += 256) t += __hip_atomic_load(Q + (size_t)k * R + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = wave_sum(t);
+        if ((threadIdx.x & 63) == 63) sh[k][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < K) {
+        const double t = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
         double *dst = o.p[threadIdx.x];
         if (dst) *dst = (o.accumulate ? *dst : 0.) + scale * t;
     }
