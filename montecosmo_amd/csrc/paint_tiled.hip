@@ -44,8 +44,6 @@ __device__ __forceinline__ void unpack_off(int v, int &ox, int &oy, int &oz) {
     oy = (int)(signed char)((v >> 8) & 0xff);
     oz = (int)(signed char)((v >> 16) & 0xff);
 }
-// byte 3 of a tile's packed word: the window halo H of THAT tile (per-tile choice, finding 43); 0 = not set
-__device__ __forceinline__ int word_halo(int v) { return (v >> 24) & 0xff; }
 __device__ __forceinline__ int pymod(int a, int n) {
     int r = a % n;
     return r < 0 ? r + n : r;
@@ -93,8 +91,8 @@ __device__ __forceinline__ void tile_of_block(int ntx, int nty, int ntz, int &tx
 // Prologue of every tiled paint, one launch: resets the bucket counts and the per-paint counters, and (toff != NULL) sets
 // o_T = rounded mean displacement of 64 lattice points (four z rows) of the Lagrangian block at tile T.
 __global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float *__restrict__ disp, int *__restrict__ toff,
-                                                            int *__restrict__ bcnt, int *__restrict__ cnts, int ntiles, int maxoff,
-                                                            int *__restrict__ redo, int *__restrict__ rng) {
+                                                            int *__restrict__ thi, int *__restrict__ bcnt, int *__restrict__ cnts, int ntiles,
+                                                            int maxoff, int *__restrict__ redo, int *__restrict__ rng, int hfix) {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x < 8 && threadIdx.x != C_LAST && threadIdx.x != C_OOB) cnts[threadIdx.x] = 0;
     if (redo && blockIdx.x == 0 && threadIdx.x == 8) redo[0] = 0;   // empty list of tiles for the f64 repaint (paint3)
@@ -118,8 +116,13 @@ __global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float 
     }
     if (lane == 0) {
         const float m = (float)maxoff;   // fmaxf / fminf return the non-NaN operand: a NaN mean gives a finite offset
-        toff[tile] = pack_off((int)rintf(fminf(fmaxf(sx * (1.f / 64.f), -m), m)), (int)rintf(fminf(fmaxf(sy * (1.f / 64.f), -m), m)),
-                              (int)rintf(fminf(fmaxf(sz * (1.f / 64.f), -m), m)));
+        const int o0 = (int)rintf(fminf(fmaxf(sx * (1.f / 64.f), -m), m)), o1 = (int)rintf(fminf(fmaxf(sy * (1.f / 64.f), -m), m)),
+                  o2 = (int)rintf(fminf(fmaxf(sz * (1.f / 64.f), -m), m));
+        if (rng) toff[tile] = pack_off(o0, o1, o2);      // box_tile_kernel turns it into the window's lower corner
+        else {      // a fixed halo: the window [o - H, o + H] per axis
+            toff[tile] = pack_off(o0 - hfix, o1 - hfix, o2 - hfix);
+            thi[tile] = pack_off(o0 + hfix, o1 + hfix, o2 + hfix);
+        }
     }
     if (!rng) return;
     // range of floor(d) over the same 64 samples, per axis (clamped to +-100; a NaN sample widens it to the clamp): what
@@ -147,16 +150,18 @@ __global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float 
 }
 
 // ------------------------------------------------------------------------------------------------
-// The window halo, chosen on the device for every input AND EVERY TILE (DESIGN findings 31, 43).  Every cell of halo costs window
-// visits ((16 + 2H + 1)^3 per tile), every particle a window misses costs the exact coverage test and a bucket deposit.  A particle
-// with floor(d) = fd lands in tile T inside T's window iff |fd_a - o_T,a| <= H_T on every axis, and the particles that land in T come
-// from the 27 Lagrangian blocks around it: H_T = the largest |fd - o_T| over the SAMPLED ranges of those blocks (tile_prologue_kernel:
-// 64 samples each), clamped to the instantiated halos 1 .. 4.  Round 3 chose ONE halo per input from the share of unsure samples
-// over the whole mesh (at most 4 %), so the roughest few per cent of the field set the window of every tile: 256^3 evolved
-// particles painted at H = 4 (3.8 window visits per particle) although most tiles need 2 or 3.  What the samples miss goes the way
-// of everything a window misses (suspects -> exact test -> buckets).  Same input, same halos: results stay bitwise reproducible, and
-// the host is not involved.  The halo rides in byte 3 of the tile's packed offset word.
-__global__ __launch_bounds__(256) void halo_tile_kernel(Geom g, int *__restrict__ toff, const int *__restrict__ rng, int ntiles) {
+// The WINDOW of every tile, chosen on the device for every input (DESIGN findings 31, 43, 46).  A particle with floor(d) = fd that lands in
+// tile T sits at the lattice point T + c - fd (c in [-1, 15] its base cell within T), so the lattice points T needs are, per axis,
+// [T - 1 - max fd, T + 15 - min fd] over the particles that land in it -- and those come from the 27 Lagrangian blocks around it.  The window
+// is that box for [lo_a, hi_a] = the hull of the SAMPLED floor(d) ranges of those blocks (tile_prologue_kernel: 64 samples each):
+// 17 + hi_a - lo_a points along axis a.  Round 3 chose ONE symmetric halo H per input ((16 + 2H + 1)^3 points for every tile) and the first
+// version of round 4 one H per tile around the block's mean offset o_T (H_T = max |fd - o_T|): a box per axis is 17-26 % smaller still
+// (`tools/window_extents.py`: 1.86 instead of 2.46 window visits per particle on the evolved 512^3 state), because the ranges are neither
+// centred on the mean nor equally wide along the three axes.  Extents above 8 (a symmetric halo of 4) are cut back around o_T; what the
+// samples or the cut miss goes the way of everything a window misses (suspects -> exact test -> buckets).  Same input, same windows:
+// results stay bitwise reproducible, and the host is not involved.  lo rides in the tile's packed offset word, hi in `thi`.
+__global__ __launch_bounds__(256) void box_tile_kernel(Geom g, int *__restrict__ toff, int *__restrict__ thi, const int *__restrict__ rng,
+                                                       int ntiles, int maxabs) {
     const int tile = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
     if (tile >= ntiles) return;      // (whole 16-lane groups leave together; the shuffles below stay within a group)
     const int ntz = g.nz / MCPM_TILE, nty = g.ny / MCPM_TILE, ntx = g.nx / MCPM_TILE;
@@ -184,13 +189,16 @@ __global__ __launch_bounds__(256) void halo_tile_kernel(Geom g, int *__restrict_
             hi[c] = max(hi[c], __shfl_xor(hi[c], m));
         }
     if (l16 == 0) {
-        const int w = toff[tile];
         int o[3];
-        unpack_off(w, o[0], o[1], o[2]);
-        int need = 0;
+        unpack_off(toff[tile], o[0], o[1], o[2]);      // the block's mean offset (tile_prologue_kernel)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) need = max(need, max(hi[c] - o[c], o[c] - lo[c]));
-        toff[tile] = (w & 0xffffff) | (min(max(need, 1), 4) << 24);
+        for (int c = 0; c < 3; ++c) {
+            if (hi[c] - lo[c] > 8) lo[c] = max(lo[c], o[c] - 4), hi[c] = min(hi[c], o[c] + 4);
+            lo[c] = min(max(lo[c], -maxabs), maxabs);
+            hi[c] = max(min(max(hi[c], -maxabs), maxabs), lo[c]);
+        }
+        toff[tile] = pack_off(lo[0], lo[1], lo[2]);
+        thi[tile] = pack_off(hi[0], hi[1], hi[2]);
     }
 }
 
@@ -219,7 +227,8 @@ __device__ __forceinline__ TScale tile_scale(const unsigned *__restrict__ wmax_b
 // ------------------------------------------------------------------------------------------------
 // lists shared by the kernels below
 struct TileLists {
-    const int *toff;   // packed window offsets per tile
+    const int *toff;   // per tile: the lower corner (lo_x, lo_y, lo_z) of its window's floor(d) box, packed (NULL: every window is +-hfix)
+    const int *thi;    // ... and the upper corner
     int *bcnt;         // bucket fill counts per tile (zeroed by the host before the paint)
     int *bucket;       // [tile][cap] particle indices
     int cap;
@@ -230,39 +239,37 @@ struct TileLists {
     int listcap;
     int *cnts;
     int order;         // order of the tile pencils within an XCD's slab (tile_of_block)
-    int hfix;          // window halo H of this paint if > 0, else the one halo_tile_kernel left in byte 3 of every tile's word
+    int hfix;          // toff == NULL (uncentred windows): the box is [-hfix, hfix] per axis for every tile
 };
 
-// the window halo of tile `word` in this launch
-__device__ __forceinline__ int tile_halo(const TileLists &L, int word) { return L.hfix > 0 ? L.hfix : word_halo(word); }
-// the tile of this workgroup's window walk and its halo (wave-uniform)
-__device__ __forceinline__ int block_halo(const Geom &g, const TileLists &L, int tile_index = -1) {
-    if (L.hfix > 0) return L.hfix;
-    if (tile_index < 0) {
-        int tx, ty, tz;
-        const int ntx = g.nx / MCPM_TILE, nty = g.ny / MCPM_TILE, ntz = g.nz / MCPM_TILE;
-        tile_of_block(ntx, nty, ntz, tx, ty, tz, L.order);
-        tile_index = (tx * nty + ty) * ntz + tz;
+// The window of a tile as the box of floor(d) values it serves: a particle with floor(d) = fd landing in the tile lies in the window iff
+// lo_a <= fd_a <= hi_a on every axis; the window's lattice points relative to the tile origin are r_a in [-1 - hi_a, 15 - lo_a].
+struct Box {
+    int lo[3], hi[3];
+};
+__device__ __forceinline__ Box tile_box(const TileLists &L, int tile_index) {
+    Box b;
+    if (L.toff) {
+        unpack_off(L.toff[tile_index], b.lo[0], b.lo[1], b.lo[2]);
+        unpack_off(L.thi[tile_index], b.hi[0], b.hi[1], b.hi[2]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b.lo[c] = -L.hfix, b.hi[c] = L.hfix;
     }
-    return __builtin_amdgcn_readfirstlane(word_halo(L.toff[tile_index]));
+    return b;
 }
-// kernels are instantiated for a fixed halo (HA = HB = HC) or for the four candidates HA, HB, HC, HC + 1 (= 1, 2, 3, 4 when every
-// tile's halo is chosen on the device) and branch once per workgroup, uniformly
-#define HALO_SWITCH(Hrt, CALL)            \
-    do {                                  \
-        if (HA == HC) {                   \
-            CALL(HA);                     \
-        } else if ((Hrt) == HA) {         \
-            CALL(HA);                     \
-        } else if ((Hrt) == HB) {         \
-            CALL(HB);                     \
-        } else if ((Hrt) == HC) {         \
-            CALL(HC);                     \
-        } else {                          \
-            constexpr int HD_ = HC + 1;   \
-            CALL(HD_);                    \
-        }                                 \
-    } while (0)
+// the same for the tile of a workgroup's window walk: wave-uniform, in scalar registers
+__device__ __forceinline__ Box block_box(const TileLists &L, int tile_index) {
+    Box b;
+    if (L.toff) {
+        unpack_off(__builtin_amdgcn_readfirstlane(L.toff[tile_index]), b.lo[0], b.lo[1], b.lo[2]);
+        unpack_off(__builtin_amdgcn_readfirstlane(L.thi[tile_index]), b.hi[0], b.hi[1], b.hi[2]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b.lo[c] = -L.hfix, b.hi[c] = L.hfix;
+    }
+    return b;
+}
 
 __device__ __forceinline__ void append_wild(const TileLists &L, int gi) {
     const int k = atomicAdd(L.cnts + C_WILD, 1);
@@ -296,7 +303,7 @@ __device__ __forceinline__ void flush_suspects(const TileLists &L, int *sus) {
 // f(tile index, base cell relative to that tile's origin) is called for each such tile.
 template <class F>
 __device__ __forceinline__ void for_uncovered(const Geom &g, const TileLists &L, int tx, int ty, int tz, int ntx, int nty, int ntz,
-                                              int oself, int rx, int ry, int rz, int ix, int iy, int iz, F f) {
+                                              const Box &self, int rx, int ry, int rz, int ix, int iy, int iz, F f) {
     const int cx = rx + ix, cy = ry + iy, cz = rz + iz;
     const int d0x = cx >> 4, d0y = cy >> 4, d0z = cz >> 4, mx = cx & 15, my = cy & 15, mz = cz & 15;
     const int nax = mx == 15 ? 2 : 1, nay = my == 15 ? 2 : 1, naz = mz == 15 ? 2 : 1;
@@ -314,12 +321,10 @@ __device__ __forceinline__ void for_uncovered(const Geom &g, const TileLists &L,
                 const int dtz = d0z + e, rlz = e ? -1 - iz : mz - iz;
                 const int Tz = pymod(tz + dtz, ntz);
                 const int tidx = (Tx * nty + Ty) * ntz + Tz;
-                int ox, oy, oz;
-                const int word = (dtx | dty | dtz) == 0 || !L.toff ? oself : L.toff[tidx];
-                unpack_off(word, ox, oy, oz);
-                const int H = tile_halo(L, word);          // the halo of the tile that would have to pull this particle
-                const unsigned W = (unsigned)(MCPM_TILE + 2 * H + 1);
-                const bool covered = (unsigned)(rlx + ox + H + 1) < W && (unsigned)(rly + oy + H + 1) < W && (unsigned)(rlz + oz + H + 1) < W;
+                const Box bx = (dtx | dty | dtz) == 0 || !L.toff ? self : tile_box(L, tidx);      // the tile that would have to pull this particle
+                const bool covered = (unsigned)(rlx + 1 + bx.hi[0]) < (unsigned)(MCPM_TILE + 1 + bx.hi[0] - bx.lo[0]) &&
+                                     (unsigned)(rly + 1 + bx.hi[1]) < (unsigned)(MCPM_TILE + 1 + bx.hi[1] - bx.lo[1]) &&
+                                     (unsigned)(rlz + 1 + bx.hi[2]) < (unsigned)(MCPM_TILE + 1 + bx.hi[2] - bx.lo[2]);
                 if (!covered) f(tidx, a ? -1 : mx, b ? -1 : my, e ? -1 : mz);
             }
         }
@@ -352,7 +357,7 @@ __device__ __forceinline__ void coverage_duty_body(const Geom &g, const float *_
             append_wild(L, gi);
             continue;
         }
-        for_uncovered(g, L, tx, ty, tz, ntx, nty, ntz, L.toff ? L.toff[(tx * nty + ty) * ntz + tz] : 0, qx & 15, qy & 15, qz & 15,
+        for_uncovered(g, L, tx, ty, tz, ntx, nty, ntz, tile_box(L, (tx * nty + ty) * ntz + tz), qx & 15, qy & 15, qz & 15,
                       (int)floorf(d.x), (int)floorf(d.y), (int)floorf(d.z), [&](int tidx, int, int, int) {
                              const int kb = atomicAdd(L.bcnt + tidx, 1);
                              if (kb == 0) L.nonempty[atomicAdd(L.cnts + C_NTILES, 1)] = tidx;
@@ -365,10 +370,10 @@ __device__ __forceinline__ void coverage_duty_body(const Geom &g, const float *_
 __global__ __launch_bounds__(256) void coverage_duty_kernel(Geom g, const float *__restrict__ disp, TileLists L) { coverage_duty_body(g, disp, L); }
 
 // Conservative form of the coverage test, as cheap as the round-1 outlier test: a particle of the home block is covered by EVERY tile
-// its stencil can touch if |floor(d)_a - o_T',a| <= H_T' on each axis for each of the 27 tiles T' around the block, i.e. if floor(d)_a
-// lies in the INTERSECTION of their intervals [o_T',a - H_T', o_T',a + H_T'].  (With per-tile halos that intersection contains the
-// block's own sampled range by construction -- every T' sized its window with it -- whereas the symmetric interval of round 3,
-// o_a +- (H - max |o_T',a - o_a|), has no slack left when each H_T' is just large enough.)  slo / shi: the interval as floats, per axis
+// its stencil can touch if lo_T',a <= floor(d)_a <= hi_T',a on each axis for each of the 27 tiles T' around the block, i.e. if floor(d)_a
+// lies in the INTERSECTION of their boxes.  (With per-tile windows that intersection contains the block's own sampled range by
+// construction -- every T' sized its window with it -- whereas the symmetric interval of round 3, o_a +- (H - max |o_T',a - o_a|), has
+// no slack left when each window is just large enough.)  slo / shi: the interval as floats, per axis
 // (empty when slo > shi: every home particle is then a suspect).  Reduced by the first wave, broadcast through LDS.
 __device__ __forceinline__ void sure_intervals(const Geom &g, const TileLists &L, int tx, int ty, int tz, int ntx, int nty, int ntz,
                                                int *sh27, float (&slo)[3], float (&shi)[3]) {
@@ -377,12 +382,9 @@ __device__ __forceinline__ void sure_intervals(const Geom &g, const TileLists &L
         if (threadIdx.x < 27) {
             const int a = (int)threadIdx.x / 9 - 1, b = ((int)threadIdx.x / 3) % 3 - 1, e = (int)threadIdx.x % 3 - 1;
             const int Tx = g.xslab ? min(max(tx + a, 0), ntx - 1) : pymod(tx + a, ntx);
-            const int word = L.toff[(Tx * nty + pymod(ty + b, nty)) * ntz + pymod(tz + e, ntz)];
-            int n3[3];
-            unpack_off(word, n3[0], n3[1], n3[2]);
-            const int H = tile_halo(L, word);
+            const Box nb = tile_box(L, (Tx * nty + pymod(ty + b, nty)) * ntz + pymod(tz + e, ntz));
 #pragma unroll
-            for (int c = 0; c < 3; ++c) lo[c] = n3[c] - H, hi[c] = n3[c] + H;
+            for (int c = 0; c < 3; ++c) lo[c] = nb.lo[c], hi[c] = nb.hi[c];
         }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1)
@@ -404,71 +406,77 @@ __device__ __forceinline__ void sure_intervals(const Geom &g, const TileLists &L
     }
 }
 
-// window point j (flat, z fastest) of a tile whose window offset is (ox, oy, oz): lattice point relative to the tile (r),
-// flat lattice index gi (-1: no such lattice point)
-template <int H>
-__device__ __forceinline__ int window_point(const Geom &g, int j, int x0, int y0, int z0, int ox, int oy, int oz, int &rx, int &ry,
-                                            int &rz) {
-    constexpr int W = MCPM_TILE + 2 * H + 1;
-    const int jz = j % W, r = j / W, jy = r % W, jx = r / W;
-    rx = jx - (H + 1) - ox;
-    ry = jy - (H + 1) - oy;
-    rz = jz - (H + 1) - oz;
-    int gx = x0 + rx;
-    if (g.xslab) {  // ghost-extended slab: lattice planes are mesh planes [xoff, xoff + px), no wrap
-        gx -= g.xoff;
-        if ((unsigned)gx >= (unsigned)g.px) return -1;
-    } else
-        gx = wrap_once(gx, g.nx);      // |window offset| <= 8 + H + 1 < n: one wrap suffices
-    const int gy = wrap_once(y0 + ry, g.ny), gz = wrap_once(z0 + rz, g.nz);
-    return (gx * g.ny + gy) * g.nz + gz;
-}
-
-// Window points of one thread, visited in the order j = tid, tid + THREADS, tid + 2 THREADS, ...: (jx, jy, jz) are carried
-// along with add-and-carry (7 instructions) instead of two divisions by W per visit, and -- FAST: power-of-two periodic
-// meshes, every single-GPU bench configuration -- the periodic wrap is one AND per axis.  The generic window_point() spends
-// ~45 vector and ~10 scalar-branch instructions per visit on the runtime choice between the slab, power-of-two and general
-// wraps; that was a quarter of the tile kernels' instruction stream.
-template <int H, int THREADS>
+// Window points of one thread, visited in the order j = tid, tid + THREADS, tid + 2 THREADS, ... of the flat index (z fastest) of a
+// window of Wx x Wy x Wz points (run-time, wave-uniform: the tile's box): (jx, jy, jz) are carried along with add-and-carry (7
+// instructions) instead of two divisions per visit, and -- FAST: power-of-two periodic meshes, every single-GPU bench configuration --
+// the periodic wrap is one AND per axis.  (The generic walk of round 2 spent ~45 vector and ~10 scalar-branch instructions per visit on
+// the run-time choice between the slab, power-of-two and general wraps: a quarter of the tile kernels' instruction stream.)
+// The few divisions of the set-up (thread index and THREADS by the window widths) are exact in float: numerators below 1024 + 1/2,
+// divisors below 1024, so the quotient's distance to the next integer (>= 1 / 2d) dwarfs the rounding of v_rcp_f32.
+__device__ __forceinline__ int small_div(int n, int d) { return (int)(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d)); }
+template <int THREADS>
 struct WinIter {
-    static constexpr int W = MCPM_TILE + 2 * H + 1;
-    static constexpr int DX = THREADS / (W * W), DY = (THREADS % (W * W)) / W, DZ = (THREADS % (W * W)) % W;
-    int jx, jy, jz;
-    __device__ __forceinline__ WinIter(int tid) {
-        jz = tid % W;
-        const int r = tid / W;
-        jy = r % W;
-        jx = r / W;
+    int jx, jy, jz, Wx, Wy, Wz, DX, DY, DZ;
+    __device__ __forceinline__ WinIter(int tid, int wx, int wy, int wz) : Wx(wx), Wy(wy), Wz(wz) {
+        const int r = small_div(tid, wz);
+        jz = tid - r * wz;
+        jx = small_div(r, wy);
+        jy = r - jx * wy;
+        const int wyz = wy * wz;
+        DX = small_div(THREADS, wyz);
+        const int rem = THREADS - DX * wyz;
+        DY = small_div(rem, wz);
+        DZ = rem - DY * wz;
     }
-    __device__ __forceinline__ bool valid() const { return jx < W; }
+    __device__ __forceinline__ bool valid() const { return jx < Wx; }
     __device__ __forceinline__ void next() {
         jz += DZ;
-        const int cz = jz >= W ? 1 : 0;
-        jz -= cz ? W : 0;
+        const int cz = jz >= Wz ? 1 : 0;
+        jz -= cz ? Wz : 0;
         jy += DY + cz;
-        const int cy = jy >= W ? 1 : 0;
-        jy -= cy ? W : 0;
+        const int cy = jy >= Wy ? 1 : 0;
+        jy -= cy ? Wy : 0;
         jx += DX + cy;
     }
     // lattice point relative to the tile (r) and flat lattice index of the current point; power-of-two periodic mesh: the index is
     // assembled with shifts (two v_lshl_or instead of two quarter-rate v_mad_u64_u32; the kernels are bound by VALU issue)
-    __device__ __forceinline__ int point_fast(const Geom &g, int x0, int y0, int z0, int ox, int oy, int oz, int &rx, int &ry, int &rz) const {
-        rx = jx - (H + 1) - ox;
-        ry = jy - (H + 1) - oy;
-        rz = jz - (H + 1) - oz;
+    __device__ __forceinline__ int point_fast(const Geom &g, int x0, int y0, int z0, const Box &b, int &rx, int &ry, int &rz) const {
+        rx = jx - 1 - b.hi[0];
+        ry = jy - 1 - b.hi[1];
+        rz = jz - 1 - b.hi[2];
         const int gx = (x0 + rx) & (g.nx - 1), gy = (y0 + ry) & (g.ny - 1), gz = (z0 + rz) & (g.nz - 1);
         const int lz = __builtin_ctz((unsigned)g.nz), ly = __builtin_ctz((unsigned)g.ny);      // uniform: scalar registers
         return (((gx << ly) | gy) << lz) | gz;
     }
     // the same on a slab plan (FAST = 2): y and z periodic powers of two, x the ghost-extended, NON-periodic local planes whose
     // lattice planes are mesh planes [xoff, xoff + px): -1 where the window leaves them
-    __device__ __forceinline__ int point_slab(const Geom &g, int x0, int y0, int z0, int ox, int oy, int oz, int &rx, int &ry, int &rz) const {
-        rx = jx - (H + 1) - ox;
-        ry = jy - (H + 1) - oy;
-        rz = jz - (H + 1) - oz;
+    __device__ __forceinline__ int point_slab(const Geom &g, int x0, int y0, int z0, const Box &b, int &rx, int &ry, int &rz) const {
+        rx = jx - 1 - b.hi[0];
+        ry = jy - 1 - b.hi[1];
+        rz = jz - 1 - b.hi[2];
         const int gx = x0 + rx - g.xoff, gy = (y0 + ry) & (g.ny - 1), gz = (z0 + rz) & (g.nz - 1);
         const int lz = __builtin_ctz((unsigned)g.nz), ly = __builtin_ctz((unsigned)g.ny);
         return (unsigned)gx < (unsigned)g.px ? ((((gx << ly) | gy) << lz) | gz) : -1;
+    }
+    // any tileable mesh (FAST = 0): one conditional wrap per axis (box_tile_kernel keeps |lo|, |hi| <= 12, so a window point is
+    // less than one period away), the ghost-extended planes of a slab plan along x
+    __device__ __forceinline__ int point_any(const Geom &g, int x0, int y0, int z0, const Box &b, int &rx, int &ry, int &rz) const {
+        rx = jx - 1 - b.hi[0];
+        ry = jy - 1 - b.hi[1];
+        rz = jz - 1 - b.hi[2];
+        int gx = x0 + rx;
+        if (g.xslab) {  // ghost-extended slab: lattice planes are mesh planes [xoff, xoff + px), no wrap
+            gx -= g.xoff;
+            if ((unsigned)gx >= (unsigned)g.px) return -1;
+        } else
+            gx = wrap_once(gx, g.nx);
+        const int gy = wrap_once(y0 + ry, g.ny), gz = wrap_once(z0 + rz, g.nz);
+        return (gx * g.ny + gy) * g.nz + gz;
+    }
+    template <int FAST>
+    __device__ __forceinline__ int point(const Geom &g, int x0, int y0, int z0, const Box &b, int &rx, int &ry, int &rz) const {
+        if (!valid()) return -1;
+        return FAST == 2 ? point_slab(g, x0, y0, z0, b, rx, ry, rz) : (FAST == 1 ? point_fast(g, x0, y0, z0, b, rx, ry, rz) : point_any(g, x0, y0, z0, b, rx, ry, rz));
     }
 };
 // 12-byte particle record i of an array of fewer than 2^32 / 12 records (what the FAST instantiations are launched for): uniform
@@ -485,11 +493,11 @@ __device__ __forceinline__ P3 load3w(const float *__restrict__ p, int i) {
 // the max|w| scale; 2: weighted, f64 accumulators (non-finite weights only: runs when tile_scale().mode == 2, WMODE 1 otherwise)
 // (amdgpu_num_sgpr: with more than 80 scalar registers a CU admits 7 waves per SIMD instead of 8, i.e. three of these
 // 512-thread workgroups instead of four -- measured +45 % on the kernel; MI355X_MICROARCH.md "Residency")
-template <int H, int WMODE, int THREADS, int U, int FAST>
+template <int WMODE, int THREADS, int U, int FAST>
 __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w,
                                                 int64_t wstride, float wscalar, float *__restrict__ mesh, int accumulate, const TileLists &L,
                                                 const unsigned *__restrict__ wmax_bits, int duty, u64 *tile, int *sh27, int *sus) {
-    constexpr int B = MCPM_TILE, W = B + 2 * H + 1, NW = W * W * W, NT = B * B * B;
+    constexpr int B = MCPM_TILE, NT = B * B * B;
     double *dtile = reinterpret_cast<double *>(tile);
     TScale sc = {1073741824.f, 9.313225746154785e-10, 1};
     if (WMODE != 0) {
@@ -502,28 +510,21 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
     const int x0 = tx * B, y0 = ty * B, z0 = tz * B;
     for (int i = threadIdx.x; i < NT; i += THREADS) tile[i] = 0ull;
     if (threadIdx.x == 0) sus[MCPM_SUS] = 0;
-    int ox = 0, oy = 0, oz = 0;
-    float slo[3] = {(float)-H, (float)-H, (float)-H}, shi[3] = {(float)H, (float)H, (float)H};
-    if (L.toff) {   // windows centred on the bulk displacement (optional)
-        unpack_off(L.toff[(tx * nty + ty) * ntz + tz], ox, oy, oz);
-        sure_intervals(g, L, tx, ty, tz, ntx, nty, ntz, sh27, slo, shi);
-    }
+    const Box bx = block_box(L, (tx * nty + ty) * ntz + tz);      // the tile's window (wave-uniform)
+    const int Wx = B + 1 + bx.hi[0] - bx.lo[0], Wy = B + 1 + bx.hi[1] - bx.lo[1], Wz = B + 1 + bx.hi[2] - bx.lo[2], NW = Wx * Wy * Wz;
+    float slo[3] = {(float)bx.lo[0], (float)bx.lo[1], (float)bx.lo[2]}, shi[3] = {(float)bx.hi[0], (float)bx.hi[1], (float)bx.hi[2]};
+    if (L.toff) sure_intervals(g, L, tx, ty, tz, ntx, nty, ntz, sh27, slo, shi);   // windows that follow the bulk displacement (optional)
     __syncthreads();
 
-    WinIter<H, THREADS> wi(threadIdx.x);
+    WinIter<THREADS> wi(threadIdx.x, Wx, Wy, Wz);
     for (int j0 = threadIdx.x; j0 < NW; j0 += THREADS * U) {
         P3 d[U];
         float wt[U];
         int rxs[U], rys[U], rzs[U], gis[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int j = j0 + u * THREADS;
-            if (FAST) {
-                gis[u] = !wi.valid() ? -1 : (FAST == 2 ? wi.point_slab(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u])
-                                                       : wi.point_fast(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]));
-                wi.next();
-            } else
-                gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
+            gis[u] = wi.template point<FAST>(g, x0, y0, z0, bx, rxs[u], rys[u], rzs[u]);
+            wi.next();
             if (gis[u] >= 0) {
                 d[u] = load3w<FAST>(disp, gis[u]);
                 wt[u] = WMODE ? w[(int64_t)gis[u] * wstride] : 1.f;
@@ -580,12 +581,12 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
             }
         }
     }
-    // home lattice points outside the own window (|o| > H on some axis): all of them are suspects
-    if (duty && (abs(ox) > H || abs(oy) > H || abs(oz) > H)) {
+    // home lattice points outside the own window (the box does not contain floor(d) = 0 .. -1 on some axis): all of them are suspects
+    if (duty && !(bx.hi[0] >= -1 && bx.lo[0] <= 0 && bx.hi[1] >= -1 && bx.lo[1] <= 0 && bx.hi[2] >= -1 && bx.lo[2] <= 0)) {
         for (int j = threadIdx.x; j < NT; j += THREADS) {
             const int rz = j % B, rr = j / B, ry = rr % B, rx = rr / B;
-            const bool inwin = (unsigned)(rx + ox + H + 1) < (unsigned)W && (unsigned)(ry + oy + H + 1) < (unsigned)W &&
-                               (unsigned)(rz + oz + H + 1) < (unsigned)W;
+            const bool inwin = (unsigned)(rx + 1 + bx.hi[0]) < (unsigned)Wx && (unsigned)(ry + 1 + bx.hi[1]) < (unsigned)Wy &&
+                               (unsigned)(rz + 1 + bx.hi[2]) < (unsigned)Wz;
             if (inwin) continue;
             int gx = x0 + rx;
             if (g.xslab) {
@@ -622,7 +623,7 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
     }
 }
 
-template <int HA, int HB, int HC, int WMODE, int THREADS, int U, int FAST = 0>
+template <int WMODE, int THREADS, int U, int FAST = 0>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void paint_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w,
                                                              int64_t wstride, float wscalar, float *__restrict__ mesh,
                                                              int accumulate, TileLists L, const unsigned *__restrict__ wmax_bits,
@@ -630,10 +631,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
     __shared__ u64 tile[MCPM_TILE * MCPM_TILE * MCPM_TILE];
     __shared__ int sh27[27];
     __shared__ int sus[MCPM_SUS + 2];
-    const int Hrt = block_halo(g, L);
-#define CALL(HH) paint_tile_body<HH, WMODE, THREADS, U, FAST>(g, disp, w, wstride, wscalar, mesh, accumulate, L, wmax_bits, duty, tile, sh27, sus)
-    HALO_SWITCH(Hrt, CALL);
-#undef CALL
+    paint_tile_body<WMODE, THREADS, U, FAST>(g, disp, w, wstride, wscalar, mesh, accumulate, L, wmax_bits, duty, tile, sh27, sus);
 }
 
 // base cell of a bucketed particle relative to the tile origin, brought into [-1, n-1) (the tile sees it at c in [-1, 16))
@@ -764,7 +762,7 @@ __device__ __forceinline__ void paint_leftover_body(const Geom &g, const float *
         if (is_wild(g, d, tx * MCPM_TILE, qx & 15)) continue;
         const float fx = floorf(d.x), fy = floorf(d.y), fz = floorf(d.z);
         const float kx[2] = {1.f - (d.x - fx), d.x - fx}, ky[2] = {1.f - (d.y - fy), d.y - fy}, kz[2] = {1.f - (d.z - fz), d.z - fz};
-        for_uncovered(g, L, tx, ty, tz, ntx, nty, ntz, L.toff ? L.toff[(tx * nty + ty) * ntz + tz] : 0, qx & 15, qy & 15, qz & 15, (int)fx, (int)fy,
+        for_uncovered(g, L, tx, ty, tz, ntx, nty, ntz, tile_box(L, (tx * nty + ty) * ntz + tz), qx & 15, qy & 15, qz & 15, (int)fx, (int)fy,
                          (int)fz, [&](int tidx, int cx, int cy, int cz) {
                              if (L.bcnt[tidx] <= L.cap) return;      // that tile's bucket was deposited by the bucket kernel
                              const int x0 = (tidx / (ntz * nty)) * MCPM_TILE, y0 = ((tidx / ntz) % nty) * MCPM_TILE, z0 = (tidx % ntz) * MCPM_TILE;
@@ -831,12 +829,12 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ w
 // redo: nullptr = first (fixed-point) pass over all tiles, appending flagged tiles to `redo_out`; otherwise the f64 pass
 // over the tiles listed in redo ([0] = count, then indices).  F64: accumulators are doubles (96 KB) instead of packed fields.
 // One tile of the three-component paint (redo_tile < 0: the tile of this block; else the given tile, for the f64 repaint).
-template <int H, bool F64, int THREADS, int U, int FAST>
+template <bool F64, int THREADS, int U, int FAST>
 __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w3,
                                                  float *__restrict__ mesh, int64_t M, int accumulate, const TileLists &L,
                                                  const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out, int redo_tile, int duty,
                                                  u64 *tile, int &flagged, int *sh27, int *sus) {
-    constexpr int B = MCPM_TILE, W = B + 2 * H + 1, NW = W * W * W, NT = B * B * B;
+    constexpr int B = MCPM_TILE, NT = B * B * B;
     double *dtile = reinterpret_cast<double *>(tile);
     const int ntx = g.nx / B, nty = g.ny / B, ntz = g.nz / B;
     int tx, ty, tz;
@@ -847,8 +845,8 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
     } else
         tile_of_block(ntx, nty, ntz, tx, ty, tz, L.order);
     const int x0 = tx * B, y0 = ty * B, z0 = tz * B, tidx = (tx * nty + ty) * ntz + tz;
-    int ox = 0, oy = 0, oz = 0;
-    if (L.toff) unpack_off(L.toff[tidx], ox, oy, oz);
+    const Box bx = block_box(L, tidx);      // the tile's window (wave-uniform)
+    const int Wx = B + 1 + bx.hi[0] - bx.lo[0], Wy = B + 1 + bx.hi[1] - bx.lo[1], Wz = B + 1 + bx.hi[2] - bx.lo[2], NW = Wx * Wy * Wz;
     bool deposit = true;
     float S = 1.f, Sinv = 1.f;
     if (!F64) {
@@ -880,23 +878,18 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
     }
     if (deposit)
         for (int i = threadIdx.x; i < (F64 ? 3 : 2) * NT; i += THREADS) tile[i] = 0ull;
-    float slo[3] = {(float)-H, (float)-H, (float)-H}, shi[3] = {(float)H, (float)H, (float)H};
+    float slo[3] = {(float)bx.lo[0], (float)bx.lo[1], (float)bx.lo[2]}, shi[3] = {(float)bx.hi[0], (float)bx.hi[1], (float)bx.hi[2]};
     if (L.toff) sure_intervals(g, L, tx, ty, tz, ntx, nty, ntz, sh27, slo, shi);
     __syncthreads();
 
-    WinIter<H, THREADS> wi(threadIdx.x);
+    WinIter<THREADS> wi(threadIdx.x, Wx, Wy, Wz);
     for (int j0 = threadIdx.x; j0 < NW; j0 += THREADS * U) {
         P3 d[U], wt[U];
         int rxs[U], rys[U], rzs[U], gis[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int j = j0 + u * THREADS;
-            if (FAST) {
-                gis[u] = !wi.valid() ? -1 : (FAST == 2 ? wi.point_slab(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u])
-                                                       : wi.point_fast(g, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]));
-                wi.next();
-            } else
-                gis[u] = j < NW ? window_point<H>(g, j, x0, y0, z0, ox, oy, oz, rxs[u], rys[u], rzs[u]) : -1;
+            gis[u] = wi.template point<FAST>(g, x0, y0, z0, bx, rxs[u], rys[u], rzs[u]);
+            wi.next();
             if (gis[u] >= 0) {
                 d[u] = load3w<FAST>(disp, gis[u]);
                 wt[u] = load3w<FAST>(w3, gis[u]);
@@ -977,11 +970,11 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
             }
         }
     }
-    if (duty && (abs(ox) > H || abs(oy) > H || abs(oz) > H)) {
+    if (duty && !(bx.hi[0] >= -1 && bx.lo[0] <= 0 && bx.hi[1] >= -1 && bx.lo[1] <= 0 && bx.hi[2] >= -1 && bx.lo[2] <= 0)) {
         for (int j = threadIdx.x; j < NT; j += THREADS) {
             const int rz = j % B, rr = j / B, ry = rr % B, rx = rr / B;
-            const bool inwin = (unsigned)(rx + ox + H + 1) < (unsigned)W && (unsigned)(ry + oy + H + 1) < (unsigned)W &&
-                               (unsigned)(rz + oz + H + 1) < (unsigned)W;
+            const bool inwin = (unsigned)(rx + 1 + bx.hi[0]) < (unsigned)Wx && (unsigned)(ry + 1 + bx.hi[1]) < (unsigned)Wy &&
+                               (unsigned)(rz + 1 + bx.hi[2]) < (unsigned)Wz;
             if (inwin) continue;
             int gx = x0 + rx;
             if (g.xslab) {
@@ -1048,7 +1041,7 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
 // ([0] = count, then indices): a small grid that walks the list (it is empty on every PM workload: a whole-mesh launch of
 // workgroups that return at once cost 30 us per adjoint step at 512^3).
 // (four waves per SIMD = two 512-thread workgroups per CU: with three candidate bodies the allocator would take 133 registers)
-template <int HA, int HB, int HC, bool F64, int THREADS, int U, int FAST = 0>
+template <bool F64, int THREADS, int U, int FAST = 0>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) void paint3_tile_kernel(Geom g, const float *__restrict__ disp, const float *__restrict__ w3,
                                                               float *__restrict__ mesh, int64_t M, int accumulate, TileLists L,
                                                               const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out,
@@ -1059,27 +1052,21 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
     __shared__ int sh27[27];
     __shared__ int sus[MCPM_SUS + 2];
     if (!redo_in) {
-        const int Hrt = block_halo(g, L);
-#define CALL(HH) paint3_tile_body<HH, F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, -1, duty, tile, flagged, sh27, sus)
-        HALO_SWITCH(Hrt, CALL);
-#undef CALL
+        paint3_tile_body<F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, -1, duty, tile, flagged, sh27, sus);
         return;
     }
     if (!F64) return;      // only the f64 instance repaints (the fixed-point one would carry three more window-walk bodies, and their
                            // scalar-register pressure, for a branch it never takes)
     const int n = redo_in[0];
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
-        const int Hrt = block_halo(g, L, redo_in[1 + k]);
-#define CALL(HH) paint3_tile_body<HH, F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, redo_in[1 + k], duty, tile, flagged, sh27, sus)
-        HALO_SWITCH(Hrt, CALL);
-#undef CALL
+        paint3_tile_body<F64, THREADS, U, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, redo_in[1 + k], duty, tile, flagged, sh27, sus);
         __syncthreads();
     }
 }
 
 // The fixed-point first pass with 1024 threads per tile, for meshes of at most 1024 tiles (128^3: 512 tiles, two per CU, and a tile's
 // time is latency): two such workgroups per CU need eight waves per SIMD, i.e. at most 64 VGPRs (the 512-thread instance takes 75).
-template <int HA, int HB, int HC, int FAST>
+template <int FAST>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void paint3_tile_wide_kernel(Geom g, const float *__restrict__ disp,
                                                               const float *__restrict__ w3, float *__restrict__ mesh, int64_t M, int accumulate,
                                                               TileLists L, const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out, int duty) {
@@ -1088,10 +1075,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     __shared__ int flagged;
     __shared__ int sh27[27];
     __shared__ int sus[MCPM_SUS + 2];
-    const int Hrt = block_halo(g, L);
-#define CALL(HH) paint3_tile_body<HH, false, 1024, 2, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, -1, duty, tile, flagged, sh27, sus)
-    HALO_SWITCH(Hrt, CALL);
-#undef CALL
+    paint3_tile_body<false, 1024, 2, FAST>(g, disp, w3, mesh, M, accumulate, L, wmax_bits, redo_out, -1, duty, tile, flagged, sh27, sus);
 }
 
 // buckets of the three-component paint: int64 fixed point with the max|w| 2^-28 scale, doubles when the weights are non-finite
@@ -1219,9 +1203,9 @@ static int tile_order() {
     return o;
 }
 
-// The halo of the next tiled paint: p->halo if the caller fixed one (mcpm_plan_set_halo, MCPM_PAINT_HALO), else 0 = chosen on the
-// device for every input by halo_tile_kernel (periodic plans of 2048 tiles or more; MCPM_PAINT_ADAPT=0, a slab plan or a
-// smaller mesh: the static rule of plan.hip)
+// The halo of the next tiled paint: p->halo if the caller fixed one (mcpm_plan_set_halo, MCPM_PAINT_HALO), else 0 = every tile's window
+// chosen on the device for every input by box_tile_kernel (plans of 2048 tiles or more: MCPM_PAINT_ADAPT_MIN_TILES; with
+// MCPM_PAINT_ADAPT=0 or on a smaller mesh: the static rule of plan.hip)
 static int halo_of(const mcpm_plan *p) {
     static const int adapt = [] { const char *e = getenv("MCPM_PAINT_ADAPT"); return e ? atoi(e) : 1; }();
     if (p->halo > 0) return p->halo;
@@ -1235,28 +1219,24 @@ static int halo_of(const mcpm_plan *p) {
 }
 
 static TileLists tile_lists(const mcpm_plan *p) {
-    return TileLists{p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, p->outliers + p->Np, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count, tile_order(), halo_of(p)};
+    const int64_t ntiles = p->M / (MCPM_TILE * MCPM_TILE * MCPM_TILE);
+    const int h = halo_of(p);
+    return TileLists{p->centre ? p->tile_off : nullptr, p->centre ? p->halo_sel + 2 * ntiles : nullptr, p->bucket_cnt, p->bucket, p->bucket_cap, p->bucket_tiles, p->outliers, p->outliers + p->Np, (int)(p->Np < (1 << 30) ? p->Np : (1 << 30)), p->outlier_count, tile_order(), h > 0 ? h : mcpm_default_halo(p->M)};
 }
 
+// p->halo_sel: [ntiles] minima and [ntiles] maxima of the blocks' sampled floor(d), then [ntiles] upper corners of the tiles' windows
 static void tiled_prologue(mcpm_plan *p, const float *pos, int *redo = nullptr) {
     const Geom &g = p->g;
     const int ntiles = (g.nx / MCPM_TILE) * (g.ny / MCPM_TILE) * (g.nz / MCPM_TILE);
-    const bool adapt = halo_of(p) == 0;      // p->halo_sel: the blocks' sampled floor(d) ranges, [ntiles] minima then [ntiles] maxima
-    tile_prologue_kernel<<<(ntiles + 3) / 4, 256, 0, p->stream>>>(g, pos, p->centre ? p->tile_off : nullptr, p->bucket_cnt, p->outlier_count,
-                                                                  ntiles, 8, redo, adapt ? p->halo_sel : nullptr);
-    if (adapt) halo_tile_kernel<<<(ntiles + 15) / 16, 256, 0, p->stream>>>(g, p->tile_off, p->halo_sel, ntiles);
+    const int h = halo_of(p);
+    const bool adapt = h == 0;
+    int *thi = p->centre ? p->halo_sel + 2 * (int64_t)ntiles : nullptr;
+    tile_prologue_kernel<<<(ntiles + 3) / 4, 256, 0, p->stream>>>(g, pos, p->centre ? p->tile_off : nullptr, thi, p->bucket_cnt, p->outlier_count,
+                                                                  ntiles, 8, redo, adapt ? p->halo_sel : nullptr, h);
+    // (window corners stay within +-12, what an offset of 8 and a halo of 4 reached: the conditional wraps of the generic walk
+    // assume a window point is less than one period away, and 48-cell meshes are tiled)
+    if (adapt) box_tile_kernel<<<(ntiles + 15) / 16, 256, 0, p->stream>>>(g, p->tile_off, thi, p->halo_sel, ntiles, 12);
 }
-
-// CALL(HA, HB, HC): the kernels' candidate halos -- all equal for a fixed halo, (1, 2, 3) [and 4: HALO_SWITCH] when the device chooses (0)
-#define DISPATCH_H(HH, CALL)        \
-    switch (HH) {                   \
-        case 0: CALL(1, 2, 3) break; \
-        case 1: CALL(1, 1, 1) break; \
-        case 2: CALL(2, 2, 2) break; \
-        case 3: CALL(3, 3, 3) break; \
-        case 4: CALL(4, 4, 4) break; \
-        default: CALL(6, 6, 6) break; \
-    }
 
 // Tiled density paint if the geometry allows; returns false if the caller must use the generic path.
 bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t wstride, float wscalar, float *mesh, int accumulate) {
@@ -1275,24 +1255,22 @@ bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t ws
     if (w) {
         (void)hipMemsetAsync(p->gx_wmax, 0, sizeof(unsigned) * MCPM_FX_SLOTS * MCPM_FX_STRIDE, p->stream);
         absmax_kernel<<<2048, 256, 0, p->stream>>>(w, wstride, p->Np, p->gx_wmax);
-#define CALLW(HA_, HB_, HC_)                                                                                                                  \
-    {                                                                                                                              \
-        paint_tile_kernel<HA_, HB_, HC_, 1, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
-        paint_tile_kernel<HA_, HB_, HC_, 2, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+        // fixed point, and doubles for non-finite weights: the instantiation the weights do not call for returns at once
+#define CALLW(FAST_)                                                                                                                  \
+    {                                                                                                                                 \
+        paint_tile_kernel<1, 512, 4, FAST_><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
+        paint_tile_kernel<2, 512, 4, FAST_><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
     }
-        DISPATCH_H(halo_of(p), CALLW)
+        if (fast == 1) CALLW(1) else if (fast == 2) CALLW(2) else CALLW(0)
 #undef CALLW
     } else {
         // meshes of at most 1024 tiles (128^3: 512) leave half of the CUs' wave slots empty with 512 threads per tile, and a tile's
         // time is latency there: 1024 threads per tile halve it (two such workgroups still fit a CU: 49 VGPRs, 37 KB of LDS)
         const bool wide = fast == 1 && nb <= 1024u;
-#define CALLU(HA_, HB_, HC_)                                                                                                                    \
-    if (wide) paint_tile_kernel<HA_, HB_, HC_, 0, 1024, 4, 1><<<nb, 1024, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
-    else if (fast == 1) paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4, 1><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
-    else if (fast == 2) paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4, 2><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1); \
-    else paint_tile_kernel<HA_, HB_, HC_, 0, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
-        DISPATCH_H(halo_of(p), CALLU)
-#undef CALLU
+        if (wide) paint_tile_kernel<0, 1024, 4, 1><<<nb, 1024, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
+        else if (fast == 1) paint_tile_kernel<0, 512, 4, 1><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
+        else if (fast == 2) paint_tile_kernel<0, 512, 4, 2><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
+        else paint_tile_kernel<0, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
     }
     coverage_duty_kernel<<<1024, 256, 0, p->stream>>>(g, pos, L);
     if (w) paint_epilogue_kernel<1><<<nbk + nlo, 256, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, p->M, L, p->gx_wmax, (int)nbk);
@@ -1316,20 +1294,13 @@ bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, fl
     }
     p->fx_src = nullptr;
     if (p->paint3_variant == 4) {   // fixed-point tiles; the tiles they flag (and every tile if max|w| is unusable) in f64
-#define CALLFX(HA_, HB_, HC_)                                                                                                                \
-    {                                                                                                                             \
-        if (fast == 1 && nb <= 1024u) paint3_tile_wide_kernel<HA_, HB_, HC_, 1><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, 1); \
-        else if (fast == 1) paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4, 1><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
-        else if (fast == 2) paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4, 2><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
-        else paint3_tile_kernel<HA_, HB_, HC_, false, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1); \
-        paint3_tile_kernel<HA_, HB_, HC_, true, 1024, 4><<<nb < 256u ? nb : 256u, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, p->fx_redo, 0); \
-    }
-        DISPATCH_H(halo_of(p), CALLFX)
-#undef CALLFX
+        if (fast == 1 && nb <= 1024u) paint3_tile_wide_kernel<1><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, 1);
+        else if (fast == 1) paint3_tile_kernel<false, 512, 4, 1><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1);
+        else if (fast == 2) paint3_tile_kernel<false, 512, 4, 2><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1);
+        else paint3_tile_kernel<false, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1);
+        paint3_tile_kernel<true, 1024, 4><<<nb < 256u ? nb : 256u, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, p->fx_redo, 0);
     } else {   // f64 tiles everywhere (A/B and tests)
-#define CALLF64(HA_, HB_, HC_) paint3_tile_kernel<HA_, HB_, HC_, true, 1024, 4><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, nullptr, 1);
-        DISPATCH_H(halo_of(p), CALLF64)
-#undef CALLF64
+        paint3_tile_kernel<true, 1024, 4><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, nullptr, nullptr, 1);
     }
     coverage_duty_kernel<<<1024, 256, 0, p->stream>>>(g, pos, L);
     const unsigned nlo = 64u;     // see mcpm_paint_tiled

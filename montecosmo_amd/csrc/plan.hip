@@ -162,7 +162,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
         p->bucket_cap = 1024;
         if (const char *e = getenv("MCPM_BUCKET_CAP")) { const int c = atoi(e); if (c >= 64 && c <= 65536) p->bucket_cap = c; }
         alloc((void **)&p->tile_off, sizeof(int) * ntiles);
-        alloc((void **)&p->halo_sel, sizeof(int) * 2 * ntiles);      // sampled floor(d) ranges of the Lagrangian blocks (paint_tiled.hip)
+        alloc((void **)&p->halo_sel, sizeof(int) * 3 * ntiles);      // sampled floor(d) ranges of the Lagrangian blocks + the windows' upper corners (paint_tiled.hip)
         alloc((void **)&p->bucket_cnt, sizeof(int) * ntiles);
         alloc((void **)&p->bucket_tiles, sizeof(int) * ntiles);
         alloc((void **)&p->bucket, sizeof(int) * ntiles * p->bucket_cap);
@@ -280,22 +280,35 @@ int mcpm_plan_last_bucketed(mcpm_plan *p, int64_t *count) {
     return MCPM_OK;
 }
 
-// out[0..7]: the last tiled paint's device counters (wild particles, last wild + overflow pairs, slab deposits beyond the ghost planes,
-// appends that found their bucket full, tiles with a non-empty bucket, bucketed pairs, suspects, -); out[8 + h], h = 0..4: tiles whose
-// window halo is h (0: no per-tile choice was made for this plan's last paint).  Synchronises the host.
+// out[0..6]: the last tiled paint's device counters (wild particles, last wild + overflow pairs, slab deposits beyond the ghost planes,
+// appends that found their bucket full, tiles with a non-empty bucket, bucketed pairs, suspects); out[7]: window points of all tiles
+// (/ particles = window visits per particle); out[8 + h], h = 0..4: tiles whose widest window axis has 17 + 2h - 1 or 17 + 2h points
+// (what a symmetric halo of h would give; all zero if the plan's windows are not centred).  Synchronises the host.
 int mcpm_plan_last_paint_stats(mcpm_plan *p, int64_t *out13) {
     if (!p || !out13) return MCPM_E_ARG;
     int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     MCPM_HIP(p, hipMemcpyAsync(c, p->outlier_count, sizeof(c), hipMemcpyDeviceToHost, p->stream));
     for (int i = 0; i < 13; ++i) out13[i] = 0;
-    std::vector<int> words;
-    if (p->tile_off) {
-        words.resize((size_t)(p->M / 4096));
-        MCPM_HIP(p, hipMemcpyAsync(words.data(), p->tile_off, sizeof(int) * words.size(), hipMemcpyDeviceToHost, p->stream));
+    std::vector<int> lo, hi;
+    if (p->tile_off && p->halo_sel && p->centre) {
+        const size_t nt = (size_t)(p->M / 4096);
+        lo.resize(nt), hi.resize(nt);
+        MCPM_HIP(p, hipMemcpyAsync(lo.data(), p->tile_off, sizeof(int) * nt, hipMemcpyDeviceToHost, p->stream));
+        MCPM_HIP(p, hipMemcpyAsync(hi.data(), p->halo_sel + 2 * nt, sizeof(int) * nt, hipMemcpyDeviceToHost, p->stream));
     }
     MCPM_HIP(p, hipStreamSynchronize(p->stream));
-    for (int i = 0; i < 8; ++i) out13[i] = c[i];
-    for (int w : words) out13[8 + std::min((w >> 24) & 0xff, 4)] += 1;
+    for (int i = 0; i < 7; ++i) out13[i] = c[i];
+    for (size_t t = 0; t < lo.size(); ++t) {
+        int64_t pts = 1;
+        int ext = 0;
+        for (int a = 0; a < 3; ++a) {
+            const int e = (int)(int8_t)((hi[t] >> (8 * a)) & 0xff) - (int)(int8_t)((lo[t] >> (8 * a)) & 0xff);
+            pts *= 17 + e;
+            ext = std::max(ext, e);
+        }
+        out13[7] += pts;
+        out13[8 + std::min((ext + 1) / 2, 4)] += 1;
+    }
     return MCPM_OK;
 }
 

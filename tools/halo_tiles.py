@@ -1,5 +1,5 @@
-"""Per-tile window halos along the bench trajectory (finding 43): for the density paint of every state x'_i, the share of tiles at
-H = 1 / 2 / 3 / 4, the suspects handed to the exact coverage test, the (particle, tile) pairs routed through buckets and the
+"""Per-tile windows along the bench trajectory (findings 43, 46): for the density paint of every state x'_i, the share of tiles by the
+extent of their widest window axis (e_h: 17 + 2h - 1 or 17 + 2h points: what a symmetric halo of h spans), the window visits per particle, the suspects handed to the exact coverage test, the (particle, tile) pairs routed through buckets and the
 overflow count, next to the paint's time.  usage: python tools/halo_tiles.py [mesh=512]"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,7 +27,7 @@ for i in range(11):
     e1.synchronize()
     r.plan.call("mcpm_plan_last_paint_stats", out)
     nt = sum(out[8:13])
-    share = " ".join(f"H{h}:{100.0 * out[8 + h] / nt:5.1f}%" for h in range(1, 5))
-    visits = sum(out[8 + h] * (16 + 2 * h + 1) ** 3 for h in range(1, 5)) / (nt * 4096.0)
+    share = " ".join(f"e{h}:{100.0 * out[8 + h] / nt:5.1f}%" for h in range(0, 5))      # widest window axis 17 + 2h - 1 or 17 + 2h points
+    visits = out[7] / (nt * 4096.0)
     print(f"{n}^3 state {i:2d}: paint {e0.elapsed_time(e1) / 5:.4f} ms  {share}  visits/particle {visits:.2f}  suspects {out[6]:9d} ({100.0 * out[6] / r.N:.2f} %)  "
           f"bucketed pairs {out[5]:8d}  bucket tiles {out[4]:6d}  overflow appends {out[3]}  wild {out[0]}", flush=True)

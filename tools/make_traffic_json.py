@@ -16,7 +16,7 @@ stage_of = [("paint3_tile_kernel", "paint3"), ("paint3_bucket_kernel", "paint3")
             ("ycol_kernel<512, 1>", "fft_c2r"), ("ycol_kernel<256, 1>", "fft_c2r"), ("zinv_kernel", "fft_c2r"), ("zinv3_il_kernel", "fft_c2r"),
             ("xfused_kernel", "kspace"), ("kick_drift_kernel", "kick_drift"), ("step_adjoint_kernel", "step_adjoint"),
             ("axpby_kernel", "axpy"), ("axpy_kernel", "axpy")]
-shared_before = ("tile_prologue_kernel", "halo_select_kernel", "halo_decide_kernel", "halo_tile_kernel")   # belong to the NEXT tile kernel
+shared_before = ("tile_prologue_kernel", "halo_select_kernel", "halo_decide_kernel", "halo_tile_kernel", "box_tile_kernel")   # belong to the NEXT tile kernel
 shared_after = ("coverage_duty_kernel", "paint_leftover_kernel", "absmax_kernel")   # belong to the PREVIOUS tile kernel
 # the kernels that count as "one launch of the stage" (its main kernel); the others only add their bytes
 main_kernels = ("paint_tile_kernel", "paint3_tile_kernel<", "paint_atomic_kernel", "zfwd_kernel", "ycol2_kernel", "ycol_kernel",
@@ -48,15 +48,15 @@ for d, key in ((fetch_dir, "fetch_kb"), (write_dir, "write_kb")):
             continue
         st = stage(nm)
         if st in ("paint", "paint3") and "tile_kernel" in nm:
-            # the f64 repaint launch (template arguments <HA, HB, HC, F64 = true, 1024 threads, U, FAST = false>) follows its
+            # the f64 repaint launch (template arguments <F64 = true, 1024 threads, U, FAST = false>) follows its
             # fixed-point pass (<..., false, 512, 4, 0 | 1 | 2>): only the first pass opens a new paint
-            if not ("paint3_tile_kernel" in nm and ", true, 1024," in nm):
+            if not ("paint3_tile_kernel" in nm and "<true, 1024," in nm):
                 tot[st][key] += pending
                 pending = 0.0
             current = st
         if st:
             tot[st][key] += v
-            if key == "fetch_kb" and any(m in nm for m in main_kernels) and not ("paint3_tile_kernel" in nm and ", true, 1024," in nm):
+            if key == "fetch_kb" and any(m in nm for m in main_kernels) and not ("paint3_tile_kernel" in nm and "<true, 1024," in nm):
                 tot[st]["launches"] += 1      # (the f64 repaint launch of the three-component paint is not a paint of its own)
 method = (
     "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --no-sub-record --no-cpu-baseline --warmup 0 "
