@@ -248,7 +248,9 @@ int mcpm_plan_set_centre(mcpm_plan *p, int centre) {
 }  // extern "C"
 
 int mcpm_det_scratch(mcpm_plan *p, int K, unsigned nblk, double **P, double **Q, unsigned **ticket, unsigned *R) {
-    const unsigned r = std::max(1u, std::min(1024u, (nblk + 255u) / 256u));      // <= 1024: four values per lane in the last stage
+    // Few first-stage workgroups: each ends with one atomic on the shared ticket, and those serialise at ~27 ns apiece (1024 of them:
+    // 34 us per fold at 512^3, against 23 us with 256); 128 workgroups still pull 12.6 MB of partials in a few microseconds.
+    const unsigned r = std::max(1u, std::min(128u, (nblk + 511u) / 512u));
     // [ticket (one double slot, kept zero)] [Q: K * 1024] [P: K * nblk]
     const int64_t need = 1 + (int64_t)K * 1024 + (int64_t)K * nblk;
     if (p->part_n < need) {
