@@ -162,6 +162,98 @@ def test_paint_tiled_lattice(nb, n, halo, sigma):
         plan.call("mcpm_plan_set_halo", 0)      # back to the default
 
 
+def expected_boxes(disp, shape):
+    """The device's window rule (paint_tiled.hip: tile_prologue_kernel + box_tile_kernel) restated in numpy: per 16^3 block the range of
+    floor(d) over 64 samples (four z rows), per tile the hull of the 27 blocks around it, extents above 8 cut back to +-4 around the
+    block's rounded mean offset, corners kept within +-12.  Returns (lo, hi), each (ntx, nty, ntz, 3)."""
+    nt = [n // 16 for n in shape]
+    d = disp.reshape(nt[0], 16, nt[1], 16, nt[2], 16, 3)[:, 4::8, :, 4::8, :, :, :].astype(np.float64)
+    off = np.clip(np.rint(d.mean(axis=(1, 3, 5))), -8, 8).astype(int)
+    f = np.clip(np.floor(d), -100, 100).astype(int)
+    lo, hi = f.min(axis=(1, 3, 5)), f.max(axis=(1, 3, 5))
+    LO, HI = lo.copy(), hi.copy()
+    for a in (-1, 0, 1):
+        for b in (-1, 0, 1):
+            for e in (-1, 0, 1):
+                LO = np.minimum(LO, np.roll(lo, (a, b, e), axis=(0, 1, 2)))
+                HI = np.maximum(HI, np.roll(hi, (a, b, e), axis=(0, 1, 2)))
+    wide = HI - LO > 8
+    LO = np.where(wide, np.maximum(LO, off - 4), LO)
+    HI = np.where(wide, np.minimum(HI, off + 4), HI)
+    LO = np.clip(LO, -12, 12)
+    HI = np.maximum(np.clip(HI, -12, 12), LO)
+    return LO, HI
+
+
+def expected_bucketed_boxes(disp, shape, LO, HI):
+    """(particle, tile) pairs whose lattice point lies outside the window of a tile the particle's CIC stencil touches."""
+    from itertools import product
+    n = np.array(shape)
+    nt = n // 16
+    fl = np.floor(disp).astype(int)
+    q = np.indices(shape).reshape(3, -1).T
+    c = q + fl
+    count = 0
+    for alt in product((0, 1), repeat=3):
+        alt = np.array(alt)
+        valid = np.all((alt == 0) | (c % 16 == 15), axis=1)
+        T = (c // 16 + alt) % nt
+        lo, hi = LO[T[:, 0], T[:, 1], T[:, 2]], HI[T[:, 0], T[:, 1], T[:, 2]]
+        rl = np.where(alt == 0, c % 16 - fl, -1 - fl)          # the lattice point relative to T; T's window: -1 - hi <= rl <= 15 - lo
+        count += int((valid & ~np.all((rl >= -1 - hi) & (rl <= 15 - lo), axis=1)).sum())
+    return count
+
+
+def test_paint_windows_are_boxes_per_tile_and_axis(nb):
+    """On meshes of 2048 tiles or more every tile's window is a box per axis, sized on the device from the sampled floor(d) ranges of
+    the 27 Lagrangian blocks around it (DESIGN finding 46).  An anisotropic field -- a bulk flow, rough along x, smooth along y, a
+    long wave along z, and a slab of tiles whose x range exceeds the largest window -- against the oracle, the device's rule against
+    its numpy restatement (window points and bucketed pairs, exactly), bit for bit from call to call, weighted and three-component
+    forms included."""
+    import ctypes as C
+    import torch
+    shape = (128, 256, 256)
+    N = int(np.prod(shape))
+    rng = np.random.default_rng(11)
+    q = o.regular_pos(shape)
+    disp = np.empty((N, 3), np.float32)
+    disp[:, 0] = 3.3 + 0.9 * rng.standard_normal(N)
+    disp[:, 1] = -6.2 + 0.05 * rng.standard_normal(N)
+    disp[:, 2] = 0.4 + 2.5 * np.sin(2 * np.pi * q[:, 0] / shape[0]) + 0.3 * rng.standard_normal(N)
+    band = (q[:, 1] >= 96) & (q[:, 1] < 128)
+    disp[band, 0] += 1.2 * rng.standard_normal(int(band.sum()))      # x extents above 8 there: the window is cut back, buckets fill
+    lp = nb.LatticePos(disp, shape)
+    plan = nb.get_plan(shape)
+    pos64 = q + disp.astype(np.float64)
+    got = to_np(nb.paint(lp, shape))
+    assert rel_l2(got, o.paint(pos64, shape)) < 2e-6
+    assert abs(got.sum() / N - 1) < 1e-6
+    st = (C.c_int64 * 13)()
+    plan.call("mcpm_plan_last_paint_stats", st)
+    LO, HI = expected_boxes(disp, shape)
+    assert st[7] == int(np.prod(17 + HI - LO, axis=-1).sum())                       # the windows the device chose
+    assert st[7] < 0.8 * (N // 4096) * 25 ** 3                                       # ... are far smaller than the static halo's
+    ext = (HI - LO).reshape(-1, 3)
+    assert ext[:, 1].max() <= 1 and ext[:, 0].min() >= 4                             # ... and anisotropic: tight along y, wide along x
+    assert plan.last_outliers() == 0
+    assert plan.last_bucketed() == expected_bucketed_boxes(disp, shape, LO, HI) > 100
+    assert np.array_equal(got, to_np(nb.paint(lp, shape)))
+    w = rng.standard_normal(N).astype(np.float32)
+    gotw = to_np(nb.paint(lp, shape, w))
+    assert rel_l2(gotw, o.paint(pos64, shape, w.astype(np.float64))) < 2e-6
+    assert np.array_equal(gotw, to_np(nb.paint(lp, shape, w)))
+    w3 = rng.standard_normal((N, 3)).astype(np.float32)
+    out = torch.empty((3,) + shape, dtype=torch.float32, device="cuda")
+    wt = torch.from_numpy(w3).cuda()
+    args = (C.c_void_p(lp.disp.data_ptr()), N, 1, C.c_void_p(wt.data_ptr()), 2, C.c_void_p(out.data_ptr()), 0)
+    plan.call("mcpm_paint3_f32", *args)
+    first = out.clone()
+    for c in range(3):
+        assert rel_l2(to_np(out[c]), o.paint(pos64, shape, w3[:, c].astype(np.float64))) < 2e-6
+    plan.call("mcpm_paint3_f32", *args)
+    assert torch.equal(out, first)
+
+
 @pytest.mark.parametrize("n", [64, 96])
 def test_paint_windows_follow_the_bulk_displacement(nb, n):
     """paint_tiled.hip: a tile's window is centred on the mean displacement of the particles around it.  A coherent flow of
