@@ -1198,6 +1198,11 @@ static int tiled_fast(const mcpm_plan *p) {
     return pow2(g.nx) ? 1 : 0;
 }
 
+static unsigned wide_max_tiles() {   // meshes of at most this many tiles paint with 1024 threads per tile (MCPM_PAINT_WIDE_MAX_TILES)
+    static const unsigned v = [] { const char *e = getenv("MCPM_PAINT_WIDE_MAX_TILES"); return e ? (unsigned)atoi(e) : 1024u; }();
+    return v;
+}
+
 static int tile_order() {
     static const int o = [] { const char *e = getenv("MCPM_TILE_ORDER"); return e ? atoi(e) : 1; }();
     return o;
@@ -1266,7 +1271,7 @@ bool mcpm_paint_tiled(mcpm_plan *p, const float *pos, const float *w, int64_t ws
     } else {
         // meshes of at most 1024 tiles (128^3: 512) leave half of the CUs' wave slots empty with 512 threads per tile, and a tile's
         // time is latency there: 1024 threads per tile halve it (two such workgroups still fit a CU: 49 VGPRs, 37 KB of LDS)
-        const bool wide = fast == 1 && nb <= 1024u;
+        const bool wide = fast == 1 && nb <= wide_max_tiles();
         if (wide) paint_tile_kernel<0, 1024, 4, 1><<<nb, 1024, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
         else if (fast == 1) paint_tile_kernel<0, 512, 4, 1><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
         else if (fast == 2) paint_tile_kernel<0, 512, 4, 2><<<nb, 512, 0, p->stream>>>(g, pos, w, wstride, wscalar, mesh, accumulate, L, p->gx_wmax, 1);
@@ -1294,7 +1299,7 @@ bool mcpm_paint3_tiled(mcpm_plan *p, const float *pos, const float *weights3, fl
     }
     p->fx_src = nullptr;
     if (p->paint3_variant == 4) {   // fixed-point tiles; the tiles they flag (and every tile if max|w| is unusable) in f64
-        if (fast == 1 && nb <= 1024u) paint3_tile_wide_kernel<1><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, 1);
+        if (fast == 1 && nb <= wide_max_tiles()) paint3_tile_wide_kernel<1><<<nb, 1024, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, 1);
         else if (fast == 1) paint3_tile_kernel<false, 512, 4, 1><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1);
         else if (fast == 2) paint3_tile_kernel<false, 512, 4, 2><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1);
         else paint3_tile_kernel<false, 512, 4><<<nb, 512, 0, p->stream>>>(g, pos, weights3, meshes3, p->M, accumulate, L, p->fx_wmax, p->fx_redo, nullptr, 1);
