@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  -- must be imported first: libmcpm.so binds to the HIP runtime / rocFFT torch loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcpm.so")
+LIB_PATH = os.environ.get("MCPM_LIB") or os.path.join(_HERE, "libmcpm.so")      # MCPM_LIB: another build of the same ABI (A/B runs on one box)
 
 OK = 0
 POS_ABSOLUTE, POS_LATTICE = 0, 1

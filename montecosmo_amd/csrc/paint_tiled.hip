@@ -278,7 +278,7 @@ __device__ __forceinline__ void append_wild(const TileLists &L, int gi) {
 
 // Suspects are staged in LDS (one global atomic per workgroup instead of one per suspect: a single global counter serialised
 // the kernel as soon as a few per cent of the particles were suspects); `sus`: MCPM_SUS ints + the count in sus[MCPM_SUS].
-#define MCPM_SUS 1024
+#define MCPM_SUS 960      // (with the z-padded density tile, 36 KB, four workgroups still fit the 160 KB of a CU)
 __device__ __forceinline__ void append_suspect(const TileLists &L, int *sus, int gi) {
     const int k = atomicAdd(sus + MCPM_SUS, 1);
     if (k < MCPM_SUS) sus[k] = gi;
@@ -497,7 +497,9 @@ template <int WMODE, int THREADS, int U, int FAST>
 __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__restrict__ disp, const float *__restrict__ w,
                                                 int64_t wstride, float wscalar, float *__restrict__ mesh, int accumulate, const TileLists &L,
                                                 const unsigned *__restrict__ wmax_bits, int duty, u64 *tile, int *sh27, int *sus) {
-    constexpr int B = MCPM_TILE, NT = B * B * B;
+    // The LDS tile is padded by one cell at either end of z (rows of BZ = 18): the two z corners of a deposit need no bounds test,
+    // four masked blocks of two atomics instead of eight of one (the pads' sums are never read)
+    constexpr int B = MCPM_TILE, BZ = B + 2, NT = B * B * B, NTP = B * B * BZ;
     double *dtile = reinterpret_cast<double *>(tile);
     TScale sc = {1073741824.f, 9.313225746154785e-10, 1};
     if (WMODE != 0) {
@@ -508,7 +510,7 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
     int tx, ty, tz;
     tile_of_block(ntx, nty, ntz, tx, ty, tz, L.order);
     const int x0 = tx * B, y0 = ty * B, z0 = tz * B;
-    for (int i = threadIdx.x; i < NT; i += THREADS) tile[i] = 0ull;
+    for (int i = threadIdx.x; i < NTP; i += THREADS) tile[i] = 0ull;
     if (threadIdx.x == 0) sus[MCPM_SUS] = 0;
     const Box bx = block_box(L, (tx * nty + ty) * ntz + tz);      // the tile's window (wave-uniform)
     const int Wx = B + 1 + bx.hi[0] - bx.lo[0], Wy = B + 1 + bx.hi[1] - bx.lo[1], Wz = B + 1 + bx.hi[2] - bx.lo[2], NW = Wx * Wy * Wz;
@@ -560,8 +562,8 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
                 const float s0 = WMODE == 2 ? wt[u] : (WMODE == 1 ? wt[u] * sc.S : sc.S);   // exact power-of-two scaling
                 const float kx[2] = {(1.f - tx1) * s0, tx1 * s0}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
                 // one LDS base address, corners at immediate offsets; a corner outside the tile is skipped
-                const bool vx[2] = {cx >= 0, cx < B - 1}, vy[2] = {cy >= 0, cy < B - 1}, vz[2] = {cz >= 0, cz < B - 1};
-                const int base = (cx * B + cy) * B + cz;
+                const bool vx[2] = {cx >= 0, cx < B - 1}, vy[2] = {cy >= 0, cy < B - 1};
+                const int base = (cx * B + cy) * BZ + cz + 1;
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -571,8 +573,8 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
                         for (int e = 0; e < 2; ++e)
                             // (depositing an outside corner into a per-lane trash cell instead, 8 unconditional atomics and no
                             // per-corner exec mask, is SLOWER: 0.956 vs 0.902 ms at 512^3 -- +90 vector instructions per 4 visits)
-                            if (vx[a] && vy[bb] && vz[e]) {
-                                const int q = base + (a * B + bb) * B + e;
+                            if (vx[a] && vy[bb]) {
+                                const int q = base + (a * B + bb) * BZ + e;
                                 if (WMODE == 2) atomicAdd(dtile + q, (double)(wxy * kz[e]));
                                 else if (WMODE == 1) atomicAdd(tile + q, (u64)(long long)cvt_rpi(wxy * kz[e]));
                                 else atomicAdd(tile + q, (u64)(unsigned)cvt_rpi(wxy * kz[e]));
@@ -604,13 +606,14 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
     for (int i = threadIdx.x; i < NT / 4; i += THREADS) {
         const int lz = (i % (B / 4)) * 4, r = i / (B / 4), ly = r % B, lx = r / B;
         float4 v;
-        if (WMODE == 2) v = make_float4((float)dtile[4 * i], (float)dtile[4 * i + 1], (float)dtile[4 * i + 2], (float)dtile[4 * i + 3]);
+        const int t0 = r * BZ + 1 + lz;      // first of the four cells in the padded tile
+        if (WMODE == 2) v = make_float4((float)dtile[t0], (float)dtile[t0 + 1], (float)dtile[t0 + 2], (float)dtile[t0 + 3]);
         else if (WMODE == 1)
-            v = make_float4((float)((double)(long long)tile[4 * i] * s), (float)((double)(long long)tile[4 * i + 1] * s),
-                            (float)((double)(long long)tile[4 * i + 2] * s), (float)((double)(long long)tile[4 * i + 3] * s));
+            v = make_float4((float)((double)(long long)tile[t0] * s), (float)((double)(long long)tile[t0 + 1] * s),
+                            (float)((double)(long long)tile[t0 + 2] * s), (float)((double)(long long)tile[t0 + 3] * s));
         else
-            v = make_float4((float)((double)tile[4 * i] * s), (float)((double)tile[4 * i + 1] * s), (float)((double)tile[4 * i + 2] * s),
-                            (float)((double)tile[4 * i + 3] * s));
+            v = make_float4((float)((double)tile[t0] * s), (float)((double)tile[t0 + 1] * s), (float)((double)tile[t0 + 2] * s),
+                            (float)((double)tile[t0 + 3] * s));
         float4 *dst = reinterpret_cast<float4 *>(mesh + ((int64_t)(x0 + lx) * g.ny + (y0 + ly)) * g.nz + z0 + lz);
         if (accumulate) {
             const float4 o = *dst;
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void 
                                                              int64_t wstride, float wscalar, float *__restrict__ mesh,
                                                              int accumulate, TileLists L, const unsigned *__restrict__ wmax_bits,
                                                              int duty) {
-    __shared__ u64 tile[MCPM_TILE * MCPM_TILE * MCPM_TILE];
+    __shared__ u64 tile[MCPM_TILE * MCPM_TILE * (MCPM_TILE + 2)];      // z-padded (paint_tile_body)
     __shared__ int sh27[27];
     __shared__ int sus[MCPM_SUS + 2];
     paint_tile_body<WMODE, THREADS, U, FAST>(g, disp, w, wstride, wscalar, mesh, accumulate, L, wmax_bits, duty, tile, sh27, sus);
@@ -834,7 +837,7 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
                                                  float *__restrict__ mesh, int64_t M, int accumulate, const TileLists &L,
                                                  const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out, int redo_tile, int duty,
                                                  u64 *tile, int &flagged, int *sh27, int *sus) {
-    constexpr int B = MCPM_TILE, NT = B * B * B;
+    constexpr int B = MCPM_TILE, BZ = B + 2, NT = B * B * B, NTP = B * B * BZ;      // z-padded LDS tiles: see paint_tile_body
     double *dtile = reinterpret_cast<double *>(tile);
     const int ntx = g.nx / B, nty = g.ny / B, ntz = g.nz / B;
     int tx, ty, tz;
@@ -877,7 +880,7 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
         sus[MCPM_SUS] = 0;
     }
     if (deposit)
-        for (int i = threadIdx.x; i < (F64 ? 3 : 2) * NT; i += THREADS) tile[i] = 0ull;
+        for (int i = threadIdx.x; i < (F64 ? 3 : 2) * NTP; i += THREADS) tile[i] = 0ull;
     float slo[3] = {(float)bx.lo[0], (float)bx.lo[1], (float)bx.lo[2]}, shi[3] = {(float)bx.hi[0], (float)bx.hi[1], (float)bx.hi[2]};
     if (L.toff) sure_intervals(g, L, tx, ty, tz, ntx, nty, ntz, sh27, slo, shi);
     __syncthreads();
@@ -923,8 +926,8 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
             if (deposit && cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
                 const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
                 const float kx[2] = {1.f - tx1, tx1}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
-                const bool vx[2] = {cx >= 0, cx < B - 1}, vy[2] = {cy >= 0, cy < B - 1}, vz[2] = {cz >= 0, cz < B - 1};
-                const int base = (cx * B + cy) * B + cz;
+                const bool vx[2] = {cx >= 0, cx < B - 1}, vy[2] = {cy >= 0, cy < B - 1};
+                const int base = (cx * B + cy) * BZ + cz + 1;
                 if (F64) {
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
@@ -933,12 +936,12 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
                             const float kxy = kx[a] * ky[bb];
 #pragma unroll
                             for (int e = 0; e < 2; ++e)
-                                if (vx[a] && vy[bb] && vz[e]) {
+                                if (vx[a] && vy[bb]) {
                                     const float k = kxy * kz[e];
-                                    double *q = dtile + base + (a * B + bb) * B + e;
+                                    double *q = dtile + base + (a * B + bb) * BZ + e;
                                     atomicAdd(q, (double)(wt[u].x * k));
-                                    atomicAdd(q + NT, (double)(wt[u].y * k));
-                                    atomicAdd(q + 2 * NT, (double)(wt[u].z * k));
+                                    atomicAdd(q + NTP, (double)(wt[u].y * k));
+                                    atomicAdd(q + 2 * NTP, (double)(wt[u].z * k));
                                 }
                         }
                 } else {
@@ -953,7 +956,7 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
                             const float kxy = kx[a] * ky[bb];
 #pragma unroll
                             for (int e = 0; e < 2; ++e)
-                                if (vx[a] && vy[bb] && vz[e]) {
+                                if (vx[a] && vy[bb]) {
                                     const float k = kxy * kz[e];
                                     const v2f kk = {k, k};
                                     const v2f p01 = s01 * kk, p2m = __builtin_elementwise_fma(s2m, kk, c01);
@@ -961,9 +964,9 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
                                     const unsigned ib = (unsigned)p2m.y;
                                     const u64 wa = ((u64)(unsigned)(i1 + (i0 >> 31)) << 32) | (unsigned)i0;
                                     const u64 wbv = ((u64)(ib + (unsigned)(i2 >> 31)) << 32) | (unsigned)i2;
-                                    u64 *q = tile + base + (a * B + bb) * B + e;
+                                    u64 *q = tile + base + (a * B + bb) * BZ + e;
                                     atomicAdd(q, wa);
-                                    atomicAdd(q + NT, wbv);
+                                    atomicAdd(q + NTP, wbv);
                                 }
                         }
                 }
@@ -992,7 +995,7 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
     if (!F64) {   // overflow proof: bound field of every cell
         int over = 0;
         for (int i = threadIdx.x; i < NT; i += THREADS) {
-            const long long bw = (long long)tile[NT + i];
+            const long long bw = (long long)tile[NTP + (i / B) * BZ + 1 + i % B];
             const int c2 = (int)(unsigned)bw;
             over |= (unsigned)((bw - (long long)c2) >> 32) >= (1u << 19);
         }
@@ -1009,11 +1012,11 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (F64) {
-                v[0][q] = (float)dtile[4 * i + q];
-                v[1][q] = (float)dtile[NT + 4 * i + q];
-                v[2][q] = (float)dtile[2 * NT + 4 * i + q];
+                v[0][q] = (float)dtile[r * BZ + 1 + lz + q];
+                v[1][q] = (float)dtile[NTP + r * BZ + 1 + lz + q];
+                v[2][q] = (float)dtile[2 * NTP + r * BZ + 1 + lz + q];
             } else {
-                const long long aw = (long long)tile[4 * i + q], bw = (long long)tile[NT + 4 * i + q];
+                const long long aw = (long long)tile[r * BZ + 1 + lz + q], bw = (long long)tile[NTP + r * BZ + 1 + lz + q];
                 const int c0 = (int)(unsigned)aw, c2 = (int)(unsigned)bw;
                 const int c1 = (int)((aw - (long long)c0) >> 32);
                 v[0][q] = (float)c0 * Sinv;
@@ -1046,8 +1049,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                                                               float *__restrict__ mesh, int64_t M, int accumulate, TileLists L,
                                                               const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out,
                                                               const int *__restrict__ redo_in, int duty) {
-    constexpr int NT = MCPM_TILE * MCPM_TILE * MCPM_TILE;
-    __shared__ u64 tile[(F64 ? 3 : 2) * NT];   // 64 KB (two workgroups per CU) / 96 KB
+    constexpr int NT = MCPM_TILE * MCPM_TILE * (MCPM_TILE + 2);      // z-padded
+    __shared__ u64 tile[(F64 ? 3 : 2) * NT];   // 72 KB (two workgroups per CU) / 108 KB
     __shared__ int flagged;
     __shared__ int sh27[27];
     __shared__ int sus[MCPM_SUS + 2];
@@ -1070,7 +1073,7 @@ template <int FAST>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void paint3_tile_wide_kernel(Geom g, const float *__restrict__ disp,
                                                               const float *__restrict__ w3, float *__restrict__ mesh, int64_t M, int accumulate,
                                                               TileLists L, const unsigned *__restrict__ wmax_bits, int *__restrict__ redo_out, int duty) {
-    constexpr int NT = MCPM_TILE * MCPM_TILE * MCPM_TILE;
+    constexpr int NT = MCPM_TILE * MCPM_TILE * (MCPM_TILE + 2);      // z-padded
     __shared__ u64 tile[2 * NT];
     __shared__ int flagged;
     __shared__ int sh27[27];
