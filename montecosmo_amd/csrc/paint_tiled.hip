@@ -549,14 +549,17 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
             // uncounted.
             const bool unsure = !(fx >= slo[0] && fx <= shi[0] && fy >= slo[1] && fy <= shi[1] && fz >= slo[2] && fz <= shi[2]);
             const bool home = (unsigned)rx < (unsigned)B && (unsigned)ry < (unsigned)B && (unsigned)rz < (unsigned)B;
-            if (unsure && !(fabsf(d[u].x) < MCPM_TAME && fabsf(d[u].y) < MCPM_TAME && fabsf(d[u].z) < MCPM_TAME)) {   // wild
-                if (duty && home) append_suspect(L, sus, gis[u]);
-                continue;
+            // (one divergent region for the rare cases -- wild: unsure and not tame; beyond: slab plans only -- and one append site: the
+            // tile kernels are bound by scalar and vector issue alike, and every divergent `if` costs four scalar instructions and a branch)
+            const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;      // (garbage for a wild particle: skipped below)
+            bool skip = false;
+            if (unsure || (FAST != 1 && g.xslab)) {
+                const bool tame = fabsf(d[u].x) < MCPM_TAME && fabsf(d[u].y) < MCPM_TAME && fabsf(d[u].z) < MCPM_TAME;
+                const bool beyond = FAST != 1 && g.xslab && tame && (x0 + cx < 0 || x0 + cx > g.nx - 2);
+                if ((unsure || beyond) && duty && home) append_suspect(L, sus, gis[u]);
+                skip = !tame || beyond;      // wild: the leftover kernel's; beyond: clamped + counted by paint_leftover_kernel
             }
-            const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
-            const bool beyond = FAST != 1 && g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
-            if ((unsure || beyond) && duty && home) append_suspect(L, sus, gis[u]);
-            if (beyond) continue;   // clamped + counted by paint_leftover_kernel
+            if (skip) continue;
             if (cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
                 const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
                 const float s0 = WMODE == 2 ? wt[u] : (WMODE == 1 ? wt[u] * sc.S : sc.S);   // exact power-of-two scaling
@@ -915,14 +918,17 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
             // uncounted.
             const bool unsure = !(fx >= slo[0] && fx <= shi[0] && fy >= slo[1] && fy <= shi[1] && fz >= slo[2] && fz <= shi[2]);
             const bool home = (unsigned)rx < (unsigned)B && (unsigned)ry < (unsigned)B && (unsigned)rz < (unsigned)B;
-            if (unsure && !(fabsf(d[u].x) < MCPM_TAME && fabsf(d[u].y) < MCPM_TAME && fabsf(d[u].z) < MCPM_TAME)) {   // wild
-                if (duty && home) append_suspect(L, sus, gis[u]);
-                continue;
+            // (one divergent region for the rare cases -- wild: unsure and not tame; beyond: slab plans only -- and one append site: the
+            // tile kernels are bound by scalar and vector issue alike, and every divergent `if` costs four scalar instructions and a branch)
+            const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;      // (garbage for a wild particle: skipped below)
+            bool skip = false;
+            if (unsure || (FAST != 1 && g.xslab)) {
+                const bool tame = fabsf(d[u].x) < MCPM_TAME && fabsf(d[u].y) < MCPM_TAME && fabsf(d[u].z) < MCPM_TAME;
+                const bool beyond = FAST != 1 && g.xslab && tame && (x0 + cx < 0 || x0 + cx > g.nx - 2);
+                if ((unsure || beyond) && duty && home) append_suspect(L, sus, gis[u]);
+                skip = !tame || beyond;      // wild: the leftover kernel's; beyond: clamped + counted by paint_leftover_kernel
             }
-            const int cx = rx + (int)fx, cy = ry + (int)fy, cz = rz + (int)fz;
-            const bool beyond = FAST != 1 && g.xslab && (x0 + cx < 0 || x0 + cx > g.nx - 2);
-            if ((unsure || beyond) && duty && home) append_suspect(L, sus, gis[u]);
-            if (beyond) continue;   // clamped + counted by paint_leftover_kernel
+            if (skip) continue;
             if (deposit && cx >= -1 && cx < B && cy >= -1 && cy < B && cz >= -1 && cz < B) {
                 const float tx1 = d[u].x - fx, ty1 = d[u].y - fy, tz1 = d[u].z - fz;
                 const float kx[2] = {1.f - tx1, tx1}, ky[2] = {1.f - ty1, ty1}, kz[2] = {1.f - tz1, tz1};
