@@ -69,21 +69,23 @@ const char *mcpm_last_error(const mcpm_plan *plan); /* plan may be NULL: last er
 /* ABI revision string; the Python loader (montecosmo_amd/_lib.py) refuses a library that reports another one. */
 #define MCPM_ABI_VERSION "mcpm 0.5 (gfx950)"
 const char *mcpm_version(void);
-/* Tiled CIC paints (montecosmo_amd/csrc/paint_tiled.hip).  A tile's window is (16 + 2 halo + 1)^3 lattice points wide,
-   centred on the tile (or, optionally, on the local bulk displacement); what a window misses travels through per-tile
+/* Tiled CIC paints (montecosmo_amd/csrc/paint_tiled.hip).  A tile's window is a box of lattice points per axis -- chosen on the device
+   for every input and every tile from the displacement field around it, or (16 + 2 halo + 1)^3 around the tile's bulk displacement when a
+   halo is fixed (mcpm_plan_set_halo) or the mesh has fewer than 2048 tiles; what a window misses travels through per-tile
    buckets (integer LDS sums, so the paint stays bitwise reproducible).  mcpm_plan_last_bucketed: (particle, tile) pairs the last tiled paint routed through
    the buckets.  mcpm_plan_last_outliers: particles / pairs it had to deposit with f32 global atomics instead (non-finite or
    absurd displacements, bucket overflow).  Both synchronise the host. */
 int mcpm_plan_last_outliers(mcpm_plan *plan, int64_t *count);
 int mcpm_plan_last_bucketed(mcpm_plan *plan, int64_t *count);
-/* Everything the last tiled paint counted, in one call (synchronises the host): out13[0..7] = wild particles, wild + overflow pairs,
+/* Everything the last tiled paint counted, in one call (synchronises the host): out13[0..6] = wild particles, wild + overflow pairs,
    slab deposits beyond the ghost planes (cumulative), appends that found their bucket full, tiles with a non-empty bucket, bucketed
-   pairs, suspects (particles handed to the exact coverage test), reserved; out13[8 + h], h = 0..4 = number of tiles whose window
-   halo is h (0: the halo was fixed, no per-tile choice). */
+   pairs, suspects (particles handed to the exact coverage test); out13[7] = window points of all tiles (divided by the particle count:
+   window visits per particle); out13[8 + h], h = 0..4 = number of tiles whose widest window axis spans what a symmetric halo of h would
+   (17 + 2h - 1 or 17 + 2h points; all zero when the plan's windows are not centred). */
 int mcpm_plan_last_paint_stats(mcpm_plan *plan, int64_t *out13);
-/* Tuning knobs: halo radius (1, 2, 3, 4 or 6 cells; 0 = the default: chosen among 1, 2, 3, 4 ON THE DEVICE for every input and every TILE from the
-   sampled displacement ranges of the Lagrangian blocks around it -- same input, same halos, so results stay bitwise reproducible; meshes below 2048
-   tiles: 4 up to 2^24 cells, 3 above) and whether windows are centred on the local bulk
+/* Tuning knobs: halo radius (1, 2, 3, 4 or 6 cells: a symmetric window around the tile's bulk displacement; 0 = the default: a window BOX per tile
+   and per axis chosen ON THE DEVICE for every input from the sampled displacement ranges of the Lagrangian blocks around the tile -- same input,
+   same windows, so results stay bitwise reproducible; meshes below 2048 tiles: halo 4 up to 2^24 cells, 3 above) and whether windows are centred on the local bulk
    displacement (default 1; 0 = on the tile itself, which needs halo 4 at the benchmark's 2-cell rms displacement). */
 int mcpm_plan_set_halo(mcpm_plan *plan, int halo);
 int mcpm_plan_set_centre(mcpm_plan *plan, int centre);
