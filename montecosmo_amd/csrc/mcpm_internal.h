@@ -71,10 +71,11 @@ struct mcpm_plan {
     int64_t M;   // nx*ny*nz
     int64_t Mh;  // nx*ny*nzh
     int64_t Np;  // px*py*pz
-    int halo;    // halo radius H of the tiled paints: a tile's window is (16 + 2H + 1)^3 lattice points
+    int halo;    // tiled paints: > 0 = fixed halo H (a tile's window is (16 + 2H + 1)^3 lattice points around its bulk offset); 0 = boxes chosen on the device
     int centre;  // tiled paints: windows centred on the local bulk displacement (paint_tiled.hip); 0 = on the tile itself
-    int *halo_sel;    // per 16^3 Lagrangian block: sampled range of floor(d) per axis ([ntiles] minima, [ntiles] maxima), from which halo_tile_kernel sizes every tile's window
-    int *tile_off;    // packed window offsets per 16^3 tile (device; NULL if the mesh cannot be tiled)
+    int *halo_sel;    // 3 x ntiles packed words: per 16^3 Lagrangian block the sampled range of floor(d) per axis ([ntiles] minima, [ntiles] maxima), from which
+                      // box_tile_kernel sizes every tile's window, then [ntiles] upper corners of the windows
+    int *tile_off;    // packed lower corners of the windows' floor(d) boxes per 16^3 tile (device; NULL if the mesh cannot be tiled)
     int *bucket_cnt;  // per-tile bucket fill counts
     int *bucket;      // [tile][bucket_cap] particles a tile's window misses
     int bucket_cap;

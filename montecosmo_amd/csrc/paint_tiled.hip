@@ -6,13 +6,15 @@
 //   * PULL, not scatter.  One workgroup owns one 16^3 Eulerian tile of the mesh in LDS and pulls the lattice particles that
 //     can land in it: coalesced 12-byte loads, lanes along z, 4 loads in flight per thread.  Only stencil points inside the
 //     tile are deposited (LDS integer atomics); the tile is written with plain 16-byte stores.  No global atomics, no sort.
-//   * BULK-CENTRED WINDOWS.  Particles are stored in Lagrangian order as displacements from their lattice point, and the
-//     displacement field is smooth: the particles that land in tile T come from lattice points around T - o_T, where o_T is
-//     the (rounded) mean displacement near T.  `tile_prologue_kernel` samples 64 particles per tile for o_T (25 MB of reads at
-//     512^3), and the window of T is the (16 + 2H + 1)^3 lattice points  T - o_T - (H+1) ... T - o_T + 15 + H  with H = 3
-//     (mcpm_plan_set_halo): 3.0 window visits per particle instead of the 3.8 of an uncentred H = 4 window (which the
-//     2-cell rms displacement of the benchmark needed), for the same outlier rate.  (H = 2, 2.3 visits, overflows the
-//     buckets on that workload: 1.54 instead of 0.92 ms at 512^3.)
+//   * WINDOWS THAT FOLLOW THE DISPLACEMENT FIELD.  Particles are stored in Lagrangian order as displacements from their lattice
+//     point, and the displacement field is smooth: a particle with floor(d) = fd that lands in tile T sits at lattice point
+//     T + c - fd (c in [-1, 15] its base cell in T), so T needs the lattice points [T - 1 - max fd, T + 15 - min fd] per axis over
+//     the particles that land in it.  `tile_prologue_kernel` samples 64 particles per 16^3 Lagrangian block (25 MB of reads at
+//     512^3) and `box_tile_kernel` gives every tile the box [lo, hi] = hull of the sampled floor(d) of the 27 blocks around it:
+//     a window of prod_a (17 + hi_a - lo_a) lattice points, 1.4-1.9 window visits per particle on the benchmark's trajectory
+//     (rms displacement 2 cells) where one symmetric halo H = 3 around the bulk offset, (16 + 2H + 1)^3 points for every tile,
+//     cost 3.0 and an uncentred H = 4 window 3.8.  A fixed halo (mcpm_plan_set_halo; meshes below 2048 tiles) is the box
+//     [o_T - H, o_T + H] around the block's rounded mean displacement o_T.
 //   * BUCKETS for what the windows miss.  Every workgroup also watches the particles of its own Lagrangian block (they lie
 //     in its window whenever |o_T| <= H; a second short loop covers them otherwise): a particle whose floor(d) leaves the
 //     interval in which every neighbouring window is sure to contain it (six compares, the cost of the round-1 outlier
