@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void tile_prologue_kernel(Geom g, const float 
     }
     if (!rng) return;
     // range of floor(d) over the same 64 samples, per axis (clamped to +-100; a NaN sample widens it to the clamp): what
-    // halo_tile_kernel sizes the windows of the tiles around this block with
+    // box_tile_kernel sizes the windows of the tiles around this block with
     const float f3[3] = {floorf(d.x), floorf(d.y), floorf(d.z)};
     float lo[3], hi[3];
 #pragma unroll

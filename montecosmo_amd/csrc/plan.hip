@@ -75,7 +75,7 @@ int mcpm_plan_create_slab(int nx, int ny, int nz, int nranks, int rank, int ghos
 // 3635 vs 3231, 192^3 993 vs 864, 256^3 689 vs 703 (but pm_forces on the evolved particles 0.552 vs 0.630 ms), 512^3 87.8 vs 90.0.
 // The choice never changes a result beyond the last bit (the sums are exact; the split between tile and bucket deposits moves).
 // This static rule is what slab plans and MCPM_PAINT_ADAPT=0 use; periodic plans choose H per input on the device
-// (paint_tiled.hip::halo_tile_kernel).  MCPM_PAINT_HALO / mcpm_plan_set_halo fix it.
+// (paint_tiled.hip::box_tile_kernel).  MCPM_PAINT_HALO / mcpm_plan_set_halo fix it.
 // (mcpm_default_halo: mcpm_internal.h)
 
 // nranks == 1, ghost == 0: ordinary periodic plan.  Otherwise (slab): (nx, ny, nz) is the GLOBAL mesh, the local
@@ -112,7 +112,7 @@ static int plan_create_impl(int nx, int ny, int nz, int px, int py, int pz, int 
     p->M = (int64_t)nx * ny * nz;
     p->Mh = (int64_t)nx * ny * p->g.nzh;
     p->Np = (int64_t)px * py * pz;
-    p->halo = 0;      // 0: chosen per input on the device (paint_tiled.hip::halo_of / halo_tile_kernel), else mcpm_default_halo
+    p->halo = 0;      // 0: chosen per input on the device (paint_tiled.hip::halo_of / box_tile_kernel), else mcpm_default_halo
     p->centre = 1;    // windows centred on the bulk displacement; on the tile itself (centre = 0) they need one more cell of halo at the
                       // benchmark's 2-cell rms displacement (bench 512^3: 12.10 vs 12.42 ms per step, pm_forces 4.38 vs 4.48 ms)
     if (const char *e = getenv("MCPM_PAINT_CENTRE")) p->centre = atoi(e) ? 1 : 0;

@@ -9,7 +9,7 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 out = {}
 for r in rows:
     k = r["Kernel_Name"].split("(")[0]
-    for key in ("paint_tile_kernel", "paint3_tile_kernel", "halo_select_kernel", "coverage_duty_kernel", "tile_prologue_kernel"):
+    for key in ("paint_tile_kernel", "paint3_tile_kernel", "box_tile_kernel", "coverage_duty_kernel", "tile_prologue_kernel"):
         if key in k:
             out.setdefault(k[:60], []).append(round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1))
 for k, v in out.items():
