@@ -271,15 +271,16 @@ static bool spec_custom(const mcpm_plan *p, const float *spec, int lap_fd, int g
            spec != p->spec1;
 }
 
-// half-spectrum -> delta2 (real, in plan->rho), Hessian meshes left in fmesh[0:6]
-static int spec_to_delta2_real(mcpm_plan *p, const float *spec, int lap_fd, int grad_fd) {
+// half-spectrum -> delta2 (real, in plan->rho), the six Hessian meshes left in `h` (default: fmesh[0:6])
+static int spec_to_delta2_real(mcpm_plan *p, const float *spec, int lap_fd, int grad_fd, float *h = nullptr) {
+    if (!h) h = p->fmesh;
     if (spec_custom(p, spec, lap_fd, grad_fd)) {
-        MCPM_TRY(mcpm_fftpm_spec_meshes(p, spec, p->fmesh, 6));
+        MCPM_TRY(mcpm_fftpm_spec_meshes(p, spec, h, 6));
     } else {
         MCPM_TRY(mcpm_kspace_hessian_f32(p, spec, p->spec, 1.f / (float)p->M, lap_fd, grad_fd));
-        MCPM_TRY(mcpm_fft_c2r(p, p->spec, p->fmesh, 6));
+        MCPM_TRY(mcpm_fft_c2r(p, p->spec, h, 6));
     }
-    MCPM_TRY(mcpm_hessian_combine_f32(p, p->fmesh, p->rho));
+    MCPM_TRY(mcpm_hessian_combine_f32(p, h, p->rho));
     return MCPM_OK;
 }
 
@@ -318,15 +319,22 @@ static int force_meshes_vjp_opts(mcpm_plan *p, const float *fbar3, float *rho_ba
 
 // Adjoint of lpt at the lattice (read_order = 1): cotangents (xb, vb) of (dpos, vel) -> init_mesh_bar (real-pair
 // convention) and three DEVICE double accumulators sb = {g_bar, -g2_bar, -dg2dg_bar} (added to, not reset).
+// `saved` (may be NULL): what the forward pass left in the checkpoint -- the first-order force meshes (3 M floats), then for
+// lpt_order = 2 the second-order ones (3 M) and the six Hessian meshes of the first-order potential (6 M): the adjoint then
+// recomputes none of them (a third of its transforms; 805 MB at 256^3 that a 288 GB part does not miss), and reads them only.
 static int lpt_vjp_device(mcpm_plan *p, const float *init_mesh, int lpt_order, const double *lpt_scalars, const float *xb,
-                          const float *vb, float *init_mesh_bar, double *sb, int lap_fd = MCPM_FD_INF, int grad_fd = MCPM_FD_INF) {
+                          const float *vb, float *init_mesh_bar, double *sb, int lap_fd = MCPM_FD_INF, int grad_fd = MCPM_FD_INF,
+                          const float *saved = nullptr) {
     const int64_t M = p->M;
     const float invM = 1.f / (float)M;
     dim3 grid, block;
     lattice_launch(p->g, grid, block);
     const float g = (float)lpt_scalars[0], g2 = (float)lpt_scalars[1], c2 = (float)lpt_scalars[2];
-    MCPM_TRY(spec_to_force_meshes(p, init_mesh, lap_fd, grad_fd, 0.f, 0, p->fmesh));
-    MCPM_TRY(lattice_dot(p, p->fmesh, xb, nullptr, sb + 0, nullptr));
+    if (saved) MCPM_TRY(lattice_dot(p, saved, xb, nullptr, sb + 0, nullptr));
+    else {
+        MCPM_TRY(spec_to_force_meshes(p, init_mesh, lap_fd, grad_fd, 0.f, 0, p->fmesh));
+        MCPM_TRY(lattice_dot(p, p->fmesh, xb, nullptr, sb + 0, nullptr));
+    }
     MCPM_TRY(lattice_scatter(p, xb, vb, g, 1.f, p->fmesh));
     const bool custom = spec_custom(p, init_mesh, lap_fd, grad_fd);
     if (custom) {
@@ -337,12 +345,18 @@ static int lpt_vjp_device(mcpm_plan *p, const float *init_mesh, int lpt_order, c
     }
     if (lpt_order == 2) {
         float *h = p->fmesh, *f2 = p->fmesh + 6 * M;
-        MCPM_TRY(spec_to_delta2_real(p, init_mesh, lap_fd, grad_fd));        // h in fmesh[0:6], delta2 in rho
-        MCPM_TRY(delta2_to_force_meshes(p, lap_fd, grad_fd, f2));            // F2 meshes
-        MCPM_TRY(lattice_dot(p, f2, xb, vb, sb + 1, sb + 2));  // negated on the host
+        const float *hsrc = h;
+        if (saved) {
+            MCPM_TRY(lattice_dot(p, saved + 3 * M, xb, vb, sb + 1, sb + 2));  // negated on the host
+            hsrc = saved + 6 * M;
+        } else {
+            MCPM_TRY(spec_to_delta2_real(p, init_mesh, lap_fd, grad_fd));        // h in fmesh[0:6], delta2 in rho
+            MCPM_TRY(delta2_to_force_meshes(p, lap_fd, grad_fd, f2));            // F2 meshes
+            MCPM_TRY(lattice_dot(p, f2, xb, vb, sb + 1, sb + 2));  // negated on the host
+        }
         MCPM_TRY(lattice_scatter(p, xb, vb, -g2, -c2, f2));
         MCPM_TRY(force_meshes_vjp_opts(p, f2, p->rho, lap_fd, grad_fd, 0));          // delta2_bar
-        MCPM_TRY(mcpm_hessian_combine_vjp_f32(p, h, p->rho, h));                      // in place: h -> h_bar
+        MCPM_TRY(mcpm_hessian_combine_vjp_f32(p, hsrc, p->rho, h));                   // h -> h_bar (in place without `saved`)
         if (custom) {
             MCPM_TRY(mcpm_fftpm_spec_meshes_vjp(p, h, init_mesh_bar, 6));
         } else {
@@ -478,27 +492,37 @@ int mcpm_lattice_dot_f32(mcpm_plan *p, const float *meshes3, const float *a, con
     return lattice_dot(p, meshes3, a, b, out2, out2 + 1);
 }
 
+// `save` (may be NULL): 3 M floats (lpt_order 1) or 12 M (lpt_order 2) that receive the first-order force meshes, the second-order
+// ones and the six Hessian meshes instead of the plan's scratch -- what lpt_vjp_device(saved) reads (mcpm_nbody_bf_f32's checkpoint)
+static int lpt_forward(mcpm_plan *p, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg, int lap_fd, int grad_fd,
+                       float *dpos, float *vel, float *save) {
+    dim3 grid, block;
+    lattice_launch(p->g, grid, block);
+    const int64_t M = p->M;
+    float *f1 = save ? save : p->fmesh;
+    MCPM_TRY(spec_to_force_meshes(p, init_mesh, lap_fd, grad_fd, 0.f, 0, f1));
+    {
+        StageTimer st_(p, ST_LPT, 12.0 * p->M + 24.0 * p->Np);
+        lpt_accum_kernel<<<grid, block, 0, p->stream>>>(p->g, f1, p->M, g, 1.f, 1, dpos, vel);
+    }
+    MCPM_LAUNCH_CHECK(p, "lpt_accum_kernel");
+    if (lpt_order == 2) {
+        float *f2 = save ? save + 3 * M : p->fmesh;
+        MCPM_TRY(spec_to_delta2_real(p, init_mesh, lap_fd, grad_fd, save ? save + 6 * M : nullptr));
+        MCPM_TRY(delta2_to_force_meshes(p, lap_fd, grad_fd, f2));
+        StageTimer st_(p, ST_LPT, 12.0 * p->M + 48.0 * p->Np);
+        lpt_accum_kernel<<<grid, block, 0, p->stream>>>(p->g, f2, p->M, -g2, -dg2dg, 0, dpos, vel);
+        MCPM_LAUNCH_CHECK(p, "lpt_accum_kernel");
+    }
+    return MCPM_OK;
+}
+
 int mcpm_lpt_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg, int lap_fd,
                  int grad_fd, float *dpos, float *vel) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, init_mesh && dpos && vel, MCPM_E_ARG, "mcpm_lpt_f32: null buffer");
     MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_lpt_f32: lpt_order must be 1 or 2");
-    dim3 grid, block;
-    lattice_launch(p->g, grid, block);
-    MCPM_TRY(spec_to_force_meshes(p, init_mesh, lap_fd, grad_fd, 0.f, 0, p->fmesh));
-    {
-        StageTimer st_(p, ST_LPT, 12.0 * p->M + 24.0 * p->Np);
-        lpt_accum_kernel<<<grid, block, 0, p->stream>>>(p->g, p->fmesh, p->M, g, 1.f, 1, dpos, vel);
-    }
-    MCPM_LAUNCH_CHECK(p, "lpt_accum_kernel");
-    if (lpt_order == 2) {
-        MCPM_TRY(spec_to_delta2_real(p, init_mesh, lap_fd, grad_fd));
-        MCPM_TRY(delta2_to_force_meshes(p, lap_fd, grad_fd, p->fmesh));
-        StageTimer st_(p, ST_LPT, 12.0 * p->M + 48.0 * p->Np);
-        lpt_accum_kernel<<<grid, block, 0, p->stream>>>(p->g, p->fmesh, p->M, -g2, -dg2dg, 0, dpos, vel);
-        MCPM_LAUNCH_CHECK(p, "lpt_accum_kernel");
-    }
-    return MCPM_OK;
+    return lpt_forward(p, init_mesh, lpt_order, g, g2, dg2dg, lap_fd, grad_fd, dpos, vel, nullptr);
 }
 
 int mcpm_bullfrog_step_f32(mcpm_plan *p, const float *pos_in, const float *vel_in, double alpha, double beta, double tau,
@@ -701,10 +725,12 @@ int mcpm_pm_forces_vjp_opts_f32(mcpm_plan *p, const float *pos, int64_t n, int m
 
 // checkpoint layout: states (x'_i, v_i) as arrays 2 i and 2 i + 1, mcpm_pitch() floats apart, in a region sized for the largest
 // candidate pitch (so that the buffer does not depend on the pitch chosen later); then the n_steps force meshes
+// ... then what the LPT start leaves for its adjoint: the first-order force meshes (3 M), and with lpt_order = 2 the second-order ones
+// (3 M) and the six Hessian meshes (6 M) -- lpt_forward(save) / lpt_vjp_device(saved)
+static int64_t ckpt_lpt_offset(const mcpm_plan *p, int n_steps) { return (int64_t)n_steps * (2 * mcpm_pitch_max(p) + 3 * p->M); }
 int64_t mcpm_nbody_ckpt_floats(const mcpm_plan *p, int n_steps, int lpt_order) {
-    (void)lpt_order;
     if (!p || n_steps < 1) return 0;
-    return (int64_t)n_steps * (2 * mcpm_pitch_max(p) + 3 * p->M);
+    return ckpt_lpt_offset(p, n_steps) + (lpt_order == 2 ? 12 : 3) * p->M;
 }
 
 int mcpm_plan_set_particle_pitch(mcpm_plan *p, int64_t pitch_floats) {
@@ -784,8 +810,9 @@ int mcpm_nbody_bf_f32(mcpm_plan *p, const float *init_mesh, int n_steps, const d
     auto state_v = [&](int i) { return ckpt + (int64_t)(2 * i + 1) * pitch; };
     auto force_m = [&](int i) { return ckpt + (int64_t)n_steps * 2 * mcpm_pitch_max(p) + (int64_t)i * 3 * M; };
     float *x = ckpt ? state_x(0) : pos_out, *v = ckpt ? state_v(0) : vel_out;
-    MCPM_TRY(mcpm_lpt_f32(p, init_mesh, lpt_order, (float)lpt_scalars[0], (float)lpt_scalars[1], (float)lpt_scalars[2],
-                          MCPM_FD_INF, MCPM_FD_INF, x, v));
+    MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_nbody_bf_f32: lpt_order must be 1 or 2");
+    MCPM_TRY(lpt_forward(p, init_mesh, lpt_order, (float)lpt_scalars[0], (float)lpt_scalars[1], (float)lpt_scalars[2], MCPM_FD_INF,
+                         MCPM_FD_INF, x, v, ckpt ? ckpt + ckpt_lpt_offset(p, n_steps) : nullptr));
     MCPM_TRY(mcpm_drift_f32(p, x, v, N, (float)(dg / 2), x));
     for (int i = 0; i < n_steps; ++i) {
         const bool last = (i == n_steps - 1);
@@ -837,7 +864,8 @@ int mcpm_nbody_bf_vjp_f32(mcpm_plan *p, const float *init_mesh, int n_steps, con
     MCPM_TRY(axpby(p, vb, xb, 3 * N, 1.f, (float)(dg / 2), vb));
 
     // ---- adjoint of lpt (nbody.py:634-667) at the lattice, read_order = 1
-    MCPM_TRY(lpt_vjp_device(p, init_mesh, lpt_order, lpt_scalars, xb, vb, init_mesh_bar, p->reduce + 2 * n_steps));
+    MCPM_TRY(lpt_vjp_device(p, init_mesh, lpt_order, lpt_scalars, xb, vb, init_mesh_bar, p->reduce + 2 * n_steps, MCPM_FD_INF, MCPM_FD_INF,
+                            ckpt + ckpt_lpt_offset(p, n_steps)));
     if (scalar_bars) {
         MCPM_HIP(p, hipMemcpyAsync(scalar_bars, p->reduce, sizeof(double) * (2 * n_steps + 4), hipMemcpyDeviceToHost, p->stream));
         MCPM_HIP(p, hipStreamSynchronize(p->stream));
