@@ -67,7 +67,7 @@ int mcpm_plan_slab_oob(mcpm_plan *plan, int64_t *count);
 int mcpm_plan_destroy(mcpm_plan *plan);
 const char *mcpm_last_error(const mcpm_plan *plan); /* plan may be NULL: last error of a failed create */
 /* ABI revision string; the Python loader (montecosmo_amd/_lib.py) refuses a library that reports another one. */
-#define MCPM_ABI_VERSION "mcpm 0.5 (gfx950)"
+#define MCPM_ABI_VERSION "mcpm 0.6 (gfx950)"
 const char *mcpm_version(void);
 /* Tiled CIC paints (montecosmo_amd/csrc/paint_tiled.hip).  A tile's window is a box of lattice points per axis -- chosen on the device
    for every input and every tile from the displacement field around it, or (16 + 2 halo + 1)^3 around the tile's bulk displacement when a
@@ -453,6 +453,13 @@ int mcpm_cgh2rg_amp_f32(void *stream, const float *spec, int nx, int ny, int nz,
 int mcpm_bias_fields_f32(mcpm_plan *plan, const float *lin_mesh, float kphys_x, float kphys_y, float kphys_z, float *fields7);
 int mcpm_bias_fields_vjp_f32(mcpm_plan *plan, const float *lin_mesh, float kphys_x, float kphys_y, float kphys_z,
                              const float *fields7_bar, float *lin_mesh_bar);
+/* The same pair with the forward pass's intermediates kept for the adjoint: hess6 (6 M floats, caller-owned; NULL = not kept) receives
+   delta and the five Hessian meshes of the shear; mcpm_bias_fields_vjp_saved_f32 reads them instead of recomputing them from
+   lin_mesh (six transforms less per gradient; 400 MB at 256^3). */
+int mcpm_bias_fields_save_f32(mcpm_plan *plan, const float *lin_mesh, float kphys_x, float kphys_y, float kphys_z, float *fields7,
+                              float *hess6);
+int mcpm_bias_fields_vjp_saved_f32(mcpm_plan *plan, float kphys_x, float kphys_y, float kphys_z, const float *hess6,
+                                   const float *fields7_bar, float *lin_mesh_bar);
 int mcpm_bias_weights_f32(mcpm_plan *plan, int64_t n, const float *dr, const float *s2r, const float *s3r, const float *lr,
                           const float *gr, int64_t gr_cstride, const float *growth, float growth_scalar, const float *bias8,
                           float *weights, float *dvel, double *sigma2_out);

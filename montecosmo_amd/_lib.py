@@ -56,6 +56,8 @@ SIGNATURES = {
     "mcpm_force_meshes_vjp_f32": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "mcpm_bias_fields_f32": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_float, C.c_float, _f32p]),
     "mcpm_bias_fields_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_float, C.c_float, _f32p, _f32p]),
+    "mcpm_bias_fields_save_f32": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_float, C.c_float, _f32p, _f32p]),
+    "mcpm_bias_fields_vjp_saved_f32": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, _f32p, _f32p, _f32p]),
     "mcpm_bias_weights_f32": (C.c_int, [C.c_void_p, C.c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int64, _f32p, C.c_float,
                                         C.POINTER(C.c_float), _f32p, _f32p, C.c_void_p]),
     "mcpm_bias_weights_vjp_f32": (C.c_int, [C.c_void_p, C.c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int64, _f32p, C.c_float,
@@ -137,7 +139,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = "mcpm 0.5 (gfx950)"   # must equal mcpm_version() of the loaded library (include/mcpm.h MCPM_ABI_VERSION)
+ABI_VERSION = "mcpm 0.6 (gfx950)"   # must equal mcpm_version() of the loaded library (include/mcpm.h MCPM_ABI_VERSION)
 
 
 def _load():

@@ -1,6 +1,8 @@
 """The pieces of montecosmo/bricks.py the PM path touches: cosmology presets (bricks.py:16-47) as a
 duck-typed object (the path reads Omega_m, Omega_de, Omega_k, w0, wa and uses `_workspace`, nbody.py:699)
 and the initial particle lattice (bricks.py:593-603)."""
+import os
+
 import numpy as np
 
 
@@ -71,7 +73,9 @@ def lagrangian_bias(cosmo, pos, a, box_size, lin_mesh, bias, png=None, png_type=
     dev = spec.device
     kphys = [float(s) / float(b) for s, b in zip(shape, box_size)]
     fields = torch.empty((7,) + tuple(shape), dtype=torch.float32, device=dev)
-    plan.call("mcpm_bias_fields_f32", nbody._ptr(spec), kphys[0], kphys[1], kphys[2], nbody._ptr(fields))
+    # with a context for the adjoint, delta and the Hessian meshes stay resident for it (six transforms less per gradient)
+    hess6 = torch.empty((6,) + tuple(shape), dtype=torch.float32, device=dev) if (return_ctx and os.environ.get("MCPM_BIAS_KEEP", "1") != "0") else None
+    plan.call("mcpm_bias_fields_save_f32", nbody._ptr(spec), kphys[0], kphys[1], kphys[2], nbody._ptr(fields), nbody._ptr(hess6))
     # NGP read at the mesh's own lattice points is the identity: the fields themselves are the reads (no pass at all)
     ident = (int(read_order) == 1 and isinstance(pos, nbody.LatticePos) and pos.is_regular and tuple(pos.ptcl_shape) == tuple(shape))
     if ident:
@@ -100,7 +104,7 @@ def lagrangian_bias(cosmo, pos, a, box_size, lin_mesh, bias, png=None, png_type=
               nbody._ptr(gr), gcs, nbody._ptr(gp), gs, b8, nbody._ptr(w), nbody._ptr(dvel), None)
     if return_ctx:
         ctx = BiasCtx(plan=plan, spec=spec, shape=shape, p=p, n=n, mode=mode, kphys=kphys, reads=reads, gr=gr, gp=gp, gs=gs,
-                      g_shape=g_shape, b8=b8, read_order=int(read_order), gcs=gcs)
+                      g_shape=g_shape, b8=b8, read_order=int(read_order), gcs=gcs, hess6=hess6)
         return (w, dvel, 0.), ctx
     return w, dvel, 0.
 
@@ -131,7 +135,10 @@ def lagrangian_bias_vjp(ctx, weights_bar, dvel_bar):
             plan.call("mcpm_paint_f32", nbody._ptr(ctx.p), n, ctx.mode, nbody._ptr(rb[c]), 1, 0.0, ctx.read_order, nbody._ptr(fb[c]), 0)
         plan.call("mcpm_paint3_f32", nbody._ptr(ctx.p), n, ctx.mode, nbody._ptr(grb), ctx.read_order, nbody._ptr(fb[4]), 0)
     out = torch.empty(tuple(ctx.spec.shape), dtype=torch.complex64, device=dev)
-    plan.call("mcpm_bias_fields_vjp_f32", nbody._ptr(ctx.spec), ctx.kphys[0], ctx.kphys[1], ctx.kphys[2], nbody._ptr(fb), nbody._ptr(out))
+    if getattr(ctx, "hess6", None) is not None:
+        plan.call("mcpm_bias_fields_vjp_saved_f32", ctx.kphys[0], ctx.kphys[1], ctx.kphys[2], nbody._ptr(ctx.hess6), nbody._ptr(fb), nbody._ptr(out))
+    else:
+        plan.call("mcpm_bias_fields_vjp_f32", nbody._ptr(ctx.spec), ctx.kphys[0], ctx.kphys[1], ctx.kphys[2], nbody._ptr(fb), nbody._ptr(out))
     s = scal.cpu().numpy()
     bias_bar = {k: float(s[i]) for i, k in enumerate(BIAS_KEYS)}
     # per-particle growth cotangents stay on the device; a scalar one comes back as a float64 array of the shape of a2g(a)

@@ -129,14 +129,14 @@ __global__ __launch_bounds__(256) void shear_combine_kernel(const float *__restr
     s3[i] = 3.f * (a * (b * c - f * f) - d * (d * c - e * f) + e * (d * f - b * e));
 }
 
-// in place: r6 (forward values) -> cotangents of {delta, h00, h11, h01, h02, h12} given those of delta, shear^2, shear^3
-__global__ __launch_bounds__(256) void shear_combine_vjp_kernel(float *r6, int64_t M, const float *__restrict__ db,
+// src (forward values; may be r6 itself) -> r6 = cotangents of {delta, h00, h11, h01, h02, h12} given those of delta, shear^2, shear^3
+__global__ __launch_bounds__(256) void shear_combine_vjp_kernel(const float *src, float *r6, int64_t M, const float *__restrict__ db,
                                                                 const float *__restrict__ s2b, const float *__restrict__ s3b) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
-    const float dl = r6[i], t = dl * (1.f / 3.f);
-    const float a = r6[M + i] - t, b = r6[2 * M + i] - t, c = -(a + b);
-    const float d = r6[3 * M + i], e = r6[4 * M + i], f = r6[5 * M + i];
+    const float dl = src[i], t = dl * (1.f / 3.f);
+    const float a = src[M + i] - t, b = src[2 * M + i] - t, c = -(a + b);
+    const float d = src[3 * M + i], e = src[4 * M + i], f = src[5 * M + i];
     const float w2 = s2b[i], w3 = 3.f * s3b[i];
     const float ca = b * c - f * f, cb = a * c - e * e, cc = a * b - d * d;
     const float ab = w2 * (2.f * a - 2.f * c) + w3 * (ca - cc), bb = w2 * (2.f * b - 2.f * c) + w3 * (cb - cc);
@@ -353,12 +353,14 @@ extern "C" {
 
 // lin_mesh (plain half-spectrum) -> fields7 = {delta, shear^2, 3 det shear, laplacian delta, grad_x, grad_y, grad_z} (7 real
 // meshes, M apart).  kphys = mesh_shape / box_size per axis (bricks.py:352: wavevectors in h/Mpc).
-int mcpm_bias_fields_f32(mcpm_plan *p, const float *lin_mesh, float kpx, float kpy, float kpz, float *fields7) {
+// hess6 (may be NULL): 6 M floats that receive delta and the five Hessian meshes the shear is built from, for mcpm_bias_fields_vjp_saved_f32
+// (the adjoint then recomputes nothing: six transforms less per gradient, 400 MB at 256^3)
+int mcpm_bias_fields_save_f32(mcpm_plan *p, const float *lin_mesh, float kpx, float kpy, float kpz, float *fields7, float *hess6) {
     if (!p) return MCPM_E_ARG;
     MCPM_REQUIRE(p, lin_mesh && fields7, MCPM_E_ARG, "mcpm_bias_fields_f32: null buffer");
     MCPM_REQUIRE(p, !p->g.xslab, MCPM_E_UNSUPPORTED, "mcpm_bias_fields_f32: not slab-decomposed");
     const int64_t M = p->M;
-    float *spec = p->spec, *r6 = p->fmesh;  // scratch: 6 plain spectra, 6 of the 9 real meshes
+    float *spec = p->spec, *r6 = hess6 ? hess6 : p->fmesh;  // scratch: 6 plain spectra, 6 of the 9 real meshes
     MCPM_TRY(fields_group(p, lin_mesh, kpx, kpy, kpz, 0, spec, r6));
     {
         StageTimer st_(p, ST_LPT, 32.0 * M);
@@ -370,18 +372,20 @@ int mcpm_bias_fields_f32(mcpm_plan *p, const float *lin_mesh, float kpx, float k
     return MCPM_OK;
 }
 
-// cotangents of the 7 fields -> cotangent of lin_mesh (real-pair convention, irfftn multiplicity weights)
-int mcpm_bias_fields_vjp_f32(mcpm_plan *p, const float *lin_mesh, float kpx, float kpy, float kpz, const float *fields7_bar,
-                             float *lin_mesh_bar) {
-    if (!p) return MCPM_E_ARG;
-    MCPM_REQUIRE(p, lin_mesh && fields7_bar && lin_mesh_bar, MCPM_E_ARG, "mcpm_bias_fields_vjp_f32: null buffer");
-    MCPM_REQUIRE(p, !p->g.xslab, MCPM_E_UNSUPPORTED, "mcpm_bias_fields_vjp_f32: not slab-decomposed");
+int mcpm_bias_fields_f32(mcpm_plan *p, const float *lin_mesh, float kpx, float kpy, float kpz, float *fields7) {
+    return mcpm_bias_fields_save_f32(p, lin_mesh, kpx, kpy, kpz, fields7, nullptr);
+}
+
+// cotangents of the 7 fields -> cotangent of lin_mesh (real-pair convention, irfftn multiplicity weights); hess6: what
+// mcpm_bias_fields_save_f32 left (read only), or NULL: delta and the Hessian meshes are recomputed from lin_mesh
+static int bias_fields_vjp(mcpm_plan *p, const float *lin_mesh, float kpx, float kpy, float kpz, const float *hess6, const float *fields7_bar,
+                           float *lin_mesh_bar) {
     const int64_t M = p->M, Mh = p->Mh;
     const unsigned nb = (unsigned)((Mh + 255) / 256);
     const float scale = 1.f / (float)M;
     float *spec = p->spec, *r6 = p->fmesh;
-    MCPM_TRY(fields_group(p, lin_mesh, kpx, kpy, kpz, 0, spec, r6));   // recompute delta and the Hessian meshes
-    shear_combine_vjp_kernel<<<(unsigned)((M + 255) / 256), 256, 0, p->stream>>>(r6, M, fields7_bar, fields7_bar + M, fields7_bar + 2 * M);
+    if (!hess6) MCPM_TRY(fields_group(p, lin_mesh, kpx, kpy, kpz, 0, spec, r6));   // recompute delta and the Hessian meshes
+    shear_combine_vjp_kernel<<<(unsigned)((M + 255) / 256), 256, 0, p->stream>>>(hess6 ? hess6 : r6, r6, M, fields7_bar, fields7_bar + M, fields7_bar + 2 * M);
     MCPM_LAUNCH_CHECK(p, "shear_combine_vjp_kernel");
     MCPM_TRY(mcpm_fft_r2c(p, r6, spec, 6));
     bias_spectra_vjp_kernel<0><<<nb, 256, 0, p->stream>>>(p->g, kpx, kpy, kpz, scale, (const float2 *)spec, (float2 *)lin_mesh_bar, Mh, 0);
@@ -392,6 +396,22 @@ int mcpm_bias_fields_vjp_f32(mcpm_plan *p, const float *lin_mesh, float kpx, flo
     bias_spectra_vjp_kernel<1><<<nb, 256, 0, p->stream>>>(p->g, kpx, kpy, kpz, scale, (const float2 *)spec, (float2 *)lin_mesh_bar, Mh, 1);
     MCPM_LAUNCH_CHECK(p, "bias_spectra_vjp_kernel");
     return MCPM_OK;
+}
+
+int mcpm_bias_fields_vjp_f32(mcpm_plan *p, const float *lin_mesh, float kpx, float kpy, float kpz, const float *fields7_bar,
+                             float *lin_mesh_bar) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, lin_mesh && fields7_bar && lin_mesh_bar, MCPM_E_ARG, "mcpm_bias_fields_vjp_f32: null buffer");
+    MCPM_REQUIRE(p, !p->g.xslab, MCPM_E_UNSUPPORTED, "mcpm_bias_fields_vjp_f32: not slab-decomposed");
+    return bias_fields_vjp(p, lin_mesh, kpx, kpy, kpz, nullptr, fields7_bar, lin_mesh_bar);
+}
+
+int mcpm_bias_fields_vjp_saved_f32(mcpm_plan *p, float kpx, float kpy, float kpz, const float *hess6, const float *fields7_bar,
+                                   float *lin_mesh_bar) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, hess6 && fields7_bar && lin_mesh_bar, MCPM_E_ARG, "mcpm_bias_fields_vjp_saved_f32: null buffer");
+    MCPM_REQUIRE(p, !p->g.xslab, MCPM_E_UNSUPPORTED, "mcpm_bias_fields_vjp_saved_f32: not slab-decomposed");
+    return bias_fields_vjp(p, nullptr, kpx, kpy, kpz, hess6, fields7_bar, lin_mesh_bar);
 }
 
 // reads (raw values of the 7 fields at the particles: dr, s2r, s3r, lr (n each), gr (n,3)) -> weights (n), dvel (n,3).

@@ -384,6 +384,8 @@ class FieldLevelLogDensity:
         white = (nbody.rfftn(w) if self.precond == "real" else rg2cgh(w)) * self.transfer
         cosmo = self.make_cosmo(base)
         bias = {k: base[k] for k in bricks.BIAS_KEYS}
+        # Omega_m sampled: the forward model makes the two evaluations of the growth-table Jacobian as soon as it has queued its kernels
+        fwd.cosmo_fd_params = ("Omega_m",) if "Omega_m" in self.latents else None
         gxy, ctx = fwd.evolve(cosmo, bias, white, return_ctx=True)
         # likelihood (model.py:852-866, :893-908): per-cell count multiplier from the shells' mean densities
         rcounts = np.atleast_1d(np.asarray(base["ngbars"], dtype=np.float64)) * fwd.cell_length ** 3

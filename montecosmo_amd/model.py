@@ -159,7 +159,9 @@ class FieldLevelForward:
         evol_k = chreshape(init_k, r2chshape(self.evol_shape))
         if self.evolution == 'kaiser':      # gxy_mesh lives on the evolution mesh (model.py:690-696: no oversampling needed)
             return self._kaiser(cosmo, bias, white, evol_k, return_ctx)
-        pos0 = nbody.LatticePos.regular(self.evol_shape, self.ptcl_shape)
+        pos0 = getattr(self, "_pos0", None)      # the undisplaced lattice: built once (201 MB of zeros per call at 256^3 otherwise); never written to
+        if pos0 is None:
+            pos0 = self._pos0 = nbody.LatticePos.regular(self.evol_shape, self.ptcl_shape)
         a = self._scale_factors(cosmo)
         (w, dvel, _), bctx = bricks.lagrangian_bias(cosmo, pos0, a, self.box_size, evol_k, bias, read_order=1, return_ctx=True)
         cosmo._workspace = {}                                                        # model.py:762, :769
@@ -179,8 +181,11 @@ class FieldLevelForward:
         gxy_k = chreshape(gxy_k * jac, r2chshape(self.paint_shape))
         gxy = nbody.irfftn(gxy_k)
         if return_ctx:
+            fd = None
+            if self.a_obs is not None and getattr(self, "cosmo_fd_params", None):      # (everything above is queued, not finished)
+                fd = self._cosmo_scalar_fd(cosmo, self.cosmo_fd_params)
             return gxy, EvolveCtx(cosmo=cosmo, white=white, evol_k=evol_k, pos0=pos0, a=a, bctx=bctx, nctx=nctx, octx=octx,
-                                  pos_c=pos_c, w=w, jac=jac)
+                                  pos_c=pos_c, w=w, jac=jac, scalar_fd=fd)
         return gxy
 
     # ---- reverse sweep -----------------------------------------------------------------------------------
@@ -225,18 +230,8 @@ class FieldLevelForward:
         if self.a_obs is None:
             return self._cosmo_vjp_lightcone(ctx, grads, params, rel_eps)
         cosmo, a = ctx.cosmo, self.a_obs
-
-        def scalars(c):
-            c._workspace = {}
-            if self.evolution == 'kaiser':
-                return np.array([float(nbody.a2g(c, a)), float(nbody.a2f(c, a))])
-            out = [float(nbody.a2g(c, a)), float(nbody.a2g(c, a) * nbody.a2f(c, a))]
-            if self.evolution == 'lpt':
-                out += [float(nbody.a2g(c, a)), float(nbody.a2g2(c, a)), float(nbody.a2dg2dg(c, a))]
-            else:
-                dg, al, be, ls = nbody._step_scalars(c, self.nbody_a_start, a, self.nbody_n_steps, "bullfrog")
-                out += [dg] + list(al) + list(be) + list(ls)
-            return np.array(out)
+        scalars = self._cosmo_scalars
+        pre = getattr(ctx, "scalar_fd", None) or {}
 
         if self.evolution == 'kaiser':
             g, bars = None, [float(grads["kaiser"]["g"]), float(grads["kaiser"]["f"])]
@@ -256,15 +251,49 @@ class FieldLevelForward:
             base = float(getattr(cosmo, attr))
             h = rel_eps * max(abs(base), 1e-2)
             vals, inits = [], []
+            cached = pre.get((name, rel_eps))      # the table Jacobian's two evaluations, made while the device ran the forward pass
             for sgn in (+1, -1):
                 c = copy.copy(cosmo)
                 setattr(c, attr, base + sgn * h)
-                vals.append(scalars(c))
+                vals.append(cached[len(vals)] if cached is not None else scalars(c))
                 if self.lin_kpow is None:      # the Eisenstein-Hu shape moves with the cosmology: init_mesh = white sqrt(P)
                     inits.append(self._power_mult(ctx.white, c))
             out[name] = float(np.dot(bars, (vals[0] - vals[1]) / (2 * h)))
             if inits:
                 out[name] += float((grads["init_bar"].conj() * (inits[0] - inits[1])).real.sum().item()) / (2 * h)
+        cosmo._workspace = {}
+        return out
+
+    def _cosmo_scalars(self, c):
+        """The host float64 scalars through which a cosmology enters `evolve` at fixed a_obs (see cosmo_vjp)."""
+        a = self.a_obs
+        c._workspace = {}
+        if self.evolution == 'kaiser':
+            return np.array([float(nbody.a2g(c, a)), float(nbody.a2f(c, a))])
+        out = [float(nbody.a2g(c, a)), float(nbody.a2g(c, a) * nbody.a2f(c, a))]
+        if self.evolution == 'lpt':
+            out += [float(nbody.a2g(c, a)), float(nbody.a2g2(c, a)), float(nbody.a2dg2dg(c, a))]
+        else:
+            dg, al, be, ls = nbody._step_scalars(c, self.nbody_a_start, a, self.nbody_n_steps, "bullfrog")
+            out += [dg] + list(al) + list(be) + list(ls)
+        return np.array(out)
+
+    def _cosmo_scalar_fd(self, cosmo, params, rel_eps=1e-5):
+        """{(name, rel_eps): (scalars at +h, scalars at -h)}: the two evaluations of cosmo_vjp's central difference.  Host work of about
+        a millisecond (two growth-table solves per parameter) that `evolve` does right after it has queued the forward pass, while the
+        device runs it; left to cosmo_vjp it sits at the very end of a gradient, with the device idle (`cosmo_fd_params`)."""
+        import copy
+        out = {}
+        for name in params:
+            attr = "Omega_c" if name == "Omega_m" else name
+            base = float(getattr(cosmo, attr))
+            h = rel_eps * max(abs(base), 1e-2)
+            pair = []
+            for sgn in (+1, -1):
+                c = copy.copy(cosmo)
+                setattr(c, attr, base + sgn * h)
+                pair.append(self._cosmo_scalars(c))
+            out[(name, rel_eps)] = tuple(pair)
         cosmo._workspace = {}
         return out
 
