@@ -395,8 +395,9 @@ int mcpm_lpt_vjp_opts_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order
    dg in growth-factor time.  alpha[i] and beta[i] = (1-alpha_i)/(g_i + dg/2) are host float64 arrays computed
    from the growth tables (alpha_bf nbody.py:907-919 or alpha_fpm :921-931, evaluated at the accumulated Euler
    time g_i); `lpt_scalars` = {a2g, a2g2, a2dg2dg}(a0).  pos_out is the displacement from the lattice
-   (MCPM_POS_LATTICE), vel_out the velocity.  ckpt (may be NULL) receives what the adjoint needs; its size is
-   mcpm_nbody_ckpt_floats() floats. */
+   (MCPM_POS_LATTICE), vel_out the velocity.  ckpt (may be NULL) receives what the adjoint needs -- the step states, the steps' force
+   meshes, and the force / Hessian meshes of the LPT start, which the reverse sweep then reads instead of recomputing them; its size is
+   mcpm_nbody_ckpt_floats(plan, n_steps, lpt_order) floats. */
 int mcpm_nbody_bf_f32(mcpm_plan *plan, const float *init_mesh, int n_steps, const double *alpha,
                       const double *beta, double dg, const double *lpt_scalars, int lpt_order, int paint_order,
                       float *pos_out, float *vel_out, float *ckpt);
