@@ -127,6 +127,20 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_DEV_CONST = {}
+
+
+def _dev_const(values, device, dtype=torch.float32):
+    """A short constant vector on the device, uploaded once per (values, device)."""
+    key = (tuple(float(v) for v in values), str(device), dtype)
+    t = _DEV_CONST.get(key)
+    if t is None:
+        if len(_DEV_CONST) > 64:
+            _DEV_CONST.clear()
+        t = _DEV_CONST[key] = torch.tensor(key[0], dtype=dtype, device=device)
+    return t
+
+
 class LatticePos:
     """Particle positions stored as float32 displacements from the regular lattice
     `regular_pos(mesh_shape, ptcl_shape)` (bricks.py:593-603).  This is how the kernels keep cell
@@ -466,8 +480,7 @@ def _scale_pos(pos, ratio, shape, final_shape):
     if all(r == 1.0 for r in ratio):
         return pos
     if isinstance(pos, LatticePos):
-        r = torch.as_tensor(np.asarray(ratio, dtype=np.float32), device=pos.disp.device)
-        return LatticePos(pos.disp * r, shape, pos.ptcl_shape)
+        return LatticePos(pos.disp * _dev_const(ratio, pos.disp.device), shape, pos.ptcl_shape)
     p = torch.as_tensor(pos)
     return p * torch.as_tensor(np.asarray(ratio), dtype=p.dtype, device=p.device)
 
@@ -530,7 +543,7 @@ def nufft_vjp(pos, final_shape: tuple, weights, mesh_bar, paint_order: int = 2, 
         pos_bar = pb if pos_bar is None else pos_bar + pb
         w_bar = wb if w_bar is None else w_bar + wb
     if jac != 1.0 or any(r != 1.0 for r in ratio):
-        pos_bar = pos_bar * torch.as_tensor(np.asarray(ratio, dtype=np.float32), device=pos_bar.device)
+        pos_bar = pos_bar * _dev_const(ratio, pos_bar.device)
     return pos_bar, w_bar
 
 
