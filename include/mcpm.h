@@ -388,6 +388,13 @@ int mcpm_lattice_dot_f32(mcpm_plan *plan, const float *meshes3, const float *a, 
    growth scalars: scalar_bars = {g_bar, g2_bar, dg2dg_bar} (host, may be NULL; forces a stream sync when given). */
 int mcpm_lpt_vjp_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, const double *lpt_scalars,
                      const float *dpos_bar, const float *vel_bar, float *init_mesh_bar, double *scalar_bars);
+/* The pair with the forward pass's meshes kept for the adjoint (ABI 0.6): `save` (caller-owned, 3 M floats for lpt_order 1, 12 M for 2)
+   receives the first-order force meshes, the second-order ones and the six Hessian meshes; mcpm_lpt_vjp_saved_f32 reads them
+   (`saved`) instead of recomputing them -- a third of the adjoint's transforms.  Infinite-order kernels only. */
+int mcpm_lpt_save_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg, float *dpos, float *vel,
+                      float *save);
+int mcpm_lpt_vjp_saved_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, const double *lpt_scalars, const float *saved,
+                           const float *dpos_bar, const float *vel_bar, float *init_mesh_bar, double *scalar_bars);
 /* The same with finite-difference kernels (lap_fd, grad_fd: MCPM_FD_*), as mcpm_lpt_f32 takes them. */
 int mcpm_lpt_vjp_opts_f32(mcpm_plan *plan, const float *init_mesh, int lpt_order, const double *lpt_scalars, int lap_fd,
                           int grad_fd, const float *dpos_bar, const float *vel_bar, float *init_mesh_bar, double *scalar_bars);

@@ -114,6 +114,8 @@ SIGNATURES = {
     "mcpm_pm_forces_vjp_opts_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p]),
     "mcpm_lpt_vjp_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f32p, _f32p, _f32p, _f64p]),
     "mcpm_lpt_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _f32p, _f32p]),
+    "mcpm_lpt_save_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_float, C.c_float, C.c_float, _f32p, _f32p, _f32p]),
+    "mcpm_lpt_vjp_saved_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f32p, _f32p, _f32p, _f32p, _f64p]),
     "mcpm_nbody_bf_f32": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f64p, _f64p, C.c_double, _f64p, C.c_int, C.c_int, _f32p, _f32p, _f32p]),
     "mcpm_nbody_ckpt_floats": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
     "mcpm_plan_probe_particle_pitch": (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.POINTER(C.c_int64)]),

@@ -687,6 +687,32 @@ int mcpm_lpt_vjp_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, const 
     return MCPM_OK;
 }
 
+// mcpm_lpt_f32 that also leaves its force and Hessian meshes in `save` (3 M floats for lpt_order 1, 12 M for 2), and the adjoint that
+// reads them there instead of recomputing them (infinite-order kernels: what the model uses)
+int mcpm_lpt_save_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, float g, float g2, float dg2dg, float *dpos, float *vel,
+                      float *save) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, init_mesh && dpos && vel && save, MCPM_E_ARG, "mcpm_lpt_save_f32: null buffer");
+    MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_lpt_save_f32: lpt_order must be 1 or 2");
+    return lpt_forward(p, init_mesh, lpt_order, g, g2, dg2dg, MCPM_FD_INF, MCPM_FD_INF, dpos, vel, save);
+}
+
+int mcpm_lpt_vjp_saved_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, const double *lpt_scalars, const float *saved,
+                           const float *dpos_bar, const float *vel_bar, float *init_mesh_bar, double *scalar_bars) {
+    if (!p) return MCPM_E_ARG;
+    MCPM_REQUIRE(p, init_mesh && lpt_scalars && saved && dpos_bar && vel_bar && init_mesh_bar, MCPM_E_ARG, "mcpm_lpt_vjp_saved_f32: null argument");
+    MCPM_REQUIRE(p, lpt_order == 1 || lpt_order == 2, MCPM_E_ORDER, "mcpm_lpt_vjp_saved_f32: lpt_order must be 1 or 2");
+    MCPM_HIP(p, hipMemsetAsync(p->reduce, 0, sizeof(double) * 3, p->stream));
+    MCPM_TRY(lpt_vjp_device(p, init_mesh, lpt_order, lpt_scalars, dpos_bar, vel_bar, init_mesh_bar, p->reduce, MCPM_FD_INF, MCPM_FD_INF, saved));
+    if (scalar_bars) {
+        MCPM_HIP(p, hipMemcpyAsync(scalar_bars, p->reduce, sizeof(double) * 3, hipMemcpyDeviceToHost, p->stream));
+        MCPM_HIP(p, hipStreamSynchronize(p->stream));
+        scalar_bars[1] = -scalar_bars[1];
+        scalar_bars[2] = -scalar_bars[2];
+    }
+    return MCPM_OK;
+}
+
 int mcpm_lpt_vjp_opts_f32(mcpm_plan *p, const float *init_mesh, int lpt_order, const double *lpt_scalars, int lap_fd, int grad_fd,
                           const float *dpos_bar, const float *vel_bar, float *init_mesh_bar, double *scalar_bars) {
     if (!p) return MCPM_E_ARG;

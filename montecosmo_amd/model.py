@@ -166,8 +166,8 @@ class FieldLevelForward:
         (w, dvel, _), bctx = bricks.lagrangian_bias(cosmo, pos0, a, self.box_size, evol_k, bias, read_order=1, return_ctx=True)
         cosmo._workspace = {}                                                        # model.py:762, :769
         if self.evolution == 'lpt':
-            dpos, vel = nbody.lpt(cosmo, evol_k, pos0, a, lpt_order=self.lpt_order, read_order=1)
-            pos, nctx = pos0 + dpos, None
+            (dpos, vel), lctx = nbody.lpt(cosmo, evol_k, pos0, a, lpt_order=self.lpt_order, read_order=1, return_ctx=True)
+            pos, nctx = pos0 + dpos, lctx      # (the LPT context rides in the N-body context's slot)
         else:
             (pos, vel), nctx = nbody.nbody_bf(cosmo, evol_k, pos0, a0=self.nbody_a_start, a1=a, n_steps=self.nbody_n_steps,
                                               paint_order=self.paint_order, lpt_order=self.lpt_order, return_ctx=True,
@@ -207,7 +207,7 @@ class FieldLevelForward:
         xb, vb, dvb, gfb = bricks.observe_pos_vjp(ctx.octx, pb)
         mesh_b, bias_bar, bg_bar = bricks.lagrangian_bias_vjp(ctx.bctx, wb, dvb)
         if self.evolution == 'lpt':
-            mb, growth = nbody.lpt_vjp(cosmo, ctx.evol_k, ctx.pos0, ctx.a, xb, vb, lpt_order=self.lpt_order)
+            mb, growth = nbody.lpt_vjp(cosmo, ctx.evol_k, ctx.pos0, ctx.a, xb, vb, lpt_order=self.lpt_order, ctx=ctx.nctx)
         else:
             mb, growth = nbody.nbody_bf_vjp(ctx.nctx, xb, vb)
         mesh_b = mesh_b + mb

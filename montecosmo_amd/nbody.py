@@ -635,10 +635,18 @@ def _growth_tab3(cosmo, a, n):
     return _f32(np.stack([a2g(cosmo, a), a2g2(cosmo, a), a2dg2dg(cosmo, a)], axis=-1))
 
 
-def lpt(cosmo, init_mesh, pos, a, lpt_order: int = 2, read_order: int = 2, grad_fd=np.inf, lap_fd=np.inf):
+class LptCtx:
+    """What `lpt(..., return_ctx=True)` keeps for `lpt_vjp(..., ctx=...)`: the force / Hessian meshes of the forward pass (`save`) and, on the
+    light cone, the per-particle force arrays F1, F2 -- the adjoint then recomputes neither (2.9 of 22.5 ms per gradient at 256^3)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def lpt(cosmo, init_mesh, pos, a, lpt_order: int = 2, read_order: int = 2, grad_fd=np.inf, lap_fd=np.inf, return_ctx=False):
     """First or second order LPT displacement and growth-time velocity at scale factor(s) `a`
     (nbody.py:634-667).  `a` may be a scalar or an (N,1) array (light-cone: per-particle growth applied by
-    mcpm_lpt_combine_f32)."""
+    mcpm_lpt_combine_f32).  `return_ctx=True` (fused path: regular lattice, NGP, infinite-order kernels) also returns an LptCtx."""
     init_mesh = torch.as_tensor(init_mesh)
     if not init_mesh.is_complex():
         init_mesh = rfftn(init_mesh)
@@ -651,16 +659,24 @@ def lpt(cosmo, init_mesh, pos, a, lpt_order: int = 2, read_order: int = 2, grad_
         n = plan.N
         dpos = torch.empty((n, 3), dtype=torch.float32, device=spec.device)
         vel = torch.empty((n, 3), dtype=torch.float32, device=spec.device)
+        keep = bool(return_ctx) and grad_fd == np.inf and lap_fd == np.inf
+        save = torch.empty(((12 if int(lpt_order) == 2 else 3) * plan.M,), dtype=torch.float32, device=spec.device) if keep else None
+
+        def run(g, g2, dg2dg, d_out, v_out):
+            if keep:
+                plan.call("mcpm_lpt_save_f32", _ptr(spec), int(lpt_order), g, g2, dg2dg, _ptr(d_out), _ptr(v_out), _ptr(save))
+            else:
+                plan.call("mcpm_lpt_f32", _ptr(spec), int(lpt_order), g, g2, dg2dg, _fd(lap_fd), _fd(grad_fd), _ptr(d_out), _ptr(v_out))
+
         if scalar_a:
-            plan.call("mcpm_lpt_f32", _ptr(spec), int(lpt_order), float(a2g(cosmo, a)), float(a2g2(cosmo, a)), float(a2dg2dg(cosmo, a)),
-                      _fd(lap_fd), _fd(grad_fd), _ptr(dpos), _ptr(vel))
-            return dpos, vel
+            run(float(a2g(cosmo, a)), float(a2g2(cosmo, a)), float(a2dg2dg(cosmo, a)), dpos, vel)
+            return ((dpos, vel), LptCtx(save=save, F1=None, F2=None)) if return_ctx else (dpos, vel)
         F2, F1 = dpos, vel                        # (g, g2, dg2dg) = (0, -1, 0): dpos = F2, vel = F1
-        plan.call("mcpm_lpt_f32", _ptr(spec), int(lpt_order), 0.0, -1.0, 0.0, _fd(lap_fd), _fd(grad_fd), _ptr(F2), _ptr(F1))
+        run(0.0, -1.0, 0.0, F2, F1)
         gt = _growth_tab3(cosmo, a, n)
         dpos, vel = torch.empty_like(F1), torch.empty_like(F1)
         plan.call("mcpm_lpt_combine_f32", _ptr(F1), _ptr(F2) if lpt_order == 2 else None, _ptr(gt), n, _ptr(dpos), _ptr(vel))
-        return dpos, vel
+        return ((dpos, vel), LptCtx(save=save, F1=F1, F2=F2)) if return_ctx else (dpos, vel)
     force1 = pm_forces(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd)
     force2 = pm_forces2(pos, init_mesh, read_order, grad_fd=grad_fd, lap_fd=lap_fd) if lpt_order == 2 else None
     n = force1.shape[0]
@@ -1097,10 +1113,10 @@ def cosmo_vjp(ctx, scalar_bars, params=("Omega_c",), rel_eps=1e-5):
     return out
 
 
-def lpt_vjp(cosmo, init_mesh, pos, a, dpos_bar, vel_bar, lpt_order: int = 2):
+def lpt_vjp(cosmo, init_mesh, pos, a, dpos_bar, vel_bar, lpt_order: int = 2, ctx=None):
     """VJP of `lpt(..., read_order=1)` on the regular lattice w.r.t. init_mesh (half-spectrum).  Scalar `a`: returns
     (init_mesh_bar, {'g','g2','dg2dg'} scalar cotangents).  `a` of shape (N,1) (light cone): the growth cotangents are
-    per-particle float32 device tensors (N,)."""
+    per-particle float32 device tensors (N,).  `ctx`: the LptCtx of the forward call (nothing is recomputed then)."""
     spec = _c64(init_mesh)
     mesh_shape = ch2rshape(spec.shape)
     ptcl_shape = pos.ptcl_shape if isinstance(pos, LatticePos) else _infer_lattice(pos, mesh_shape)
@@ -1108,21 +1124,31 @@ def lpt_vjp(cosmo, init_mesh, pos, a, dpos_bar, vel_bar, lpt_order: int = 2):
     xb, vb = _f32(dpos_bar, (plan.N, 3)), _f32(vel_bar, (plan.N, 3))
     out = torch.empty(tuple(spec.shape), dtype=torch.complex64, device=spec.device)
     sb = np.zeros(3)
+    saved = ctx.save if ctx is not None else None
     if not isinstance(a, torch.Tensor) and (np.ndim(a) == 0 or np.size(a) == 1):
         sc = np.array([float(a2g(cosmo, a)), float(a2g2(cosmo, a)), float(a2dg2dg(cosmo, a))])
-        plan.call("mcpm_lpt_vjp_f32", _ptr(spec), int(lpt_order), _dptr(sc), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
+        if saved is not None:
+            plan.call("mcpm_lpt_vjp_saved_f32", _ptr(spec), int(lpt_order), _dptr(sc), _ptr(saved), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
+        else:
+            plan.call("mcpm_lpt_vjp_f32", _ptr(spec), int(lpt_order), _dptr(sc), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
         return out, {"g": sb[0], "g2": sb[1], "dg2dg": sb[2]}
     # light cone: (F2, F1) = mcpm_lpt_f32 with (g, g2, dg2dg) = (0, -1, 0); the per-particle combination is adjointed by
     # mcpm_lpt_combine_vjp_f32, the rest by the scalar LPT adjoint with the same three scalars
     gt = _growth_tab3(cosmo, a, plan.N)
-    F2 = torch.empty((plan.N, 3), dtype=torch.float32, device=spec.device)
-    F1 = torch.empty((plan.N, 3), dtype=torch.float32, device=spec.device)
-    plan.call("mcpm_lpt_f32", _ptr(spec), int(lpt_order), 0.0, -1.0, 0.0, 0, 0, _ptr(F2), _ptr(F1))
+    if ctx is not None and ctx.F1 is not None:
+        F1, F2 = ctx.F1, ctx.F2
+    else:
+        F2 = torch.empty((plan.N, 3), dtype=torch.float32, device=spec.device)
+        F1 = torch.empty((plan.N, 3), dtype=torch.float32, device=spec.device)
+        plan.call("mcpm_lpt_f32", _ptr(spec), int(lpt_order), 0.0, -1.0, 0.0, 0, 0, _ptr(F2), _ptr(F1))
     xb, vb = xb.clone(), vb.clone()
     gtb = torch.empty((plan.N, 3), dtype=torch.float32, device=spec.device)
     plan.call("mcpm_lpt_combine_vjp_f32", _ptr(F1), _ptr(F2) if lpt_order == 2 else None, _ptr(gt), plan.N, _ptr(xb), _ptr(vb), _ptr(gtb))
     sc = np.array([0.0, -1.0, 0.0])
-    plan.call("mcpm_lpt_vjp_f32", _ptr(spec), int(lpt_order), _dptr(sc), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
+    if saved is not None:
+        plan.call("mcpm_lpt_vjp_saved_f32", _ptr(spec), int(lpt_order), _dptr(sc), _ptr(saved), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
+    else:
+        plan.call("mcpm_lpt_vjp_f32", _ptr(spec), int(lpt_order), _dptr(sc), _ptr(xb), _ptr(vb), _ptr(out), _dptr(sb))
     return out, {"g": gtb[:, 0], "g2": gtb[:, 1], "dg2dg": gtb[:, 2]}      # per-particle cotangents stay on the device
 
 
