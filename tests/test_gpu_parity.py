@@ -688,6 +688,55 @@ def test_lpt_light_cone(nb, lpt_order):
         assert rel_l2(to_np(sb_g["g2"]), sb_o["g2"]) < 1e-5 and rel_l2(to_np(sb_g["dg2dg"]), sb_o["dg2dg"]) < 1e-5
 
 
+@pytest.mark.parametrize("n,lpt_order,light_cone", [(16, 2, False), (64, 2, True), (64, 1, True), (64, 2, False)])
+def test_adjoints_that_keep_the_forward_meshes_equal_the_recomputing_ones(nb, n, lpt_order, light_cone):
+    """The forward passes can leave their force / Hessian meshes for the adjoint instead of having it recompute them (DESIGN finding 48):
+    `lpt(..., return_ctx=True)` -> `lpt_vjp(..., ctx=...)` (mcpm_lpt_save_f32 / mcpm_lpt_vjp_saved_f32), the checkpoint of nbody_bf, the
+    bias context (mcpm_bias_fields_save_f32 / mcpm_bias_fields_vjp_saved_f32).  Same meshes, same arithmetic: every output is bitwise
+    equal to the recomputing path's."""
+    import os
+    import torch
+    from montecosmo_amd import bricks, synth
+    shape = (n, n, n)
+    spec = synth.init_mesh(n, seed=12, rms_disp=1.0)
+    lat = nb.LatticePos.regular(shape)
+    rng = np.random.default_rng(6)
+    a = (0.3 + 0.6 * rng.uniform(size=(n ** 3, 1))) if light_cone else 0.4
+    cosmo = bricks.Planck18()
+    xb, vb = rng.standard_normal((n ** 3, 3)).astype(np.float32), rng.standard_normal((n ** 3, 3)).astype(np.float32)
+    (dp, v), ctx = nb.lpt(cosmo, spec, lat, a, lpt_order=lpt_order, read_order=1, return_ctx=True)
+    dp0, v0 = nb.lpt(cosmo, spec, lat, a, lpt_order=lpt_order, read_order=1)
+    assert torch.equal(dp, dp0) and torch.equal(v, v0) and ctx.save is not None
+    mb1, sb1 = nb.lpt_vjp(cosmo, spec, lat, a, xb, vb, lpt_order=lpt_order, ctx=ctx)
+    mb0, sb0 = nb.lpt_vjp(cosmo, spec, lat, a, xb, vb, lpt_order=lpt_order)
+    assert torch.equal(mb1, mb0)
+    for k in ("g", "g2", "dg2dg"):
+        assert np.array_equal(to_np(sb1[k]) if torch.is_tensor(sb1[k]) else sb1[k], to_np(sb0[k]) if torch.is_tensor(sb0[k]) else sb0[k]), k
+    mb2, _ = nb.lpt_vjp(cosmo, spec, lat, a, xb, vb, lpt_order=lpt_order, ctx=ctx)       # the context is read, not consumed
+    assert torch.equal(mb2, mb1)
+    # the trajectory's checkpoint against the stand-alone adjoint chain: nbody_bf_vjp twice on one context (read only, again)
+    if not light_cone:
+        (lp, vel), nctx = nb.nbody_bf(cosmo, spec, lat, a0=0.1, a1=0.5, n_steps=2, lpt_order=lpt_order, return_ctx=True, lattice_out=True)
+        g1 = nb.nbody_bf_vjp(nctx, xb, vb)
+        g2 = nb.nbody_bf_vjp(nctx, xb, vb)
+        assert torch.equal(g1[0], g2[0]) and all(np.array_equal(np.asarray(g1[1][k]), np.asarray(g2[1][k])) for k in g1[1])
+    # bias fields: kept Hessian meshes against recomputed ones
+    bias = dict(b1=1.3, b2=0.4, bs2=-0.3, bn2=0.2)
+    wb_, dvb_ = rng.standard_normal(n ** 3).astype(np.float32), rng.standard_normal((n ** 3, 3)).astype(np.float32)
+    outs = []
+    try:
+        for keep in ("1", "0"):
+            os.environ["MCPM_BIAS_KEEP"] = keep
+            (w, dvel, _), bctx = bricks.lagrangian_bias(cosmo, lat, 0.5, (100.,) * 3, spec, bias, read_order=1, return_ctx=True)
+            assert (bctx.hess6 is not None) == (keep == "1")
+            mbar, bbar, gbar = bricks.lagrangian_bias_vjp(bctx, wb_, dvb_)
+            outs.append((w, dvel, mbar, bbar, np.asarray(gbar)))
+    finally:
+        os.environ.pop("MCPM_BIAS_KEEP", None)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert outs[0][3] == outs[1][3] and np.array_equal(outs[0][4], outs[1][4])
+
+
 @pytest.mark.parametrize("opts", [dict(paint_deconv=True), dict(grad_fd=4, lap_fd=2), dict(paint_deconv=True, grad_fd=2, lap_fd=4)])
 def test_nbody_bf_deconv_and_fd_kernels(nb, opts):
     """nbody.py:967-1002 with the options the model leaves at their defaults: paint_deconv (:590-593) and the
