@@ -7,7 +7,8 @@
 //   other axes: z[-s/2]      <- (z[s/2] + z[-s/2]) / sqrt2
 // then crop / pad and scale by the real cell-count ratio, then for padded axes, first axis first,
 //   other axes: out[-ms/2] /= sqrt2 ; out[ms/2] = out[-ms/2]        last axis: out[..., ms-1] /= sqrt2.
-// Here every output element gathers its (at most 8) sources directly; the VJP scatters the same terms.
+// Here every output element gathers its (at most 8) sources directly; the VJP is a gather too: every input element collects the terms of
+// the outputs that list it (chreshape_vjp_gather_kernel).
 #include "mcpm_internal.h"
 
 namespace {
@@ -55,48 +56,7 @@ __device__ __forceinline__ void sources(const RS &r, int ix, int iy, int k, floa
     }
 }
 
-// Scale of the fixed-point accumulators of the adjoint scatter: S = 2^(40 - e) with 2^e <= max|cotangent| < 2^(e+1), from the
-// float bits of the maximum (fxmax[0]); mode 0: all zero, 1: fixed point, 2: non-finite input (plain float atomics, the result
-// is non-finite either way).  One contribution is below 2^41 r.scale, a destination takes at most 8: no overflow for any
-// mesh ratio below 2^18.
-struct FxS {
-    float S;
-    double Sinv;
-    int mode;
-};
-__device__ __forceinline__ FxS fx_scale(const unsigned *__restrict__ fxmax) {
-    const unsigned wb = fxmax[0];
-    int be = (int)(wb >> 23);
-    FxS r;
-    r.mode = wb == 0u ? 0 : (be >= 255 ? 2 : 1);
-    be = min(max(be, 42), 254);
-    const int e = be - 127;
-    r.S = __uint_as_float((unsigned)(127 + 40 - e) << 23);
-    r.Sinv = __longlong_as_double((long long)(1023 - 40 + e) << 52);
-    return r;
-}
-__global__ __launch_bounds__(256) void absmax_bits_kernel(const float *__restrict__ v, int64_t n, unsigned *__restrict__ out) {
-    unsigned m = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = max(m, __float_as_uint(v[i]) & 0x7fffffffu);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
-}
-__global__ __launch_bounds__(256) void fx_flush_kernel(const long long *__restrict__ acc, float *__restrict__ out, int64_t n,
-                                                       const unsigned *__restrict__ fxmax) {
-    const FxS sc = fx_scale(fxmax);
-    if (sc.mode == 2) return;       // the float path wrote `out` directly
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (float)((double)acc[i] * sc.Sinv);
-}
-
-template <bool ADJOINT>
-__global__ __launch_bounds__(256) void chreshape_kernel(RS r, const float2 *__restrict__ in, float2 *__restrict__ out,
-                                                        long long *__restrict__ acc = nullptr, const unsigned *__restrict__ fxmax = nullptr) {
-    // forward: in = input spectrum, out = reshaped.  adjoint: in = cotangent of the reshaped spectrum, out = cotangent
-    // of the input.  Up to 8 outputs share an input (Nyquist planes), so the adjoint is a scatter; its sums are taken in
-    // 64-bit FIXED POINT (integer atomics into `acc`, zeroed by the caller, flushed by fx_flush_kernel): float atomics would
-    // add the contributions in arrival order and change the last bit of a few elements from call to call, which a
-    // sampler then amplifies into different chains from the same seed.
+__global__ __launch_bounds__(256) void chreshape_kernel(RS r, const float2 *__restrict__ in, float2 *__restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n = (int64_t)r.sx * r.sy * r.szc;
     if (idx >= n) return;
@@ -110,33 +70,93 @@ __global__ __launch_bounds__(256) void chreshape_kernel(RS r, const float2 *__re
         if (ok > r.mzc - 1) valid = false;
         if (ok == r.mzc - 1) fz = R2;
     }
-    if (!ADJOINT) {
-        float2 acc = make_float2(0.f, 0.f);
-        if (valid)
-            sources(r, ix, iy, ok, r.scale * fx * fy * fz, [&](int jx, int jy, int k, float w, bool cj) {
-                const float2 v = in[((int64_t)jx * r.my + jy) * r.mzc + k];
-                acc.x += w * v.x;
-                acc.y += cj ? -w * v.y : w * v.y;
-            });
-        out[idx] = acc;
-    } else {
-        if (!valid) return;
-        const float2 ob = in[idx];
-        const FxS sc = fx_scale(fxmax);
-        if (sc.mode == 0) return;
+    float2 acc = make_float2(0.f, 0.f);
+    if (valid)
         sources(r, ix, iy, ok, r.scale * fx * fy * fz, [&](int jx, int jy, int k, float w, bool cj) {
-            const int64_t e = 2 * (((int64_t)jx * r.my + jy) * r.mzc + k);
-            const float vx = w * ob.x, vy = cj ? -w * ob.y : w * ob.y;
-            if (sc.mode == 2) {
-                float *dst = reinterpret_cast<float *>(out) + e;
-                atomicAdd(dst, vx);
-                atomicAdd(dst + 1, vy);
-            } else {
-                atomicAdd(reinterpret_cast<unsigned long long *>(acc) + e, (unsigned long long)__float2ll_rn(vx * sc.S));
-                atomicAdd(reinterpret_cast<unsigned long long *>(acc) + e + 1, (unsigned long long)__float2ll_rn(vy * sc.S));
-            }
+            const float2 v = in[((int64_t)jx * r.my + jy) * r.mzc + k];
+            acc.x += w * v.x;
+            acc.y += cj ? -w * v.y : w * v.y;
         });
+    out[idx] = acc;
+}
+
+// Outputs (along one full axis) that read input index i: the inverse of axis_src.  At most two (a padded axis splits the input
+// Nyquist plane between +ms/2 and -ms/2).  Returns the count.
+__device__ __forceinline__ int axis_dst(int i, int ms, int s, int (&o)[2]) {
+    const int f = i < ms / 2 ? i : i - ms;      // frequency of the input index (i = ms/2 is -ms/2)
+    if (s > ms) {
+        if (i == ms / 2) {
+            o[0] = s - ms / 2;
+            o[1] = ms / 2;
+            return 2;
+        }
+        o[0] = f < 0 ? f + s : f;
+        return 1;
     }
+    if (f < -s / 2 || f > s / 2 - 1) return 0;
+    o[0] = f < 0 ? f + s : f;
+    return 1;
+}
+// candidate outputs along one axis for input index j: through j itself, through its mirror -j (the conjugated Nyquist term of the last
+// axis), and through the aggregated plane ms - s/2 that also reads +s/2 on a truncated axis; deduplicated.  A superset: the caller
+// keeps a candidate's terms only where the forward enumeration really lists (jx, jy, k).
+__device__ __forceinline__ int axis_candidates(int j, int ms, int s, int (&c)[6]) {
+    const int nj = j ? ms - j : 0;
+    int src[3] = {j, nj, (s < ms && (j == s / 2 || nj == s / 2)) ? ms - s / 2 : -1};
+    int n = 0;
+    for (int a = 0; a < 3; ++a) {
+        if (src[a] < 0) continue;
+        int o[2];
+        const int m = axis_dst(src[a], ms, s, o);
+        for (int q = 0; q < m; ++q) {
+            bool dup = false;
+            for (int t = 0; t < n; ++t) dup = dup || c[t] == o[q];
+            if (!dup) c[n++] = o[q];
+        }
+    }
+    return n;
+}
+
+// The adjoint as a GATHER (round 4): every element of the input's cotangent collects its terms itself, in a fixed order -- no atomics,
+// no fixed-point accumulators, no maximum pass, no flush: one launch instead of three and two memsets, and bitwise reproducible by
+// construction.  Which outputs list a given input is not guessed: the candidates above are a superset, and each candidate runs the
+// FORWARD enumeration (`sources`), keeping the terms that name this input -- the adjoint cannot drift from the forward rule.
+__global__ __launch_bounds__(256) void chreshape_vjp_gather_kernel(RS r, const float2 *__restrict__ ob, float2 *__restrict__ in_bar) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = (int64_t)r.mx * r.my * r.mzc;
+    if (idx >= n) return;
+    const int k = (int)(idx % r.mzc);
+    const int64_t t = idx / r.mzc;
+    const int jy = (int)(t % r.my), jx = (int)(t / r.my);
+    float2 acc = make_float2(0.f, 0.f);
+    if (k < r.szc) {      // the last axis maps k -> k (cropped above szc - 1, zero-padded above mzc - 1)
+        float fz = 1.f;
+        if (r.szc > r.mzc && k == r.mzc - 1) fz = R2;
+        int cx[6], cy[6];
+        const int nx = axis_candidates(jx, r.mx, r.sx, cx), ny = axis_candidates(jy, r.my, r.sy, cy);
+        for (int a = 0; a < nx; ++a) {
+            int ix;
+            float fx;
+            if (!axis_src(cx[a], r.mx, r.sx, ix, fx)) continue;
+            for (int b = 0; b < ny; ++b) {
+                int iy;
+                float fy;
+                if (!axis_src(cy[b], r.my, r.sy, iy, fy)) continue;
+                bool have = false;
+                float2 o = make_float2(0.f, 0.f);
+                sources(r, ix, iy, k, r.scale * fx * fy * fz, [&](int sx_, int sy_, int sk, float w, bool cj) {
+                    if (sx_ != jx || sy_ != jy || sk != k) return;
+                    if (!have) {
+                        o = ob[((int64_t)cx[a] * r.sy + cy[b]) * r.szc + k];
+                        have = true;
+                    }
+                    acc.x += w * o.x;
+                    acc.y += cj ? -w * o.y : w * o.y;
+                });
+            }
+        }
+    }
+    in_bar[idx] = acc;
 }
 
 // ---- rg2cgh / cgh2rg (montecosmo/utils.py:785-921, norm = "backward") ----------------------------------------------
@@ -257,7 +277,7 @@ int mcpm_chreshape_c64(void *stream, const float *in, int in_nx, int in_ny, int 
     const RS r{in_nx, in_ny, in_nz / 2 + 1, out_nx, out_ny, out_nz / 2 + 1,
                (float)(((double)out_nx * out_ny * out_nz) / ((double)in_nx * in_ny * in_nz))};
     const int64_t n = (int64_t)r.sx * r.sy * r.szc;
-    chreshape_kernel<false><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(r, (const float2 *)in, (float2 *)out);
+    chreshape_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(r, (const float2 *)in, (float2 *)out);
     return hipGetLastError() == hipSuccess ? MCPM_OK : MCPM_E_HIP;
 }
 
@@ -266,24 +286,9 @@ int mcpm_chreshape_vjp_c64(void *stream, const float *out_bar, int out_nx, int o
     if (int rc = check(out_bar, in_bar, in_nx, in_ny, in_nz, out_nx, out_ny, out_nz)) return rc;
     const RS r{in_nx, in_ny, in_nz / 2 + 1, out_nx, out_ny, out_nz / 2 + 1,
                (float)(((double)out_nx * out_ny * out_nz) / ((double)in_nx * in_ny * in_nz))};
-    const int64_t n = (int64_t)r.sx * r.sy * r.szc, ni = (int64_t)r.mx * r.my * r.mzc;
-    hipStream_t st = (hipStream_t)stream;
-    // scratch of the call: 2 ni 64-bit accumulators + the maximum (stream-ordered allocation, freed behind the flush)
-    char *scratch = nullptr;
-    const size_t acc_bytes = sizeof(long long) * 2 * (size_t)ni;
-    if (hipMallocAsync((void **)&scratch, acc_bytes + 256, st) != hipSuccess) return MCPM_E_NOMEM;
-    long long *acc = (long long *)scratch;
-    unsigned *fxmax = (unsigned *)(scratch + acc_bytes);
-    bool ok = hipMemsetAsync(scratch, 0, acc_bytes + 256, st) == hipSuccess &&
-              hipMemsetAsync(in_bar, 0, sizeof(float2) * ni, st) == hipSuccess;
-    if (ok) {
-        absmax_bits_kernel<<<1024, 256, 0, st>>>(out_bar, 2 * n, fxmax);
-        chreshape_kernel<true><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(r, (const float2 *)out_bar, (float2 *)in_bar, acc, fxmax);
-        fx_flush_kernel<<<1024, 256, 0, st>>>(acc, in_bar, 2 * ni, fxmax);
-        ok = hipGetLastError() == hipSuccess;
-    }
-    (void)hipFreeAsync(scratch, st);
-    return ok ? MCPM_OK : MCPM_E_HIP;
+    const int64_t ni = (int64_t)r.mx * r.my * r.mzc;
+    chreshape_vjp_gather_kernel<<<(unsigned)((ni + 255) / 256), 256, 0, (hipStream_t)stream>>>(r, (const float2 *)out_bar, (float2 *)in_bar);
+    return hipGetLastError() == hipSuccess ? MCPM_OK : MCPM_E_HIP;
 }
 
 int mcpm_rg2cgh_f32(void *stream, const float *real, int nx, int ny, int nz, float *spec) {

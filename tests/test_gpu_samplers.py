@@ -44,8 +44,8 @@ def _cos(c, s8):
 
 def test_log_density_and_gradient_are_bitwise_reproducible(gpu):
     """The same state gives the same log density and the same gradient, bit for bit, call after call: every sum on the path
-    is order-independent (integer accumulators in the paints and in the scatter adjoint of chreshape, whose float atomics
-    once changed the last bit of a few Nyquist-plane elements from call to call -- enough for a seeded NUTS chain to end
+    is order-independent or taken in a fixed order (integer accumulators in the paints; the adjoint of chreshape is a gather -- its
+    float atomics once changed the last bit of a few Nyquist-plane elements from call to call -- enough for a seeded NUTS chain to end
     1 % away from its twin)."""
     import torch
     samplers, flat, q0, ref = _setup()
