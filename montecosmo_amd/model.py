@@ -173,6 +173,8 @@ class FieldLevelForward:
                                               paint_order=self.paint_order, lpt_order=self.lpt_order, return_ctx=True,
                                               lattice_out=True)
             vel = vel.reshape(-1, 3)
+        # the growth-table Jacobian of cosmo_vjp: a millisecond of host work, done HERE -- the device has the whole evolution queued
+        fd = self._cosmo_scalar_fd(cosmo, self.cosmo_fd_params) if (return_ctx and self.a_obs is not None and getattr(self, "cosmo_fd_params", None)) else None
         pos_c, octx = bricks.observe_pos(cosmo, pos, vel, self.box_center, self.box_rotvec, self.box_size, self.evol_shape,
                                          self.init_shape, a_obs=self.a_obs, curved_sky=self.curved_sky, dvel=dvel, return_ctx=True)
         gxy_k = nbody.nufft(pos_c, self.init_shape, self.paint_shape, weights=w, paint_order=self.paint_order,
@@ -181,9 +183,6 @@ class FieldLevelForward:
         gxy_k = chreshape(gxy_k * jac, r2chshape(self.paint_shape))
         gxy = nbody.irfftn(gxy_k)
         if return_ctx:
-            fd = None
-            if self.a_obs is not None and getattr(self, "cosmo_fd_params", None):      # (everything above is queued, not finished)
-                fd = self._cosmo_scalar_fd(cosmo, self.cosmo_fd_params)
             return gxy, EvolveCtx(cosmo=cosmo, white=white, evol_k=evol_k, pos0=pos0, a=a, bctx=bctx, nctx=nctx, octx=octx,
                                   pos_c=pos_c, w=w, jac=jac, scalar_fd=fd)
         return gxy
@@ -294,8 +293,7 @@ class FieldLevelForward:
                 setattr(c, attr, base + sgn * h)
                 pair.append(self._cosmo_scalars(c))
             out[(name, rel_eps)] = tuple(pair)
-        cosmo._workspace = {}
-        return out
+        return out      # (the copies carry their own tables: `cosmo`'s cached ones stay for the rest of evolve)
 
     # ---- light cone: the cosmology enters through per-particle table look-ups -----------------------------------------
     _LC_TABLES = ("chi", "g", "g2", "f", "f2")
