@@ -527,15 +527,18 @@ __device__ __forceinline__ void paint_tile_body(const Geom &g, const float *__re
         int rxs[U], rys[U], rzs[U], gis[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            gis[u] = wi.template point<FAST>(g, x0, y0, z0, bx, rxs[u], rys[u], rzs[u]);
-            wi.next();
-            if (gis[u] >= 0) {
-                d[u] = load3w<FAST>(disp, gis[u]);
-                wt[u] = WMODE ? w[(int64_t)gis[u] * wstride] : 1.f;
-            } else {
-                d[u] = P3{0.f, 0.f, 0.f};
-                wt[u] = 0.f;
+            // (one guard for index and load: on periodic plans a window point always has a lattice point)
+            gis[u] = -1;
+            d[u] = P3{0.f, 0.f, 0.f};
+            wt[u] = 0.f;
+            if (wi.valid()) {
+                gis[u] = wi.template point<FAST>(g, x0, y0, z0, bx, rxs[u], rys[u], rzs[u]);
+                if (FAST == 1 || gis[u] >= 0) {
+                    d[u] = load3w<FAST>(disp, gis[u]);
+                    wt[u] = WMODE ? w[(int64_t)gis[u] * wstride] : 1.f;
+                }
             }
+            wi.next();
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -896,15 +899,17 @@ __device__ __forceinline__ void paint3_tile_body(const Geom &g, const float *__r
         int rxs[U], rys[U], rzs[U], gis[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            gis[u] = wi.template point<FAST>(g, x0, y0, z0, bx, rxs[u], rys[u], rzs[u]);
-            wi.next();
-            if (gis[u] >= 0) {
-                d[u] = load3w<FAST>(disp, gis[u]);
-                wt[u] = load3w<FAST>(w3, gis[u]);
-            } else {
-                d[u] = P3{0.f, 0.f, 0.f};
-                wt[u] = P3{0.f, 0.f, 0.f};
+            gis[u] = -1;
+            d[u] = P3{0.f, 0.f, 0.f};
+            wt[u] = P3{0.f, 0.f, 0.f};
+            if (wi.valid()) {
+                gis[u] = wi.template point<FAST>(g, x0, y0, z0, bx, rxs[u], rys[u], rzs[u]);
+                if (FAST == 1 || gis[u] >= 0) {
+                    d[u] = load3w<FAST>(disp, gis[u]);
+                    wt[u] = load3w<FAST>(w3, gis[u]);
+                }
             }
+            wi.next();
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
