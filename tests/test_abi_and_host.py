@@ -184,3 +184,27 @@ def test_std2trunc_body_and_12_sigma_tails_match_restatement():
             assert abs(d2 - (f(x + h, loc, sc, low, high)[1] - f(x - h, loc, sc, low, high)[1]) / (2 * h)) < 1e-4 * abs(d2) + 1e-10
             assert low <= y <= high
         assert abs(f(-12.0 - 1e-9, loc, sc, low, high)[0] - f(-12.0 + 1e-9, loc, sc, low, high)[0]) < 1e-6 * sc
+
+
+def test_window_walk_float_divisions_are_exact():
+    """paint_tiled.hip::small_div: the set-up of a tile's window walk divides the thread index and the workgroup size by the run-time window
+    widths as (int)((n + 0.5) * rcp(d)) instead of an integer division.  Exact for every case the kernels can meet -- n below 1024 by a
+    width of 17 .. 29, 512 or 1024 by a product of two widths and the remainder by a width -- with the reciprocal one ulp off either way
+    (v_rcp_f32's accuracy)."""
+    f32 = np.float32
+
+    def check(n, d):
+        r = f32(1) / f32(d)
+        for rr in (np.nextafter(r, f32(0)), r, np.nextafter(r, f32(2))):
+            assert int(f32(f32(n) + f32(0.5)) * rr) == n // d, (n, d)
+
+    for d in range(17, 30):
+        for n in range(1024):
+            check(n, d)
+    for wy in range(17, 30):
+        for r in range(61):
+            check(r, wy)
+        for wz in range(17, 30):
+            for threads in (512, 1024):
+                check(threads, wy * wz)
+                check(threads - (threads // (wy * wz)) * wy * wz, wz)
